@@ -1,0 +1,88 @@
+"""ctypes binding of libgoalforce_hip.so — the C ABI declared in include/goalforce.h.
+
+The product path has NO fallback: if the shared library is missing or an entry point
+fails, a GoalForceError is raised (never a silent torch/CPU substitute).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgoalforce_hip.so")
+
+# every symbol include/goalforce.h declares (tests check the .so exports exactly these)
+SYMBOLS = (
+    "gf_version", "gf_last_error", "gf_abi_version",
+    "gf_layernorm_modulate", "gf_rmsnorm_rope", "gf_gemm_bf16", "gf_flash_attn_fwd",
+    "gf_patchify_im2col", "gf_unpatchify", "gf_cfg_euler_step", "gf_act", "gf_add_bf16",
+    "gf_force_map",
+)
+
+EPI_BIAS, EPI_BIAS_GELU_TANH, EPI_BIAS_GATE_RESID, EPI_BIAS_RESID, EPI_BIAS_SILU = range(5)
+
+
+class GoalForceError(RuntimeError):
+    """Raised when the HIP library is missing or a gf_* call returns an error."""
+
+
+_lib = None
+_lock = threading.Lock()
+
+_vp, _i64, _f32, _int = ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_int
+
+
+def _declare(lib):
+    lib.gf_version.restype = ctypes.c_char_p
+    lib.gf_version.argtypes = []
+    lib.gf_last_error.restype = ctypes.c_char_p
+    lib.gf_last_error.argtypes = []
+    lib.gf_abi_version.restype = _int
+    lib.gf_abi_version.argtypes = []
+    sigs = {
+        "gf_layernorm_modulate": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _vp],
+        "gf_rmsnorm_rope": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _vp],
+        "gf_gemm_bf16": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _i64, _vp, _vp],
+        "gf_flash_attn_fwd": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _vp],
+        "gf_patchify_im2col": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp],
+        "gf_unpatchify": [_vp, _vp, _i64, _i64, _i64, _i64, _vp],
+        "gf_cfg_euler_step": [_vp, _vp, _vp, _f32, _f32, _i64, _vp],
+        "gf_act": [_vp, _vp, _i64, _int, _vp],
+        "gf_add_bf16": [_vp, _vp, _vp, _i64, _vp],
+        "gf_force_map": [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _int, _vp],
+    }
+    for name, argtypes in sigs.items():
+        fn = getattr(lib, name)
+        fn.restype = _int
+        fn.argtypes = argtypes
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises GoalForceError if the .so is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise GoalForceError(
+                    f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                    "or `make -C goal_force_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+            try:
+                lib = ctypes.CDLL(LIB_PATH)
+            except OSError as e:  # pragma: no cover
+                raise GoalForceError(f"cannot load {LIB_PATH}: {e}") from e
+            _declare(lib)
+            _lib = lib
+    return _lib
+
+
+def check(status: int, what: str):
+    if status != 0:
+        msg = load().gf_last_error().decode("utf-8", "replace")
+        raise GoalForceError(f"{what} failed with status {status}: {msg}")
+
+
+def version() -> str:
+    return load().gf_version().decode()

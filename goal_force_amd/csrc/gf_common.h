@@ -1,0 +1,77 @@
+// gf_common.h — shared device helpers for the goalforce HIP kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "goalforce.h"
+
+typedef unsigned short u16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define GF_LDS __attribute__((address_space(3)))
+#define GF_GLOBAL __attribute__((address_space(1)))
+
+// bf16 <-> f32.  The plain cast lowers to v_cvt_pk_bf16_f32 (round-to-nearest-even,
+// NaN stays NaN) on gfx950.
+__device__ __forceinline__ float bf2f(u16 u) { return __uint_as_float(((unsigned)u) << 16); }
+__device__ __forceinline__ u16 f2bf(float f) { return __builtin_bit_cast(u16, (__bf16)f); }
+// round an fp32 value to the nearest bf16 and return it as fp32 (the reference's
+// eager bf16 ops round after every elementwise op; we reproduce those roundings)
+__device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
+    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
+
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+    // torch GELU(approximate='tanh'): 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715*x^3)))
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    float inner = k0 * (x + k1 * x * x * x);
+    return 0.5f * x * (1.0f + tanhf(inner));
+}
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// block-wide sum for blockDim.x == THREADS (multiple of 64); `red` is THREADS/64 floats of LDS
+template <int THREADS>
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < THREADS / 64; ++i) t += red[i];
+    return t;
+}
+
+// host side ---------------------------------------------------------------
+void gf_set_error(const char* fmt, ...);
+#define GF_CHECK_ARG(cond, ...)                 \
+    do {                                        \
+        if (!(cond)) {                          \
+            gf_set_error(__VA_ARGS__);          \
+            return GF_ERR_INVALID_ARG;          \
+        }                                       \
+    } while (0)
+#define GF_CHECK_LAUNCH(name)                                                        \
+    do {                                                                             \
+        hipError_t e_ = hipGetLastError();                                           \
+        if (e_ != hipSuccess) {                                                      \
+            gf_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));      \
+            return GF_ERR_LAUNCH;                                                    \
+        }                                                                            \
+    } while (0)
+static inline bool gf_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }

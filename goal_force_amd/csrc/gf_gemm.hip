@@ -1,0 +1,273 @@
+// gf_gemm.hip — bf16 GEMM  C[M,N] = epi(A[M,K] · W[N,K]^T + bias)  for every Linear / 1x1 conv of
+// the Wan DiT forward (reference: F.linear call sites diffsynth/models/wan_video_dit.py:131-146,
+// 209-210, 263, 309-320; zero-conv src/goal_force/wan_video_new.py:1565-1570).
+//
+// CDNA4 design (gfx950):
+//   * 256x256 output tile per 512-thread workgroup (8 waves as 2(M) x 4(N), 128x64 per wave),
+//     K-step 64, v_mfma_f32_16x16x32_bf16, fp32 accumulators (128 VGPRs per lane).
+//   * Both operands have K contiguous (activations [M,K], nn.Linear weight [N,K]), which is the
+//     native fragment order of the 16x16x32 MFMA: each lane reads 8 consecutive k of one row.
+//   * Tiles are staged HBM -> LDS with global_load_lds_dwordx4 (LDS-DMA, 1 KiB per wave
+//     instruction, no VGPR round trip), double buffered (2 x (32 KiB A + 32 KiB B) = 128 KiB),
+//     one barrier per K-step: the DMA of tile t+1 is in flight while tile t is multiplied.
+//   * LDS image: 128-byte rows, 16-byte chunk index XOR (row & 7).  The DMA writes lane-linear, so
+//     the permutation is applied to the per-lane SOURCE address and again on the ds_read_b128
+//     (conflict-free for the 16x16x32 fragment read).
+//   * MFMA operands are swapped (D = W_frag x A_frag) so each lane ends up with 4 consecutive n of
+//     one m; the epilogue transposes through LDS and touches HBM only with full 128-byte rows
+//     (16 B per lane) for C, the residual and the bias/gate vectors.
+//   * blockIdx -> tile map is XCD-aware: each XCD (blockIdx % 8) owns a contiguous range of tiles,
+//     walked in groups of 8 M-tiles x all N-tiles so the 32 co-resident blocks of an XCD share
+//     A/W panels through that XCD's L2.
+//   * M and N tails: loads clamp the row index, stores are masked.
+#include "gf_common.h"
+
+namespace {
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int GEMM_THREADS = 512;
+constexpr int TILE_BYTES = BM * BK * 2;       // 32 KiB per operand tile
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;   // A + B
+constexpr int GEMM_LDS = 2 * STAGE_BYTES;     // 128 KiB
+constexpr int GROUP_M = 8;
+
+struct GemmArgs {
+    const u16* A;
+    const u16* W;
+    const u16* bias;
+    u16* C;
+    const u16* R;
+    const u16* gate;
+    int M, N, K;
+    long lda, ldw, ldc, ldr;
+    int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ void glds16(const void* g, GF_LDS char* l) {
+    __builtin_amdgcn_global_load_lds((const GF_GLOBAL void*)g, (GF_LDS void*)l, 16, 0, 0);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    GF_LDS char* lds = (GF_LDS char*)smem;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- XCD-aware tile mapping (bijective for any grid size) ------------------------------
+    const int nwg = p.tiles_m * p.tiles_n;
+    int v;
+    {
+        const int pid = blockIdx.x;
+        const int xcd = pid & 7, local = pid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    }
+    const int per_group = GROUP_M * p.tiles_n;
+    const int group = v / per_group;
+    const int first_m = group * GROUP_M;
+    const int gsz = min(p.tiles_m - first_m, GROUP_M);
+    const int in_group = v - group * per_group;
+    const int tile_m = first_m + in_group % gsz;
+    const int tile_n = in_group / gsz;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // ---- staging addresses: wave w issues row-groups g = 4w..4w+3 (8 rows x 128 B each) -------
+    // lane l of a DMA instruction fills LDS chunk (l&7) of row (l>>3); it must hold the logical
+    // chunk (l&7) ^ (row&7) of that row.
+    const int srow = lane >> 3;
+    const int schunk = (lane & 7) ^ srow;
+    const u16* a_src[4];
+    const u16* b_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + srow;
+        const int am = min(m0 + row, p.M - 1);
+        const int bn = min(n0 + row, p.N - 1);
+        a_src[i] = p.A + (long)am * p.lda + schunk * 8;
+        b_src[i] = p.W + (long)bn * p.ldw + schunk * 8;
+    }
+    auto stage = [&](int buf, int kt) {
+        GF_LDS char* sa = lds + buf * STAGE_BYTES + wave * 4096;
+        GF_LDS char* sb = sa + TILE_BYTES;
+        const int koff = kt * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            glds16(a_src[i] + koff, sa + i * 1024);
+            glds16(b_src[i] + koff, sb + i * 1024);
+        }
+    };
+
+    // ---- fragment read addresses ---------------------------------------------------------------
+    const int wm = wave >> 2, wn = wave & 3;
+    const int frow = lane & 15;   // row inside a 16-row fragment
+    const int fq = lane >> 4;     // k-chunk (8 elements) inside a 32-deep MFMA step
+    // byte offset of (row, chunk) in a tile: row*128 + ((chunk ^ (row&7)) << 4); row&7 == frow&7
+    // because all fragment bases are multiples of 16.
+    const int sw = frow & 7;
+    const int a_base = (wm * 128 + frow) * 128;
+    const int b_base = TILE_BYTES + (wn * 64 + frow) * 128;
+    const int ch0 = ((0 * 4 + fq) ^ sw) << 4;   // k-substep 0
+    const int ch1 = ((1 * 4 + fq) ^ sw) << 4;   // k-substep 1
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK;
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // tile kt landed for every wave; everyone is done reading the other buffer
+        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+        GF_LDS char* sbuf = lds + (kt & 1) * STAGE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int ch = ks ? ch1 : ch0;
+            bf16x8 af[8], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) af[i] = *(GF_LDS bf16x8*)(sbuf + a_base + i * 2048 + ch);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = *(GF_LDS bf16x8*)(sbuf + b_base + j * 2048 + ch);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    // swapped operands: D[n-local][m-local]; lane holds 4 consecutive n of one m
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue -----------------------------------------------------------------------------
+    // acc[i][j][r] = C[m = m0 + wm*128 + i*16 + (lane&15)][n = n0 + wn*64 + j*16 + (lane>>4)*4 + r]
+    __syncthreads();  // all waves finished reading the stage buffers
+    GF_LDS char* ep = lds + wave * 16384;  // private 128 rows x 128 B (64 bf16) per wave
+    {
+        const int nb = n0 + wn * 64 + fq * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            const int n = nb + j * 16;
+            if (p.bias && n < p.N) {  // N % 8 == 0 so n..n+3 are all valid
+                const u16x4 b4 = *reinterpret_cast<const u16x4*>(p.bias + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bv[r] = bf2f(b4[r]);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float y[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    y[r] = rbf(acc[i][j][r] + bv[r]);  // the Linear's own bf16 output
+                    if (EPI == GF_EPI_BIAS_GELU_TANH) y[r] = gelu_tanh_f(y[r]);
+                    if (EPI == GF_EPI_BIAS_SILU) y[r] = y[r] / (1.0f + expf(-y[r]));
+                }
+                u32x2 pk;
+                pk[0] = pack2bf(y[0], y[1]);
+                pk[1] = pack2bf(y[2], y[3]);
+                const int row = i * 16 + frow;
+                const int slot = (j * 4 + fq) ^ ((row & 7) << 1);  // 8-byte slot, pairs stay together
+                *(GF_LDS u32x2*)(ep + row * 128 + slot * 8) = pk;
+            }
+        }
+    }
+    // each wave reads back only its own region: no workgroup barrier needed, only the LDS wait
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    {
+        const int rr = lane >> 3, cc = lane & 7;
+        const int n = n0 + wn * 64 + cc * 8;
+        const bool n_ok = n < p.N;
+        u16x8 g8;
+        if (EPI == GF_EPI_BIAS_GATE_RESID && n_ok) g8 = *reinterpret_cast<const u16x8*>(p.gate + n);
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int row = it * 8 + rr;
+            const int m = m0 + wm * 128 + row;
+            const u16x8 yv = *(GF_LDS u16x8*)(ep + row * 128 + ((cc ^ (row & 7)) << 4));
+            if (m < p.M && n_ok) {
+                u16x8 o = yv;
+                if (EPI == GF_EPI_BIAS_GATE_RESID || EPI == GF_EPI_BIAS_RESID) {
+                    const u16x8 r8 = *reinterpret_cast<const u16x8*>(p.R + (long)m * p.ldr + n);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float t = bf2f(yv[e]);
+                        if (EPI == GF_EPI_BIAS_GATE_RESID) t = rbf(bf2f(g8[e]) * t);  // gate * residual
+                        o[e] = f2bf(bf2f(r8[e]) + t);                                 // x + ...
+                    }
+                }
+                *reinterpret_cast<u16x8*>(p.C + (long)m * p.ldc + n) = o;
+            }
+        }
+    }
+}
+
+template <int EPI>
+int launch_gemm(const GemmArgs& a, hipStream_t stream) {
+    static bool attr_set = false;  // per-instantiation; benign race (idempotent call)
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+        if (e != hipSuccess) {
+            gf_set_error("gf_gemm_bf16: hipFuncSetAttribute(%d B LDS) failed: %s", GEMM_LDS, hipGetErrorString(e));
+            return GF_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(GEMM_THREADS), GEMM_LDS,
+                       stream, a);
+    GF_CHECK_LAUNCH("gf_gemm_bf16");
+    return GF_OK;
+}
+
+}  // namespace
+
+extern "C" GF_API int gf_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias, void* C,
+                            int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue, const void* resid,
+                            int64_t ldr, const void* gate, void* stream) {
+    GF_CHECK_ARG(A && W && C, "gf_gemm_bf16: null A/W/C");
+    GF_CHECK_ARG(M >= 0 && N > 0 && K > 0, "gf_gemm_bf16: bad sizes M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
+    GF_CHECK_ARG(K % BK == 0, "gf_gemm_bf16: K=%ld must be a multiple of %d", (long)K, BK);
+    GF_CHECK_ARG(N % 8 == 0, "gf_gemm_bf16: N=%ld must be a multiple of 8", (long)N);
+    GF_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0 && ldc % 8 == 0 && lda >= K && ldw >= K && ldc >= N,
+                 "gf_gemm_bf16: leading dimensions must be multiples of 8 and cover the row");
+    GF_CHECK_ARG(gf_aligned16(A) && gf_aligned16(W) && gf_aligned16(C) && (!bias || gf_aligned16(bias)),
+                 "gf_gemm_bf16: 16-byte alignment required");
+    GF_CHECK_ARG(M < (1 << 30) && N < (1 << 30), "gf_gemm_bf16: M/N too large");
+    const bool need_r = epilogue == GF_EPI_BIAS_GATE_RESID || epilogue == GF_EPI_BIAS_RESID;
+    GF_CHECK_ARG(!need_r || (resid && ldr % 8 == 0 && ldr >= N && gf_aligned16(resid)),
+                 "gf_gemm_bf16: residual epilogue needs an aligned resid with ldr >= N");
+    GF_CHECK_ARG(epilogue != GF_EPI_BIAS_GATE_RESID || (gate && gf_aligned16(gate)),
+                 "gf_gemm_bf16: gate epilogue needs an aligned gate vector");
+    if (M == 0) return GF_OK;
+    GemmArgs a;
+    a.A = (const u16*)A;
+    a.W = (const u16*)W;
+    a.bias = (const u16*)bias;
+    a.C = (u16*)C;
+    a.R = (const u16*)resid;
+    a.gate = (const u16*)gate;
+    a.M = (int)M;
+    a.N = (int)N;
+    a.K = (int)K;
+    a.lda = lda;
+    a.ldw = ldw;
+    a.ldc = ldc;
+    a.ldr = ldr;
+    a.tiles_m = (int)((M + BM - 1) / BM);
+    a.tiles_n = (int)((N + BN - 1) / BN);
+    hipStream_t s = (hipStream_t)stream;
+    switch (epilogue) {
+        case GF_EPI_BIAS: return launch_gemm<GF_EPI_BIAS>(a, s);
+        case GF_EPI_BIAS_GELU_TANH: return launch_gemm<GF_EPI_BIAS_GELU_TANH>(a, s);
+        case GF_EPI_BIAS_GATE_RESID: return launch_gemm<GF_EPI_BIAS_GATE_RESID>(a, s);
+        case GF_EPI_BIAS_RESID: return launch_gemm<GF_EPI_BIAS_RESID>(a, s);
+        case GF_EPI_BIAS_SILU: return launch_gemm<GF_EPI_BIAS_SILU>(a, s);
+        default:
+            gf_set_error("gf_gemm_bf16: unknown epilogue %d", epilogue);
+            return GF_ERR_INVALID_ARG;
+    }
+}

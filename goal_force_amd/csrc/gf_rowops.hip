@@ -1,0 +1,175 @@
+// gf_rowops.hip — HBM-bound row kernels of the DiT block: LayerNorm(+modulate) and
+// full-width RMSNorm(+3-D RoPE).  One workgroup of 128 threads per token row; the row
+// (<= 8192 bf16) lives in registers between the reduction and the write, so every byte is
+// read once and written once (algorithmic bytes: 2 * rows * dim * 2 B).
+//
+// Reference semantics (file:line relative to the reference tree):
+//   LayerNorm fp32 math + one rounding ......... diffsynth/vram_management/layers.py:78-92
+//   modulate x*(1+scale)+shift (bf16 eager) ..... diffsynth/models/wan_video_dit.py:64-65
+//   RMSNorm .float() norm, .to(bf16), * weight .. diffsynth/models/wan_video_dit.py:100-111
+//   rope_apply on adjacent pairs ................ diffsynth/models/wan_video_dit.py:92-97
+#include "gf_common.h"
+
+namespace {
+
+constexpr int ROW_THREADS = 128;
+constexpr int ROW_NCH = 8;  // 16-byte chunks per thread -> dim <= 128*8*8 = 8192
+
+__global__ __launch_bounds__(ROW_THREADS) void layernorm_modulate_kernel(
+    const u16* __restrict__ x, u16* __restrict__ out, const u16* __restrict__ weight,
+    const u16* __restrict__ bias, const u16* __restrict__ scale1p, const u16* __restrict__ shift,
+    int dim, long x_stride, long out_stride, float eps) {
+    __shared__ float red[ROW_THREADS / 64];
+    const long row = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int nchunks = dim >> 3;
+    const u16* xr = x + row * x_stride;
+    u16x8 v[ROW_NCH];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < ROW_NCH; ++i) {
+        const int c = tid + i * ROW_THREADS;
+        if (c < nchunks) {
+            v[i] = *reinterpret_cast<const u16x8*>(xr + (c << 3));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += bf2f(v[i][j]);
+        }
+    }
+    const float mean = block_sum<ROW_THREADS>(s, red) / (float)dim;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < ROW_NCH; ++i) {
+        const int c = tid + i * ROW_THREADS;
+        if (c < nchunks) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d = bf2f(v[i][j]) - mean;
+                q += d * d;
+            }
+        }
+    }
+    const float var = block_sum<ROW_THREADS>(q, red) / (float)dim;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    u16* orow = out + row * out_stride;
+#pragma unroll
+    for (int i = 0; i < ROW_NCH; ++i) {
+        const int c = tid + i * ROW_THREADS;
+        if (c < nchunks) {
+            u16x8 w8, b8, sc8, sh8;
+            if (weight) w8 = *reinterpret_cast<const u16x8*>(weight + (c << 3));
+            if (bias) b8 = *reinterpret_cast<const u16x8*>(bias + (c << 3));
+            if (scale1p) sc8 = *reinterpret_cast<const u16x8*>(scale1p + (c << 3));
+            if (shift) sh8 = *reinterpret_cast<const u16x8*>(shift + (c << 3));
+            u16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float y = (bf2f(v[i][j]) - mean) * rstd;
+                if (weight) y = y * bf2f(w8[j]);
+                if (bias) y = y + bf2f(b8[j]);
+                y = rbf(y);                                   // .type_as(x)
+                if (scale1p) y = rbf(y * bf2f(sc8[j]));       // x * (1 + scale)
+                if (shift) y = rbf(y + bf2f(sh8[j]));         // + shift
+                o[j] = f2bf(y);
+            }
+            *reinterpret_cast<u16x8*>(orow + (c << 3)) = o;
+        }
+    }
+}
+
+__global__ __launch_bounds__(ROW_THREADS) void rmsnorm_rope_kernel(
+    u16* __restrict__ x, const u16* __restrict__ weight, const float* __restrict__ cos_tab,
+    const float* __restrict__ sin_tab, int dim, int head_dim, long x_stride, float eps) {
+    __shared__ float red[ROW_THREADS / 64];
+    const long row = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int nchunks = dim >> 3;
+    u16* xr = x + row * x_stride;
+    u16x8 v[ROW_NCH];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < ROW_NCH; ++i) {
+        const int c = tid + i * ROW_THREADS;
+        if (c < nchunks) {
+            v[i] = *reinterpret_cast<const u16x8*>(xr + (c << 3));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float f = bf2f(v[i][j]);
+                s += f * f;
+            }
+        }
+    }
+    const float ms = block_sum<ROW_THREADS>(s, red) / (float)dim;
+    const float rstd = 1.0f / sqrtf(ms + eps);
+    const int half = head_dim >> 1;
+#pragma unroll
+    for (int i = 0; i < ROW_NCH; ++i) {
+        const int c = tid + i * ROW_THREADS;
+        if (c < nchunks) {
+            const u16x8 w8 = *reinterpret_cast<const u16x8*>(weight + (c << 3));
+            float y[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float n = rbf(bf2f(v[i][j]) * rstd);  // norm(x.float()).to(dtype)
+                y[j] = rbf(n * bf2f(w8[j]));                // * weight (bf16 multiply)
+            }
+            u16x8 o;
+            if (cos_tab) {
+                const int p0 = ((c << 3) % head_dim) >> 1;  // first complex pair of this chunk
+                const f32x4 cs = *reinterpret_cast<const f32x4*>(cos_tab + row * half + p0);
+                const f32x4 sn = *reinterpret_cast<const f32x4*>(sin_tab + row * half + p0);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const float a = y[2 * p], b = y[2 * p + 1];
+                    o[2 * p] = f2bf(a * cs[p] - b * sn[p]);
+                    o[2 * p + 1] = f2bf(a * sn[p] + b * cs[p]);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = f2bf(y[j]);
+            }
+            *reinterpret_cast<u16x8*>(xr + (c << 3)) = o;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" GF_API int gf_layernorm_modulate(const void* x, void* out, const void* weight, const void* bias,
+                                     const void* scale1p, const void* shift, int64_t rows, int64_t dim,
+                                     int64_t x_stride, int64_t out_stride, float eps, void* stream) {
+    GF_CHECK_ARG(x && out, "gf_layernorm_modulate: null x/out");
+    GF_CHECK_ARG(rows >= 0 && dim > 0 && dim % 8 == 0 && dim <= ROW_THREADS * ROW_NCH * 8,
+                 "gf_layernorm_modulate: dim=%ld must be a multiple of 8 and <= %d", (long)dim,
+                 ROW_THREADS * ROW_NCH * 8);
+    GF_CHECK_ARG(x_stride % 8 == 0 && out_stride % 8 == 0 && gf_aligned16(x) && gf_aligned16(out),
+                 "gf_layernorm_modulate: rows must be 16-byte aligned");
+    GF_CHECK_ARG((!weight || gf_aligned16(weight)) && (!bias || gf_aligned16(bias)) &&
+                     (!scale1p || gf_aligned16(scale1p)) && (!shift || gf_aligned16(shift)),
+                 "gf_layernorm_modulate: vectors must be 16-byte aligned");
+    if (rows == 0) return GF_OK;
+    hipLaunchKernelGGL(layernorm_modulate_kernel, dim3((unsigned)rows), dim3(ROW_THREADS), 0,
+                       (hipStream_t)stream, (const u16*)x, (u16*)out, (const u16*)weight, (const u16*)bias,
+                       (const u16*)scale1p, (const u16*)shift, (int)dim, (long)x_stride, (long)out_stride, eps);
+    GF_CHECK_LAUNCH("gf_layernorm_modulate");
+    return GF_OK;
+}
+
+extern "C" GF_API int gf_rmsnorm_rope(void* x, const void* weight, const float* cos_tab, const float* sin_tab,
+                               int64_t rows, int64_t dim, int64_t head_dim, int64_t x_stride, float eps,
+                               void* stream) {
+    GF_CHECK_ARG(x && weight, "gf_rmsnorm_rope: null x/weight");
+    GF_CHECK_ARG(rows >= 0 && dim > 0 && dim % 8 == 0 && dim <= ROW_THREADS * ROW_NCH * 8,
+                 "gf_rmsnorm_rope: dim=%ld must be a multiple of 8 and <= %d", (long)dim,
+                 ROW_THREADS * ROW_NCH * 8);
+    GF_CHECK_ARG((cos_tab == nullptr) == (sin_tab == nullptr), "gf_rmsnorm_rope: cos/sin must both be set or both NULL");
+    GF_CHECK_ARG(head_dim > 0 && head_dim % 8 == 0 && dim % head_dim == 0,
+                 "gf_rmsnorm_rope: head_dim=%ld must be a multiple of 8 dividing dim", (long)head_dim);
+    GF_CHECK_ARG(x_stride % 8 == 0 && gf_aligned16(x) && gf_aligned16(weight) &&
+                     (!cos_tab || (gf_aligned16(cos_tab) && gf_aligned16(sin_tab))),
+                 "gf_rmsnorm_rope: 16-byte alignment required");
+    if (rows == 0) return GF_OK;
+    hipLaunchKernelGGL(rmsnorm_rope_kernel, dim3((unsigned)rows), dim3(ROW_THREADS), 0, (hipStream_t)stream,
+                       (u16*)x, (const u16*)weight, cos_tab, sin_tab, (int)dim, (int)head_dim, (long)x_stride, eps);
+    GF_CHECK_LAUNCH("gf_rmsnorm_rope");
+    return GF_OK;
+}

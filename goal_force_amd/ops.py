@@ -1,0 +1,222 @@
+"""Torch-tensor front end of the C ABI (include/goalforce.h).
+
+Every function enqueues exactly the named HIP kernel on torch's current stream; tensors
+are only used for device memory + stream plumbing (data_ptr()), never for the arithmetic.
+There is no CPU path: tensors must live on a HIP device.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import _lib
+from ._lib import (EPI_BIAS, EPI_BIAS_GATE_RESID, EPI_BIAS_GELU_TANH, EPI_BIAS_RESID, EPI_BIAS_SILU,
+                   GoalForceError)
+
+__all__ = [
+    "layernorm_modulate", "rmsnorm_rope", "gemm", "flash_attn", "patchify_im2col", "unpatchify",
+    "cfg_euler_step", "act", "add", "force_map",
+    "EPI_BIAS", "EPI_BIAS_GELU_TANH", "EPI_BIAS_GATE_RESID", "EPI_BIAS_RESID", "EPI_BIAS_SILU",
+]
+
+_BF16 = torch.bfloat16
+
+
+def _stream(t: torch.Tensor):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _req(t: torch.Tensor, name: str, dtype=_BF16):
+    if not t.is_cuda:
+        raise GoalForceError(f"{name}: tensor must be on the GPU (no CPU fallback exists)")
+    if t.dtype != dtype:
+        raise GoalForceError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+
+
+def _rows2d(t: torch.Tensor, name: str):
+    """Return (tensor, rows, dim, row_stride) for a tensor whose last dim is contiguous and whose
+    leading dims collapse to one row index with a single stride."""
+    if t.stride(-1) != 1:
+        raise GoalForceError(f"{name}: last dim must be contiguous")
+    if t.dim() == 1:
+        return t, 1, t.shape[0], t.shape[0]
+    v = t.reshape(-1, t.shape[-1]) if t.is_contiguous() else t
+    if v.dim() != 2:
+        raise GoalForceError(f"{name}: cannot view as [rows, dim] without a copy")
+    return v, v.shape[0], v.shape[1], v.stride(0)
+
+
+def layernorm_modulate(x, weight=None, bias=None, scale1p=None, shift=None, eps=1e-6, out=None):
+    """LayerNorm(+affine)(+modulate) — gf_layernorm_modulate."""
+    _req(x, "layernorm_modulate.x")
+    xv, rows, dim, xs = _rows2d(x, "layernorm_modulate.x")
+    if out is None:
+        out = torch.empty(x.shape, dtype=_BF16, device=x.device)
+    ov, _, _, os_ = _rows2d(out, "layernorm_modulate.out")
+    for n, t in (("weight", weight), ("bias", bias), ("scale1p", scale1p), ("shift", shift)):
+        if t is not None:
+            _req(t, f"layernorm_modulate.{n}")
+            if t.numel() != dim or not t.is_contiguous():
+                raise GoalForceError(f"layernorm_modulate.{n}: expected contiguous [{dim}]")
+    _lib.check(_lib.load().gf_layernorm_modulate(_ptr(xv), _ptr(ov), _ptr(weight), _ptr(bias), _ptr(scale1p),
+                                                 _ptr(shift), rows, dim, xs, os_, float(eps), _stream(x)),
+               "gf_layernorm_modulate")
+    return out
+
+
+def rmsnorm_rope(x, weight, cos=None, sin=None, head_dim=128, eps=1e-6):
+    """In-place full-width RMSNorm (+RoPE) — gf_rmsnorm_rope."""
+    _req(x, "rmsnorm_rope.x")
+    _req(weight, "rmsnorm_rope.weight")
+    xv, rows, dim, xs = _rows2d(x, "rmsnorm_rope.x")
+    if cos is not None:
+        _req(cos, "rmsnorm_rope.cos", torch.float32)
+        _req(sin, "rmsnorm_rope.sin", torch.float32)
+        if cos.shape != (rows, head_dim // 2) or sin.shape != cos.shape or not cos.is_contiguous() \
+                or not sin.is_contiguous():
+            raise GoalForceError(f"rmsnorm_rope: cos/sin must be contiguous [{rows}, {head_dim // 2}]")
+    _lib.check(_lib.load().gf_rmsnorm_rope(_ptr(xv), _ptr(weight), _ptr(cos), _ptr(sin), rows, dim, head_dim, xs,
+                                           float(eps), _stream(x)), "gf_rmsnorm_rope")
+    return x
+
+
+def gemm(a, w, bias=None, epilogue=EPI_BIAS, resid=None, gate=None, out=None):
+    """out[M,N] = epilogue(a[M,K] @ w[N,K]^T + bias) — gf_gemm_bf16."""
+    _req(a, "gemm.a")
+    _req(w, "gemm.w")
+    av, M, K, lda = _rows2d(a, "gemm.a")
+    if w.dim() != 2 or w.stride(1) != 1 or w.shape[1] != K:
+        raise GoalForceError(f"gemm.w: expected [N, {K}] with contiguous rows, got {tuple(w.shape)}")
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(a.shape[:-1] + (N,), dtype=_BF16, device=a.device)
+    ov, Mo, No, ldc = _rows2d(out, "gemm.out")
+    if (Mo, No) != (M, N):
+        raise GoalForceError(f"gemm.out: expected [{M}, {N}], got [{Mo}, {No}]")
+    ldr = 0
+    if resid is not None:
+        _req(resid, "gemm.resid")
+        rv, Mr, Nr, ldr = _rows2d(resid, "gemm.resid")
+        if (Mr, Nr) != (M, N):
+            raise GoalForceError("gemm.resid: shape mismatch")
+        resid = rv
+    if gate is not None:
+        _req(gate, "gemm.gate")
+        if gate.numel() != N or not gate.is_contiguous():
+            raise GoalForceError(f"gemm.gate: expected contiguous [{N}]")
+    if bias is not None:
+        _req(bias, "gemm.bias")
+        if bias.numel() != N or not bias.is_contiguous():
+            raise GoalForceError(f"gemm.bias: expected contiguous [{N}]")
+    _lib.check(_lib.load().gf_gemm_bf16(_ptr(av), lda, _ptr(w), w.stride(0), _ptr(bias), _ptr(ov), ldc, M, N, K,
+                                        int(epilogue), _ptr(resid), ldr, _ptr(gate), _stream(a)), "gf_gemm_bf16")
+    return out
+
+
+def flash_attn(q, k, v, num_heads, out=None, scale=None):
+    """softmax(q k^T / sqrt(d)) v per head; q [Sq, H*128], k/v [Skv, H*128] (row-strided views OK)."""
+    for n, t in (("q", q), ("k", k), ("v", v)):
+        _req(t, f"flash_attn.{n}")
+        if t.dim() != 2 or t.stride(1) != 1:
+            raise GoalForceError(f"flash_attn.{n}: expected 2-D [len, heads*head_dim] with contiguous rows")
+    sq, hd_all = q.shape
+    skv = k.shape[0]
+    head_dim = hd_all // num_heads
+    if k.shape[1] != hd_all or v.shape != k.shape or head_dim * num_heads != hd_all:
+        raise GoalForceError("flash_attn: q/k/v shape mismatch")
+    if out is None:
+        out = torch.empty((sq, hd_all), dtype=_BF16, device=q.device)
+    if scale is None:
+        scale = 1.0 / math.sqrt(head_dim)
+    _lib.check(_lib.load().gf_flash_attn_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), sq, skv, num_heads, head_dim,
+                                             q.stride(0), k.stride(0), v.stride(0), out.stride(0), float(scale),
+                                             _stream(q)), "gf_flash_attn_fwd")
+    return out
+
+
+def patchify_im2col(src0, src1=None, kpad=None):
+    """[c,F,H,W] (+[c1,F,H,W]) -> [F*(H/2)*(W/2), kpad] token-major patches (Conv3d weight column order)."""
+    _req(src0, "patchify.src0")
+    if src0.dim() != 4 or not src0.is_contiguous():
+        raise GoalForceError("patchify.src0: expected contiguous [c,F,H,W]")
+    c0, F, H, W = src0.shape
+    c1 = 0
+    if src1 is not None:
+        _req(src1, "patchify.src1")
+        if src1.dim() != 4 or not src1.is_contiguous() or src1.shape[1:] != src0.shape[1:]:
+            raise GoalForceError("patchify.src1: expected contiguous [c1,F,H,W] matching src0")
+        c1 = src1.shape[0]
+    if kpad is None:
+        kpad = -(-((c0 + c1) * 4) // 64) * 64
+    out = torch.empty((F * (H // 2) * (W // 2), kpad), dtype=_BF16, device=src0.device)
+    _lib.check(_lib.load().gf_patchify_im2col(_ptr(src0), c0, _ptr(src1), c1, _ptr(out), F, H, W, kpad,
+                                              _stream(src0)), "gf_patchify_im2col")
+    return out
+
+
+def unpatchify(tokens, c, f, h, w):
+    """[f*h*w, 4c] -> [c, f, 2h, 2w]."""
+    _req(tokens, "unpatchify.tokens")
+    if tokens.shape != (f * h * w, 4 * c) or not tokens.is_contiguous():
+        raise GoalForceError(f"unpatchify.tokens: expected contiguous [{f * h * w}, {4 * c}]")
+    out = torch.empty((c, f, 2 * h, 2 * w), dtype=_BF16, device=tokens.device)
+    _lib.check(_lib.load().gf_unpatchify(_ptr(tokens), _ptr(out), c, f, h, w, _stream(tokens)), "gf_unpatchify")
+    return out
+
+
+def cfg_euler_step(latents, posi, nega, cfg_scale, dsigma):
+    """In place: latents += (nega + cfg*(posi-nega)) * dsigma with bf16 rounding after every op."""
+    _req(latents, "cfg_euler_step.latents")
+    _req(posi, "cfg_euler_step.posi")
+    if not latents.is_contiguous() or not posi.is_contiguous() or posi.numel() != latents.numel():
+        raise GoalForceError("cfg_euler_step: latents/posi must be contiguous and equal-sized")
+    if nega is not None:
+        _req(nega, "cfg_euler_step.nega")
+        if not nega.is_contiguous() or nega.numel() != latents.numel():
+            raise GoalForceError("cfg_euler_step: nega must be contiguous and equal-sized")
+    _lib.check(_lib.load().gf_cfg_euler_step(_ptr(latents), _ptr(posi), _ptr(nega), float(cfg_scale), float(dsigma),
+                                             latents.numel(), _stream(latents)), "gf_cfg_euler_step")
+    return latents
+
+
+def act(x, kind: str):
+    _req(x, "act.x")
+    if not x.is_contiguous():
+        raise GoalForceError("act.x must be contiguous")
+    out = torch.empty_like(x)
+    _lib.check(_lib.load().gf_act(_ptr(x), _ptr(out), x.numel(), {"silu": 0, "gelu_tanh": 1}[kind], _stream(x)),
+               "gf_act")
+    return out
+
+
+def add(a, b, out=None):
+    _req(a, "add.a")
+    _req(b, "add.b")
+    if not a.is_contiguous() or not b.is_contiguous() or a.numel() != b.numel():
+        raise GoalForceError("add: a/b must be contiguous and equal-sized")
+    if out is None:
+        out = torch.empty_like(a)
+    _lib.check(_lib.load().gf_add_bf16(_ptr(a), _ptr(b), _ptr(out), a.numel(), _stream(a)), "gf_add_bf16")
+    return out
+
+
+def force_map(frames, H, W, channels, params, centers, clamp01, device):
+    """Render the control-signal video [frames,H,W,3] bf16; blob arrays are torch tensors on `device`."""
+    out = torch.empty((frames, H, W, 3), dtype=_BF16, device=device)
+    n = int(channels.numel())
+    if n:
+        _req(channels, "force_map.channels", torch.int32)
+        _req(params, "force_map.params", torch.float32)
+        _req(centers, "force_map.centers", torch.float32)
+        if params.shape != (n, 2) or centers.shape != (n, frames, 2) or not params.is_contiguous() \
+                or not centers.is_contiguous():
+            raise GoalForceError("force_map: params [n,2] / centers [n,frames,2] expected")
+    _lib.check(_lib.load().gf_force_map(_ptr(out), frames, H, W, _ptr(channels) if n else None,
+                                        _ptr(params) if n else None, _ptr(centers) if n else None, n,
+                                        1 if clamp01 else 0, _stream(out)), "gf_force_map")
+    return out

@@ -1,0 +1,181 @@
+/*
+ * goalforce.h — C ABI of libgoalforce_hip.so (MI355X / gfx950 only).
+ *
+ * This is the drop-in boundary underneath the reference's Python call sites
+ * (level B5).  The reference (brown-palm/goal-force) has no
+ * FFI of its own: every entry point below replaces a *Python* interface, cited
+ * as file:line relative to the reference tree.  Abbreviations:
+ *   DIT  = diffsynth/models/wan_video_dit.py
+ *   GF   = src/goal_force/wan_video_new.py
+ *   FM   = diffsynth/schedulers/flow_match.py
+ *   VAE  = diffsynth/models/wan_video_vae.py
+ *   VRAM = diffsynth/vram_management/layers.py
+ *   DS   = src/goal_force/unified_dataset.py
+ *
+ * Conventions
+ *   - All pointers are DEVICE pointers (HBM) unless a parameter says "host".
+ *   - bf16 tensors are passed as `const void*` / `void*` (raw 16-bit storage).
+ *   - The caller owns all memory; the library never allocates or frees
+ *     user-visible buffers and never synchronises: kernels are enqueued on
+ *     `stream` (a hipStream_t passed as void*; NULL = the null stream).
+ *   - Return value: 0 on success, negative gf_status on error; the message is
+ *     available from gf_last_error() (thread-local).
+ *   - Row-major everywhere; `ld*`/`*_stride` are in ELEMENTS.
+ */
+#ifndef GOALFORCE_H
+#define GOALFORCE_H
+
+#include <stdint.h>
+
+#if defined(GF_BUILD)
+#define GF_API __attribute__((visibility("default")))
+#else
+#define GF_API
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    GF_OK = 0,
+    GF_ERR_INVALID_ARG = -1,   /* bad shape / alignment / null pointer */
+    GF_ERR_UNSUPPORTED = -2,   /* shape outside what the kernels are built for */
+    GF_ERR_LAUNCH = -3         /* hipLaunchKernel / hipFuncSetAttribute failed */
+} gf_status;
+
+/* library identity ------------------------------------------------------- */
+GF_API const char* gf_version(void);      /* "goalforce-hip <semver> gfx950" */
+GF_API const char* gf_last_error(void);   /* thread-local message of the last failure */
+GF_API int gf_abi_version(void);          /* bumped on any signature change */
+
+/* ------------------------------------------------------------------------
+ * gf_layernorm_modulate — LayerNorm over the last dim (fp32 math, one
+ * rounding to bf16), optionally affine, optionally followed by the AdaLN
+ * modulate y*(1+scale)+shift with the reference's bf16 rounding after each op.
+ * Replaces: nn.LayerNorm norm1/norm2/norm3 + modulate() (DIT:64-65, 206-208,
+ * 225-228), WanAutoCastLayerNorm.forward (VRAM:78-92), Head.norm (DIT:258,268).
+ *   x, out     [rows, dim] bf16 (out may alias x)
+ *   weight,bias[dim] bf16 or NULL  (norm3 affine)
+ *   scale1p    [dim] bf16 or NULL  — the already-formed (1+scale) vector
+ *   shift      [dim] bf16 or NULL
+ * dim % 8 == 0, dim <= 8192.
+ */
+GF_API int gf_layernorm_modulate(const void* x, void* out, const void* weight, const void* bias,
+                          const void* scale1p, const void* shift,
+                          int64_t rows, int64_t dim, int64_t x_stride, int64_t out_stride,
+                          float eps, void* stream);
+
+/* ------------------------------------------------------------------------
+ * gf_rmsnorm_rope — in place: RMSNorm over the FULL row (all heads jointly;
+ * fp32 math, round to bf16, then bf16 multiply by weight) followed by 3-D RoPE
+ * on adjacent element pairs.  Replaces RMSNorm.forward (DIT:100-111) and
+ * rope_apply (DIT:92-97) as used by SelfAttention.forward (DIT:141-145) and
+ * CrossAttention.forward (DIT:177-178; cos/sin NULL => no RoPE).
+ *   x       [rows, dim] bf16, row stride x_stride
+ *   weight  [dim] bf16
+ *   cos,sin [rows, head_dim/2] fp32 or NULL
+ * dim % 8 == 0, dim <= 8192, head_dim % 8 == 0.
+ */
+GF_API int gf_rmsnorm_rope(void* x, const void* weight, const float* cos_tab, const float* sin_tab,
+                    int64_t rows, int64_t dim, int64_t head_dim, int64_t x_stride,
+                    float eps, void* stream);
+
+/* ------------------------------------------------------------------------
+ * gf_gemm_bf16 — C[M,N] = epilogue(A[M,K] · W[N,K]^T + bias[N]); bf16 in/out,
+ * fp32 MFMA accumulate (v_mfma_f32_16x16x32_bf16).  Replaces nn.Linear /
+ * F.linear at DIT:131-134,146 (q,k,v,o), DIT:209-210 (ffn), DIT:309-320
+ * (text/time embeddings), DIT:263 (head), the Conv3d patch embeddings
+ * (DIT:307-308,342; GF:85,92 — after gf_patchify_im2col) and the ControlNet
+ * zero-conv Conv1d(k=1) (GF:113-116, 1565-1570).
+ *   epilogue: see gf_epilogue.  resid [M,N] (ldr) and gate [N] are bf16.
+ *   C may alias resid (in-place residual update).
+ * K % 64 == 0, N % 8 == 0, lda/ldw/ldc/ldr % 8 == 0, 16-byte aligned bases.
+ */
+typedef enum {
+    GF_EPI_BIAS = 0,           /* bf16(acc + bias)                               */
+    GF_EPI_BIAS_GELU_TANH = 1, /* bf16(gelu_tanh(bf16(acc + bias)))              */
+    GF_EPI_BIAS_GATE_RESID = 2,/* bf16(resid + bf16(gate * bf16(acc + bias)))    */
+    GF_EPI_BIAS_RESID = 3,     /* bf16(resid + bf16(acc + bias))                 */
+    GF_EPI_BIAS_SILU = 4       /* bf16(silu(bf16(acc + bias)))                   */
+} gf_epilogue;
+
+GF_API int gf_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias,
+                 void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                 int epilogue, const void* resid, int64_t ldr, const void* gate,
+                 void* stream);
+
+/* ------------------------------------------------------------------------
+ * gf_flash_attn_fwd — softmax(Q K^T * scale) V per head, non-causal, no mask,
+ * no dropout, head_dim 128.  Replaces flash_attention() (DIT:28-61) /
+ * AttentionModule (DIT:114-121).  q,k,v,o are [len, heads*128] bf16 with the
+ * head h at columns [h*128, (h+1)*128) ("b s (n d)" layout, DIT:56-60); row
+ * strides in elements (so q/k/v may be slices of one fused buffer).
+ */
+GF_API int gf_flash_attn_fwd(const void* q, const void* k, const void* v, void* o,
+                      int64_t q_len, int64_t kv_len, int64_t heads, int64_t head_dim,
+                      int64_t q_stride, int64_t k_stride, int64_t v_stride, int64_t o_stride,
+                      float scale, void* stream);
+
+/* ------------------------------------------------------------------------
+ * gf_patchify_im2col — gathers the (1,2,2) patches of an NCTHW latent into a
+ * token-major matrix for the patch-embedding GEMM.  Replaces the data movement
+ * of WanModel.patchify (DIT:341-349) / ControlNet_PatchEmbedding.forward
+ * (GF:85-94) for the concatenated input x = cat([latents, y]) (GF:1458).
+ *   src0 [c0,F,H,W], src1 [c1,F,H,W] (src1 may be NULL with c1 = 0), bf16
+ *   out  [F*(H/2)*(W/2), kpad] bf16, column = c*4 + dy*2 + dx (Conv3d weight
+ *   order), columns >= (c0+c1)*4 zero-filled.
+ */
+GF_API int gf_patchify_im2col(const void* src0, int64_t c0, const void* src1, int64_t c1,
+                       void* out, int64_t F, int64_t H, int64_t W, int64_t kpad, void* stream);
+
+/* ------------------------------------------------------------------------
+ * gf_unpatchify — 'b (f h w) (x y z c) -> b c (f x) (h y) (w z)' with patch
+ * (1,2,2).  Replaces WanModel.unpatchify (DIT:351-356).
+ *   tokens [f*h*w, 4*c] bf16  ->  out [c, f, 2h, 2w] bf16
+ */
+GF_API int gf_unpatchify(const void* tokens, void* out, int64_t c, int64_t f, int64_t h, int64_t w,
+                  void* stream);
+
+/* ------------------------------------------------------------------------
+ * gf_cfg_euler_step — classifier-free guidance + flow-match Euler update in
+ * one pass, with the reference's bf16 rounding after every op:
+ *   pred = nega + cfg*(posi - nega)            (GF:716)
+ *   latents = latents + pred * dsigma          (FM:72-82; dsigma = sigma_next - sigma)
+ * nega may be NULL (cfg_scale == 1: pred = posi, GF:717-718).  In place on latents.
+ */
+GF_API int gf_cfg_euler_step(void* latents, const void* posi, const void* nega,
+                      float cfg_scale, float dsigma, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------
+ * gf_act — elementwise activation bf16 -> bf16 (fp32 math, one rounding):
+ * kind 0 = SiLU (DIT:316,320), 1 = GELU-tanh (DIT:311).
+ */
+GF_API int gf_act(const void* x, void* out, int64_t n, int kind, void* stream);
+
+/* ------------------------------------------------------------------------
+ * gf_add_bf16 — out = bf16(a + b), elementwise (x + controlnet_state,
+ * GF:1570).  out may alias a.
+ */
+GF_API int gf_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------
+ * gf_force_map — renders the Goal-Force control-signal video on the GPU.
+ * Replaces the pixel work of ControlSignalDataset_Balls._generate_control_video
+ * / get_gaussian_blob / get_blob_for_mass (DS:775-940): every blob contributes
+ * amp * exp(-((x-cx)^2 + (y-cy)^2) / denom) to its channel (fp32, summed in blob
+ * order, optional clamp to [0,1] as DS:887, one rounding to bf16).
+ *   out      [frames, H, W, 3] bf16 (THWC, DS:842)
+ *   channels [n_blobs] int32      0 direct force, 1 goal force, 2 mass
+ *   params   [n_blobs, 2] fp32    {denom = 2*radius^2, amp}
+ *   centers  [n_blobs, frames, 2] fp32  {cx, cy} per frame (host computes them
+ *            in float64 exactly as DS:817-823 and rounds once to fp32)
+ */
+GF_API int gf_force_map(void* out, int64_t frames, int64_t H, int64_t W,
+                 const int32_t* channels, const float* params, const float* centers,
+                 int64_t n_blobs, int clamp01, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GOALFORCE_H */

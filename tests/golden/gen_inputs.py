@@ -1,0 +1,132 @@
+"""Seeded inputs + random weights shared by the golden generator (make_goldens.py, build container
+only) and the tests.  Pure torch CPU RNG: the same torch build on the GPU box reproduces the same
+tensors; every fixture stores a checksum of what was generated so a drift is caught, not hidden.
+
+State-dict key names are the reference's (WanModel: diffsynth/models/wan_video_dit.py:273-340;
+ControlNet checkpoint layout: SURVEY.md §5 'checkpoint / resume').
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+TINY = dict(dim=256, in_dim=36, ffn_dim=512, out_dim=16, text_dim=64, freq_dim=256, eps=1e-6,
+            patch_size=(1, 2, 2), num_heads=2, num_layers=2)
+TINY_LATENT = (1, 16, 3, 8, 12)       # -> grid (3,4,6) = 72 tokens
+TINY_CTX_LEN = 7
+TINY_CONTROLNET_LAYERS = 1
+
+# Wan-1.3B-like mid size (head_dim 128, 12 heads)
+MID = dict(dim=1536, in_dim=36, ffn_dim=8960, out_dim=16, text_dim=4096, freq_dim=256, eps=1e-6,
+           patch_size=(1, 2, 2), num_heads=12, num_layers=1)
+
+A14B = dict(dim=5120, in_dim=36, ffn_dim=13824, out_dim=16, text_dim=4096, freq_dim=256, eps=1e-6,
+            patch_size=(1, 2, 2), num_heads=40, num_layers=40)
+
+
+def _randn(g, shape, std=1.0):
+    return torch.randn(shape, generator=g) * std
+
+
+def block_sd(g, dim, ffn_dim, prefix, dtype):
+    sd = {}
+    for att in ("self_attn", "cross_attn"):
+        for p in ("q", "k", "v", "o"):
+            sd[f"{prefix}{att}.{p}.weight"] = _randn(g, (dim, dim), 1.0 / math.sqrt(dim))
+            sd[f"{prefix}{att}.{p}.bias"] = _randn(g, (dim,), 0.02)
+        sd[f"{prefix}{att}.norm_q.weight"] = 1.0 + _randn(g, (dim,), 0.1)
+        sd[f"{prefix}{att}.norm_k.weight"] = 1.0 + _randn(g, (dim,), 0.1)
+    sd[f"{prefix}norm3.weight"] = 1.0 + _randn(g, (dim,), 0.1)
+    sd[f"{prefix}norm3.bias"] = _randn(g, (dim,), 0.05)
+    sd[f"{prefix}ffn.0.weight"] = _randn(g, (ffn_dim, dim), 1.0 / math.sqrt(dim))
+    sd[f"{prefix}ffn.0.bias"] = _randn(g, (ffn_dim,), 0.02)
+    sd[f"{prefix}ffn.2.weight"] = _randn(g, (dim, ffn_dim), 1.0 / math.sqrt(ffn_dim))
+    sd[f"{prefix}ffn.2.bias"] = _randn(g, (dim,), 0.02)
+    sd[f"{prefix}modulation"] = _randn(g, (1, 6, dim), 1.0 / math.sqrt(dim))
+    return {k: v.to(dtype) for k, v in sd.items()}
+
+
+def dit_sd(cfg, seed, dtype=torch.bfloat16):
+    g = torch.Generator().manual_seed(seed)
+    d, pk = cfg["dim"], cfg["in_dim"] * 4
+    sd = {
+        "patch_embedding.weight": _randn(g, (d, cfg["in_dim"], 1, 2, 2), 1.0 / math.sqrt(pk)),
+        "patch_embedding.bias": _randn(g, (d,), 0.02),
+        "text_embedding.0.weight": _randn(g, (d, cfg["text_dim"]), 1.0 / math.sqrt(cfg["text_dim"])),
+        "text_embedding.0.bias": _randn(g, (d,), 0.02),
+        "text_embedding.2.weight": _randn(g, (d, d), 1.0 / math.sqrt(d)),
+        "text_embedding.2.bias": _randn(g, (d,), 0.02),
+        "time_embedding.0.weight": _randn(g, (d, cfg["freq_dim"]), 1.0 / math.sqrt(cfg["freq_dim"])),
+        "time_embedding.0.bias": _randn(g, (d,), 0.02),
+        "time_embedding.2.weight": _randn(g, (d, d), 1.0 / math.sqrt(d)),
+        "time_embedding.2.bias": _randn(g, (d,), 0.02),
+        "time_projection.1.weight": _randn(g, (6 * d, d), 1.0 / math.sqrt(d)),
+        "time_projection.1.bias": _randn(g, (6 * d,), 0.02),
+        "head.head.weight": _randn(g, (cfg["out_dim"] * 4, d), 1.0 / math.sqrt(d)),
+        "head.head.bias": _randn(g, (cfg["out_dim"] * 4,), 0.02),
+        "head.modulation": _randn(g, (1, 2, d), 1.0 / math.sqrt(d)),
+    }
+    sd = {k: v.to(dtype) for k, v in sd.items()}
+    for i in range(cfg["num_layers"]):
+        sd.update(block_sd(g, d, cfg["ffn_dim"], f"blocks.{i}.", dtype))
+    return sd
+
+
+def controlnet_sd(cfg, n_layers, seed, dtype=torch.bfloat16, zero_convs_zero=False):
+    g = torch.Generator().manual_seed(seed)
+    d = cfg["dim"]
+    sd = {
+        "controlnet_patch_embedding.patch_embedding.weight": _randn(g, (d, 16, 1, 2, 2), 1.0 / 8.0).to(dtype),
+        "controlnet_patch_embedding.patch_embedding.bias": _randn(g, (d,), 0.02).to(dtype),
+    }
+    for i in range(n_layers):
+        sd.update(block_sd(g, d, cfg["ffn_dim"], f"controlnet_dit.blocks.{i}.", dtype))
+    for i in range(n_layers):
+        w = _randn(g, (d, d, 1), 0.5 / math.sqrt(d))
+        b = _randn(g, (d,), 0.02)
+        if zero_convs_zero:
+            w, b = torch.zeros_like(w), torch.zeros_like(b)
+        sd[f"controlnet_zero_convs_after.{i}.weight"] = w.to(dtype)
+        sd[f"controlnet_zero_convs_after.{i}.bias"] = b.to(dtype)
+    return sd
+
+
+def tiny_inputs(seed=1234, dtype=torch.bfloat16):
+    g = torch.Generator().manual_seed(seed)
+    b, c, f, h, w = TINY_LATENT
+    latents = _randn(g, (b, c, f, h, w)).to(dtype)
+    y = _randn(g, (b, 20, f, h, w)).to(dtype)
+    y[:, :4] = (y[:, :4] > 0).to(dtype)  # mask channels are {0,1} (GF:905-912)
+    control = _randn(g, (b, 16, f, h, w)).to(dtype)
+    ctx_posi = _randn(g, (1, TINY_CTX_LEN, TINY["text_dim"])).to(dtype)
+    ctx_nega = _randn(g, (1, TINY_CTX_LEN, TINY["text_dim"])).to(dtype)
+    return dict(latents=latents, y=y, control=control, ctx_posi=ctx_posi, ctx_nega=ctx_nega)
+
+
+def block_inputs(dim, tokens, ctx_len, seed, dtype=torch.bfloat16):
+    """Inputs of one DiT block as BASELINE config 1 prescribes: randn x/context, 0.5*randn t_mod."""
+    g = torch.Generator().manual_seed(seed)
+    x = _randn(g, (1, tokens, dim)).to(dtype)
+    ctx = _randn(g, (1, ctx_len, dim)).to(dtype)
+    t_mod = _randn(g, (1, 6, dim), 0.5).to(dtype)
+    return x, ctx, t_mod
+
+
+def checksum(tensors) -> float:
+    """Order-dependent fp64 checksum of a dict/list of tensors (detects RNG / generation drift)."""
+    items = tensors.items() if isinstance(tensors, dict) else enumerate(tensors)
+    acc = 0.0
+    for i, (k, t) in enumerate(items):
+        acc += (i + 1) * float(t.double().sum()) + 0.5 * float(t.double().abs().sum())
+    return acc
+
+
+def to_u16(t: torch.Tensor) -> np.ndarray:
+    assert t.dtype == torch.bfloat16
+    return t.contiguous().view(torch.int16).numpy().view(np.uint16)
+
+
+def from_u16(a: np.ndarray) -> torch.Tensor:
+    return torch.from_numpy(a.view(np.int16).copy()).view(torch.bfloat16)
