@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libgoalforce_hip.so")
 # every symbol include/goalforce.h declares (tests check the .so exports exactly these)
 SYMBOLS = (
     "gf_version", "gf_last_error", "gf_abi_version",
-    "gf_layernorm_modulate", "gf_rmsnorm_rope", "gf_gemm_bf16", "gf_flash_attn_fwd",
+    "gf_modulation", "gf_layernorm_modulate", "gf_rmsnorm_rope", "gf_gemm_bf16", "gf_flash_attn_fwd",
     "gf_patchify_im2col", "gf_unpatchify", "gf_cfg_euler_step", "gf_act", "gf_add_bf16",
     "gf_force_map",
 )
@@ -42,6 +42,7 @@ def _declare(lib):
     lib.gf_abi_version.argtypes = []
     sigs = {
         "gf_layernorm_modulate": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _vp],
+        "gf_modulation": [_vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_uint32, _vp],
         "gf_rmsnorm_rope": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _vp],
         "gf_gemm_bf16": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _i64, _vp, _vp],
         "gf_flash_attn_fwd": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _vp],

@@ -75,6 +75,20 @@ __global__ __launch_bounds__(EW_THREADS) void add_kernel(const u16* __restrict__
     }
 }
 
+// out[i, :] = bf16(param[i, :] + t[i % t_rows, :]); rows whose bit is set in onep_mask become bf16(1 + .)
+__global__ __launch_bounds__(EW_THREADS) void modulation_kernel(const u16* __restrict__ param,
+                                                                const u16* __restrict__ t, u16* __restrict__ out,
+                                                                int k, int dim, int t_rows, unsigned onep_mask) {
+    const long total = (long)k * dim;
+    const long stride = (long)gridDim.x * EW_THREADS;
+    for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += stride) {
+        const int row = (int)(i / dim), col = (int)(i % dim);
+        float v = rbf(bf2f(param[i]) + bf2f(t[(long)(row % t_rows) * dim + col]));
+        if ((onep_mask >> row) & 1u) v = rbf(1.0f + v);
+        out[i] = f2bf(v);
+    }
+}
+
 // out[token, c*4 + dy*2 + dx] = src[c][f][2hh+dy][2ww+dx]; one thread per (token, channel slot),
 // channel fastest so the 8-byte stores of a token row are contiguous.
 __global__ __launch_bounds__(EW_THREADS) void patchify_kernel(const u16* __restrict__ s0, int c0,
@@ -194,6 +208,17 @@ extern "C" GF_API int gf_add_bf16(const void* a, const void* b, void* out, int64
     hipLaunchKernelGGL(add_kernel, dim3(ew_grid(n >> 3)), dim3(EW_THREADS), 0, (hipStream_t)stream, (const u16*)a,
                        (const u16*)b, (u16*)out, (long)n);
     GF_CHECK_LAUNCH("gf_add_bf16");
+    return GF_OK;
+}
+
+extern "C" GF_API int gf_modulation(const void* param, const void* t, void* out, int64_t k, int64_t dim,
+                                    int64_t t_rows, uint32_t onep_mask, void* stream) {
+    GF_CHECK_ARG(param && t && out, "gf_modulation: null pointer");
+    GF_CHECK_ARG(k > 0 && k <= 32 && dim > 0 && t_rows > 0 && t_rows <= k, "gf_modulation: bad k=%ld dim=%ld t_rows=%ld",
+                 (long)k, (long)dim, (long)t_rows);
+    hipLaunchKernelGGL(modulation_kernel, dim3(ew_grid(k * dim)), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                       (const u16*)param, (const u16*)t, (u16*)out, (int)k, (int)dim, (int)t_rows, onep_mask);
+    GF_CHECK_LAUNCH("gf_modulation");
     return GF_OK;
 }
 

@@ -1,0 +1,326 @@
+"""Wan DiT (Wan2.2-I2V-A14B expert) — host-side mirror of the reference's module interface with
+every forward implemented by the HIP kernels in libgoalforce_hip.so.
+
+Drop-in surface: class names, constructor arguments, forward signatures and
+state_dict key names follow diffsynth/models/wan_video_dit.py (DIT) so reference checkpoints load
+unchanged (`blocks.N.self_attn.q.weight`, ..., DIT:273-340).  The nn.Linear / nn.LayerNorm
+submodules are parameter containers only — their torch forwards are never called.
+
+Activations are token-major [S, D] bf16 (batch 1 per call on the hot path; B > 1 is looped).
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import GoalForceError
+
+
+# ------------------------------------------------------------------ RoPE tables (host, fp64 -> fp32)
+def precompute_freqs_cis(dim: int, end: int = 1024, theta: float = 10000.0):
+    """DIT:83-89 — complex128 table [end, dim/2]."""
+    freqs = 1.0 / (theta ** (torch.arange(0, dim, 2)[: (dim // 2)].double() / dim))
+    freqs = torch.outer(torch.arange(end), freqs)
+    return torch.polar(torch.ones_like(freqs), freqs)
+
+
+def precompute_freqs_cis_3d(dim: int, end: int = 1024, theta: float = 10000.0):
+    """DIT:75-80 — (frame, height, width) tables; pairs split (d-2(d//3))/2, (d//3)/2, (d//3)/2."""
+    return (precompute_freqs_cis(dim - 2 * (dim // 3), end, theta),
+            precompute_freqs_cis(dim // 3, end, theta),
+            precompute_freqs_cis(dim // 3, end, theta))
+
+
+class RopeTable:
+    """cos/sin of the per-token rotary phases, resident in HBM as fp32 [S, head_dim/2] each.
+    Built once per (f, h, w) grid instead of the reference's per-forward CPU rebuild + H2D copy
+    (GF:1474-1478)."""
+
+    def __init__(self, freqs_complex: torch.Tensor, device):
+        fc = freqs_complex.reshape(freqs_complex.shape[0], -1)
+        self.cos = fc.real.to(torch.float32).contiguous().to(device)
+        self.sin = fc.imag.to(torch.float32).contiguous().to(device)
+        self.tokens = fc.shape[0]
+
+    @staticmethod
+    def from_grid(freqs3: Tuple[torch.Tensor, torch.Tensor, torch.Tensor], f: int, h: int, w: int, device):
+        tab = torch.cat([
+            freqs3[0][:f].view(f, 1, 1, -1).expand(f, h, w, -1),
+            freqs3[1][:h].view(1, h, 1, -1).expand(f, h, w, -1),
+            freqs3[2][:w].view(1, 1, w, -1).expand(f, h, w, -1),
+        ], dim=-1).reshape(f * h * w, -1)
+        return RopeTable(tab, device)
+
+
+def _as_rope(freqs, device) -> RopeTable:
+    if isinstance(freqs, RopeTable):
+        return freqs
+    if torch.is_tensor(freqs) and freqs.is_complex():  # the reference's [S,1,d/2] complex table
+        return RopeTable(freqs.detach().cpu(), device)
+    raise GoalForceError("freqs must be a RopeTable or the reference's complex [S,1,d/2] tensor")
+
+
+def sinusoidal_embedding_1d(dim, position):
+    """DIT:68-72 (host side: 1 timestep -> `dim` numbers, fp64 math)."""
+    pos = position.detach().to("cpu")
+    sinusoid = torch.outer(pos.type(torch.float64),
+                           torch.pow(10000, -torch.arange(dim // 2, dtype=torch.float64).div(dim // 2)))
+    x = torch.cat([torch.cos(sinusoid), torch.sin(sinusoid)], dim=1)
+    return x.to(position.dtype).to(position.device)
+
+
+def _tokens2d(x: torch.Tensor) -> torch.Tensor:
+    """[1,S,D] or [S,D] -> [S,D] view."""
+    if x.dim() == 3:
+        if x.shape[0] != 1:
+            raise GoalForceError("hot-path modules take batch 1 ([1,S,D]); loop over the batch")
+        return x[0]
+    return x
+
+
+# ------------------------------------------------------------------ modules
+class RMSNorm(nn.Module):
+    """DIT:100-111 (full-width, fp32 math, bf16 weight multiply)."""
+
+    def __init__(self, dim, eps=1e-5):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(dim))
+
+    def forward(self, x):
+        y = x.clone()
+        ops.rmsnorm_rope(_tokens2d(y), self.weight, None, None, head_dim=8, eps=self.eps)
+        return y
+
+
+class SelfAttention(nn.Module):
+    """DIT:124-147."""
+
+    def __init__(self, dim: int, num_heads: int, eps: float = 1e-6):
+        super().__init__()
+        self.dim, self.num_heads, self.head_dim = dim, num_heads, dim // num_heads
+        self.q, self.k, self.v, self.o = (nn.Linear(dim, dim) for _ in range(4))
+        self.norm_q, self.norm_k = RMSNorm(dim, eps=eps), RMSNorm(dim, eps=eps)
+
+    def attend(self, x2: torch.Tensor, rope: RopeTable) -> torch.Tensor:
+        """x2 [S,D] -> attention output BEFORE the o projection, [S,D]."""
+        q = ops.gemm(x2, self.q.weight, self.q.bias)
+        k = ops.gemm(x2, self.k.weight, self.k.bias)
+        v = ops.gemm(x2, self.v.weight, self.v.bias)
+        ops.rmsnorm_rope(q, self.norm_q.weight, rope.cos, rope.sin, self.head_dim, self.norm_q.eps)
+        ops.rmsnorm_rope(k, self.norm_k.weight, rope.cos, rope.sin, self.head_dim, self.norm_k.eps)
+        return ops.flash_attn(q, k, v, self.num_heads)
+
+    def forward(self, x, freqs):
+        x2 = _tokens2d(x)
+        a = self.attend(x2, _as_rope(freqs, x.device))
+        return ops.gemm(a, self.o.weight, self.o.bias).view(x.shape)
+
+
+class CrossAttention(nn.Module):
+    """DIT:150-186, has_image_input=False branch (A14B I2V: DIT:703-718)."""
+
+    def __init__(self, dim: int, num_heads: int, eps: float = 1e-6, has_image_input: bool = False):
+        super().__init__()
+        if has_image_input:
+            raise NotImplementedError("has_image_input=True (CLIP image tokens) is outside the Goal-Force path")
+        self.dim, self.num_heads, self.head_dim = dim, num_heads, dim // num_heads
+        self.q, self.k, self.v, self.o = (nn.Linear(dim, dim) for _ in range(4))
+        self.norm_q, self.norm_k = RMSNorm(dim, eps=eps), RMSNorm(dim, eps=eps)
+        self.has_image_input = False
+
+    def context_kv(self, ctx2: torch.Tensor):
+        """k = norm_k(Wk ctx), v = Wv ctx — constant per (expert, prompt, block); cacheable over steps."""
+        k = ops.gemm(ctx2, self.k.weight, self.k.bias)
+        v = ops.gemm(ctx2, self.v.weight, self.v.bias)
+        ops.rmsnorm_rope(k, self.norm_k.weight, None, None, self.head_dim, self.norm_k.eps)
+        return k, v
+
+    def attend(self, x2, kv):
+        q = ops.gemm(x2, self.q.weight, self.q.bias)
+        ops.rmsnorm_rope(q, self.norm_q.weight, None, None, self.head_dim, self.norm_q.eps)
+        return ops.flash_attn(q, kv[0], kv[1], self.num_heads)
+
+    def forward(self, x: torch.Tensor, y: torch.Tensor):
+        x2 = _tokens2d(x)
+        a = self.attend(x2, self.context_kv(_tokens2d(y)))
+        return ops.gemm(a, self.o.weight, self.o.bias).view(x.shape)
+
+
+class GateModule(nn.Module):
+    """DIT:189-194 — kept for interface parity; the gated residual is fused into the GEMM epilogue."""
+
+    def forward(self, x, gate, residual):
+        raise NotImplementedError("gate*residual is fused into gf_gemm_bf16(GF_EPI_BIAS_GATE_RESID)")
+
+
+class DiTBlock(nn.Module):
+    """DIT:197-230.  forward(x, context, t_mod, freqs) -> new x; x [1,S,D] bf16, context [1,L,D],
+    t_mod [1,6,D], freqs RopeTable (or the reference's complex tensor)."""
+
+    def __init__(self, has_image_input: bool, dim: int, num_heads: int, ffn_dim: int, eps: float = 1e-6):
+        super().__init__()
+        self.dim, self.num_heads, self.ffn_dim, self.eps = dim, num_heads, ffn_dim, eps
+        self.self_attn = SelfAttention(dim, num_heads, eps)
+        self.cross_attn = CrossAttention(dim, num_heads, eps, has_image_input=has_image_input)
+        self.norm1 = nn.LayerNorm(dim, eps=eps, elementwise_affine=False)
+        self.norm2 = nn.LayerNorm(dim, eps=eps, elementwise_affine=False)
+        self.norm3 = nn.LayerNorm(dim, eps=eps)
+        self.ffn = nn.Sequential(nn.Linear(dim, ffn_dim), nn.GELU(approximate="tanh"), nn.Linear(ffn_dim, dim))
+        self.modulation = nn.Parameter(torch.randn(1, 6, dim) / dim ** 0.5)
+        self.gate = GateModule()
+
+    def forward(self, x, context, t_mod, freqs, context_kv=None, out=None):
+        if t_mod.dim() == 4:
+            raise NotImplementedError("per-token t_mod (seperated_timestep) is outside the Goal-Force path")
+        x2 = _tokens2d(x)
+        rope = _as_rope(freqs, x.device)
+        # rows: shift_msa, 1+scale_msa, gate_msa, shift_mlp, 1+scale_mlp, gate_mlp   (DIT:218-219, 64-65)
+        mod = ops.modulation(self.modulation, t_mod.contiguous(), onep_mask=0b010010)
+        h = ops.layernorm_modulate(x2, scale1p=mod[1], shift=mod[0], eps=self.eps)              # DIT:225
+        a = self.self_attn.attend(h, rope)
+        x_new = out if out is not None else torch.empty_like(x2)
+        ops.gemm(a, self.self_attn.o.weight, self.self_attn.o.bias, epilogue=ops.EPI_BIAS_GATE_RESID,
+                 resid=x2, gate=mod[2], out=x_new)                                               # DIT:226
+        ops.layernorm_modulate(x_new, weight=self.norm3.weight, bias=self.norm3.bias, eps=self.eps, out=h)
+        if context_kv is None:
+            context_kv = self.cross_attn.context_kv(_tokens2d(context))
+        a = self.cross_attn.attend(h, context_kv)
+        ops.gemm(a, self.cross_attn.o.weight, self.cross_attn.o.bias, epilogue=ops.EPI_BIAS_RESID,
+                 resid=x_new, out=x_new)                                                          # DIT:227
+        ops.layernorm_modulate(x_new, scale1p=mod[4], shift=mod[3], eps=self.eps, out=h)         # DIT:228
+        f1 = ops.gemm(h, self.ffn[0].weight, self.ffn[0].bias, epilogue=ops.EPI_BIAS_GELU_TANH)
+        ops.gemm(f1, self.ffn[2].weight, self.ffn[2].bias, epilogue=ops.EPI_BIAS_GATE_RESID,
+                 resid=x_new, gate=mod[5], out=x_new)                                             # DIT:229
+        return x_new.view(x.shape)
+
+
+class Head(nn.Module):
+    """DIT:253-269."""
+
+    def __init__(self, dim: int, out_dim: int, patch_size: Tuple[int, int, int], eps: float):
+        super().__init__()
+        self.dim, self.patch_size, self.eps = dim, patch_size, eps
+        self.norm = nn.LayerNorm(dim, eps=eps, elementwise_affine=False)
+        self.head = nn.Linear(dim, out_dim * math.prod(patch_size))
+        self.modulation = nn.Parameter(torch.randn(1, 2, dim) / dim ** 0.5)
+
+    def forward(self, x, t_mod):
+        if t_mod.dim() == 3:
+            raise NotImplementedError("per-token head modulation is outside the Goal-Force path")
+        x2 = _tokens2d(x)
+        mod = ops.modulation(self.modulation, t_mod.contiguous(), onep_mask=0b10)   # rows: shift, 1+scale
+        h = ops.layernorm_modulate(x2, scale1p=mod[1], shift=mod[0], eps=self.eps)
+        y = ops.gemm(h, self.head.weight, self.head.bias)
+        return y.view(x.shape[:-1] + (y.shape[-1],))
+
+
+class WanModel(nn.Module):
+    """DIT:272-340.  A14B I2V config: dim 5120, in_dim 36, ffn 13824, out 16, text 4096, freq 256,
+    40 heads, 40 layers, has_image_input=False, require_clip_embedding=False (DIT:703-718)."""
+
+    def __init__(self, dim: int, in_dim: int, ffn_dim: int, out_dim: int, text_dim: int, freq_dim: int, eps: float,
+                 patch_size: Tuple[int, int, int], num_heads: int, num_layers: int, has_image_input: bool,
+                 has_image_pos_emb: bool = False, has_ref_conv: bool = False, add_control_adapter: bool = False,
+                 in_dim_control_adapter: int = 24, seperated_timestep: bool = False,
+                 require_vae_embedding: bool = True, require_clip_embedding: bool = True,
+                 fuse_vae_embedding_in_latents: bool = False):
+        super().__init__()
+        if has_image_input or has_ref_conv or add_control_adapter or seperated_timestep:
+            raise NotImplementedError("only the Wan2.2-I2V-A14B configuration (DIT:703-718) is built")
+        if tuple(patch_size) != (1, 2, 2):
+            raise NotImplementedError("patch_size must be (1,2,2)")
+        self.dim, self.in_dim, self.freq_dim, self.out_dim = dim, in_dim, freq_dim, out_dim
+        self.has_image_input = has_image_input
+        self.patch_size = tuple(patch_size)
+        self.seperated_timestep = seperated_timestep
+        self.require_vae_embedding = require_vae_embedding
+        self.require_clip_embedding = require_clip_embedding
+        self.fuse_vae_embedding_in_latents = fuse_vae_embedding_in_latents
+        self.num_heads = num_heads
+        self.eps = eps
+        self.patch_embedding = nn.Conv3d(in_dim, dim, kernel_size=patch_size, stride=patch_size)
+        self.text_embedding = nn.Sequential(nn.Linear(text_dim, dim), nn.GELU(approximate="tanh"), nn.Linear(dim, dim))
+        self.time_embedding = nn.Sequential(nn.Linear(freq_dim, dim), nn.SiLU(), nn.Linear(dim, dim))
+        self.time_projection = nn.Sequential(nn.SiLU(), nn.Linear(dim, dim * 6))
+        self.blocks = nn.ModuleList([DiTBlock(has_image_input, dim, num_heads, ffn_dim, eps) for _ in range(num_layers)])
+        self.head = Head(dim, out_dim, patch_size, eps)
+        self.freqs = precompute_freqs_cis_3d(dim // num_heads)  # plain CPU tuple, like DIT:328
+        self.control_adapter = None
+        self._rope_cache = {}
+        self._patch_w = None  # K-padded [dim, kpad] copy of patch_embedding.weight for the GEMM
+
+    # ---- pieces used by model_fn ---------------------------------------------------------------
+    def rope_table(self, f, h, w, device) -> RopeTable:
+        key = (f, h, w, str(device))
+        if key not in self._rope_cache:
+            self._rope_cache[key] = RopeTable.from_grid(self.freqs, f, h, w, device)
+        return self._rope_cache[key]
+
+    def time_embed(self, timestep: torch.Tensor):
+        """GF:1441-1442 — t [1,D], t_mod [1,6,D]."""
+        e = sinusoidal_embedding_1d(self.freq_dim, timestep)
+        te = self.time_embedding
+        t = ops.gemm(ops.gemm(e, te[0].weight, te[0].bias, epilogue=ops.EPI_BIAS_SILU), te[2].weight, te[2].bias)
+        tp = self.time_projection[1]
+        t_mod = ops.gemm(ops.act(t, "silu"), tp.weight, tp.bias).unflatten(1, (6, self.dim))
+        return t, t_mod
+
+    def embed_text(self, context: torch.Tensor):
+        """DIT:309-313 — [1,L,text_dim] -> [1,L,D]."""
+        te = self.text_embedding
+        c2 = _tokens2d(context)
+        y = ops.gemm(ops.gemm(c2, te[0].weight, te[0].bias, epilogue=ops.EPI_BIAS_GELU_TANH), te[2].weight, te[2].bias)
+        return y.view(context.shape[:-1] + (self.dim,))
+
+    @staticmethod
+    def padded_patch_weight(conv: nn.Conv3d) -> torch.Tensor:
+        w = conv.weight
+        k = w.shape[1] * 4
+        kpad = -(-k // 64) * 64
+        wp = torch.zeros((w.shape[0], kpad), dtype=w.dtype, device=w.device)
+        wp[:, :k] = w.reshape(w.shape[0], k)
+        return wp
+
+    def patchify(self, x: torch.Tensor, control_camera_latents_input: Optional[torch.Tensor] = None, extra=None):
+        """DIT:341-349 — Conv3d k=s=(1,2,2) as im2col gather + MFMA GEMM; returns ([1,S,D], (f,h,w)).
+        `extra` lets model_fn pass y without materialising cat([latents, y]) (GF:1458)."""
+        if control_camera_latents_input is not None:
+            raise NotImplementedError("camera control adapter is outside the Goal-Force path")
+        if x.shape[0] != 1:
+            raise GoalForceError("patchify takes batch 1")
+        if self._patch_w is None or self._patch_w.device != x.device:
+            self._patch_w = self.padded_patch_weight(self.patch_embedding)
+        s0 = x[0].contiguous()
+        s1 = None if extra is None else extra[0].contiguous()
+        f, hh, ww = s0.shape[1], s0.shape[2] // 2, s0.shape[3] // 2
+        cols = ops.patchify_im2col(s0, s1, kpad=self._patch_w.shape[1])
+        tok = ops.gemm(cols, self._patch_w, self.patch_embedding.bias)
+        return tok.unsqueeze(0), (f, hh, ww)
+
+    def unpatchify(self, x: torch.Tensor, grid_size):
+        """DIT:351-356."""
+        f, h, w = grid_size
+        return ops.unpatchify(_tokens2d(x).contiguous(), self.out_dim, f, h, w).unsqueeze(0)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._patch_w = None
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def forward(self, x, timestep, context, clip_feature=None, y=None, **kwargs):
+        """DIT:358-... plain forward without ControlNet (model_fn is the Goal-Force entry point)."""
+        from .model_fn import model_fn_wan_video
+        return model_fn_wan_video(self, latents=x, timestep=timestep, context=context, clip_feature=clip_feature, y=y)
+
+    @staticmethod
+    def state_dict_converter():
+        raise NotImplementedError("checkpoint key conversion is host-side I/O outside the hot path (SURVEY §2 #9)")
+
+
+A14B_CONFIG = dict(has_image_input=False, patch_size=(1, 2, 2), in_dim=36, dim=5120, ffn_dim=13824, freq_dim=256,
+                   text_dim=4096, out_dim=16, num_heads=40, num_layers=40, eps=1e-6,
+                   require_clip_embedding=False)  # DIT:703-718

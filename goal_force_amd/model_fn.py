@@ -1,0 +1,142 @@
+"""model_fn_wan_video — one noise prediction of the Goal-Force sampler (the reference's own swap point
+`pipe.model_fn`, src/goal_force/wan_video_new.py:161, 1349-1591), rebuilt on the HIP kernels.
+
+Same keyword interface as the reference; branches the Goal-Force inference scripts never take
+(S2V, VACE, camera/motion control, TeaCache, sliding window, USP, reference latents, cfg-merged batches)
+raise NotImplementedError instead of silently doing something else.
+
+Differences that do not change results:
+  * RoPE tables live on the device and are built once per grid (the reference rebuilds them on the CPU
+    and copies 33.5 MB host->device every forward, GF:1474-1478);
+  * ControlNet block i runs just before DiT block i (same arithmetic, but no list of 10 saved states);
+  * zero-conv + residual add is one GEMM epilogue;
+  * a ControlNet whose zero-convs are all exactly zero is skipped (x + 0 == x bitwise) unless
+    `elide_zero_controlnet=False`;
+  * `context_cache` (optional) memoises text_embedding(context) and the per-block cross-attention K/V,
+    which are constant over the denoising steps for one (expert, prompt).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import ops
+from ._lib import GoalForceError
+from .dit import WanModel
+
+
+class ContextCache:
+    """Per (expert, prompt) memo of text_embedding(context) and the cross-attention K/V of every block
+    of the DiT and of its ControlNet (GF:1447, DIT:177-179 are recomputed each call in the reference)."""
+
+    def __init__(self):
+        self.ctx = None
+        self.dit_kv = {}
+        self.cn_kv = {}
+
+
+def _unsupported(name, value, default=None):
+    if value is not None and value is not default and value is not False:
+        raise NotImplementedError(f"model_fn_wan_video: `{name}` is outside the Goal-Force sampling path "
+                                  "(SURVEY.md §2 #2)")
+
+
+@torch.no_grad()
+def model_fn_wan_video(
+    dit: WanModel,
+    motion_controller=None,
+    vace=None,
+    latents: torch.Tensor = None,
+    timestep: torch.Tensor = None,
+    context: torch.Tensor = None,
+    clip_feature: Optional[torch.Tensor] = None,
+    y: Optional[torch.Tensor] = None,
+    reference_latents=None,
+    vace_context=None,
+    vace_scale=1.0,
+    audio_embeds: Optional[torch.Tensor] = None,
+    motion_latents: Optional[torch.Tensor] = None,
+    s2v_pose_latents: Optional[torch.Tensor] = None,
+    drop_motion_frames: bool = True,
+    tea_cache=None,
+    use_unified_sequence_parallel: bool = False,
+    motion_bucket_id: Optional[torch.Tensor] = None,
+    sliding_window_size: Optional[int] = None,
+    sliding_window_stride: Optional[int] = None,
+    cfg_merge: bool = False,
+    use_gradient_checkpointing: bool = False,
+    use_gradient_checkpointing_offload: bool = False,
+    control_camera_latents_input=None,
+    fuse_vae_embedding_in_latents: bool = False,
+    controlnet=None,
+    context_cache: Optional[ContextCache] = None,
+    elide_zero_controlnet: bool = True,
+    **kwargs,
+):
+    for name, val in (("motion_controller", motion_controller), ("vace", vace), ("reference_latents", reference_latents),
+                      ("vace_context", vace_context), ("audio_embeds", audio_embeds), ("tea_cache", tea_cache),
+                      ("motion_bucket_id", motion_bucket_id), ("sliding_window_size", sliding_window_size),
+                      ("control_camera_latents_input", control_camera_latents_input),
+                      ("clip_feature", clip_feature if dit.require_clip_embedding else None)):
+        _unsupported(name, val)
+    if use_unified_sequence_parallel:
+        raise NotImplementedError("USP (xfuser Ulysses) is not wired for the ControlNet path in the reference either")
+    if cfg_merge or latents.shape[0] != 1 or context.shape[0] != 1:
+        raise NotImplementedError("cfg_merge / batch > 1: run the cond and uncond forwards separately (GF:710-716)")
+    if dit.seperated_timestep and fuse_vae_embedding_in_latents:
+        raise NotImplementedError("seperated_timestep is a Wan2.2-TI2V-5B feature")
+    if not latents.is_cuda:
+        raise GoalForceError("model_fn_wan_video: tensors must be on the GPU (no CPU fallback exists)")
+
+    use_controlnet = controlnet is not None
+
+    # Timestep (GF:1441-1442)
+    t, t_mod = dit.time_embed(timestep)
+
+    # Text embedding (GF:1447)
+    if context_cache is not None and context_cache.ctx is not None:
+        ctx = context_cache.ctx
+    else:
+        ctx = dit.embed_text(context)
+        if context_cache is not None:
+            context_cache.ctx = ctx
+
+    # Image embedding + patchify (GF:1456-1464) — cat([latents, y]) is folded into the patch gather
+    x, (f, h, w) = dit.patchify(latents, extra=y if (y is not None and dit.require_vae_embedding) else None)
+    x = x[0]
+    rope = dit.rope_table(f, h, w, latents.device)
+
+    run_cn = use_controlnet and not (elide_zero_controlnet and controlnet.all_zero())
+    c = None
+    if run_cn:
+        if controlnet.stride is not None:
+            raise NotImplementedError("strided ControlNet (apply_strided_controlnet) is not used by Goal Force")
+        control_latents = kwargs.get("control_signal_video_latents", None)
+        if control_latents is None:
+            raise GoalForceError("controlnet given but control_signal_video_latents missing")
+        c = controlnet.controlnet_patch_embedding(control_latents)[0]      # GF:1493
+        n_cn = controlnet.controlnet_dit.num_layers
+    else:
+        n_cn = 0
+
+    def kv_for(cache_dict, block, idx):
+        if context_cache is None:
+            return None
+        if idx not in cache_dict:
+            cache_dict[idx] = block.cross_attn.context_kv(ctx[0])
+        return cache_dict[idx]
+
+    # blocks (GF:1503-1570); ControlNet block i is evaluated right before DiT block i
+    for block_id, block in enumerate(dit.blocks):
+        if block_id < n_cn:
+            cb = controlnet.controlnet_dit.blocks[block_id]
+            c = cb(c, ctx, t_mod, rope, context_kv=kv_for(context_cache.cn_kv if context_cache else None, cb, block_id))
+        x = block(x, ctx, t_mod, rope, context_kv=kv_for(context_cache.dit_kv if context_cache else None, block, block_id))
+        if block_id < n_cn:
+            # x = x + zero_conv(state)   (GF:1565-1570) — Conv1d(k=1) == Linear, fused residual epilogue
+            ops.gemm(c, controlnet.zero_conv_weight(block_id), controlnet.controlnet_zero_convs_after[block_id].bias,
+                     epilogue=ops.EPI_BIAS_RESID, resid=x, out=x)
+
+    x = dit.head(x.unsqueeze(0), t)          # GF:1581
+    return dit.unpatchify(x, (f, h, w))      # GF:1590

@@ -15,7 +15,7 @@ from ._lib import (EPI_BIAS, EPI_BIAS_GATE_RESID, EPI_BIAS_GELU_TANH, EPI_BIAS_R
                    GoalForceError)
 
 __all__ = [
-    "layernorm_modulate", "rmsnorm_rope", "gemm", "flash_attn", "patchify_im2col", "unpatchify",
+    "modulation", "layernorm_modulate", "rmsnorm_rope", "gemm", "flash_attn", "patchify_im2col", "unpatchify",
     "cfg_euler_step", "act", "add", "force_map",
     "EPI_BIAS", "EPI_BIAS_GELU_TANH", "EPI_BIAS_GATE_RESID", "EPI_BIAS_RESID", "EPI_BIAS_SILU",
 ]
@@ -49,6 +49,22 @@ def _rows2d(t: torch.Tensor, name: str):
     if v.dim() != 2:
         raise GoalForceError(f"{name}: cannot view as [rows, dim] without a copy")
     return v, v.shape[0], v.shape[1], v.stride(0)
+
+
+def modulation(param, t, onep_mask: int):
+    """out[i] = bf16(param[i] + t[i % t_rows]); rows in onep_mask get bf16(1 + .) — gf_modulation.
+    param [.., k, dim], t [.., t_rows, dim] -> out [k, dim]."""
+    _req(param, "modulation.param")
+    _req(t, "modulation.t")
+    dim = param.shape[-1]
+    k = param.numel() // dim
+    t_rows = t.numel() // dim
+    if not param.is_contiguous() or not t.is_contiguous() or t.shape[-1] != dim:
+        raise GoalForceError("modulation: param/t must be contiguous with equal last dim")
+    out = torch.empty((k, dim), dtype=_BF16, device=param.device)
+    _lib.check(_lib.load().gf_modulation(_ptr(param), _ptr(t), _ptr(out), k, dim, t_rows, int(onep_mask),
+                                         _stream(param)), "gf_modulation")
+    return out
 
 
 def layernorm_modulate(x, weight=None, bias=None, scale1p=None, shift=None, eps=1e-6, out=None):

@@ -1,0 +1,307 @@
+"""WanVideoPipeline — drop-in for the Goal-Force fork of the DiffSynth pipeline
+(src/goal_force/wan_video_new.py:120-737; `pipe(...)` kwargs GF:599-661 kept verbatim).
+
+MI355X design choices (SURVEY.md §7 'Memory plan'): both 14B experts, both ControlNets and the VAE stay
+resident in the 288 GB of HBM — there is no offload state machine, `enable_vram_management()` is an
+accepted no-op (the fp32-LayerNorm numerics it switches on in the reference are what the HIP
+LayerNorm kernel always computes).  The denoising loop is `denoise()`: two model_fn calls per step
+(cond / uncond), CFG + Euler update fused in one kernel, expert switch by pointer swap.
+
+Pre-loop conditioning that needs models outside the hot path (umT5 text encoder, VAE *encoder*:
+SURVEY.md §8f 'next' rows) can be supplied pre-computed: `context_posi`, `context_nega`, `y`,
+`control_signal_video_latents`.
+"""
+from __future__ import annotations
+
+import copy
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import GoalForceError
+from .controlnet import ControlNet
+from .dit import A14B_CONFIG, WanModel
+from .model_fn import ContextCache, model_fn_wan_video
+from .scheduler import FlowMatchScheduler
+
+
+class ModelConfig:
+    """Host-side record of where a checkpoint lives (diffsynth/utils ModelConfig, UTIL:137-...).
+    Downloading is out of scope (no network): `path` must point at local .safetensors file(s)."""
+
+    def __init__(self, path=None, model_id=None, origin_file_pattern=None, offload_device=None, offload_dtype=None,
+                 **kwargs):
+        self.path, self.model_id, self.origin_file_pattern = path, model_id, origin_file_pattern
+        self.offload_device, self.offload_dtype = offload_device, offload_dtype
+
+
+def load_state_dict(path, torch_dtype=None, device="cpu"):
+    """safetensors / torch checkpoint reader (diffsynth/models/utils.py load_state_dict)."""
+    paths = path if isinstance(path, (list, tuple)) else [path]
+    sd = {}
+    for p in paths:
+        if str(p).endswith(".safetensors"):
+            from safetensors import safe_open
+            with safe_open(p, framework="pt", device=str(device)) as f:
+                for k in f.keys():
+                    t = f.get_tensor(k)
+                    sd[k] = t.to(torch_dtype) if torch_dtype is not None else t
+        else:
+            part = torch.load(p, map_location=device, weights_only=True)
+            for k, t in part.items():
+                sd[k] = t.to(torch_dtype) if (torch_dtype is not None and torch.is_tensor(t)) else t
+    return sd
+
+
+class WanVideoPipeline:
+    def __init__(self, device="cuda", torch_dtype=torch.bfloat16, tokenizer_path=None, controlnet=False,
+                 controlnet_num_layers=0, controlnet_stride=None):
+        if torch_dtype != torch.bfloat16:
+            raise GoalForceError("the HIP kernels compute in bf16 storage / fp32 accumulate only")
+        self.device, self.torch_dtype = device, torch_dtype
+        self.height_division_factor, self.width_division_factor = 16, 16
+        self.time_division_factor, self.time_division_remainder = 4, 1
+        self.scheduler = FlowMatchScheduler(shift=5, sigma_min=0.0, extra_one_step=True)  # GF:127
+        self.text_encoder = None
+        self.image_encoder = None
+        self.dit: Optional[WanModel] = None
+        self.dit2: Optional[WanModel] = None
+        self.vae = None
+        self.motion_controller = None
+        self.vace = None
+        self.controlnet: Optional[ControlNet] = None
+        self.controlnet2: Optional[ControlNet] = None
+        self.model_fn = model_fn_wan_video  # GF:161 — the reference's own swap point
+        self.vram_management_enabled = False
+        self.elide_zero_controlnet = True
+        self.num_layers = controlnet_num_layers
+        self._want_controlnet = controlnet
+        self._controlnet_stride = controlnet_stride
+        self.last_step_ms = []
+
+    # ------------------------------------------------------------------ construction
+    @staticmethod
+    def from_pretrained(torch_dtype=torch.bfloat16, device="cuda", model_configs=(), tokenizer_config=None,
+                        audio_processor_config=None, redirect_common_files=True, use_usp=False, controlnet=False,
+                        controlnet_num_layers=0, controlnet_stride=None, apply_strided_controlnet=False):
+        """GF:483-595.  Loads local Wan2.2-I2V-A14B expert checkpoints (high-noise first, then low-noise);
+        ControlNet blocks are initialised as copies of DiT blocks 0..N-1 of the matching expert and
+        controlnet2 is a copy made before any ControlNet weights are loaded (GF:559-568)."""
+        if use_usp or apply_strided_controlnet:
+            raise NotImplementedError("USP / strided ControlNet are not part of the Goal-Force sampling path")
+        pipe = WanVideoPipeline(device=device, torch_dtype=torch_dtype, controlnet=controlnet,
+                                controlnet_num_layers=controlnet_num_layers, controlnet_stride=controlnet_stride)
+        dits = []
+        for mc in model_configs:
+            if mc.path is None:
+                raise GoalForceError("ModelConfig.path must name local checkpoint files (no network here)")
+            sd = load_state_dict(mc.path, torch_dtype=torch_dtype)
+            if "blocks.0.self_attn.q.weight" in sd and "patch_embedding.weight" in sd:
+                m = WanModel(**A14B_CONFIG)
+                m.load_state_dict(sd, strict=True)
+                dits.append(m.to(dtype=torch_dtype, device=device))
+            else:
+                raise NotImplementedError(f"checkpoint {mc.path}: only Wan DiT experts are loaded here; text encoder "
+                                          "and VAE-encoder weights belong to the 'next' rows (SURVEY §8f)")
+        if dits:
+            pipe.dit = dits[0]
+            pipe.dit2 = dits[1] if len(dits) > 1 else None
+        if controlnet:
+            pipe.init_controlnets()
+        return pipe
+
+    @staticmethod
+    def from_modules(dit, dit2=None, controlnet=None, controlnet2=None, vae=None, device="cuda"):
+        """Assemble a pipeline from already-built modules (synthetic weights: tests, bench)."""
+        pipe = WanVideoPipeline(device=device, controlnet=controlnet is not None,
+                                controlnet_num_layers=0 if controlnet is None else controlnet.num_layers)
+        pipe.dit, pipe.dit2, pipe.controlnet, pipe.controlnet2, pipe.vae = dit, dit2, controlnet, controlnet2, vae
+        return pipe
+
+    def init_controlnets(self):
+        d = self.dit
+        kw = dict(dim=d.dim, num_heads=d.num_heads, ffn_dim=d.blocks[0].ffn_dim, eps=d.eps)
+        self.controlnet = ControlNet(self.num_layers, stride=None, **kw).to(dtype=self.torch_dtype, device=self.device)
+        for i in range(self.num_layers):
+            self.controlnet.controlnet_dit.blocks[i].load_state_dict(d.blocks[i].state_dict())
+        if self.dit2 is not None:
+            self.controlnet2 = copy.deepcopy(self.controlnet)
+            for i in range(self.num_layers):
+                self.controlnet2.controlnet_dit.blocks[i].load_state_dict(self.dit2.blocks[i].state_dict())
+
+    def load_controlnet_weights(self, module, path, torch_dtype=torch.bfloat16):
+        """GF:176-178 — strips the 'pipe.controlnet.' prefix, strict load."""
+        sd = load_state_dict(path, torch_dtype=torch_dtype)
+        module.load_state_dict({k.replace("pipe.controlnet.", "", 1): v for k, v in sd.items()}, strict=True)
+
+    def enable_vram_management(self, num_persistent_param_in_dit=None, vram_limit=None, vram_buffer=0.5):
+        """GF:196-452 — accepted for interface parity; everything is already resident in HBM."""
+        self.vram_management_enabled = True
+
+    def load_models_to_device(self, model_names=()):
+        return None  # no offload state machine on 288 GB parts
+
+    # ------------------------------------------------------------------ host helpers (UTIL)
+    def check_resize_height_width(self, height, width, num_frames=None):
+        """UTIL:41-57 (round up to the division factors)."""
+        if height % self.height_division_factor != 0:
+            height = (height + self.height_division_factor - 1) // self.height_division_factor * self.height_division_factor
+        if width % self.width_division_factor != 0:
+            width = (width + self.width_division_factor - 1) // self.width_division_factor * self.width_division_factor
+        if num_frames is None:
+            return height, width
+        if num_frames % self.time_division_factor != self.time_division_remainder:
+            num_frames = (num_frames + self.time_division_factor - 1) // self.time_division_factor \
+                * self.time_division_factor + self.time_division_remainder
+        return height, width, num_frames
+
+    def generate_noise(self, shape, seed=None, rand_device="cpu", rand_torch_dtype=torch.float32, device=None,
+                       torch_dtype=None):
+        """UTIL:117-122 — CPU generator, fp32 randn, then cast/move."""
+        generator = None if seed is None else torch.Generator(rand_device).manual_seed(seed)
+        noise = torch.randn(shape, generator=generator, device=rand_device, dtype=rand_torch_dtype)
+        return noise.to(dtype=torch_dtype or self.torch_dtype, device=device or self.device)
+
+    def vae_output_to_video(self, vae_output, min_value=-1, max_value=1):
+        """UTIL:76-91 — [1,3,T,H,W] in [-1,1] -> list of PIL frames."""
+        from PIL import Image
+        v = vae_output.float().mean(dim=0).permute(1, 2, 3, 0)  # T H W C
+        v = ((v - min_value) * (255 / (max_value - min_value))).clip(0, 255).to(device="cpu", dtype=torch.uint8)
+        return [Image.fromarray(f.numpy()) for f in v]
+
+    # ------------------------------------------------------------------ the hot loop
+    @torch.no_grad()
+    def denoise(self, latents, context_posi, context_nega, y, control_signal_video_latents, num_inference_steps=50,
+                cfg_scale=5.0, switch_DiT_boundary=0.875, sigma_shift=5.0, denoising_strength=1.0, controlnet=True,
+                progress_bar_cmd=None, record_step_times=False, step_ids=None):
+        """GF:663 + GF:697-723.  Returns the final latents [1,16,f,H/8,W/8] (a new tensor).
+        `step_ids` (optional) restricts the loop to a sub-range of the schedule (benchmarks)."""
+        self.scheduler.set_timesteps(num_inference_steps, denoising_strength=denoising_strength, shift=sigma_shift)
+        latents = latents.clone()
+        models = {"dit": self.dit, "controlnet": self.controlnet if controlnet else None}
+        caches = {}
+        self.last_step_ms = []
+        ids = range(len(self.scheduler.timesteps)) if step_ids is None else step_ids
+        it = ids if progress_bar_cmd is None else progress_bar_cmd(ids)
+        for progress_id in it:
+            timestep = self.scheduler.timesteps[progress_id]
+            # expert switch (GF:699-704): both experts are resident, so this is a pointer swap
+            if timestep.item() < switch_DiT_boundary * self.scheduler.num_train_timesteps and self.dit2 is not None \
+                    and models["dit"] is not self.dit2:
+                models["dit"] = self.dit2
+                if controlnet:
+                    models["controlnet"] = self.controlnet2
+            ts = timestep.unsqueeze(0).to(dtype=self.torch_dtype, device=self.device)  # bf16-rounded (GF:707)
+            key = id(models["dit"])
+            if key not in caches:
+                caches[key] = (ContextCache(), ContextCache())
+            if record_step_times:
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
+            shared = dict(latents=latents, timestep=ts, y=y, control_signal_video_latents=control_signal_video_latents,
+                          elide_zero_controlnet=self.elide_zero_controlnet)
+            posi = self.model_fn(**models, **shared, context=context_posi, context_cache=caches[key][0])
+            nega = None
+            if cfg_scale != 1.0:
+                nega = self.model_fn(**models, **shared, context=context_nega, context_cache=caches[key][1])
+            sigma, sigma_ = self.scheduler.sigma_pair(self.scheduler.timesteps[progress_id])
+            # noise_pred = nega + cfg*(posi - nega); latents += noise_pred*(sigma_next - sigma)  (GF:716, FM:81)
+            ops.cfg_euler_step(latents, posi.contiguous(), None if nega is None else nega.contiguous(), cfg_scale,
+                               float(sigma_ - sigma))
+            if record_step_times:
+                ev1.record()
+                self.last_step_ms.append((ev0, ev1, models["dit"] is self.dit2))
+        if record_step_times:
+            torch.cuda.synchronize()
+            self.last_step_ms = [(a.elapsed_time(b), low) for a, b, low in self.last_step_ms]
+        return latents
+
+    @torch.no_grad()
+    def __call__(self, prompt: str = "", negative_prompt: Optional[str] = "", input_image=None, end_image=None,
+                 input_video=None, denoising_strength: Optional[float] = 1.0, input_audio=None, audio_embeds=None,
+                 audio_sample_rate=16000, s2v_pose_video=None, s2v_pose_latents=None, motion_video=None,
+                 control_video=None, reference_image=None, camera_control_direction=None, camera_control_speed=1 / 54,
+                 camera_control_origin=None, vace_video=None, vace_video_mask=None, vace_reference_image=None,
+                 vace_scale=1.0, seed: Optional[int] = None, rand_device: Optional[str] = "cpu",
+                 height: Optional[int] = 480, width: Optional[int] = 832, num_frames=81,
+                 cfg_scale: Optional[float] = 5.0, cfg_merge: Optional[bool] = False,
+                 switch_DiT_boundary: Optional[float] = 0.875, num_inference_steps: Optional[int] = 50,
+                 sigma_shift: Optional[float] = 5.0, motion_bucket_id=None, tiled: Optional[bool] = True,
+                 tile_size=(30, 52), tile_stride=(15, 26), sliding_window_size=None, sliding_window_stride=None,
+                 tea_cache_l1_thresh=None, tea_cache_model_id="", progress_bar_cmd=None, controlnet=False,
+                 control_signal_video=None,
+                 # pre-computed conditioning (outputs of the pre-loop units GF:791-917 / GF:808)
+                 context_posi=None, context_nega=None, y=None, control_signal_video_latents=None,
+                 output_type="pil"):
+        for name, val in (("end_image", end_image), ("input_video", input_video), ("input_audio", input_audio),
+                          ("audio_embeds", audio_embeds), ("s2v_pose_video", s2v_pose_video),
+                          ("motion_video", motion_video), ("control_video", control_video),
+                          ("reference_image", reference_image), ("camera_control_direction", camera_control_direction),
+                          ("vace_video", vace_video), ("vace_reference_image", vace_reference_image),
+                          ("motion_bucket_id", motion_bucket_id), ("sliding_window_size", sliding_window_size),
+                          ("tea_cache_l1_thresh", tea_cache_l1_thresh)):
+            if val is not None:
+                raise NotImplementedError(f"`{name}` belongs to a pipeline branch Goal Force never takes (SURVEY §2 #2)")
+        if cfg_merge:
+            raise NotImplementedError("cfg_merge=True: the reference default (two sequential forwards) is what is built")
+        height, width, num_frames = self.check_resize_height_width(height, width, num_frames)
+        length = (num_frames - 1) // 4 + 1
+        noise = self.generate_noise((1, 16, length, height // 8, width // 8), seed=seed, rand_device=rand_device)
+        if context_posi is None or (cfg_scale != 1.0 and context_nega is None):
+            if self.text_encoder is None:
+                raise NotImplementedError("no text encoder loaded: pass context_posi/context_nega "
+                                          "([1,512,4096] umT5 embeddings); the encoder is a 'next' row (SURVEY §8f)")
+            context_posi = self.text_encoder.encode_prompt(prompt, device=self.device)
+            context_nega = self.text_encoder.encode_prompt(negative_prompt, device=self.device)
+        if y is None and input_image is not None:
+            y = self.embed_image(input_image, num_frames, height, width, tiled, tile_size, tile_stride)
+        if controlnet and control_signal_video_latents is None:
+            if control_signal_video is None:
+                raise GoalForceError("controlnet=True needs control_signal_video or control_signal_video_latents")
+            control_signal_video_latents = self.embed_control_video(control_signal_video, tiled, tile_size, tile_stride)
+        latents = self.denoise(noise, context_posi, context_nega, y, control_signal_video_latents,
+                               num_inference_steps=num_inference_steps, cfg_scale=cfg_scale,
+                               switch_DiT_boundary=switch_DiT_boundary, sigma_shift=sigma_shift,
+                               denoising_strength=denoising_strength, controlnet=controlnet,
+                               progress_bar_cmd=progress_bar_cmd)
+        if output_type == "latent":
+            return latents
+        if self.vae is None:
+            raise GoalForceError("no VAE loaded: call with output_type='latent' or attach pipe.vae")
+        video = self.vae.decode(latents, device=self.device, tiled=tiled, tile_size=tile_size, tile_stride=tile_stride)
+        return video if output_type == "pt" else self.vae_output_to_video(video)
+
+    # pre-loop conditioning that needs the VAE encoder ('next' row)
+    def embed_image(self, input_image, num_frames, height, width, tiled, tile_size, tile_stride):
+        raise NotImplementedError("ImageEmbedderVAE (GF:887-917) needs the VAE encoder: pass `y` pre-computed")
+
+    def embed_control_video(self, control_signal_video, tiled, tile_size, tile_stride):
+        raise NotImplementedError("ControlVideoEmbedder (GF:791-805) needs the VAE encoder: pass "
+                                  "`control_signal_video_latents` pre-computed")
+
+
+def build_random_expert(cfg=None, seed=0, device="cuda", std=0.02):
+    """Random-init expert for benchmarks/tests: weights ~ N(0, std^2) generated ON the device (no
+    checkpoints or network here).  norm weights 1, modulation as the reference initialises it."""
+    cfg = dict(A14B_CONFIG if cfg is None else cfg)
+    with torch.device("meta"):
+        m = WanModel(**cfg)
+    m = m.to_empty(device=device).to(torch.bfloat16)
+    m.freqs = None
+    g = torch.Generator(device=device).manual_seed(seed)
+    for name, p in m.named_parameters():
+        if name.endswith("norm_q.weight") or name.endswith("norm_k.weight") or name.endswith("norm3.weight"):
+            p.data.fill_(1.0)
+        elif name.endswith("norm3.bias"):
+            p.data.zero_()
+        elif name.endswith("modulation"):
+            p.data.copy_(torch.randn(p.shape, generator=g, device=device, dtype=torch.float32) / cfg["dim"] ** 0.5)
+        elif name.endswith(".bias"):
+            p.data.copy_(torch.randn(p.shape, generator=g, device=device, dtype=torch.float32) * 0.01)
+        else:
+            p.data.copy_(torch.randn(p.shape, generator=g, device=device, dtype=torch.float32) * std)
+    from .dit import precompute_freqs_cis_3d
+    m.freqs = precompute_freqs_cis_3d(cfg["dim"] // cfg["num_heads"])
+    return m

@@ -67,6 +67,17 @@ GF_API int gf_layernorm_modulate(const void* x, void* out, const void* weight, c
                           float eps, void* stream);
 
 /* ------------------------------------------------------------------------
+ * gf_modulation — forms the AdaLN vectors of one block in bf16 exactly as the
+ * reference's eager ops do: out[i,:] = bf16(param[i,:] + t[i % t_rows,:]) and,
+ * for rows whose bit is set in onep_mask, out[i,:] = bf16(1 + out[i,:]).
+ * Replaces `(self.modulation + t_mod).chunk(6)` and the `1 + scale` of
+ * modulate() (DIT:64-65, 218-219) and Head's `(modulation + t).chunk(2)` (DIT:264-268).
+ *   param [k, dim] bf16, t [t_rows, dim] bf16, out [k, dim] bf16; k <= 32.
+ */
+GF_API int gf_modulation(const void* param, const void* t, void* out, int64_t k, int64_t dim,
+                         int64_t t_rows, uint32_t onep_mask, void* stream);
+
+/* ------------------------------------------------------------------------
  * gf_rmsnorm_rope — in place: RMSNorm over the FULL row (all heads jointly;
  * fp32 math, round to bf16, then bf16 multiply by weight) followed by 3-D RoPE
  * on adjacent element pairs.  Replaces RMSNorm.forward (DIT:100-111) and

@@ -1,0 +1,310 @@
+"""GPU parity tests of every C-ABI kernel against the CPU oracle (same seeded inputs).
+All calls go through goal_force_amd.ops -> ctypes -> libgoalforce_hip.so.
+
+Tolerances: per-op rel-L2 <= 2e-3 vs the fp32-math oracle for floating point; integer /
+layout tests are exact.  Where the kernel reproduces the reference's bf16 rounding sequence the test
+also bounds the fraction of elements that differ from the bf16 oracle by more than 1 ulp.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import gen_inputs as gi
+from conftest import GOLDEN, rel_l2
+from oracle import wan_oracle as wo
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+torch.set_grad_enabled(False)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from goal_force_amd import ops as _ops
+    return _ops
+
+
+def dev(t):
+    return t.cuda()
+
+
+def ulp_mismatch_frac(got: torch.Tensor, ref: torch.Tensor, ulps=1):
+    """fraction of bf16 elements whose bit patterns differ by more than `ulps` (same sign region)."""
+    a = got.cpu().contiguous().view(torch.int16).to(torch.int32)
+    b = ref.cpu().contiguous().view(torch.int16).to(torch.int32)
+    return float(((a - b).abs() > ulps).float().mean())
+
+
+# ------------------------------------------------------------------ row ops
+@pytest.mark.parametrize("rows,dim", [(72, 256), (515, 5120), (33, 1536)])
+@pytest.mark.parametrize("variant", ["plain", "modulate", "affine"])
+def test_layernorm_modulate(ops, rows, dim, variant):
+    g = torch.Generator().manual_seed(rows + dim)
+    x = (torch.randn((rows, dim), generator=g) * 2 + 0.3).to(BF)
+    w = (1 + 0.1 * torch.randn(dim, generator=g)).to(BF)
+    b = (0.1 * torch.randn(dim, generator=g)).to(BF)
+    scale = (0.5 * torch.randn(dim, generator=g)).to(BF)
+    shift = (0.5 * torch.randn(dim, generator=g)).to(BF)
+    if variant == "plain":
+        ref = wo.layer_norm(x, eps=1e-6)
+        got = ops.layernorm_modulate(dev(x))
+    elif variant == "modulate":
+        ref = wo.modulate(wo.layer_norm(x, eps=1e-6), shift, scale)
+        got = ops.layernorm_modulate(dev(x), scale1p=dev(1 + scale), shift=dev(shift))
+    else:
+        ref = wo.layer_norm(x, w, b, eps=1e-6)
+        got = ops.layernorm_modulate(dev(x), weight=dev(w), bias=dev(b))
+    e = rel_l2(got.cpu().float(), ref.float())
+    frac = ulp_mismatch_frac(got, ref)
+    assert e < 2e-3 and frac < 2e-3, f"rel_l2={e:.3e} >1ulp frac={frac:.3e}"
+
+
+@pytest.mark.parametrize("rows,dim,heads,rope", [(72, 256, 2, True), (515, 5120, 40, True), (300, 1536, 12, False)])
+def test_rmsnorm_rope(ops, rows, dim, heads, rope):
+    g = torch.Generator().manual_seed(rows)
+    x = (torch.randn((1, rows, dim), generator=g) * 1.7).to(BF)
+    w = (1 + 0.1 * torch.randn(dim, generator=g)).to(BF)
+    ref = wo.rms_norm(x, w, 1e-6)
+    cos = sin = None
+    if rope:
+        f, h, wd = 3, 4, rows // 12 + 1
+        freqs = wo.rope_freqs_3d(dim // heads, f, h, wd)[:rows]
+        ref = wo.rope_apply(ref, freqs, heads)
+        cos, sin = dev(freqs.real.float().contiguous()), dev(freqs.imag.float().contiguous())
+    xg = dev(x).clone()
+    ops.rmsnorm_rope(xg[0], dev(w), cos, sin, head_dim=dim // heads, eps=1e-6)
+    e = rel_l2(xg.cpu().float(), ref.float())
+    frac = ulp_mismatch_frac(xg, ref)
+    assert e < 2e-3 and frac < 2e-3, f"rel_l2={e:.3e} >1ulp frac={frac:.3e}"
+
+
+def test_rmsnorm_strided_rows(ops):
+    """q/k living as column slices of one fused [S, 3D] buffer (row stride 3D)."""
+    g = torch.Generator().manual_seed(5)
+    buf = torch.randn((100, 3 * 256), generator=g).to(BF)
+    w = (1 + 0.1 * torch.randn(256, generator=g)).to(BF)
+    bg = dev(buf).clone()
+    ops.rmsnorm_rope(bg[:, 256:512], dev(w), head_dim=128)
+    ref = buf.clone()
+    ref[:, 256:512] = wo.rms_norm(buf[:, 256:512], w, 1e-6)
+    assert torch.equal(bg.cpu()[:, :256], buf[:, :256]) and torch.equal(bg.cpu()[:, 512:], buf[:, 512:])
+    assert rel_l2(bg.cpu().float(), ref.float()) < 2e-3
+
+
+# ------------------------------------------------------------------ GEMM
+def test_gemm_exact_integer_layout(ops):
+    """Small-integer operands: every product and sum is exact in bf16/fp32, so any fragment / tile /
+    transpose mistake shows up as a hard mismatch (asymmetric operands)."""
+    g = torch.Generator().manual_seed(3)
+    M, N, K = 300, 520, 192
+    a = torch.randint(-2, 3, (M, K), generator=g).float()
+    w = torch.randint(-1, 2, (N, K), generator=g).float()
+    w[:, 0] += torch.arange(N) % 3  # asymmetric
+    bias = torch.randint(-4, 5, (N,), generator=g).float()
+    ref = a @ w.t() + bias
+    assert ref.abs().max() < 256  # exactly representable in bf16
+    got = ops.gemm(dev(a.to(BF)), dev(w.to(BF)), dev(bias.to(BF)))
+    assert torch.equal(got.cpu().float(), ref)
+
+
+GEMM_SHAPES = [(72, 256, 256), (300, 512, 256), (1000, 5120, 5120), (257, 64, 5120), (1, 1536, 256),
+               (513, 13824 // 2, 512), (512, 256, 4096)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+@pytest.mark.parametrize("epi", ["bias", "gelu", "gate_resid", "resid", "silu", "nobias"])
+def test_gemm_epilogues(ops, M, N, K, epi):
+    if epi not in ("bias", "gate_resid") and K > 1024 and M > 300:
+        pytest.skip("epilogue variants covered at the smaller shapes")
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    a = torch.randn((M, K), generator=g).to(BF)
+    w = (torch.randn((N, K), generator=g) / math.sqrt(K)).to(BF)
+    bias = (0.1 * torch.randn(N, generator=g)).to(BF)
+    resid = torch.randn((M, N), generator=g).to(BF)
+    gate = torch.randn(N, generator=g).to(BF)
+    lin = F.linear(a.float(), w.float(), None if epi == "nobias" else bias.float())  # fp32-math oracle
+    y = lin.to(BF)
+    if epi in ("bias", "nobias"):
+        ref, kw = y, dict(epilogue=ops.EPI_BIAS)
+    elif epi == "gelu":
+        ref, kw = F.gelu(y, approximate="tanh"), dict(epilogue=ops.EPI_BIAS_GELU_TANH)
+    elif epi == "silu":
+        ref, kw = F.silu(y), dict(epilogue=ops.EPI_BIAS_SILU)
+    elif epi == "resid":
+        ref, kw = resid + y, dict(epilogue=ops.EPI_BIAS_RESID, resid=dev(resid))
+    else:
+        ref, kw = resid + gate * y, dict(epilogue=ops.EPI_BIAS_GATE_RESID, resid=dev(resid), gate=dev(gate))
+    got = ops.gemm(dev(a), dev(w), None if epi == "nobias" else dev(bias), **kw)
+    e = rel_l2(got.cpu().float(), ref.float())
+    frac = ulp_mismatch_frac(got, ref, ulps=2)
+    assert e < 2e-3 and frac < 5e-3, f"rel_l2={e:.3e} >2ulp frac={frac:.3e}"
+
+
+def test_gemm_inplace_residual_and_strided_output(ops):
+    g = torch.Generator().manual_seed(9)
+    M, N, K = 400, 256, 256
+    a = torch.randn((M, K), generator=g).to(BF)
+    w = (torch.randn((N, K), generator=g) / 16).to(BF)
+    b = torch.randn(N, generator=g).to(BF)
+    x = torch.randn((M, N), generator=g).to(BF)
+    ref = x + F.linear(a.float(), w.float(), b.float()).to(BF)
+    xg = dev(x).clone()
+    ops.gemm(dev(a), dev(w), dev(b), epilogue=ops.EPI_BIAS_RESID, resid=xg, out=xg)  # C aliases resid
+    assert rel_l2(xg.cpu().float(), ref.float()) < 2e-3
+    big = torch.zeros((M, 3 * N), dtype=BF, device="cuda")
+    ops.gemm(dev(a), dev(w), dev(b), out=big[:, N:2 * N])  # write into a column slice (ldc = 3N)
+    assert rel_l2(big[:, N:2 * N].cpu().float(), F.linear(a.float(), w.float(), b.float())) < 2e-3
+    assert float(big[:, :N].abs().sum()) == 0 and float(big[:, 2 * N:].abs().sum()) == 0
+
+
+def test_gemm_full_size_sampled_rows(ops):
+    """Production shape (S=32760 rows incl. the ragged last M tile, D=5120): sampled rows against an fp64
+    reference + every row finite with a sane norm."""
+    g = torch.Generator().manual_seed(1)
+    M, N, K = 32760, 5120, 5120
+    a = torch.randn((M, K), generator=g).to(BF)
+    w = (torch.randn((N, K), generator=g) / math.sqrt(K)).to(BF)
+    got = ops.gemm(dev(a), dev(w)).cpu()
+    rows = torch.tensor([0, 1, 255, 256, 8191, 20000, 32511, 32512, 32759])
+    ref = a[rows].double() @ w.double().t()
+    assert rel_l2(got[rows].float(), ref) < 2e-3
+    norms = got.float().norm(dim=1)
+    assert torch.isfinite(norms).all() and float(norms.min()) > 0.5 * float(norms.median())
+
+
+# ------------------------------------------------------------------ attention
+@pytest.mark.parametrize("sq,skv,heads", [(72, 72, 2), (300, 7, 2), (1000, 512, 12), (777, 1333, 3), (256, 64, 8),
+                                          (4100, 4100, 8)])
+def test_flash_attn(ops, sq, skv, heads):
+    g = torch.Generator().manual_seed(sq + skv)
+    d = 128
+    q = (torch.randn((1, sq, heads * d), generator=g) * 1.5).to(BF)
+    k = (torch.randn((1, skv, heads * d), generator=g) * 1.5).to(BF)
+    v = torch.randn((1, skv, heads * d), generator=g).to(BF)
+    ref = wo.attention_fp64(q, k, v, heads)[0]
+    got = ops.flash_attn(dev(q[0]), dev(k[0]), dev(v[0]), heads).cpu()
+    e = rel_l2(got.float(), ref)
+    assert e < 4e-3, f"rel_l2={e:.3e}"
+    # and against the reference's own bf16 SDPA path (CPU)
+    e2 = rel_l2(got.float(), wo.attention(q, k, v, heads)[0].float())
+    assert e2 < 8e-3, f"vs bf16 SDPA rel_l2={e2:.3e}"
+
+
+def test_flash_attn_forced_rescale_branch(ops):
+    """One key row spiked against one query row so the running max jumps far past the lazy-rescale
+    threshold in the middle of the KV sweep (guide rule: a rare data-dependent branch needs its own
+    test).  Full-tensor fp64 reference."""
+    g = torch.Generator().manual_seed(77)
+    sq, skv, heads, d = 300, 900, 2, 128
+    q = (torch.randn((1, sq, heads * d), generator=g) * 0.3).to(BF)
+    k = (torch.randn((1, skv, heads * d), generator=g) * 0.3).to(BF)
+    v = torch.randn((1, skv, heads * d), generator=g).to(BF)
+    for key, qrow in ((500, 10), (640, 200), (899, 299)):
+        k[0, key, :d] = q[0, qrow, :d] * 40.0  # huge positive score for (qrow, key) in head 0
+    ref = wo.attention_fp64(q, k, v, heads)[0]
+    got = ops.flash_attn(dev(q[0]), dev(k[0]), dev(v[0]), heads).cpu()
+    e = rel_l2(got.float(), ref)
+    worst = float((got.double() - ref).abs().max())
+    assert e < 4e-3 and worst < 0.05, f"rel_l2={e:.3e} max_abs={worst:.3e}"
+
+
+def test_flash_attn_strided_qkv(ops):
+    """q,k,v as column slices of one fused [S, 3D] buffer."""
+    g = torch.Generator().manual_seed(2)
+    s, heads, d = 500, 2, 128
+    qkv = torch.randn((s, 3 * heads * d), generator=g).to(BF)
+    D = heads * d
+    ref = wo.attention_fp64(qkv[None, :, :D], qkv[None, :, D:2 * D], qkv[None, :, 2 * D:], heads)[0]
+    gq = dev(qkv)
+    got = ops.flash_attn(gq[:, :D], gq[:, D:2 * D], gq[:, 2 * D:], heads).cpu()
+    assert rel_l2(got.float(), ref) < 4e-3
+
+
+def test_flash_attn_full_size_properties(ops):
+    """Production size S=32760, 40 heads: (1) V constant along keys => output equals that constant
+    (softmax rows sum to 1) for every row incl. the ragged last tiles; (2) sampled query rows against
+    an fp64 reference."""
+    g = torch.Generator().manual_seed(4)
+    s, heads, d = 32760, 40, 128
+    q = torch.randn((s, heads * d), generator=g).to(BF)
+    k = torch.randn((s, heads * d), generator=g).to(BF)
+    vrow = torch.randn((1, heads * d), generator=g).to(BF)
+    v = vrow.expand(s, -1).contiguous()
+    got = ops.flash_attn(dev(q), dev(k), dev(v), heads).cpu()
+    assert float((got.float() - vrow.float()).abs().max()) < 2e-2
+    v2 = torch.randn((s, heads * d), generator=g).to(BF)
+    got2 = ops.flash_attn(dev(q), dev(k), dev(v2), heads).cpu()
+    rows = torch.tensor([0, 31, 255, 256, 16000, 32511, 32512, 32759])
+    hsel = [0, 7, 39]
+    for h in hsel:
+        sl = slice(h * d, (h + 1) * d)
+        ref = wo.attention_fp64(q[None, rows][:, :, sl], k[None, :, sl], v2[None, :, sl], 1)[0]
+        e = rel_l2(got2[rows][:, sl].float(), ref)
+        assert e < 4e-3, f"head {h}: rel_l2={e:.3e}"
+
+
+# ------------------------------------------------------------------ elementwise
+def test_cfg_euler_step_bit_exact(ops):
+    g = torch.Generator().manual_seed(8)
+    shape = (1, 16, 3, 8, 12)
+    lat, posi, nega = (torch.randn(shape, generator=g).to(BF) for _ in range(3))
+    sig, _ = wo.flow_match_sigmas(50, 5.0)
+    for i in (0, 20, 49):
+        ref = wo.euler_step(wo.cfg_combine(posi, nega, 5.0), i, lat, sig)
+        ds = float((0 if i == 49 else sig[i + 1]) - sig[i])
+        got = ops.cfg_euler_step(dev(lat).clone(), dev(posi), dev(nega), 5.0, ds)
+        assert torch.equal(got.cpu(), ref), f"step {i}"
+    ref = wo.euler_step(posi, 3, lat, sig)  # cfg_scale == 1 path (GF:717-718)
+    got = ops.cfg_euler_step(dev(lat).clone(), dev(posi), None, 1.0, float(sig[4] - sig[3]))
+    assert torch.equal(got.cpu(), ref)
+    # odd length (tail path)
+    n = 1003
+    a, b, c = (torch.randn(n, generator=g).to(BF) for _ in range(3))
+    ref = a + (c + 5.0 * (b - c)) * torch.tensor(-0.25)
+    assert torch.equal(ops.cfg_euler_step(dev(a).clone(), dev(b), dev(c), 5.0, -0.25).cpu(), ref)
+
+
+def test_add_act(ops):
+    g = torch.Generator().manual_seed(6)
+    a, b = torch.randn(4099, generator=g).to(BF), torch.randn(4099, generator=g).to(BF)
+    assert torch.equal(ops.add(dev(a), dev(b)).cpu(), a + b)
+    assert ulp_mismatch_frac(ops.act(dev(a), "silu"), F.silu(a)) < 1e-3
+    assert ulp_mismatch_frac(ops.act(dev(a), "gelu_tanh"), F.gelu(a, approximate="tanh")) < 1e-3
+
+
+def test_patchify_unpatchify_exact(ops):
+    g = torch.Generator().manual_seed(10)
+    lat = torch.randn((16, 3, 8, 12), generator=g).to(BF)
+    y = torch.randn((20, 3, 8, 12), generator=g).to(BF)
+    cols = ops.patchify_im2col(dev(lat), dev(y), kpad=192).cpu()
+    x = torch.cat([lat, y], 0)  # [36,3,8,12]
+    ref = x.reshape(36, 3, 4, 2, 6, 2).permute(1, 2, 4, 0, 3, 5).reshape(72, 144)
+    assert torch.equal(cols[:, :144], ref) and float(cols[:, 144:].abs().sum()) == 0
+    # im2col + GEMM == Conv3d (the patch embedding, DIT:342)
+    w = (torch.randn((256, 36, 1, 2, 2), generator=g) / 12).to(BF)
+    b = torch.randn(256, generator=g).to(BF)
+    emb_ref, grid = wo.patch_embed(x[None].float(), w.float(), b.float())
+    wp = torch.zeros((256, 192), dtype=BF)
+    wp[:, :144] = w.reshape(256, 144)
+    emb = ops.gemm(dev(cols), dev(wp), dev(b)).cpu()
+    assert grid == (3, 4, 6) and rel_l2(emb.float(), emb_ref[0]) < 2e-3
+    tok = torch.randn((72, 64), generator=g).to(BF)
+    assert torch.equal(ops.unpatchify(dev(tok), 16, 3, 4, 6).cpu(), wo.unpatchify(tok[None], (3, 4, 6), 16)[0])
+
+
+def test_abi_error_channel(ops):
+    from goal_force_amd import _lib
+    a = torch.zeros((8, 100), dtype=BF, device="cuda")  # K=100 is not a multiple of 64
+    w = torch.zeros((8, 100), dtype=BF, device="cuda")
+    with pytest.raises(_lib.GoalForceError, match="multiple of 64"):
+        ops.gemm(a, w)
+    with pytest.raises(_lib.GoalForceError, match="GPU"):
+        ops.gemm(a.cpu(), w.cpu())
+    q = torch.zeros((8, 2 * 64), dtype=BF, device="cuda")
+    with pytest.raises(_lib.GoalForceError, match="head_dim"):
+        ops.flash_attn(q, q, q, 2)
