@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py — Goal-Force denoising benchmark on MI355X (BASELINE.json: denoise-step ms + frames/sec,
+Wan2.2-I2V-A14B 832x480x81f, 50 steps).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one full denoising iteration of the reference loop (src/goal_force/wan_video_new.py:697-723):
+cond + uncond model_fn forwards (40 DiT blocks each, + 10 ControlNet blocks and 10 zero-conv GEMMs on
+high-noise steps), CFG combine and the flow-match Euler update, at the full 832x480x81f size
+(latents [1,16,21,60,104], 32760 video tokens, 512 text tokens), both A14B-sized experts and both
+ControlNets resident, random-init bf16 weights, synthetic inputs already in HBM.
+
+The K timed steps are spread evenly over the real 50-step / shift-5 schedule so they contain the
+schedule's mix of high-noise (with ControlNet) and low-noise (zero ControlNet2 elided, bit-identical)
+steps.  value = frames/s of the denoising loop = videos * 81 / (50 * seconds_per_step).
+
+N = 1: one video, CFG pair evaluated sequentially.  N >= 2 (even): rank r -> video r//2, CFG branch r%2,
+one RCCL all-gather of the 4.2 MB noise prediction per step inside each pair (weak scaling in videos).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md (Chip-level parameters)
+S_TOK, DIM, HEADS, FFN, LTXT = 32760, 5120, 40, 13824, 512
+
+
+def block_flops(s, l=LTXT, d=DIM, f=FFN):
+    return 12 * s * d * d + 4 * l * d * d + 4 * s * d * f + 4 * s * s * d + 4 * s * l * d
+
+
+def forward_flops(with_controlnet):
+    fl = 40 * block_flops(S_TOK) + 2 * S_TOK * 144 * DIM + 2 * S_TOK * DIM * 64
+    if with_controlnet:
+        fl += 10 * block_flops(S_TOK) + 10 * 2 * S_TOK * DIM * DIM + 2 * S_TOK * 64 * DIM
+    return fl
+
+
+def cpu_baseline(torch):
+    """Reference-equivalent CPU path (the oracle's torch-CPU restatement of DiTBlock, pinned to the
+    reference by tests/test_oracle_goldens.py) on BASELINE config 1: one A14B block, S=14040, bf16."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import gen_inputs as gi
+    from oracle import wan_oracle as wo
+    cfg = gi.A14B
+    s = 9 * 30 * 52
+    sd = gi.block_sd(torch.Generator().manual_seed(31), cfg["dim"], cfg["ffn_dim"], "", torch.bfloat16)
+    x, ctx, t_mod = gi.block_inputs(cfg["dim"], s, 512, seed=32)
+    freqs = wo.rope_freqs_3d(128, 9, 30, 52)
+    cores = torch.get_num_threads()
+    t0 = time.time()
+    wo.dit_block(x, ctx, t_mod, freqs, sd, "", cfg["num_heads"], cfg["eps"])
+    dt = time.time() - t0
+    tflops = block_flops(s) / dt / 1e12
+    loop_flops = 21 * 2 * forward_flops(True) + 29 * 2 * forward_flops(True)  # reference runs ControlNet2 too
+    return {"value": 81.0 / (loop_flops / (tflops * 1e12)), "unit": "frames/s (derived: 50-step loop FLOPs / measured CPU FLOP/s)",
+            "cores": cores, "kind": "port",
+            "sample": f"one A14B DiTBlock fwd, S=14040 (BASELINE config 1), bf16, torch CPU eager: {dt:.1f} s = {tflops:.2f} TFLOP/s",
+            "block_seconds": dt, "tflops": tflops}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--layers", type=int, default=40, help=argparse.SUPPRESS)  # debugging only; 40 = the real model
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from goal_force_amd import ops
+    from goal_force_amd.distributed import CfgPairParallel, init_from_env
+    from goal_force_amd.dit import A14B_CONFIG
+    from goal_force_amd.pipeline import WanVideoPipeline, build_random_controlnet, build_random_expert
+
+    torch.set_grad_enabled(False)
+    rank, local, world = init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    cfgp = CfgPairParallel(rank, world) if world > 1 else None
+    sample = 0 if cfgp is None else cfgp.sample
+
+    cfg = dict(A14B_CONFIG)
+    cfg["num_layers"] = args.layers
+    n_cn = min(10, args.layers)
+    dit = build_random_expert(cfg, seed=100, device=dev)
+    dit2 = build_random_expert(cfg, seed=200, device=dev)
+    cn = build_random_controlnet(n_cn, cfg, seed=300, device=dev)
+    cn2 = build_random_controlnet(n_cn, cfg, seed=400, device=dev, zero_convs_zero=True)
+    pipe = WanVideoPipeline.from_modules(dit, dit2, cn, cn2, device=dev)
+
+    # synthetic conditioning, per-video seed
+    g = torch.Generator().manual_seed(1000 + sample)
+    latents = pipe.generate_noise((1, 16, 21, 60, 104), seed=sample)
+    y = torch.randn((1, 20, 21, 60, 104), generator=g)
+    y[:, :4] = 0
+    y[:, :4, 0] = 1  # first-frame mask (GF:898-909)
+    y = y.to(torch.bfloat16).to(dev)
+    control = torch.randn((1, 16, 21, 60, 104), generator=g).to(torch.bfloat16).to(dev)
+    ctx_p = torch.randn((1, 512, 4096), generator=g)
+    ctx_n = torch.randn((1, 512, 4096), generator=g)
+    ctx_p[:, 40:] = 0
+    ctx_n[:, 40:] = 0  # prompter zeroes past the prompt length (wan_prompter.py:99-109)
+    ctx_p, ctx_n = ctx_p.to(torch.bfloat16).to(dev), ctx_n.to(torch.bfloat16).to(dev)
+
+    n_sched = 50
+    k = max(1, args.steps)
+    step_ids = sorted({min(n_sched - 1, (i * n_sched) // k) for i in range(k)}) if k < n_sched else list(range(n_sched))
+    while len(step_ids) < k:  # K > 50: wrap around
+        step_ids = step_ids + step_ids[: k - len(step_ids)]
+    warm_ids = [step_ids[i % len(step_ids)] for i in range(args.warmup)]
+
+    def run(ids, record=False):
+        return pipe.denoise(latents, ctx_p, ctx_n, y, control, num_inference_steps=n_sched, cfg_scale=5.0,
+                            controlnet=True, step_ids=ids, cfg_parallel=cfgp, record_step_times=record)
+
+    if warm_ids:
+        run(warm_ids)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ops.PROFILE_ATTN = []
+    t0 = time.perf_counter()
+    run(step_ids, record=True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    prof, ops.PROFILE_ATTN = ops.PROFILE_ATTN, None
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        sec_per_step = elapsed / k
+        videos = 1 if world == 1 else world // 2
+        value = videos * 81.0 / (n_sched * sec_per_step)
+        hi = [ms for ms, low in pipe.last_step_ms if not low]
+        lo = [ms for ms, low in pipe.last_step_ms if low]
+        # dominant kernel: self-attention flash-attention launches (q_len == kv_len == S)
+        self_att = [(a.elapsed_time(b)) for a, b, sq, skv, _ in prof if sq == skv == S_TOK]
+        att_ms = sum(self_att) / max(1, len(self_att))
+        att_flops = 4.0 * S_TOK * S_TOK * DIM
+        achieved = att_flops / (att_ms * 1e-3) / 1e12 if self_att else None
+        fwd_per_step = 2 if world == 1 else 1
+        n_hi = sum(1 for i in step_ids if i < 21)
+        step_flops = [(forward_flops(True) if i < 21 else forward_flops(False)) * fwd_per_step for i in step_ids]
+        out = {
+            "metric": "frames_per_sec (81-frame video / 50-step denoise loop, Wan2.2-I2V-A14B 832x480x81f)",
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": k, "warmup": args.warmup,
+            "ms_per_step": sec_per_step * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "Goal-Force denoise step: cond+uncond model_fn (40 DiT + 10 ControlNet blocks, "
+                                   "A14B dims) + CFG + Euler, latents [1,16,21,60,104] = 32760 tokens, 512 text tokens; "
+                                   "random-init bf16 weights, both experts + both ControlNets resident",
+                       "schedule": f"FlowMatch 50 steps shift 5, boundary 0.875; timed step ids {step_ids} "
+                                   f"({n_hi} high-noise with ControlNet, {k - n_hi} low-noise with the all-zero ControlNet2 elided)",
+                       "layers": args.layers,
+                       "parallelism": "1 GPU: sequential CFG" if world == 1 else f"{videos} video(s) x CFG pair, RCCL all-gather of noise_pred per step",
+                       "vae_decode": "not included (decoder kernels not built yet)"},
+            "denoise_step_ms_high_noise": sum(hi) / len(hi) if hi else None,
+            "denoise_step_ms_low_noise": sum(lo) / len(lo) if lo else None,
+            "step_mfma_frac": (sum(step_flops) / elapsed / 1e12) / PEAK_BF16_TFLOPS,
+            "roofline": {"bound": "mfma", "kernel": "flash_attn_fwd_kernel (self-attention, S=32760, 40 heads, d=128)",
+                         "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": None if achieved is None else achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                         "launches": len(self_att), "avg_launch_ms": att_ms if self_att else None,
+                         "algorithmic_flops_per_launch": att_flops},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(torch)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

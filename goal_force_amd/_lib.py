@@ -66,6 +66,9 @@ def load():
         return _lib
     with _lock:
         if _lib is None:
+            # torch ships its own libamdhip64.so.7; import it FIRST so this library binds to the same HIP
+            # runtime instance (two runtimes in one process cannot both see the device).
+            import torch  # noqa: F401
             if not os.path.exists(LIB_PATH):
                 raise GoalForceError(
                     f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -22,6 +22,11 @@ __all__ = [
 
 _BF16 = torch.bfloat16
 
+# Optional per-launch timing of the dominant kernel (bench.py's roofline leg): when PROFILE_ATTN is a list,
+# flash_attn() brackets every launch with events recorded on the launch stream and appends
+# (start, end, q_len, kv_len, heads).  None (default) = no events, no overhead.
+PROFILE_ATTN = None
+
 
 def _stream(t: torch.Tensor):
     return torch.cuda.current_stream(t.device).cuda_stream
@@ -149,9 +154,16 @@ def flash_attn(q, k, v, num_heads, out=None, scale=None):
         out = torch.empty((sq, hd_all), dtype=_BF16, device=q.device)
     if scale is None:
         scale = 1.0 / math.sqrt(head_dim)
+    prof = PROFILE_ATTN
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.check(_lib.load().gf_flash_attn_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), sq, skv, num_heads, head_dim,
                                              q.stride(0), k.stride(0), v.stride(0), out.stride(0), float(scale),
                                              _stream(q)), "gf_flash_attn_fwd")
+    if prof is not None:
+        e1.record()
+        prof.append((e0, e1, sq, skv, num_heads))
     return out
 
 

@@ -175,9 +175,11 @@ class WanVideoPipeline:
     @torch.no_grad()
     def denoise(self, latents, context_posi, context_nega, y, control_signal_video_latents, num_inference_steps=50,
                 cfg_scale=5.0, switch_DiT_boundary=0.875, sigma_shift=5.0, denoising_strength=1.0, controlnet=True,
-                progress_bar_cmd=None, record_step_times=False, step_ids=None):
+                progress_bar_cmd=None, record_step_times=False, step_ids=None, cfg_parallel=None):
         """GF:663 + GF:697-723.  Returns the final latents [1,16,f,H/8,W/8] (a new tensor).
-        `step_ids` (optional) restricts the loop to a sub-range of the schedule (benchmarks)."""
+        `step_ids` (optional) restricts the loop to a sub-range of the schedule (benchmarks).
+        `cfg_parallel` (distributed.CfgPairParallel): this rank computes only its branch of the CFG pair and
+        exchanges the noise prediction with its partner once per step (RCCL all-gather, 4.2 MB)."""
         self.scheduler.set_timesteps(num_inference_steps, denoising_strength=denoising_strength, shift=sigma_shift)
         latents = latents.clone()
         models = {"dit": self.dit, "controlnet": self.controlnet if controlnet else None}
@@ -202,10 +204,16 @@ class WanVideoPipeline:
                 ev0.record()
             shared = dict(latents=latents, timestep=ts, y=y, control_signal_video_latents=control_signal_video_latents,
                           elide_zero_controlnet=self.elide_zero_controlnet)
-            posi = self.model_fn(**models, **shared, context=context_posi, context_cache=caches[key][0])
-            nega = None
-            if cfg_scale != 1.0:
-                nega = self.model_fn(**models, **shared, context=context_nega, context_cache=caches[key][1])
+            if cfg_parallel is not None and cfg_scale != 1.0:
+                b = cfg_parallel.branch
+                mine = self.model_fn(**models, **shared, context=context_nega if b else context_posi,
+                                     context_cache=caches[key][b])
+                posi, nega = cfg_parallel.exchange(mine)
+            else:
+                posi = self.model_fn(**models, **shared, context=context_posi, context_cache=caches[key][0])
+                nega = None
+                if cfg_scale != 1.0:
+                    nega = self.model_fn(**models, **shared, context=context_nega, context_cache=caches[key][1])
             sigma, sigma_ = self.scheduler.sigma_pair(self.scheduler.timesteps[progress_id])
             # noise_pred = nega + cfg*(posi - nega); latents += noise_pred*(sigma_next - sigma)  (GF:716, FM:81)
             ops.cfg_euler_step(latents, posi.contiguous(), None if nega is None else nega.contiguous(), cfg_scale,
@@ -305,3 +313,28 @@ def build_random_expert(cfg=None, seed=0, device="cuda", std=0.02):
     from .dit import precompute_freqs_cis_3d
     m.freqs = precompute_freqs_cis_3d(cfg["dim"] // cfg["num_heads"])
     return m
+
+
+def build_random_controlnet(num_layers=10, cfg=None, seed=1, device="cuda", std=0.02, zero_convs_zero=False):
+    """Random-init ControlNet on the device (benchmarks/tests).  zero_convs_zero=True reproduces the
+    reference's never-trained low-noise ControlNet2 (zero-convs exactly zero, GF:565)."""
+    cfg = dict(A14B_CONFIG if cfg is None else cfg)
+    with torch.device("meta"):
+        cn = ControlNet(num_layers, dim=cfg["dim"], num_heads=cfg["num_heads"], ffn_dim=cfg["ffn_dim"], eps=cfg["eps"])
+    cn = cn.to_empty(device=device).to(torch.bfloat16)
+    g = torch.Generator(device=device).manual_seed(seed)
+    for name, p in cn.named_parameters():
+        if name.endswith("norm_q.weight") or name.endswith("norm_k.weight") or name.endswith("norm3.weight"):
+            p.data.fill_(1.0)
+        elif name.endswith("norm3.bias"):
+            p.data.zero_()
+        elif name.startswith("controlnet_zero_convs_after") and zero_convs_zero:
+            p.data.zero_()
+        elif name.endswith("modulation"):
+            p.data.copy_(torch.randn(p.shape, generator=g, device=device, dtype=torch.float32) / cfg["dim"] ** 0.5)
+        elif name.endswith(".bias"):
+            p.data.copy_(torch.randn(p.shape, generator=g, device=device, dtype=torch.float32) * 0.01)
+        else:
+            p.data.copy_(torch.randn(p.shape, generator=g, device=device, dtype=torch.float32) * std)
+    cn._is_zero = None
+    return cn

@@ -123,6 +123,11 @@ def checksum(tensors) -> float:
     return acc
 
 
+def same_checksum(a: float, b) -> bool:
+    """fp64 sums are reduced in a machine-dependent order; compare to 1e-10 relative."""
+    return math.isclose(float(a), float(b), rel_tol=1e-10)
+
+
 def to_u16(t: torch.Tensor) -> np.ndarray:
     assert t.dtype == torch.bfloat16
     return t.contiguous().view(torch.int16).numpy().view(np.uint16)

@@ -43,7 +43,7 @@ def test_tiny_block_and_submodules_vs_goldens():
     cfg = gi.TINY
     sd = gi.block_sd(torch.Generator().manual_seed(11), cfg["dim"], cfg["ffn_dim"], "", BF)
     x, ctx, t_mod = gi.block_inputs(cfg["dim"], 72, gi.TINY_CTX_LEN, seed=12)
-    assert gi.checksum(sd) == float(g["ck_weights"]) and gi.checksum([x, ctx, t_mod]) == float(g["ck_inputs"])
+    assert gi.same_checksum(gi.checksum(sd), g["ck_weights"]) and gi.same_checksum(gi.checksum([x, ctx, t_mod]), g["ck_inputs"])
     blk = _block(cfg, sd)
     rope = _rope(cfg, (3, 4, 6))
     xg, cg, tg = x.cuda(), ctx.cuda(), t_mod.cuda()
@@ -60,7 +60,10 @@ def test_tiny_block_and_submodules_vs_goldens():
         ref_bf = _bf(g[f"{k}_bf16"])
         e = rel_l2(got.cpu().float(), f32)
         e_ref = rel_l2(ref_bf.float(), f32)
-        assert e < 5e-3 and e < 2 * e_ref + 1e-4, f"{k}: rel_l2 vs fp32 {e:.3e} (reference bf16 itself {e_ref:.3e})"
+        # bar: <= 5e-3 for the block, and never worse than 1.25x the reference-bf16's own error vs fp32 math
+        # (at this tiny width the reference's self-attention alone already sits at 5.3e-3)
+        lim = 5e-3 if k == "block" else 1e-2
+        assert e < lim and e < 1.25 * e_ref + 1e-4, f"{k}: rel_l2 vs fp32 {e:.3e} (reference bf16 itself {e_ref:.3e})"
     # the block must not modify its input
     assert torch.equal(xg.cpu(), x)
 
@@ -91,7 +94,7 @@ def test_mid_block_vs_golden():
     grid = (5, 12, 16)
     sd = gi.block_sd(torch.Generator().manual_seed(21), cfg["dim"], cfg["ffn_dim"], "", BF)
     x, ctx, t_mod = gi.block_inputs(cfg["dim"], 960, 512, seed=22)
-    assert gi.checksum(sd) == float(g["ck_weights"]) and gi.checksum([x, ctx, t_mod]) == float(g["ck_inputs"])
+    assert gi.same_checksum(gi.checksum(sd), g["ck_weights"]) and gi.same_checksum(gi.checksum([x, ctx, t_mod]), g["ck_inputs"])
     got = _block(cfg, sd)(x.cuda(), ctx.cuda(), t_mod.cuda(), _rope(cfg, grid))
     rows = torch.from_numpy(g["rows"])
     e32 = rel_l2(got.cpu().float()[0][rows], torch.from_numpy(g["f32_rows"]))
@@ -108,7 +111,7 @@ def test_a14b_block_config1_vs_golden():
     grid = (9, 30, 52)
     sd = gi.block_sd(torch.Generator().manual_seed(31), cfg["dim"], cfg["ffn_dim"], "", BF)
     x, ctx, t_mod = gi.block_inputs(cfg["dim"], 14040, 512, seed=32)
-    assert gi.checksum(sd) == float(g["ck_weights"]) and gi.checksum([x, ctx, t_mod]) == float(g["ck_inputs"])
+    assert gi.same_checksum(gi.checksum(sd), g["ck_weights"]) and gi.same_checksum(gi.checksum([x, ctx, t_mod]), g["ck_inputs"])
     got = _block(cfg, sd)(x.cuda(), ctx.cuda(), t_mod.cuda(), _rope(cfg, grid))
     e_rows, e_norm = _check_sparse(got, g, "a14b")
     # both sides carry ~3e-3 of bf16 noise vs exact math, so their mutual distance is ~sqrt(2) of that
@@ -162,7 +165,11 @@ def test_three_step_cfg_loop_vs_golden():
     f32 = torch.from_numpy(g["loop3_f32"])
     e = rel_l2(lat.cpu().float(), f32)
     e_ref = rel_l2(_bf(g["loop3_bf16"]).float(), f32)
-    assert e < 2e-2 and e < 2 * e_ref + 1e-3, f"vs fp32 {e:.3e} (reference bf16 {e_ref:.3e})"
+    # CFG x5 over 3 steps of a random tiny model amplifies bf16 noise: the reference's own bf16 run is 0.153
+    # away from its fp32 run, so the SURVEY's 2e-2 guess is unattainable by the reference itself.  Bar: not
+    # measurably worse than the reference (<= 1.25x its own error) and within 2x of it from the bf16 golden.
+    e_bf = rel_l2(lat.cpu().float(), _bf(g["loop3_bf16"]).float())
+    assert e < 1.25 * e_ref + 1e-3 and e_bf < 2 * e_ref, f"vs fp32 {e:.3e}, vs ref-bf16 {e_bf:.3e} (reference bf16 vs fp32 {e_ref:.3e})"
     # context K/V caching and ControlNet2 elision must not change a single bit
     pipe.elide_zero_controlnet = False
     lat2 = pipe.denoise(inp["latents"], inp["ctx_posi"], inp["ctx_nega"], inp["y"], inp["control"],
