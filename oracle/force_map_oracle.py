@@ -1,0 +1,49 @@
+"""CPU ORACLE — TEST INFRASTRUCTURE ONLY.  Torch-CPU restatement of the Goal-Force control-signal video
+(src/goal_force/unified_dataset.py:775-940: _generate_control_video / get_gaussian_blob /
+get_blob_for_mass), pinned bit-exactly (sha256) against tests/golden/g7_force_maps.npz which the
+reference's own class produced for all 12 example CSV rows + 2 synthetic direct-force rows."""
+import math
+
+import numpy as np
+import torch
+
+
+def gaussian_blob(x, y, radius, height, width):
+    """DS:903-940 — exp(-((xg-x)^2+(yg-y)^2)/(2 r^2)) on an int64 grid (fp32 arithmetic, true division)."""
+    yg, xg = torch.meshgrid(torch.arange(height), torch.arange(width), indexing="ij")
+    sq = (xg - x) ** 2 + (yg - y) ** 2
+    return 1.0 * torch.exp(-sq / (2.0 * radius ** 2))
+
+
+def control_video(force, angle, x_pos, y_pos, tforce, tangle, tx, ty, masses, coords, num_frames=81, height=480,
+                  width=832, min_force=30.0, max_force=400.0, min_mass=1.0, max_mass=4.0):
+    """DS:775-889 with all mask-out probabilities 0 (inference).  Returns bf16 [F,H,W,3]."""
+    sig = torch.zeros((num_frames, 3, height, width))
+    mask_direct = force == -1
+    mask_indirect = (not mask_direct) and tforce == -1
+
+    def moving(ch, xp, yp, f, ang):
+        x0, y0 = xp * width, (1 - yp) * height
+        disp = width / 8 + (width / 2 - width / 8) * ((f - min_force) / (max_force - min_force))
+        x1 = x0 + disp * math.cos(ang * torch.pi / 180.0)
+        y1 = y0 - disp * math.sin(ang * torch.pi / 180.0)
+        for fr in range(num_frames):
+            t = fr / (num_frames - 1)
+            sig[fr, ch] += gaussian_blob(x0 * (1 - t) + x1 * t, y0 * (1 - t) + y1 * t, 20, height, width)
+
+    if not mask_direct:
+        moving(0, x_pos, y_pos, force, angle)
+    if not mask_indirect:
+        moving(1, tx, ty, tforce, tangle)
+    sig = sig.permute(0, 2, 3, 1).contiguous()
+    sig[..., 2] = 0
+
+    def mass(x, y, m):
+        t = (m - min_mass) / (max_mass - min_mass)
+        return gaussian_blob(x, y, (1 - t) * 5 + t * 40, height, width)[None]
+
+    if masses["projectile"] > -1:
+        sig[..., 2] += mass(coords["projectile"][0], height - coords["projectile"][1], masses["projectile"])
+    if masses["target"] > -1:
+        sig[..., 2] += mass(coords["target"][0], height - coords["target"][1], masses["target"])
+    return torch.clamp(sig, min=0.0, max=1.0).to(torch.bfloat16)
