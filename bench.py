@@ -14,7 +14,7 @@ ControlNets resident, random-init bf16 weights, synthetic inputs already in HBM.
 
 The K timed steps are spread evenly over the real 50-step / shift-5 schedule so they contain the
 schedule's mix of high-noise (with ControlNet) and low-noise (zero ControlNet2 elided, bit-identical)
-steps.  value = frames/s of the denoising loop = videos * 81 / (50 * seconds_per_step).
+steps.  value = frames/s = videos * 81 / (50 * seconds_per_step + measured tiled VAE decode seconds).
 
 N = 1: one video, CFG pair evaluated sequentially.  N >= 2 (even): rank r -> video r//2, CFG branch r%2,
 one RCCL all-gather of the 4.2 MB noise prediction per step inside each pair (weak scaling in videos).
@@ -98,7 +98,10 @@ def main():
     dit2 = build_random_expert(cfg, seed=200, device=dev)
     cn = build_random_controlnet(n_cn, cfg, seed=300, device=dev)
     cn2 = build_random_controlnet(n_cn, cfg, seed=400, device=dev, zero_convs_zero=True)
-    pipe = WanVideoPipeline.from_modules(dit, dit2, cn, cn2, device=dev)
+    from goal_force_amd.vae import WanVideoVAE
+    torch.manual_seed(7)
+    vae = WanVideoVAE().to(torch.bfloat16).to(dev)   # real Wan VAE architecture, random-init decoder weights
+    pipe = WanVideoPipeline.from_modules(dit, dit2, cn, cn2, vae=vae, device=dev)
 
     # synthetic conditioning, per-video seed
     g = torch.Generator().manual_seed(1000 + sample)
@@ -138,6 +141,15 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     prof, ops.PROFILE_ATTN = ops.PROFILE_ATTN, None
+    # VAE tiled decode of one video (GF:733; tile (30,52)/(15,26)), timed after the K steps: 1 warm-up + 1 timed
+    zlat = pipe.generate_noise((1, 16, 21, 60, 104), seed=11)
+    vae.decode(zlat, tiled=True, tile_size=(30, 52), tile_stride=(15, 26))
+    torch.cuda.synchronize()
+    tv = time.perf_counter()
+    frames = vae.decode(zlat, tiled=True, tile_size=(30, 52), tile_stride=(15, 26))
+    torch.cuda.synchronize()
+    vae_s = time.perf_counter() - tv
+    assert tuple(frames.shape) == (1, 3, 81, 480, 832)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -146,7 +158,8 @@ def main():
     if rank == 0:
         sec_per_step = elapsed / k
         videos = 1 if world == 1 else world // 2
-        value = videos * 81.0 / (n_sched * sec_per_step)
+        loop_s = n_sched * sec_per_step
+        value = videos * 81.0 / (loop_s + vae_s)
         hi = [ms for ms, low in pipe.last_step_ms if not low]
         lo = [ms for ms, low in pipe.last_step_ms if low]
         # dominant kernel: self-attention flash-attention launches (q_len == kv_len == S)
@@ -158,7 +171,7 @@ def main():
         n_hi = sum(1 for i in step_ids if i < 21)
         step_flops = [(forward_flops(True) if i < 21 else forward_flops(False)) * fwd_per_step for i in step_ids]
         out = {
-            "metric": "frames_per_sec (81-frame video / 50-step denoise loop, Wan2.2-I2V-A14B 832x480x81f)",
+            "metric": "frames_per_sec (81-frame video / (50-step denoise loop + VAE decode), Wan2.2-I2V-A14B 832x480x81f)",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": k, "warmup": args.warmup,
             "ms_per_step": sec_per_step * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
@@ -169,7 +182,10 @@ def main():
                                    f"({n_hi} high-noise with ControlNet, {k - n_hi} low-noise with the all-zero ControlNet2 elided)",
                        "layers": args.layers,
                        "parallelism": "1 GPU: sequential CFG" if world == 1 else f"{videos} video(s) x CFG pair, RCCL all-gather of noise_pred per step",
-                       "vae_decode": "not included (decoder kernels not built yet)"},
+                       "vae_decode": "tiled (30,52)/(15,26) decode of [1,16,21,60,104] on the HIP kernels, measured after the "
+                                     "timed steps and included in value: frames/s = videos*81 / (50*s_per_step + vae_s)"},
+            "vae_decode_s": vae_s, "denoise_loop_s_50_steps": loop_s,
+            "frames_per_sec_denoise_only": videos * 81.0 / loop_s,
             "denoise_step_ms_high_noise": sum(hi) / len(hi) if hi else None,
             "denoise_step_ms_low_noise": sum(lo) / len(lo) if lo else None,
             "step_mfma_frac": (sum(step_flops) / elapsed / 1e12) / PEAK_BF16_TFLOPS,

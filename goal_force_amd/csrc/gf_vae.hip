@@ -1,0 +1,285 @@
+// gf_vae.hip — data-movement / normalisation kernels of the Wan 3-D causal VAE decoder
+// (reference diffsynth/models/wan_video_vae.py: CausalConv3d 33-52, RMS_norm 55-70, Resample 82-174,
+// ResidualBlock 267-301, AttentionBlock 304-342, Decoder3d 736-838, VideoVAE_.decode 1011-1034,
+// WanVideoVAE.tiled_decode 1103-1152).
+//
+// Layout: decoder activations are channels-last [T, H, W, C] bf16, so a pixel's channel vector is one
+// contiguous row.  Every convolution is  patch-gather (this file)  +  the MFMA GEMM of gf_gemm.hip with the
+// weight pre-permuted to [Cout, (dt, dy, dx, cin)]:
+//   * causal 3x3x3 / 3x1x1 convs read their 2-frame temporal halo from the per-layer feature cache
+//     (the reference's feat_cache with CACHE_T = 2; an all-zero cache == "no cache yet" zero padding);
+//   * the nearest-exact 2x upsample of Resample is folded into the gather of the following 3x3 conv.
+// All kernels are HBM-bound: 16 bytes per lane, one pixel row per wave where a reduction is needed.
+#include "gf_common.h"
+
+namespace {
+
+constexpr int VT = 256;
+static inline unsigned vgrid(long items) {
+    long b = (items + VT - 1) / VT;
+    if (b < 1) b = 1;
+    if (b > 256 * 16) b = 256 * 16;
+    return (unsigned)b;
+}
+
+// z (NCTHW slice, arbitrary strides) -> channels-last [T,H,W,cpad]: bf16(bf16(z / inv_std) + mean)
+// (VideoVAE_.decode VAE:1014-1020 with scale = [mean, 1/std] cast to bf16), channels >= C zero.
+__global__ __launch_bounds__(VT) void prep_latent_kernel(const u16* __restrict__ z, long sc, long st, long sy, long sx,
+                                                         const u16* __restrict__ mean, const u16* __restrict__ inv_std,
+                                                         u16* __restrict__ out, int C, int T, int H, int W, int cpad) {
+    const long total = (long)T * H * W * cpad;
+    const long stride = (long)gridDim.x * VT;
+    for (long i = (long)blockIdx.x * VT + threadIdx.x; i < total; i += stride) {
+        const int c = (int)(i % cpad);
+        long p = i / cpad;
+        const int x = (int)(p % W);
+        p /= W;
+        const int y = (int)(p % H);
+        const int t = (int)(p / H);
+        u16 v = 0;
+        if (c < C) {
+            const float zz = bf2f(z[c * sc + t * st + y * sy + x * sx]);
+            v = f2bf(rbf(zz / bf2f(inv_std[c])) + bf2f(mean[c]));
+        }
+        out[i] = v;
+    }
+}
+
+// Patch gather for conv-as-GEMM.  out[(t, Y, X), ((dt*ks + dy)*ks + dx)*C + c] with zero fill for spatial
+// padding, temporal history from `cache` (2 frames) and the K padding columns.  up2: the conv runs on the
+// nearest-2x-upsampled image (source pixel = (Y', X') >> 1).  One thread per 16-byte chunk (8 channels).
+__global__ __launch_bounds__(VT) void im2col_kernel(const u16* __restrict__ src, const u16* __restrict__ cache,
+                                                    u16* __restrict__ out, int T, int H, int W, int C, int kt, int ks,
+                                                    int up2, int kpad) {
+    const int Ho = up2 ? 2 * H : H, Wo = up2 ? 2 * W : W;
+    const int cpc = C >> 3;                  // chunks per tap
+    const int kchunks = kpad >> 3;           // chunks per output row
+    const int taps = kt * ks * ks;
+    const long rows = (long)T * Ho * Wo;
+    const long total = rows * kchunks;
+    const long frame = (long)H * W * C;
+    const int half = ks >> 1;
+    const long stride = (long)gridDim.x * VT;
+    for (long i = (long)blockIdx.x * VT + threadIdx.x; i < total; i += stride) {
+        const int kc = (int)(i % kchunks);
+        const long row = i / kchunks;
+        u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int tap = kc / cpc;
+        if (tap < taps) {
+            const int c8 = kc - tap * cpc;
+            const int dx = tap % ks, dy = (tap / ks) % ks, dt = tap / (ks * ks);
+            const int X = (int)(row % Wo);
+            const int Y = (int)((row / Wo) % Ho);
+            const int t = (int)(row / ((long)Wo * Ho));
+            const int yy = Y + dy - half, xx = X + dx - half;
+            if (yy >= 0 && yy < Ho && xx >= 0 && xx < Wo) {
+                const int sy = up2 ? (yy >> 1) : yy, sx = up2 ? (xx >> 1) : xx;
+                const int f = t - (kt - 1) + dt;  // causal: taps reach kt-1 frames into the past
+                const u16* base = (f >= 0) ? (src + (long)f * frame) : (cache + (long)(2 + f) * frame);
+                v = *reinterpret_cast<const u16x8*>(base + ((long)sy * W + sx) * C + (c8 << 3));
+            }
+        }
+        *reinterpret_cast<u16x8*>(out + row * kpad + ((long)kc << 3)) = v;
+    }
+}
+
+// RMS_norm (VAE:55-70): F.normalize(x, dim=channel) * sqrt(C) * gamma, then optional SiLU; every eager op of
+// the reference rounds to bf16 and so do we.  One wave per pixel row (C <= 512), 4 rows per workgroup.
+__global__ __launch_bounds__(VT) void rmsnorm_silu_kernel(const u16* __restrict__ x, const u16* __restrict__ gamma,
+                                                          u16* __restrict__ out, long rows, int C, float scale,
+                                                          int silu) {
+    const int lane = threadIdx.x & 63;
+    const long row0 = (long)blockIdx.x * (VT / 64) + (threadIdx.x >> 6);
+    const long rstride = (long)gridDim.x * (VT / 64);
+    const int nch = C >> 3;
+    for (long row = row0; row < rows; row += rstride) {
+        u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        float s = 0.f;
+        if (lane < nch) {
+            v = *reinterpret_cast<const u16x8*>(x + row * C + (lane << 3));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float f = bf2f(v[j]);
+                s += f * f;
+            }
+        }
+        s = wave_sum(s);
+        const float nrm = fmaxf(rbf(sqrtf(s)), 1e-12f);  // x.norm(2, dim).clamp_min(eps), bf16 tensor
+        if (lane < nch) {
+            const u16x8 g8 = *reinterpret_cast<const u16x8*>(gamma + (lane << 3));
+            u16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float y = rbf(bf2f(v[j]) / nrm);   // x / norm
+                y = rbf(y * scale);                // * dim**0.5
+                y = rbf(y * bf2f(g8[j]));          // * gamma  (+ bias 0.)
+                if (silu) y = y / (1.0f + expf(-y));
+                o[j] = f2bf(y);
+            }
+            *reinterpret_cast<u16x8*>(out + row * C + (lane << 3)) = o;
+        }
+    }
+}
+
+// out[r, :ncols] = softmax(x[r, :ncols] * scale) (fp32 math, bf16 out), out[r, ncols:ldo] = 0.
+// One workgroup per row.  (AttentionBlock's single-head SDPA over h*w tokens, VAE:326-333.)
+__global__ __launch_bounds__(VT) void softmax_rows_kernel(const u16* __restrict__ x, long ldx, u16* __restrict__ out,
+                                                          long ldo, int ncols, float scale) {
+    __shared__ float red[VT / 64];
+    const long row = blockIdx.x;
+    const u16* xr = x + row * ldx;
+    float mx = -INFINITY;
+    for (int c = threadIdx.x; c < ncols; c += VT) mx = fmaxf(mx, bf2f(xr[c]) * scale);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float s = 0.f;
+    for (int c = threadIdx.x; c < ncols; c += VT) s += expf(bf2f(xr[c]) * scale - mx);
+    const float tot = block_sum<VT>(s, red);
+    const float inv = 1.0f / tot;
+    u16* orow = out + row * ldo;
+    for (int c = threadIdx.x; c < (int)ldo; c += VT)
+        orow[c] = c < ncols ? f2bf(expf(bf2f(xr[c]) * scale - mx) * inv) : (u16)0;
+}
+
+// dst[c, r] = src[r, c] for r < R (zero for R <= r < rpad); 32x32 tiles through LDS.
+__global__ __launch_bounds__(VT) void transpose_pad_kernel(const u16* __restrict__ src, long lds_, u16* __restrict__ dst,
+                                                           int R, int C, int rpad) {
+    __shared__ u16 tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    for (int j = ty; j < 32; j += 8) {
+        const int r = r0 + j, c = c0 + tx;
+        tile[j][tx] = (r < R && c < C) ? src[(long)r * lds_ + c] : (u16)0;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, r = r0 + tx;
+        if (c < C && r < rpad) dst[(long)c * rpad + r] = tile[tx][j];
+    }
+}
+
+// Tile blend accumulate (WanVideoVAE.tiled_decode VAE:1128-1150, bf16 accumulators):
+//   values[c,t,Y,X] += tile[t,y,x,c] * mask(y,x);  weight[Y,X] += mask(y,x)
+// mask = min(ramp_h(y), ramp_w(x)) with ramps (i+1)/border on non-boundary sides (build_mask VAE:1081-1100).
+__global__ __launch_bounds__(VT) void tile_blend_kernel(u16* __restrict__ values, u16* __restrict__ weight,
+                                                        const u16* __restrict__ tile, int T, int th, int tw, int tc,
+                                                        int H, int W, int y0, int x0, int top, int bottom, int left,
+                                                        int right, int bh, int bw) {
+    const long total = (long)T * th * tw;
+    const long stride = (long)gridDim.x * VT;
+    for (long i = (long)blockIdx.x * VT + threadIdx.x; i < total; i += stride) {
+        const int x = (int)(i % tw);
+        const int y = (int)((i / tw) % th);
+        const int t = (int)(i / ((long)tw * th));
+        float mh = 1.f, mw = 1.f;
+        if (!top && y < bh) mh = (float)(y + 1) / (float)bh;
+        if (!bottom && y >= th - bh) mh = (float)(th - y) / (float)bh;
+        if (!left && x < bw) mw = (float)(x + 1) / (float)bw;
+        if (!right && x >= tw - bw) mw = (float)(tw - x) / (float)bw;
+        const float m = rbf(fminf(mh, mw));  // mask.to(bf16)
+        const long pix = (long)(y0 + y) * W + (x0 + x);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            u16* vp = values + ((long)c * T + t) * H * W + pix;
+            *vp = f2bf(bf2f(*vp) + rbf(bf2f(tile[i * tc + c]) * m));
+        }
+        if (t == 0) weight[pix] = f2bf(bf2f(weight[pix]) + m);
+    }
+}
+
+// values = clamp(values / weight, -1, 1)   (VAE:1149-1151)
+__global__ __launch_bounds__(VT) void tile_finalize_kernel(u16* __restrict__ values, const u16* __restrict__ weight,
+                                                           long planes, long hw) {
+    const long total = planes * hw;
+    const long stride = (long)gridDim.x * VT;
+    for (long i = (long)blockIdx.x * VT + threadIdx.x; i < total; i += stride) {
+        const float v = rbf(bf2f(values[i]) / bf2f(weight[i % hw]));
+        values[i] = f2bf(fminf(fmaxf(v, -1.f), 1.f));
+    }
+}
+
+}  // namespace
+
+extern "C" GF_API int gf_vae_prep_latent(const void* z, int64_t sc, int64_t st, int64_t sy, int64_t sx,
+                                         const void* mean, const void* inv_std, void* out, int64_t C, int64_t T,
+                                         int64_t H, int64_t W, int64_t cpad, void* stream) {
+    GF_CHECK_ARG(z && mean && inv_std && out && C > 0 && cpad >= C && T > 0 && H > 0 && W > 0,
+                 "gf_vae_prep_latent: bad arguments");
+    hipLaunchKernelGGL(prep_latent_kernel, dim3(vgrid(T * H * W * cpad)), dim3(VT), 0, (hipStream_t)stream,
+                       (const u16*)z, (long)sc, (long)st, (long)sy, (long)sx, (const u16*)mean, (const u16*)inv_std,
+                       (u16*)out, (int)C, (int)T, (int)H, (int)W, (int)cpad);
+    GF_CHECK_LAUNCH("gf_vae_prep_latent");
+    return GF_OK;
+}
+
+extern "C" GF_API int gf_vae_im2col(const void* src, const void* cache, void* out, int64_t T, int64_t H, int64_t W,
+                                    int64_t C, int64_t kt, int64_t ks, int upsample2x, int64_t kpad, void* stream) {
+    GF_CHECK_ARG(src && out && T > 0 && H > 0 && W > 0, "gf_vae_im2col: bad arguments");
+    GF_CHECK_ARG(C > 0 && C % 8 == 0 && kpad % 8 == 0 && kpad >= kt * ks * ks * C,
+                 "gf_vae_im2col: C=%ld must be a multiple of 8 and kpad=%ld >= taps*C", (long)C, (long)kpad);
+    GF_CHECK_ARG((kt == 1 || kt == 3) && (ks == 1 || ks == 3), "gf_vae_im2col: kernel must be 1 or 3 per axis");
+    GF_CHECK_ARG(kt == 1 || cache, "gf_vae_im2col: a temporal kernel needs the 2-frame cache (zeros = no history)");
+    GF_CHECK_ARG(gf_aligned16(src) && gf_aligned16(out) && (!cache || gf_aligned16(cache)),
+                 "gf_vae_im2col: 16-byte alignment required");
+    const long rows = T * H * W * (upsample2x ? 4 : 1);
+    hipLaunchKernelGGL(im2col_kernel, dim3(vgrid(rows * (kpad / 8))), dim3(VT), 0, (hipStream_t)stream,
+                       (const u16*)src, (const u16*)cache, (u16*)out, (int)T, (int)H, (int)W, (int)C, (int)kt, (int)ks,
+                       upsample2x ? 1 : 0, (int)kpad);
+    GF_CHECK_LAUNCH("gf_vae_im2col");
+    return GF_OK;
+}
+
+extern "C" GF_API int gf_vae_rmsnorm_silu(const void* x, const void* gamma, void* out, int64_t rows, int64_t C,
+                                          int silu, void* stream) {
+    GF_CHECK_ARG(x && gamma && out && rows >= 0, "gf_vae_rmsnorm_silu: bad arguments");
+    GF_CHECK_ARG(C > 0 && C % 8 == 0 && C <= 512, "gf_vae_rmsnorm_silu: C=%ld must be a multiple of 8 and <= 512", (long)C);
+    GF_CHECK_ARG(gf_aligned16(x) && gf_aligned16(out) && gf_aligned16(gamma), "gf_vae_rmsnorm_silu: alignment");
+    if (rows == 0) return GF_OK;
+    hipLaunchKernelGGL(rmsnorm_silu_kernel, dim3(vgrid(rows * 64)), dim3(VT), 0, (hipStream_t)stream, (const u16*)x,
+                       (const u16*)gamma, (u16*)out, (long)rows, (int)C, sqrtf((float)C), silu ? 1 : 0);
+    GF_CHECK_LAUNCH("gf_vae_rmsnorm_silu");
+    return GF_OK;
+}
+
+extern "C" GF_API int gf_softmax_rows(const void* x, int64_t ldx, void* out, int64_t ldo, int64_t rows, int64_t ncols,
+                                      float scale, void* stream) {
+    GF_CHECK_ARG(x && out && rows >= 0 && ncols > 0 && ldx >= ncols && ldo >= ncols, "gf_softmax_rows: bad arguments");
+    if (rows == 0) return GF_OK;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(VT), 0, (hipStream_t)stream, (const u16*)x,
+                       (long)ldx, (u16*)out, (long)ldo, (int)ncols, scale);
+    GF_CHECK_LAUNCH("gf_softmax_rows");
+    return GF_OK;
+}
+
+extern "C" GF_API int gf_transpose_pad(const void* src, int64_t ld_src, void* dst, int64_t R, int64_t C, int64_t rpad,
+                                       void* stream) {
+    GF_CHECK_ARG(src && dst && R > 0 && C > 0 && rpad >= R && ld_src >= C, "gf_transpose_pad: bad arguments");
+    hipLaunchKernelGGL(transpose_pad_kernel, dim3((unsigned)((rpad + 31) / 32), (unsigned)((C + 31) / 32)), dim3(VT), 0,
+                       (hipStream_t)stream, (const u16*)src, (long)ld_src, (u16*)dst, (int)R, (int)C, (int)rpad);
+    GF_CHECK_LAUNCH("gf_transpose_pad");
+    return GF_OK;
+}
+
+extern "C" GF_API int gf_vae_tile_blend(void* values, void* weight, const void* tile, int64_t T, int64_t th, int64_t tw,
+                                        int64_t tc, int64_t H, int64_t W, int64_t y0, int64_t x0, int top, int bottom,
+                                        int left, int right, int64_t border_h, int64_t border_w, void* stream) {
+    GF_CHECK_ARG(values && weight && tile && T > 0 && th > 0 && tw > 0 && tc >= 3, "gf_vae_tile_blend: bad arguments");
+    GF_CHECK_ARG(y0 >= 0 && x0 >= 0 && y0 + th <= H && x0 + tw <= W, "gf_vae_tile_blend: tile outside the frame");
+    GF_CHECK_ARG(border_h > 0 && border_w > 0, "gf_vae_tile_blend: borders must be positive");
+    hipLaunchKernelGGL(tile_blend_kernel, dim3(vgrid(T * th * tw)), dim3(VT), 0, (hipStream_t)stream, (u16*)values,
+                       (u16*)weight, (const u16*)tile, (int)T, (int)th, (int)tw, (int)tc, (int)H, (int)W, (int)y0,
+                       (int)x0, top, bottom, left, right, (int)border_h, (int)border_w);
+    GF_CHECK_LAUNCH("gf_vae_tile_blend");
+    return GF_OK;
+}
+
+extern "C" GF_API int gf_vae_tile_finalize(void* values, const void* weight, int64_t planes, int64_t hw, void* stream) {
+    GF_CHECK_ARG(values && weight && planes > 0 && hw > 0, "gf_vae_tile_finalize: bad arguments");
+    hipLaunchKernelGGL(tile_finalize_kernel, dim3(vgrid(planes * hw)), dim3(VT), 0, (hipStream_t)stream, (u16*)values,
+                       (const u16*)weight, (long)planes, (long)hw);
+    GF_CHECK_LAUNCH("gf_vae_tile_finalize");
+    return GF_OK;
+}

@@ -248,3 +248,88 @@ def force_map(frames, H, W, channels, params, centers, clamp01, device):
                                         _ptr(params) if n else None, _ptr(centers) if n else None, n,
                                         1 if clamp01 else 0, _stream(out)), "gf_force_map")
     return out
+
+
+# ---------------------------------------------------------------------------------- VAE decoder kernels
+def vae_prep_latent(z_slice, mean, inv_std, cpad=64):
+    """z_slice: [C,T,H,W] bf16 view (any strides) -> channels-last [T,H,W,cpad], un-normalised."""
+    _req(z_slice, "vae_prep_latent.z")
+    _req(mean, "vae_prep_latent.mean")
+    _req(inv_std, "vae_prep_latent.inv_std")
+    C, T, H, W = z_slice.shape
+    out = torch.empty((T, H, W, cpad), dtype=_BF16, device=z_slice.device)
+    sc, st, sy, sx = z_slice.stride()
+    _lib.check(_lib.load().gf_vae_prep_latent(_ptr(z_slice), sc, st, sy, sx, _ptr(mean), _ptr(inv_std), _ptr(out), C, T,
+                                              H, W, cpad, _stream(z_slice)), "gf_vae_prep_latent")
+    return out
+
+
+def vae_im2col(src, cache, kt, ks, kpad, upsample2x=False):
+    """src [T,H,W,C] (+cache [2,H,W,C]) -> [T*Ho*Wo, kpad] patch matrix."""
+    _req(src, "vae_im2col.src")
+    if not src.is_contiguous():
+        raise GoalForceError("vae_im2col.src must be contiguous [T,H,W,C]")
+    T, H, W, C = src.shape
+    if cache is not None:
+        _req(cache, "vae_im2col.cache")
+        if tuple(cache.shape) != (2, H, W, C) or not cache.is_contiguous():
+            raise GoalForceError(f"vae_im2col.cache must be contiguous [2,{H},{W},{C}]")
+    rows = T * H * W * (4 if upsample2x else 1)
+    out = torch.empty((rows, kpad), dtype=_BF16, device=src.device)
+    _lib.check(_lib.load().gf_vae_im2col(_ptr(src), _ptr(cache), _ptr(out), T, H, W, C, kt, ks, 1 if upsample2x else 0,
+                                         kpad, _stream(src)), "gf_vae_im2col")
+    return out
+
+
+def vae_rmsnorm_silu(x, gamma, silu=True):
+    """x [..., C] channels-last -> RMS_norm(+SiLU), same shape."""
+    _req(x, "vae_rmsnorm_silu.x")
+    _req(gamma, "vae_rmsnorm_silu.gamma")
+    if not x.is_contiguous() or gamma.numel() != x.shape[-1]:
+        raise GoalForceError("vae_rmsnorm_silu: x must be contiguous and gamma match the channel dim")
+    out = torch.empty_like(x)
+    C = x.shape[-1]
+    _lib.check(_lib.load().gf_vae_rmsnorm_silu(_ptr(x), _ptr(gamma), _ptr(out), x.numel() // C, C, 1 if silu else 0,
+                                               _stream(x)), "gf_vae_rmsnorm_silu")
+    return out
+
+
+def softmax_rows(x, scale, ldo):
+    _req(x, "softmax_rows.x")
+    if x.dim() != 2 or x.stride(1) != 1:
+        raise GoalForceError("softmax_rows.x must be 2-D with contiguous rows")
+    out = torch.empty((x.shape[0], ldo), dtype=_BF16, device=x.device)
+    _lib.check(_lib.load().gf_softmax_rows(_ptr(x), x.stride(0), _ptr(out), ldo, x.shape[0], x.shape[1], float(scale),
+                                           _stream(x)), "gf_softmax_rows")
+    return out
+
+
+def transpose_pad(x, rpad):
+    _req(x, "transpose_pad.x")
+    if x.dim() != 2 or x.stride(1) != 1:
+        raise GoalForceError("transpose_pad.x must be 2-D with contiguous rows")
+    R, C = x.shape
+    out = torch.empty((C, rpad), dtype=_BF16, device=x.device)
+    _lib.check(_lib.load().gf_transpose_pad(_ptr(x), x.stride(0), _ptr(out), R, C, rpad, _stream(x)), "gf_transpose_pad")
+    return out
+
+
+def vae_tile_blend(values, weight, tile, y0, x0, bounds, border):
+    """values [3,T,H,W], weight [H,W], tile [T,th,tw,tc] channels-last; bounds=(top,bottom,left,right)."""
+    for n, t in (("values", values), ("weight", weight), ("tile", tile)):
+        _req(t, f"vae_tile_blend.{n}")
+        if not t.is_contiguous():
+            raise GoalForceError(f"vae_tile_blend.{n} must be contiguous")
+    _, T, H, W = values.shape
+    Tt, th, tw, tc = tile.shape
+    if Tt != T or tuple(weight.shape) != (H, W):
+        raise GoalForceError("vae_tile_blend: shape mismatch")
+    _lib.check(_lib.load().gf_vae_tile_blend(_ptr(values), _ptr(weight), _ptr(tile), T, th, tw, tc, H, W, y0, x0,
+                                             int(bounds[0]), int(bounds[1]), int(bounds[2]), int(bounds[3]),
+                                             border[0], border[1], _stream(values)), "gf_vae_tile_blend")
+
+
+def vae_tile_finalize(values, weight):
+    _lib.check(_lib.load().gf_vae_tile_finalize(_ptr(values), _ptr(weight), values.shape[0] * values.shape[1],
+                                                weight.numel(), _stream(values)), "gf_vae_tile_finalize")
+    return values

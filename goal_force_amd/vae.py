@@ -1,0 +1,342 @@
+"""WanVideoVAE (Wan2.1 VAE, z=16, base dim 96) — decoder path on the HIP kernels.
+
+Drop-in surface: `WanVideoVAE.decode(hidden_states, device, tiled, tile_size,
+tile_stride) -> [B,3,T,H,W]` in [-1,1], `.upsampling_factor = 8`, `.model.z_dim = 16`, state_dict keys of the
+reference (`model.decoder.*`, `model.conv2.*`; diffsynth/models/wan_video_vae.py, "VAE").  The encoder
+(`model.encoder.*`, `model.conv1.*`) is a 'next' row — its keys are accepted and ignored on load.
+
+How the reference's algorithm maps here
+  * VideoVAE_.decode (VAE:1011-1034) decodes latent frame by latent frame through Decoder3d with a per-conv
+    feature cache of the last CACHE_T=2 input frames.  We keep exactly that streaming structure: every
+    causal conv owns a [2,H,W,C] cache (all-zero = the reference's `None`, i.e. zero temporal padding) and
+    after each chunk stores the last two frames of (cache ++ input) — the same rule as VAE:283-294 incl.
+    the `cache_x.shape[2] < 2` branch.
+  * the 'Rep' sentinel of upsample3d (VAE:125-153): the first chunk skips time_conv (no temporal
+    doubling), so chunk 0 yields 1 frame and every later chunk 4 — reproduced by `first`.
+  * activations are channels-last [T,H,W,C]; conv = gf_vae_im2col + gf_gemm_bf16 (weights permuted once to
+    [Cout,(dt,dy,dx,cin)]); RMS_norm+SiLU fused; residual adds are GEMM epilogues; nearest-exact 2x upsample is
+    folded into the following conv's gather; AttentionBlock = 2 GEMMs + row softmax + GEMM.
+  * tiled_decode (VAE:1103-1152): same tile order, ramps and bf16 accumulators, but the blend runs on the GPU
+    (the reference moves every tile to the CPU) and the result stays a device tensor.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import GoalForceError
+
+CACHE_T = 2
+VAE_MEAN = [-0.7571, -0.7089, -0.9113, 0.1075, -0.1745, 0.9653, -0.1517, 1.5508,
+            0.4134, -0.0715, 0.5517, -0.3632, -0.1922, -0.9497, 0.2503, -0.2921]   # VAE:1063-1066
+VAE_STD = [2.8184, 1.4541, 2.3275, 2.6558, 1.2196, 1.7708, 2.6052, 2.0743,
+           3.2687, 2.1526, 2.8652, 1.5579, 1.6382, 1.1253, 2.8251, 1.9160]        # VAE:1067-1070
+
+
+def _pad_to(n, m):
+    return -(-n // m) * m
+
+
+def decoder_layout(dim=96, z_dim=16, dim_mult=(1, 2, 4, 4), num_res_blocks=2, temperal_upsample=(True, True, False)):
+    """Decoder3d structure (VAE:736-786) as a flat list of (kind, name, ...) + parameter shapes."""
+    dims = [dim * u for u in [dim_mult[-1]] + list(dim_mult[::-1])]
+    shapes: Dict[str, Tuple[int, ...]] = {}
+    plan: List[tuple] = []
+
+    def conv3(name, cin, cout, k=(3, 3, 3)):
+        shapes[name + ".weight"] = (cout, cin) + tuple(k)
+        shapes[name + ".bias"] = (cout,)
+
+    def res(name, cin, cout):
+        shapes[f"{name}.residual.0.gamma"] = (cin, 1, 1, 1)
+        conv3(f"{name}.residual.2", cin, cout)
+        shapes[f"{name}.residual.3.gamma"] = (cout, 1, 1, 1)
+        conv3(f"{name}.residual.6", cout, cout)
+        if cin != cout:
+            conv3(f"{name}.shortcut", cin, cout, (1, 1, 1))
+        plan.append(("res", name, cin, cout))
+
+    conv3("decoder.conv1", z_dim, dims[0])
+    plan.append(("conv1", "decoder.conv1", z_dim, dims[0]))
+    res("decoder.middle.0", dims[0], dims[0])
+    shapes["decoder.middle.1.norm.gamma"] = (dims[0], 1, 1)
+    shapes["decoder.middle.1.to_qkv.weight"] = (dims[0] * 3, dims[0], 1, 1)
+    shapes["decoder.middle.1.to_qkv.bias"] = (dims[0] * 3,)
+    shapes["decoder.middle.1.proj.weight"] = (dims[0], dims[0], 1, 1)
+    shapes["decoder.middle.1.proj.bias"] = (dims[0],)
+    plan.append(("attn", "decoder.middle.1", dims[0]))
+    res("decoder.middle.2", dims[0], dims[0])
+    idx = 0
+    for i, (in_dim, out_dim) in enumerate(zip(dims[:-1], dims[1:])):
+        if i in (1, 2, 3):
+            in_dim = in_dim // 2
+        for _ in range(num_res_blocks + 1):
+            res(f"decoder.upsamples.{idx}", in_dim, out_dim)
+            idx += 1
+            in_dim = out_dim
+        if i != len(dim_mult) - 1:
+            name = f"decoder.upsamples.{idx}"
+            shapes[name + ".resample.1.weight"] = (out_dim // 2, out_dim, 3, 3)
+            shapes[name + ".resample.1.bias"] = (out_dim // 2,)
+            t3 = bool(temperal_upsample[i])
+            if t3:
+                conv3(name + ".time_conv", out_dim, out_dim * 2, (3, 1, 1))
+            plan.append(("up", name, out_dim, t3))
+            idx += 1
+    shapes["decoder.head.0.gamma"] = (dims[-1], 1, 1, 1)
+    conv3("decoder.head.2", dims[-1], 3)
+    plan.append(("head", "decoder.head", dims[-1]))
+    conv3("conv2", z_dim, z_dim, (1, 1, 1))
+    return plan, shapes
+
+
+class _ParamTree(nn.Module):
+    """nn.Module whose parameters are registered under dotted names so state_dict() keys equal the
+    reference's (e.g. 'decoder.upsamples.4.shortcut.weight')."""
+
+    def put(self, dotted: str, value: torch.Tensor):
+        mod = self
+        parts = dotted.split(".")
+        for p in parts[:-1]:
+            if not hasattr(mod, p):
+                mod.add_module(p, _ParamTree())
+            mod = getattr(mod, p)
+        mod.register_parameter(parts[-1], nn.Parameter(value, requires_grad=False))
+
+    def get(self, dotted: str) -> torch.Tensor:
+        mod = self
+        for p in dotted.split("."):
+            mod = getattr(mod, p)
+        return mod
+
+
+class VideoVAE_(_ParamTree):
+    """Parameter container for VideoVAE_ (VAE:951-977): decoder + conv2 (dim 96, z 16)."""
+
+    def __init__(self, dim=96, z_dim=16):
+        super().__init__()
+        self.dim, self.z_dim = dim, z_dim
+        self.plan, self.shapes = decoder_layout(dim, z_dim)
+        for name, shp in self.shapes.items():
+            if name.endswith("gamma"):
+                t = torch.ones(shp)
+            elif name.endswith("bias"):
+                t = torch.zeros(shp)
+            else:
+                fan_in = math.prod(shp[1:])
+                t = torch.randn(shp) / math.sqrt(fan_in)
+            self.put(name, t)
+
+
+class WanVideoVAE(nn.Module):
+    def __init__(self, z_dim=16):
+        super().__init__()
+        self.mean = torch.tensor(VAE_MEAN)
+        self.std = torch.tensor(VAE_STD)
+        self.scale = [self.mean, 1.0 / self.std]
+        self.model = VideoVAE_(z_dim=z_dim)
+        self.upsampling_factor = 8
+        self.z_dim = z_dim
+        self._prepared = None     # GEMM-ready weights (built lazily, invalidated on load)
+        self._cache: Dict[str, torch.Tensor] = {}
+
+    # ---------------------------------------------------------------- state dict
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        """Encoder keys (model.encoder.*, model.conv1.*) are accepted and ignored: the encoder is a 'next' row."""
+        sd = {k: v for k, v in state_dict.items() if not (k.startswith("model.encoder.") or k.startswith("model.conv1."))}
+        self._prepared = None
+        return super().load_state_dict(sd, strict=strict, **kw)
+
+    def _apply(self, fn, *a, **k):
+        self._prepared = None
+        return super()._apply(fn, *a, **k)
+
+    # ---------------------------------------------------------------- weight preparation
+    def _prep_conv(self, name, cout_pad_to=8):
+        w = self.model.get(name + ".weight")
+        b = self.model.get(name + ".bias")
+        cout, cin = w.shape[0], w.shape[1]
+        if w.dim() == 5:
+            kt, ks = w.shape[2], w.shape[3]
+            wm = w.permute(0, 2, 3, 4, 1).reshape(cout, -1)
+        else:
+            kt, ks = 1, w.shape[2]
+            wm = w.permute(0, 2, 3, 1).reshape(cout, -1)
+        k = wm.shape[1]
+        kpad, npad = _pad_to(k, 64), _pad_to(cout, cout_pad_to)
+        wp = torch.zeros((npad, kpad), dtype=w.dtype, device=w.device)
+        wp[:cout, :k] = wm
+        bp = torch.zeros((npad,), dtype=b.dtype, device=b.device)
+        bp[:cout] = b
+        return dict(w=wp.contiguous(), b=bp.contiguous(), kt=kt, ks=ks, cin=cin, cout=cout, kpad=kpad)
+
+    def _prepare(self):
+        if self._prepared is not None:
+            return self._prepared
+        dev = self.model.get("conv2.weight").device
+        if dev.type != "cuda" or self.model.get("conv2.weight").dtype != torch.bfloat16:
+            raise GoalForceError("WanVideoVAE must be moved to the GPU in bf16 before decode (no CPU fallback exists)")
+        P = {}
+        for name in self.model.shapes:
+            if name.endswith(".weight"):
+                base = name[:-len(".weight")]
+                P[base] = self._prep_conv(base)
+        # conv2 consumes the 64-channel padded latent: K padded from 16 to 64 already by _prep_conv
+        for name in self.model.shapes:
+            if name.endswith("gamma"):
+                P[name] = self.model.get(name).reshape(-1).contiguous()
+        P["mean"] = self.mean.to(dev, torch.bfloat16)
+        P["inv_std"] = (1.0 / self.std).to(dev, torch.bfloat16)
+        self._prepared = P
+        return P
+
+    # ---------------------------------------------------------------- building blocks (channels-last [T,H,W,C])
+    def _causal_conv(self, P, name, x, resid=None):
+        """CausalConv3d with its feature cache (VAE:33-52 + the cache handling of VAE:283-294)."""
+        c = P[name]
+        T, H, W, C = x.shape
+        if c["kt"] == 3:
+            cache = self._cache.get(name)
+            if cache is None:
+                cache = torch.zeros((CACHE_T, H, W, C), dtype=x.dtype, device=x.device)
+            cols = ops.vae_im2col(x, cache, 3, c["ks"], c["kpad"])
+            self._cache[name] = torch.cat([cache, x], dim=0)[-CACHE_T:].contiguous()
+        elif c["ks"] == 1:
+            cols = x.reshape(T * H * W, C)
+        else:
+            cols = ops.vae_im2col(x, None, 1, c["ks"], c["kpad"])
+        out = ops.gemm(cols, c["w"], c["b"], epilogue=ops.EPI_BIAS if resid is None else ops.EPI_BIAS_RESID,
+                       resid=None if resid is None else resid.reshape(T * H * W, -1))
+        return out.view(T, H, W, -1)
+
+    def _res_block(self, P, name, x, cin, cout):
+        """ResidualBlock (VAE:267-301)."""
+        h = x if cin == cout else self._causal_conv(P, name + ".shortcut", x)
+        y = ops.vae_rmsnorm_silu(x, P[name + ".residual.0.gamma"], silu=True)
+        y = self._causal_conv(P, name + ".residual.2", y)
+        y = ops.vae_rmsnorm_silu(y, P[name + ".residual.3.gamma"], silu=True)
+        return self._causal_conv(P, name + ".residual.6", y, resid=h)
+
+    def _attention(self, P, name, x, C):
+        """AttentionBlock (VAE:304-342): single head of width C over the h*w positions of each frame."""
+        T, H, W, _ = x.shape
+        hw = H * W
+        if hw % 8:
+            raise GoalForceError("VAE attention needs h*w to be a multiple of 8")
+        kp = _pad_to(hw, 64)
+        xn = ops.vae_rmsnorm_silu(x, P[name + ".norm.gamma"], silu=False)
+        qkv_c, proj_c = P[name + ".to_qkv"], P[name + ".proj"]
+        out = torch.empty_like(x)
+        for t in range(T):
+            qkv = ops.gemm(xn[t].reshape(hw, C), qkv_c["w"], qkv_c["b"])                  # [hw, 3C]
+            scores = ops.gemm(qkv[:, :C], qkv[:, C:2 * C])                                 # q k^T  [hw, hw]
+            p = ops.softmax_rows(scores, 1.0 / math.sqrt(C), kp)                           # [hw, kp]
+            vt = ops.transpose_pad(qkv[:, 2 * C:], kp)                                     # [C, kp]
+            o = ops.gemm(p, vt)                                                            # [hw, C]
+            ops.gemm(o, proj_c["w"], proj_c["b"], epilogue=ops.EPI_BIAS_RESID, resid=x[t].reshape(hw, C),
+                     out=out[t].reshape(hw, C))
+        return out
+
+    def _upsample(self, P, name, x, C, temporal, first):
+        """Resample upsample2d / upsample3d (VAE:82-174)."""
+        T, H, W, _ = x.shape
+        if temporal and not first:
+            tc = P[name + ".time_conv"]
+            cache = self._cache.get(name + ".time_conv")
+            if cache is None:  # 'Rep': the first executed time_conv sees zero history (VAE:139-147)
+                cache = torch.zeros((CACHE_T, H, W, C), dtype=x.dtype, device=x.device)
+            cols = ops.vae_im2col(x, cache, 3, 1, tc["kpad"])
+            self._cache[name + ".time_conv"] = torch.cat([cache, x], dim=0)[-CACHE_T:].contiguous()
+            y = torch.empty((2 * T, H, W, C), dtype=x.dtype, device=x.device)
+            hw = H * W
+            for t in range(T):
+                for j in range(2):  # channels [jC,(j+1)C) of frame t become frame 2t+j (VAE:155-158)
+                    ops.gemm(cols[t * hw:(t + 1) * hw], tc["w"][j * C:(j + 1) * C], tc["b"][j * C:(j + 1) * C],
+                             out=y[2 * t + j].reshape(hw, C))
+            x, T = y, 2 * T
+        rc = P[name + ".resample.1"]
+        cols = ops.vae_im2col(x, None, 1, 3, rc["kpad"], upsample2x=True)
+        return ops.gemm(cols, rc["w"], rc["b"]).view(T, 2 * H, 2 * W, -1)
+
+    def _decode_chunk(self, P, x, first):
+        """Decoder3d.forward on one latent frame (VAE:788-838).  x [1,h,w,16] -> [1 or 4, 8h, 8w, 8]."""
+        for step in self.model.plan:
+            kind, name = step[0], step[1]
+            if kind == "conv1":
+                x = self._causal_conv(P, name, x)
+            elif kind == "res":
+                x = self._res_block(P, name, x, step[2], step[3])
+            elif kind == "attn":
+                x = self._attention(P, name, x, step[2])
+            elif kind == "up":
+                x = self._upsample(P, name, x, step[2], step[3], first)
+            elif kind == "head":
+                x = ops.vae_rmsnorm_silu(x, P[name + ".0.gamma"], silu=True)
+                x = self._causal_conv(P, name + ".2", x)
+        return x
+
+    def decode_tile_channels_last(self, z_slice: torch.Tensor) -> torch.Tensor:
+        """VideoVAE_.decode (VAE:1011-1034) for one [16,T,h,w] latent slice -> [4T-3, 8h, 8w, 8] (RGB in 0..2)."""
+        P = self._prepare()
+        self._cache = {}
+        zc = ops.vae_prep_latent(z_slice, P["mean"], P["inv_std"], cpad=64)         # z / (1/std) + mean
+        T, h, w, _ = zc.shape
+        c2 = P["conv2"]
+        x = ops.gemm(zc.reshape(T * h * w, 64), c2["w"], c2["b"]).view(T, h, w, -1)  # conv2, 1x1x1
+        frames = [self._decode_chunk(P, x[i:i + 1].contiguous(), first=(i == 0)) for i in range(T)]
+        self._cache = {}
+        return torch.cat(frames, dim=0)
+
+    # ---------------------------------------------------------------- public API (VAE:1103-1152, 1211-1247)
+    def tiled_decode(self, hidden_states, device, tile_size, tile_stride):
+        _, _, T, H, W = hidden_states.shape
+        size_h, size_w = tile_size
+        stride_h, stride_w = tile_stride
+        tasks = []
+        for h in range(0, H, stride_h):
+            if h - stride_h >= 0 and h - stride_h + size_h >= H:
+                continue
+            for w in range(0, W, stride_w):
+                if w - stride_w >= 0 and w - stride_w + size_w >= W:
+                    continue
+                tasks.append((h, h + size_h, w, w + size_w))
+        u = self.upsampling_factor
+        out_T = T * 4 - 3
+        values = torch.zeros((3, out_T, H * u, W * u), dtype=torch.bfloat16, device=hidden_states.device)
+        weight = torch.zeros((H * u, W * u), dtype=torch.bfloat16, device=hidden_states.device)
+        for (h, h_, w, w_) in tasks:
+            tile = self.decode_tile_channels_last(hidden_states[0, :, :, h:h_, w:w_])
+            ops.vae_tile_blend(values, weight, tile.contiguous(), h * u, w * u,
+                               bounds=(h == 0, h_ >= H, w == 0, w_ >= W),
+                               border=((size_h - stride_h) * u, (size_w - stride_w) * u))
+        ops.vae_tile_finalize(values, weight)
+        return values.unsqueeze(0)
+
+    def single_decode(self, hidden_state, device):
+        _, _, T, H, W = hidden_state.shape
+        u = self.upsampling_factor
+        tile = self.decode_tile_channels_last(hidden_state[0])
+        values = torch.zeros((3, T * 4 - 3, H * u, W * u), dtype=torch.bfloat16, device=hidden_state.device)
+        weight = torch.zeros((H * u, W * u), dtype=torch.bfloat16, device=hidden_state.device)
+        ops.vae_tile_blend(values, weight, tile.contiguous(), 0, 0, bounds=(True, True, True, True), border=(1, 1))
+        ops.vae_tile_finalize(values, weight)   # mask == 1 everywhere: clamp(tile, -1, 1)
+        return values.unsqueeze(0)
+
+    @torch.no_grad()
+    def decode(self, hidden_states, device=None, tiled=False, tile_size=(34, 34), tile_stride=(18, 16)):
+        """[B,16,T,h,w] bf16 latents -> [B,3,4T-3,8h,8w] bf16 in [-1,1] (device tensor)."""
+        videos = []
+        for hs in hidden_states:
+            hs = hs.unsqueeze(0)
+            if not hs.is_cuda:
+                hs = hs.to(device or "cuda")
+            v = self.tiled_decode(hs, device, tile_size, tile_stride) if tiled else self.single_decode(hs, device)
+            videos.append(v.squeeze(0))
+        return torch.stack(videos)
+
+    def encode(self, videos, device=None, tiled=False, tile_size=(34, 34), tile_stride=(18, 16)):
+        raise NotImplementedError("VAE encoder is a 'next' row (SURVEY §8f rank 1); pass pre-computed latents")

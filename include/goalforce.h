@@ -186,6 +186,56 @@ GF_API int gf_force_map(void* out, int64_t frames, int64_t H, int64_t W,
                  const int32_t* channels, const float* params, const float* centers,
                  int64_t n_blobs, int clamp01, void* stream);
 
+/* ========================================================================
+ * Wan 3-D causal VAE decoder (VAE = diffsynth/models/wan_video_vae.py).
+ * Decoder activations are channels-last [T, H, W, C] bf16; every convolution is
+ * gf_vae_im2col (patch gather, temporal halo from the 2-frame feature cache)
+ * followed by gf_gemm_bf16 on the weight pre-permuted to [Cout, (dt,dy,dx,cin)].
+ * ======================================================================== */
+
+/* gf_vae_prep_latent — un-normalise a latent tile and make it channels-last:
+ * out[t,y,x,c] = bf16(bf16(z[c,t,y,x] / inv_std[c]) + mean[c]), c >= C zero-filled.
+ * Replaces VideoVAE_.decode's scale step (VAE:1014-1020); z is addressed with
+ * element strides (sc,st,sy,sx) so a tile slice needs no copy (VAE:1125).     */
+GF_API int gf_vae_prep_latent(const void* z, int64_t sc, int64_t st, int64_t sy, int64_t sx,
+                              const void* mean, const void* inv_std, void* out,
+                              int64_t C, int64_t T, int64_t H, int64_t W, int64_t cpad, void* stream);
+
+/* gf_vae_im2col — patch gather for CausalConv3d (VAE:33-52; kt in {1,3}, ks in {1,3},
+ * zero spatial padding ks/2, causal temporal padding kt-1 taken from `cache`
+ * [2,H,W,C] = the reference's feat_cache entry, all-zero when there is no history)
+ * and for Resample's Upsample(nearest-exact 2x)+Conv2d(3x3) when upsample2x != 0
+ * (VAE:91-99).  src [T,H,W,C] -> out [T*Ho*Wo, kpad], column ((dt*ks+dy)*ks+dx)*C+c. */
+GF_API int gf_vae_im2col(const void* src, const void* cache, void* out, int64_t T, int64_t H, int64_t W,
+                         int64_t C, int64_t kt, int64_t ks, int upsample2x, int64_t kpad, void* stream);
+
+/* gf_vae_rmsnorm_silu — RMS_norm over channels (F.normalize * sqrt(C) * gamma, bf16
+ * rounding after each eager op, VAE:55-70) optionally followed by SiLU
+ * (ResidualBlock VAE:277-281, Decoder3d.head VAE:785).  x,out [rows, C], C <= 512.  */
+GF_API int gf_vae_rmsnorm_silu(const void* x, const void* gamma, void* out, int64_t rows, int64_t C,
+                               int silu, void* stream);
+
+/* gf_softmax_rows — out[r,:ncols] = softmax(x[r,:ncols]*scale), out[r,ncols:ldo] = 0
+ * (the single-head SDPA of AttentionBlock, VAE:326-333, between its two GEMMs).      */
+GF_API int gf_softmax_rows(const void* x, int64_t ldx, void* out, int64_t ldo, int64_t rows, int64_t ncols,
+                           float scale, void* stream);
+
+/* gf_transpose_pad — dst[c, r] = src[r, c], r >= R zero-filled up to rpad (V^T operand
+ * of the AttentionBlock's P·V GEMM).                                                   */
+GF_API int gf_transpose_pad(const void* src, int64_t ld_src, void* dst, int64_t R, int64_t C, int64_t rpad,
+                            void* stream);
+
+/* gf_vae_tile_blend / gf_vae_tile_finalize — WanVideoVAE.tiled_decode's weighted tile
+ * accumulation (VAE:1128-1150, build_mask VAE:1081-1100) with bf16 accumulators:
+ *   values[c,t,y0+y,x0+x] += tile[t,y,x,c]*mask(y,x); weight[y0+y,x0+x] += mask(y,x)
+ * then values = clamp(values/weight, -1, 1).  tile is channels-last [T,th,tw,tc>=3];
+ * top/bottom/left/right = the tile touches that frame border (no ramp on that side).   */
+GF_API int gf_vae_tile_blend(void* values, void* weight, const void* tile, int64_t T, int64_t th, int64_t tw,
+                             int64_t tc, int64_t H, int64_t W, int64_t y0, int64_t x0,
+                             int top, int bottom, int left, int right, int64_t border_h, int64_t border_w,
+                             void* stream);
+GF_API int gf_vae_tile_finalize(void* values, const void* weight, int64_t planes, int64_t hw, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

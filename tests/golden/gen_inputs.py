@@ -114,6 +114,23 @@ def block_inputs(dim, tokens, ctx_len, seed, dtype=torch.bfloat16):
     return x, ctx, t_mod
 
 
+def vae_decoder_sd(names, shapes, seed, dtype=torch.bfloat16):
+    """Seeded random weights for the VAE decoder + conv2; `names`/`shapes` come from the fixture (they were read
+    from the reference's own state_dict, in its order)."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for n, shp in zip(names, shapes):
+        shp = tuple(int(v) for v in shp if int(v) > 0)
+        if n.endswith("gamma"):
+            t = 1.0 + _randn(g, shp, 0.1)
+        elif n.endswith("bias"):
+            t = _randn(g, shp, 0.02)
+        else:
+            t = _randn(g, shp, 1.0 / math.sqrt(math.prod(shp[1:])))
+        sd[n] = t.to(dtype)
+    return sd
+
+
 def checksum(tensors) -> float:
     """Order-dependent fp64 checksum of a dict/list of tensors (detects RNG / generation drift)."""
     items = tensors.items() if isinstance(tensors, dict) else enumerate(tensors)

@@ -1,0 +1,154 @@
+"""VAE decoder: (CPU) oracle pinned to the reference's own WanVideoVAE outputs; (GPU) HIP decode path vs the
+same goldens.  Tolerances: bf16 oracle vs reference bf16 bit-exact (same torch ops); HIP vs fp32 golden
+rel-L2 <= max(1.5e-2, 1.5x the reference-bf16's own distance from fp32) — the decoder is ~50 bf16 convs deep."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import gen_inputs as gi
+from conftest import GOLDEN, rel_l2
+from oracle import vae_oracle as vo
+
+BF = torch.bfloat16
+torch.set_grad_enabled(False)
+
+
+def _fixture():
+    g = np.load(os.path.join(GOLDEN, "g6_vae.npz"))
+    sd = gi.vae_decoder_sd(list(g["names"]), g["shapes"], seed=61)
+    gen = torch.Generator().manual_seed(62)
+    z1 = torch.randn((1, 16, 3, 8, 8), generator=gen).to(BF)
+    z2 = torch.randn((1, 16, 2, 12, 16), generator=gen).to(BF)
+    assert gi.same_checksum(gi.checksum(sd), g["ck_weights"]) and gi.same_checksum(gi.checksum([z1, z2]), g["ck_inputs"])
+    return g, sd, z1, z2
+
+
+def test_decoder_layout_matches_reference_state_dict():
+    from goal_force_amd.vae import WanVideoVAE, decoder_layout
+    g = np.load(os.path.join(GOLDEN, "g6_vae.npz"))
+    _, shapes = decoder_layout()
+    ref = {n: tuple(int(v) for v in s if int(v) > 0) for n, s in zip(g["names"], g["shapes"])}
+    assert ref == {k: tuple(v) for k, v in shapes.items()}
+    assert sorted(WanVideoVAE().state_dict().keys()) == sorted("model." + n for n in ref)
+    assert sum(int(np.prod(s)) for s in ref.values()) == 73_295_603 - 0  # decoder + conv2 params of the reference
+
+
+def test_oracle_decode_matches_reference():
+    g, sd, z1, z2 = _fixture()
+    raw = vo.decode(z1, sd)
+    assert torch.equal(raw, gi.from_u16(g["decode_raw_bf16"]))               # bit-exact in the reference's arithmetic
+    assert torch.equal(raw.clamp(-1, 1), gi.from_u16(g["decode_bf16"]))
+    sd32 = {k: v.float() for k, v in sd.items()}
+    assert rel_l2(vo.decode(z1.float(), sd32), torch.from_numpy(g["decode_raw_f32"])) < 1e-5
+
+
+def test_oracle_tiled_decode_matches_reference():
+    g, sd, z1, z2 = _fixture()
+    got = vo.tiled_decode(z2, sd, (8, 8), (4, 4))
+    assert torch.equal(got, gi.from_u16(g["tiled_bf16"]))
+    sd32 = {k: v.float() for k, v in sd.items()}
+    assert rel_l2(vo.tiled_decode(z2.float(), sd32, (8, 8), (4, 4)), torch.from_numpy(g["tiled_f32"])) < 1e-5
+
+
+def _gpu_vae(sd):
+    from goal_force_amd.vae import WanVideoVAE
+    v = WanVideoVAE()
+    v.load_state_dict({"model." + k: t for k, t in sd.items()}, strict=True)
+    return v.to(BF).cuda()
+
+
+@pytest.mark.gpu
+def test_hip_vae_im2col_and_norm_kernels_exact():
+    from goal_force_amd import ops
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(5)
+    T, H, W, C = 2, 5, 6, 16
+    x = torch.randn((T, H, W, C), generator=g).to(BF)
+    cache = torch.randn((2, H, W, C), generator=g).to(BF)
+    cols = ops.vae_im2col(x.cuda(), cache.cuda(), 3, 3, 448).cpu()
+    seq = torch.cat([cache, x], 0).permute(3, 0, 1, 2)[None].float()            # [1,C,T+2,H,W]
+    pad = F.pad(seq, (1, 1, 1, 1, 0, 0))
+    patches = pad.unfold(2, 3, 1).unfold(3, 3, 1).unfold(4, 3, 1)                # [1,C,T,H,W,3,3,3]
+    ref = patches[0].permute(1, 2, 3, 4, 5, 6, 0).reshape(T * H * W, 27 * C).to(BF)
+    assert torch.equal(cols[:, :432], ref) and float(cols[:, 432:].abs().sum()) == 0
+    # upsample-folded 3x3 gather == unfold of the nearest-exact upsampled image
+    cols2 = ops.vae_im2col(x.cuda(), None, 1, 3, 192, upsample2x=True).cpu()
+    up = F.interpolate(x.permute(0, 3, 1, 2).float(), scale_factor=(2.0, 2.0), mode="nearest-exact")
+    p2 = F.pad(up, (1, 1, 1, 1)).unfold(2, 3, 1).unfold(3, 3, 1)                 # [T,C,2H,2W,3,3]
+    ref2 = p2.permute(0, 2, 3, 4, 5, 1).reshape(T * 4 * H * W, 9 * C).to(BF)
+    assert torch.equal(cols2[:, :144], ref2)
+    # RMS_norm + SiLU against the oracle's eager bf16 ops
+    xx = (torch.randn((7, 9, 96), generator=g) * 3).to(BF)
+    gam = (1 + 0.1 * torch.randn(96, generator=g)).to(BF)
+    ref3 = F.silu(F.normalize(xx, dim=-1) * (96 ** 0.5) * gam)
+    got3 = ops.vae_rmsnorm_silu(xx.cuda(), gam.cuda(), silu=True).cpu()
+    bad = ((got3.view(torch.int16).int() - ref3.view(torch.int16).int()).abs() > 1).float().mean()
+    assert rel_l2(got3.float(), ref3.float()) < 3e-3 and float(bad) < 5e-3
+    # softmax rows + transpose
+    s = torch.randn((20, 24), generator=g).to(BF)
+    p = ops.softmax_rows(s.cuda(), 0.3, 64).cpu()
+    assert rel_l2(p[:, :24].float(), torch.softmax(s.float() * 0.3, -1)) < 3e-3 and float(p[:, 24:].abs().sum()) == 0
+    tp = ops.transpose_pad(s.cuda(), 64).cpu()
+    assert torch.equal(tp[:, :20], s.t()) and float(tp[:, 20:].abs().sum()) == 0
+
+
+@pytest.mark.gpu
+def test_hip_vae_decode_vs_reference_golden():
+    g, sd, z1, z2 = _fixture()
+    vae = _gpu_vae(sd)
+    got = vae.decode(z1.cuda(), tiled=False).cpu()
+    f32 = torch.from_numpy(g["decode_f32"])
+    ref_bf = gi.from_u16(g["decode_bf16"]).float()
+    e, e_ref = rel_l2(got.float(), f32), rel_l2(ref_bf, f32)
+    assert got.shape == (1, 3, 9, 64, 64)
+    assert e < max(1.5e-2, 1.5 * e_ref), f"vs fp32 {e:.3e} (reference bf16 {e_ref:.3e})"
+    # streaming property: the first output frame depends only on the first latent frame
+    got1 = vae.decode(z1[:, :, :1].cuda(), tiled=False).cpu()
+    assert torch.equal(got1[:, :, 0], got[:, :, 0])
+
+
+@pytest.mark.gpu
+def test_hip_vae_tiled_decode_vs_reference_golden():
+    g, sd, z1, z2 = _fixture()
+    vae = _gpu_vae(sd)
+    got = vae.decode(z2.cuda(), tiled=True, tile_size=(8, 8), tile_stride=(4, 4)).cpu()
+    f32 = torch.from_numpy(g["tiled_f32"])
+    ref_bf = gi.from_u16(g["tiled_bf16"]).float()
+    e, e_ref = rel_l2(got.float(), f32), rel_l2(ref_bf, f32)
+    assert got.shape == (1, 3, 5, 96, 128) and float(got.float().abs().max()) <= 1.0
+    assert e < max(1.5e-2, 1.5 * e_ref), f"vs fp32 {e:.3e} (reference bf16 {e_ref:.3e})"
+
+
+@pytest.mark.gpu
+def test_hip_tile_blend_exact_against_oracle_arithmetic():
+    """constant tiles through the blend: ramps, bf16 accumulation order and the final divide are exact."""
+    from goal_force_amd import ops
+    T, H, W, u = 2, 16, 24, 1
+    values = torch.zeros((3, T, H, W), dtype=BF, device="cuda")
+    weight = torch.zeros((H, W), dtype=BF, device="cuda")
+    ref_v = torch.zeros((1, 3, T, H, W), dtype=BF)
+    ref_w = torch.zeros((1, 1, T, H, W), dtype=BF)
+    g = torch.Generator().manual_seed(3)
+    size, stride = (8, 8), (4, 4)
+    tasks = []
+    for h in range(0, H, stride[0]):
+        if h - stride[0] >= 0 and h - stride[0] + size[0] >= H:
+            continue
+        for w in range(0, W, stride[1]):
+            if w - stride[1] >= 0 and w - stride[1] + size[1] >= W:
+                continue
+            tasks.append((h, h + size[0], w, w + size[1]))
+    for (h, h_, w, w_) in tasks:
+        tile = torch.randn((T, 8, 8, 8), generator=g).to(BF)
+        ops.vae_tile_blend(values, weight, tile.cuda(), h, w, (h == 0, h_ >= H, w == 0, w_ >= W), (4, 4))
+        mh = vo._ramp(8, h == 0, h_ >= H, 4)
+        mw = vo._ramp(8, w == 0, w_ >= W, 4)
+        mask = torch.minimum(mh[:, None].expand(-1, 8), mw[None, :].expand(8, -1)).view(1, 1, 1, 8, 8).to(BF)
+        t5 = tile[..., :3].permute(3, 0, 1, 2)[None]
+        ref_v[:, :, :, h:h_, w:w_] += t5 * mask
+        ref_w[:, :, :, h:h_, w:w_] += mask
+    ops.vae_tile_finalize(values, weight)
+    ref = (ref_v / ref_w).clamp_(-1, 1)
+    assert torch.equal(values.cpu()[None], ref)
