@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fp8", action="store_true", help="BASELINE config 5: block Linears on the fp8_linear contract (e4m3 MFMA)")
     ap.add_argument("--layers", type=int, default=40, help=argparse.SUPPRESS)  # debugging only; 40 = the real model
     args = ap.parse_args()
 
@@ -98,6 +99,10 @@ def main():
     dit2 = build_random_expert(cfg, seed=200, device=dev)
     cn = build_random_controlnet(n_cn, cfg, seed=300, device=dev)
     cn2 = build_random_controlnet(n_cn, cfg, seed=400, device=dev, zero_convs_zero=True)
+    if args.fp8:
+        from goal_force_amd.dit import enable_fp8
+        for m in (dit, dit2, cn, cn2):
+            enable_fp8(m)
     from goal_force_amd.vae import WanVideoVAE
     torch.manual_seed(7)
     vae = WanVideoVAE().to(torch.bfloat16).to(dev)   # real Wan VAE architecture, random-init decoder weights
@@ -174,7 +179,7 @@ def main():
             "metric": "frames_per_sec (81-frame video / (50-step denoise loop + VAE decode), Wan2.2-I2V-A14B 832x480x81f)",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": k, "warmup": args.warmup,
             "ms_per_step": sec_per_step * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "fp8-e4m3 block Linears (bf16 elsewhere, fp32 accumulate)" if args.fp8 else "bf16", "data": "synthetic",
             "config": {"workload": "Goal-Force denoise step: cond+uncond model_fn (40 DiT + 10 ControlNet blocks, "
                                    "A14B dims) + CFG + Euler, latents [1,16,21,60,104] = 32760 tokens, 512 text tokens; "
                                    "random-init bf16 weights, both experts + both ControlNets resident",

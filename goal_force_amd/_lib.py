@@ -20,6 +20,7 @@ SYMBOLS = (
     "gf_force_map",
     "gf_vae_prep_latent", "gf_vae_im2col", "gf_vae_rmsnorm_silu", "gf_softmax_rows", "gf_transpose_pad",
     "gf_vae_tile_blend", "gf_vae_tile_finalize",
+    "gf_quant_fp8_rowscale", "gf_cast_fp8", "gf_gemm_fp8",
 )
 
 EPI_BIAS, EPI_BIAS_GELU_TANH, EPI_BIAS_GATE_RESID, EPI_BIAS_RESID, EPI_BIAS_SILU = range(5)
@@ -61,6 +62,9 @@ def _declare(lib):
         "gf_vae_tile_blend": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _int, _int, _int, _int,
                               _i64, _i64, _vp],
         "gf_vae_tile_finalize": [_vp, _vp, _i64, _i64, _vp],
+        "gf_quant_fp8_rowscale": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp],
+        "gf_cast_fp8": [_vp, _vp, _i64, _vp],
+        "gf_gemm_fp8": [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _i64, _vp, _vp],
         "gf_force_map": [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _int, _vp],
     }
     for name, argtypes in sigs.items():

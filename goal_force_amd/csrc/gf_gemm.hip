@@ -38,6 +38,7 @@ struct GemmArgs {
     u16* C;
     const u16* R;
     const u16* gate;
+    const float* row_scale;  // FP8 only: per-row dequant scale of A (gf_quant_fp8_rowscale)
     int M, N, K;
     long lda, ldw, ldc, ldr;
     int tiles_m, tiles_n;
@@ -47,8 +48,16 @@ __device__ __forceinline__ void glds16(const void* g, GF_LDS char* l) {
     __builtin_amdgcn_global_load_lds((const GF_GLOBAL void*)g, (GF_LDS void*)l, 16, 0, 0);
 }
 
-template <int EPI>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmArgs p) {
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+
+// FP8 = false: A/W are bf16, K-step 64 elements.  FP8 = true: A/W are OCP e4m3 bytes, K-step 128 elements — the
+// LDS image is the same 128-byte rows, each lane's fragment is 32 consecutive k (two 16-byte chunks) and the
+// product runs on v_mfma_scale_f32_16x16x128_f8f6f4 with unit (E8M0 = 127) block scales: 2x the bf16 MFMA rate.
+// p.lda / p.ldw / p.K are in ELEMENTS of the operand type; the staging code works in 16-byte chunks.
+template <int EPI, bool FP8>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmArgs p) {
+    constexpr int ESZ = FP8 ? 1 : 2;          // bytes per operand element
+    constexpr int BKE = 128 / ESZ;            // K elements per 128-byte tile row
     extern __shared__ __attribute__((aligned(16))) char smem[];
     GF_LDS char* lds = (GF_LDS char*)smem;
 
@@ -79,20 +88,20 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmAr
     // chunk (l&7) ^ (row&7) of that row.
     const int srow = lane >> 3;
     const int schunk = (lane & 7) ^ srow;
-    const u16* a_src[4];
-    const u16* b_src[4];
+    const char* a_src[4];
+    const char* b_src[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = (wave * 4 + i) * 8 + srow;
         const int am = min(m0 + row, p.M - 1);
         const int bn = min(n0 + row, p.N - 1);
-        a_src[i] = p.A + (long)am * p.lda + schunk * 8;
-        b_src[i] = p.W + (long)bn * p.ldw + schunk * 8;
+        a_src[i] = (const char*)p.A + ((long)am * p.lda) * ESZ + schunk * 16;
+        b_src[i] = (const char*)p.W + ((long)bn * p.ldw) * ESZ + schunk * 16;
     }
     auto stage = [&](int buf, int kt) {
         GF_LDS char* sa = lds + buf * STAGE_BYTES + wave * 4096;
         GF_LDS char* sb = sa + TILE_BYTES;
-        const int koff = kt * BK;
+        const int koff = kt * 128;  // bytes along K
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             glds16(a_src[i] + koff, sa + i * 1024);
@@ -118,27 +127,50 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmAr
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = p.K / BK;
+    const int nk = p.K / BKE;
     stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // tile kt landed for every wave; everyone is done reading the other buffer
         if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
         GF_LDS char* sbuf = lds + (kt & 1) * STAGE_BYTES;
+        if constexpr (!FP8) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int ch = ks ? ch1 : ch0;
-            bf16x8 af[8], bfr[4];
+            for (int ks = 0; ks < 2; ++ks) {
+                const int ch = ks ? ch1 : ch0;
+                bf16x8 af[8], bfr[4];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) af[i] = *(GF_LDS bf16x8*)(sbuf + a_base + i * 2048 + ch);
+                for (int i = 0; i < 8; ++i) af[i] = *(GF_LDS bf16x8*)(sbuf + a_base + i * 2048 + ch);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bfr[j] = *(GF_LDS bf16x8*)(sbuf + b_base + j * 2048 + ch);
+                for (int j = 0; j < 4; ++j) bfr[j] = *(GF_LDS bf16x8*)(sbuf + b_base + j * 2048 + ch);
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        // swapped operands: D[n-local][m-local]; lane holds 4 consecutive n of one m
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+            }
+        } else {
+            // lane (row = lane&15, kb = lane>>4) holds bytes [32kb, 32kb+32) of its row = chunks 2kb, 2kb+1.
+            // A and W fragments are loaded by the same rule, so slot e of lane-group kb pairs the same k on both.
+            const int c0 = ((2 * fq) ^ sw) << 4, c1 = ((2 * fq + 1) ^ sw) << 4;
+            i32x8 bfr[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const u32x4 lo = *(GF_LDS u32x4*)(sbuf + b_base + j * 2048 + c0);
+                const u32x4 hi = *(GF_LDS u32x4*)(sbuf + b_base + j * 2048 + c1);
+                bfr[j] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const u32x4 lo = *(GF_LDS u32x4*)(sbuf + a_base + i * 2048 + c0);
+                const u32x4 hi = *(GF_LDS u32x4*)(sbuf + a_base + i * 2048 + c1);
+                const i32x8 af = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    // swapped operands: D[n-local][m-local]; lane holds 4 consecutive n of one m
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bfr[j], af, acc[i][j], 0, 0, 0,
+                                                                                  0x7F7F7F7F, 0, 0x7F7F7F7F);
+            }
         }
     }
 
@@ -160,9 +192,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmAr
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 float y[4];
+                float rs = 1.0f;
+                if constexpr (FP8) rs = p.row_scale[min(m0 + wm * 128 + i * 16 + frow, p.M - 1)];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    y[r] = rbf(acc[i][j][r] + bv[r]);  // the Linear's own bf16 output
+                    y[r] = rbf(acc[i][j][r] * rs + bv[r]);  // the Linear's own bf16 output (x scale_a for fp8)
                     if (EPI == GF_EPI_BIAS_GELU_TANH) y[r] = gelu_tanh_f(y[r]);
                     if (EPI == GF_EPI_BIAS_SILU) y[r] = y[r] / (1.0f + expf(-y[r]));
                 }
@@ -205,43 +239,46 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmAr
     }
 }
 
-template <int EPI>
+template <int EPI, bool FP8>
 int launch_gemm(const GemmArgs& a, hipStream_t stream) {
     static bool attr_set = false;  // per-instantiation; benign race (idempotent call)
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<EPI>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<EPI, FP8>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
         if (e != hipSuccess) {
-            gf_set_error("gf_gemm_bf16: hipFuncSetAttribute(%d B LDS) failed: %s", GEMM_LDS, hipGetErrorString(e));
+            gf_set_error("gf_gemm: hipFuncSetAttribute(%d B LDS) failed: %s", GEMM_LDS, hipGetErrorString(e));
             return GF_ERR_LAUNCH;
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(GEMM_THREADS), GEMM_LDS,
+    hipLaunchKernelGGL((gemm_kernel<EPI, FP8>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(GEMM_THREADS), GEMM_LDS,
                        stream, a);
-    GF_CHECK_LAUNCH("gf_gemm_bf16");
+    GF_CHECK_LAUNCH(FP8 ? "gf_gemm_fp8" : "gf_gemm_bf16");
     return GF_OK;
 }
 
 }  // namespace
 
-extern "C" GF_API int gf_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias, void* C,
-                            int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue, const void* resid,
-                            int64_t ldr, const void* gate, void* stream) {
-    GF_CHECK_ARG(A && W && C, "gf_gemm_bf16: null A/W/C");
-    GF_CHECK_ARG(M >= 0 && N > 0 && K > 0, "gf_gemm_bf16: bad sizes M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
-    GF_CHECK_ARG(K % BK == 0, "gf_gemm_bf16: K=%ld must be a multiple of %d", (long)K, BK);
-    GF_CHECK_ARG(N % 8 == 0, "gf_gemm_bf16: N=%ld must be a multiple of 8", (long)N);
-    GF_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0 && ldc % 8 == 0 && lda >= K && ldw >= K && ldc >= N,
-                 "gf_gemm_bf16: leading dimensions must be multiples of 8 and cover the row");
+static int gemm_dispatch(bool fp8, const void* A, int64_t lda, const void* W, int64_t ldw, const float* row_scale,
+                         const void* bias, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue,
+                         const void* resid, int64_t ldr, const void* gate, void* stream) {
+    const char* fn = fp8 ? "gf_gemm_fp8" : "gf_gemm_bf16";
+    const int bke = fp8 ? 128 : 64, lal = fp8 ? 16 : 8;
+    GF_CHECK_ARG(A && W && C, "%s: null A/W/C", fn);
+    GF_CHECK_ARG(M >= 0 && N > 0 && K > 0, "%s: bad sizes M=%ld N=%ld K=%ld", fn, (long)M, (long)N, (long)K);
+    GF_CHECK_ARG(K % bke == 0, "%s: K=%ld must be a multiple of %d", fn, (long)K, bke);
+    GF_CHECK_ARG(N % 8 == 0, "%s: N=%ld must be a multiple of 8", fn, (long)N);
+    GF_CHECK_ARG(lda % lal == 0 && ldw % lal == 0 && ldc % 8 == 0 && lda >= K && ldw >= K && ldc >= N,
+                 "%s: leading dimensions must be multiples of %d (A/W) / 8 (C) and cover the row", fn, lal);
     GF_CHECK_ARG(gf_aligned16(A) && gf_aligned16(W) && gf_aligned16(C) && (!bias || gf_aligned16(bias)),
-                 "gf_gemm_bf16: 16-byte alignment required");
-    GF_CHECK_ARG(M < (1 << 30) && N < (1 << 30), "gf_gemm_bf16: M/N too large");
+                 "%s: 16-byte alignment required", fn);
+    GF_CHECK_ARG(M < (1 << 30) && N < (1 << 30), "%s: M/N too large", fn);
+    GF_CHECK_ARG(!fp8 || row_scale, "%s: row_scale is required", fn);
     const bool need_r = epilogue == GF_EPI_BIAS_GATE_RESID || epilogue == GF_EPI_BIAS_RESID;
     GF_CHECK_ARG(!need_r || (resid && ldr % 8 == 0 && ldr >= N && gf_aligned16(resid)),
-                 "gf_gemm_bf16: residual epilogue needs an aligned resid with ldr >= N");
+                 "%s: residual epilogue needs an aligned resid with ldr >= N", fn);
     GF_CHECK_ARG(epilogue != GF_EPI_BIAS_GATE_RESID || (gate && gf_aligned16(gate)),
-                 "gf_gemm_bf16: gate epilogue needs an aligned gate vector");
+                 "%s: gate epilogue needs an aligned gate vector", fn);
     if (M == 0) return GF_OK;
     GemmArgs a;
     a.A = (const u16*)A;
@@ -250,6 +287,7 @@ extern "C" GF_API int gf_gemm_bf16(const void* A, int64_t lda, const void* W, in
     a.C = (u16*)C;
     a.R = (const u16*)resid;
     a.gate = (const u16*)gate;
+    a.row_scale = row_scale;
     a.M = (int)M;
     a.N = (int)N;
     a.K = (int)K;
@@ -260,14 +298,28 @@ extern "C" GF_API int gf_gemm_bf16(const void* A, int64_t lda, const void* W, in
     a.tiles_m = (int)((M + BM - 1) / BM);
     a.tiles_n = (int)((N + BN - 1) / BN);
     hipStream_t s = (hipStream_t)stream;
+#define GF_GEMM_CASE(E) case E: return fp8 ? launch_gemm<E, true>(a, s) : launch_gemm<E, false>(a, s);
     switch (epilogue) {
-        case GF_EPI_BIAS: return launch_gemm<GF_EPI_BIAS>(a, s);
-        case GF_EPI_BIAS_GELU_TANH: return launch_gemm<GF_EPI_BIAS_GELU_TANH>(a, s);
-        case GF_EPI_BIAS_GATE_RESID: return launch_gemm<GF_EPI_BIAS_GATE_RESID>(a, s);
-        case GF_EPI_BIAS_RESID: return launch_gemm<GF_EPI_BIAS_RESID>(a, s);
-        case GF_EPI_BIAS_SILU: return launch_gemm<GF_EPI_BIAS_SILU>(a, s);
+        GF_GEMM_CASE(GF_EPI_BIAS)
+        GF_GEMM_CASE(GF_EPI_BIAS_GELU_TANH)
+        GF_GEMM_CASE(GF_EPI_BIAS_GATE_RESID)
+        GF_GEMM_CASE(GF_EPI_BIAS_RESID)
+        GF_GEMM_CASE(GF_EPI_BIAS_SILU)
         default:
-            gf_set_error("gf_gemm_bf16: unknown epilogue %d", epilogue);
+            gf_set_error("%s: unknown epilogue %d", fn, epilogue);
             return GF_ERR_INVALID_ARG;
     }
+#undef GF_GEMM_CASE
+}
+
+extern "C" GF_API int gf_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias, void* C,
+                                   int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue, const void* resid,
+                                   int64_t ldr, const void* gate, void* stream) {
+    return gemm_dispatch(false, A, lda, W, ldw, nullptr, bias, C, ldc, M, N, K, epilogue, resid, ldr, gate, stream);
+}
+
+extern "C" GF_API int gf_gemm_fp8(const void* A8, int64_t lda, const void* W8, int64_t ldw, const float* row_scale,
+                                  const void* bias, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue,
+                                  const void* resid, int64_t ldr, const void* gate, void* stream) {
+    return gemm_dispatch(true, A8, lda, W8, ldw, row_scale, bias, C, ldc, M, N, K, epilogue, resid, ldr, gate, stream);
 }

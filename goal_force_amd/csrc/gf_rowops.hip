@@ -132,7 +132,97 @@ __global__ __launch_bounds__(ROW_THREADS) void rmsnorm_rope_kernel(
     }
 }
 
+// fp8 activation quantisation of AutoWrappedLinear.fp8_linear (VRAM:115-140):
+//   scale_a = clamp(rowmax|x| / 448, min=1)  (fp32);   x8 = e4m3(float(x) / (scale_a + 1e-8))
+// OCP e4m3fn on gfx950 (not MI300's fnuz).  One workgroup per row, row kept in registers.
+__global__ __launch_bounds__(ROW_THREADS) void quant_fp8_rowscale_kernel(const u16* __restrict__ x,
+                                                                         unsigned char* __restrict__ out,
+                                                                         float* __restrict__ scale, int dim,
+                                                                         long x_stride, long out_stride) {
+    __shared__ float red[ROW_THREADS / 64];
+    const long row = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int nchunks = dim >> 3;
+    const u16* xr = x + row * x_stride;
+    constexpr int NCH = 14;  // dim <= 128*14*8 = 14336 (FFN hidden 13824)
+    u16x8 v[NCH];
+    float mx = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = tid + i * ROW_THREADS;
+        if (c < nchunks) {
+            v[i] = *reinterpret_cast<const u16x8*>(xr + (c << 3));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fabsf(bf2f(v[i][j])));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(red[0], red[1]);
+    const float sc = fmaxf(mx / 448.0f, 1.0f);
+    if (tid == 0) scale[row] = sc;
+    const float den = sc + 1e-8f;
+    unsigned char* orow = out + row * out_stride;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = tid + i * ROW_THREADS;
+        if (c < nchunks) {
+            float f[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = bf2f(v[i][j]) / den;
+            unsigned w0 = 0, w1 = 0;
+            w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], w0, false);
+            w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w0, true);
+            w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], w1, false);
+            w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], w1, true);
+            *reinterpret_cast<u32x2*>(orow + (c << 3)) = u32x2{w0, w1};
+        }
+    }
+}
+
+// plain bf16 -> e4m3 cast (the weight side of fp8_linear: `weight.to(float8_e4m3fn)`, unit scale, VRAM:138)
+__global__ __launch_bounds__(256) void cast_fp8_kernel(const u16* __restrict__ x, unsigned char* __restrict__ out, long n8) {
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += stride) {
+        const u16x8 v = reinterpret_cast<const u16x8*>(x)[i];
+        unsigned w0 = 0, w1 = 0;
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f(v[0]), bf2f(v[1]), w0, false);
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f(v[2]), bf2f(v[3]), w0, true);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f(v[4]), bf2f(v[5]), w1, false);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f(v[6]), bf2f(v[7]), w1, true);
+        reinterpret_cast<u32x2*>(out)[i] = u32x2{w0, w1};
+    }
+}
+
 }  // namespace
+
+extern "C" GF_API int gf_quant_fp8_rowscale(const void* x, void* out8, float* scale, int64_t rows, int64_t dim,
+                                            int64_t x_stride, int64_t out_stride, void* stream) {
+    GF_CHECK_ARG(x && out8 && scale && rows >= 0, "gf_quant_fp8_rowscale: null pointer");
+    GF_CHECK_ARG(dim > 0 && dim % 8 == 0 && dim <= ROW_THREADS * 14 * 8, "gf_quant_fp8_rowscale: dim=%ld must be a multiple of 8 and <= %d",
+                 (long)dim, ROW_THREADS * 14 * 8);
+    GF_CHECK_ARG(x_stride % 8 == 0 && out_stride % 8 == 0 && gf_aligned16(x) && (((uintptr_t)out8) & 7u) == 0,
+                 "gf_quant_fp8_rowscale: alignment");
+    if (rows == 0) return GF_OK;
+    hipLaunchKernelGGL(quant_fp8_rowscale_kernel, dim3((unsigned)rows), dim3(ROW_THREADS), 0, (hipStream_t)stream,
+                       (const u16*)x, (unsigned char*)out8, scale, (int)dim, (long)x_stride, (long)out_stride);
+    GF_CHECK_LAUNCH("gf_quant_fp8_rowscale");
+    return GF_OK;
+}
+
+extern "C" GF_API int gf_cast_fp8(const void* x, void* out8, int64_t n, void* stream) {
+    GF_CHECK_ARG(x && out8 && n >= 0 && n % 8 == 0, "gf_cast_fp8: n must be a multiple of 8");
+    GF_CHECK_ARG(gf_aligned16(x) && (((uintptr_t)out8) & 7u) == 0, "gf_cast_fp8: alignment");
+    if (n == 0) return GF_OK;
+    long blocks = (n / 8 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(cast_fp8_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const u16*)x,
+                       (unsigned char*)out8, (long)(n / 8));
+    GF_CHECK_LAUNCH("gf_cast_fp8");
+    return GF_OK;
+}
 
 extern "C" GF_API int gf_layernorm_modulate(const void* x, void* out, const void* weight, const void* bias,
                                      const void* scale1p, const void* shift, int64_t rows, int64_t dim,

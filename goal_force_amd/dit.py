@@ -73,6 +73,36 @@ def sinusoidal_embedding_1d(dim, position):
     return x.to(position.dtype).to(position.device)
 
 
+class QuantizedInput:
+    """Row-quantised activation (e4m3 bytes + per-row scale) shared by the GEMMs that read the same input."""
+
+    def __init__(self, x2):
+        self.x8, self.scale = ops.quant_fp8_rowscale(x2)
+
+
+def linear(x2, lin: nn.Linear, epilogue=ops.EPI_BIAS, resid=None, gate=None, out=None):
+    """One nn.Linear on the MFMA GEMM.  If the layer carries an fp8 weight copy (enable_fp8) the reference's
+    fp8_linear contract is used (VRAM:115-151: per-row dynamic activation scale, unit weight scale, e4m3),
+    otherwise the bf16 kernel.  x2 may be a QuantizedInput to reuse one quantisation for several layers."""
+    w8 = getattr(lin, "_gf_w8", None)
+    if w8 is None:
+        return ops.gemm(x2, lin.weight, lin.bias, epilogue=epilogue, resid=resid, gate=gate, out=out)
+    q = x2 if isinstance(x2, QuantizedInput) else QuantizedInput(x2)
+    return ops.gemm_fp8(q.x8, q.scale, w8, lin.bias, epilogue=epilogue, resid=resid, gate=gate, out=out)
+
+
+def enable_fp8(module: nn.Module, enabled=True):
+    """BASELINE config 5: every nn.Linear inside the DiT / ControlNet *blocks* runs the fp8_linear contract
+    (the reference would set computation_dtype=float8_e4m3fn in enable_vram_management, VRAM:113).  Weights are
+    cast once to OCP e4m3 (unit scale) and kept beside the bf16 master copy."""
+    for blk in module.modules():
+        if isinstance(blk, DiTBlock):
+            for lin in blk.modules():
+                if isinstance(lin, nn.Linear):
+                    lin._gf_w8 = ops.cast_fp8(lin.weight.detach().contiguous()) if enabled else None
+    return module
+
+
 def _tokens2d(x: torch.Tensor) -> torch.Tensor:
     """[1,S,D] or [S,D] -> [S,D] view."""
     if x.dim() == 3:
@@ -108,9 +138,8 @@ class SelfAttention(nn.Module):
 
     def attend(self, x2: torch.Tensor, rope: RopeTable) -> torch.Tensor:
         """x2 [S,D] -> attention output BEFORE the o projection, [S,D]."""
-        q = ops.gemm(x2, self.q.weight, self.q.bias)
-        k = ops.gemm(x2, self.k.weight, self.k.bias)
-        v = ops.gemm(x2, self.v.weight, self.v.bias)
+        xin = QuantizedInput(x2) if getattr(self.q, "_gf_w8", None) is not None else x2
+        q, k, v = linear(xin, self.q), linear(xin, self.k), linear(xin, self.v)
         ops.rmsnorm_rope(q, self.norm_q.weight, rope.cos, rope.sin, self.head_dim, self.norm_q.eps)
         ops.rmsnorm_rope(k, self.norm_k.weight, rope.cos, rope.sin, self.head_dim, self.norm_k.eps)
         return ops.flash_attn(q, k, v, self.num_heads)
@@ -118,7 +147,7 @@ class SelfAttention(nn.Module):
     def forward(self, x, freqs):
         x2 = _tokens2d(x)
         a = self.attend(x2, _as_rope(freqs, x.device))
-        return ops.gemm(a, self.o.weight, self.o.bias).view(x.shape)
+        return linear(a, self.o).view(x.shape)
 
 
 class CrossAttention(nn.Module):
@@ -135,20 +164,20 @@ class CrossAttention(nn.Module):
 
     def context_kv(self, ctx2: torch.Tensor):
         """k = norm_k(Wk ctx), v = Wv ctx — constant per (expert, prompt, block); cacheable over steps."""
-        k = ops.gemm(ctx2, self.k.weight, self.k.bias)
-        v = ops.gemm(ctx2, self.v.weight, self.v.bias)
+        cin = QuantizedInput(ctx2) if getattr(self.k, "_gf_w8", None) is not None else ctx2
+        k, v = linear(cin, self.k), linear(cin, self.v)
         ops.rmsnorm_rope(k, self.norm_k.weight, None, None, self.head_dim, self.norm_k.eps)
         return k, v
 
     def attend(self, x2, kv):
-        q = ops.gemm(x2, self.q.weight, self.q.bias)
+        q = linear(x2, self.q)
         ops.rmsnorm_rope(q, self.norm_q.weight, None, None, self.head_dim, self.norm_q.eps)
         return ops.flash_attn(q, kv[0], kv[1], self.num_heads)
 
     def forward(self, x: torch.Tensor, y: torch.Tensor):
         x2 = _tokens2d(x)
         a = self.attend(x2, self.context_kv(_tokens2d(y)))
-        return ops.gemm(a, self.o.weight, self.o.bias).view(x.shape)
+        return linear(a, self.o).view(x.shape)
 
 
 class GateModule(nn.Module):
@@ -184,18 +213,15 @@ class DiTBlock(nn.Module):
         h = ops.layernorm_modulate(x2, scale1p=mod[1], shift=mod[0], eps=self.eps)              # DIT:225
         a = self.self_attn.attend(h, rope)
         x_new = out if out is not None else torch.empty_like(x2)
-        ops.gemm(a, self.self_attn.o.weight, self.self_attn.o.bias, epilogue=ops.EPI_BIAS_GATE_RESID,
-                 resid=x2, gate=mod[2], out=x_new)                                               # DIT:226
+        linear(a, self.self_attn.o, epilogue=ops.EPI_BIAS_GATE_RESID, resid=x2, gate=mod[2], out=x_new)   # DIT:226
         ops.layernorm_modulate(x_new, weight=self.norm3.weight, bias=self.norm3.bias, eps=self.eps, out=h)
         if context_kv is None:
             context_kv = self.cross_attn.context_kv(_tokens2d(context))
         a = self.cross_attn.attend(h, context_kv)
-        ops.gemm(a, self.cross_attn.o.weight, self.cross_attn.o.bias, epilogue=ops.EPI_BIAS_RESID,
-                 resid=x_new, out=x_new)                                                          # DIT:227
+        linear(a, self.cross_attn.o, epilogue=ops.EPI_BIAS_RESID, resid=x_new, out=x_new)               # DIT:227
         ops.layernorm_modulate(x_new, scale1p=mod[4], shift=mod[3], eps=self.eps, out=h)         # DIT:228
-        f1 = ops.gemm(h, self.ffn[0].weight, self.ffn[0].bias, epilogue=ops.EPI_BIAS_GELU_TANH)
-        ops.gemm(f1, self.ffn[2].weight, self.ffn[2].bias, epilogue=ops.EPI_BIAS_GATE_RESID,
-                 resid=x_new, gate=mod[5], out=x_new)                                             # DIT:229
+        f1 = linear(h, self.ffn[0], epilogue=ops.EPI_BIAS_GELU_TANH)
+        linear(f1, self.ffn[2], epilogue=ops.EPI_BIAS_GATE_RESID, resid=x_new, gate=mod[5], out=x_new)  # DIT:229
         return x_new.view(x.shape)
 
 

@@ -333,3 +333,61 @@ def vae_tile_finalize(values, weight):
     _lib.check(_lib.load().gf_vae_tile_finalize(_ptr(values), _ptr(weight), values.shape[0] * values.shape[1],
                                                 weight.numel(), _stream(values)), "gf_vae_tile_finalize")
     return values
+
+
+# ---------------------------------------------------------------------------------- fp8 Linear (VRAM:115-151)
+_FP8 = torch.float8_e4m3fn
+
+
+def quant_fp8_rowscale(x):
+    """x [M,K] bf16 -> (x8 [M,K] float8_e4m3fn, scale_a [M] fp32) — gf_quant_fp8_rowscale."""
+    _req(x, "quant_fp8_rowscale.x")
+    xv, rows, dim, xs = _rows2d(x, "quant_fp8_rowscale.x")
+    out = torch.empty((rows, dim), dtype=_FP8, device=x.device)
+    scale = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().gf_quant_fp8_rowscale(_ptr(xv), _ptr(out), _ptr(scale), rows, dim, xs, dim, _stream(x)),
+               "gf_quant_fp8_rowscale")
+    return out, scale
+
+
+def cast_fp8(w):
+    """bf16 -> float8_e4m3fn, elementwise (weights; unit scale)."""
+    _req(w, "cast_fp8.w")
+    if not w.is_contiguous() or w.numel() % 8:
+        raise GoalForceError("cast_fp8: contiguous tensor with numel % 8 == 0 expected")
+    out = torch.empty(w.shape, dtype=_FP8, device=w.device)
+    _lib.check(_lib.load().gf_cast_fp8(_ptr(w), _ptr(out), w.numel(), _stream(w)), "gf_cast_fp8")
+    return out
+
+
+def gemm_fp8(a8, row_scale, w8, bias=None, epilogue=EPI_BIAS, resid=None, gate=None, out=None):
+    """out[M,N] = epilogue((a8 @ w8^T) * row_scale[:,None] + bias) — gf_gemm_fp8."""
+    _req(a8, "gemm_fp8.a8", _FP8)
+    _req(w8, "gemm_fp8.w8", _FP8)
+    _req(row_scale, "gemm_fp8.row_scale", torch.float32)
+    if a8.dim() != 2 or w8.dim() != 2 or a8.stride(1) != 1 or w8.stride(1) != 1 or a8.shape[1] != w8.shape[1]:
+        raise GoalForceError("gemm_fp8: a8 [M,K], w8 [N,K] with contiguous rows expected")
+    M, K = a8.shape
+    N = w8.shape[0]
+    if row_scale.numel() != M or not row_scale.is_contiguous():
+        raise GoalForceError("gemm_fp8.row_scale: contiguous [M] expected")
+    if out is None:
+        out = torch.empty((M, N), dtype=_BF16, device=a8.device)
+    ov, Mo, No, ldc = _rows2d(out, "gemm_fp8.out")
+    if (Mo, No) != (M, N):
+        raise GoalForceError("gemm_fp8.out: shape mismatch")
+    ldr = 0
+    if resid is not None:
+        _req(resid, "gemm_fp8.resid")
+        resid, Mr, Nr, ldr = _rows2d(resid, "gemm_fp8.resid")
+        if (Mr, Nr) != (M, N):
+            raise GoalForceError("gemm_fp8.resid: shape mismatch")
+    for n, t in (("gate", gate), ("bias", bias)):
+        if t is not None:
+            _req(t, f"gemm_fp8.{n}")
+            if t.numel() != N or not t.is_contiguous():
+                raise GoalForceError(f"gemm_fp8.{n}: expected contiguous [{N}]")
+    _lib.check(_lib.load().gf_gemm_fp8(_ptr(a8), a8.stride(0), _ptr(w8), w8.stride(0), _ptr(row_scale), _ptr(bias),
+                                       _ptr(ov), ldc, M, N, K, int(epilogue), _ptr(resid), ldr, _ptr(gate), _stream(a8)),
+               "gf_gemm_fp8")
+    return out

@@ -236,6 +236,29 @@ GF_API int gf_vae_tile_blend(void* values, void* weight, const void* tile, int64
                              void* stream);
 GF_API int gf_vae_tile_finalize(void* values, const void* weight, int64_t planes, int64_t hw, void* stream);
 
+/* ========================================================================
+ * fp8 Linear — the contract of AutoWrappedLinear.fp8_linear (VRAM:115-151):
+ *   scale_a = clamp(rowmax|x| / 448, min=1);  x8 = e4m3(x / (scale_a + 1e-8));  W8 = e4m3(W) (unit scale)
+ *   out = bf16((x8 · W8^T) * scale_a + bias)          [torch._scaled_mm, out_dtype bf16]
+ * e4m3 is OCP e4m3fn (gfx950 native; the reference halves fp8_max only for MI300's fnuz).
+ * ======================================================================== */
+
+/* gf_quant_fp8_rowscale — per-row dynamic activation quantisation (VRAM:124-137).
+ * x [rows, dim] bf16 -> out8 [rows, dim] e4m3 bytes, scale [rows] fp32; dim % 8 == 0, dim <= 14336. */
+GF_API int gf_quant_fp8_rowscale(const void* x, void* out8, float* scale, int64_t rows, int64_t dim,
+                                 int64_t x_stride, int64_t out_stride, void* stream);
+
+/* gf_cast_fp8 — bf16 -> e4m3 elementwise (weight.to(float8_e4m3fn), VRAM:138); n % 8 == 0. */
+GF_API int gf_cast_fp8(const void* x, void* out8, int64_t n, void* stream);
+
+/* gf_gemm_fp8 — C = epilogue((A8 · W8^T) * row_scale[m] + bias); A8 [M,K], W8 [N,K] e4m3 bytes (K contiguous),
+ * fp32 accumulate on v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales (2x the bf16 MFMA rate);
+ * same epilogues / residual / gate semantics as gf_gemm_bf16 (torch._scaled_mm, VRAM:141-148).
+ * K % 128 == 0, lda/ldw % 16 == 0. */
+GF_API int gf_gemm_fp8(const void* A8, int64_t lda, const void* W8, int64_t ldw, const float* row_scale,
+                       const void* bias, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                       int epilogue, const void* resid, int64_t ldr, const void* gate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -110,8 +110,11 @@ def attention_fp64(q, k, v, num_heads: int) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------ DiT block (DIT:124-230)
+LINEAR = F.linear   # tests swap in oracle.fp8_oracle.fp8_linear to restate BASELINE config 5 (VRAM:115-151)
+
+
 def _lin(x, sd, name):
-    return F.linear(x, sd[name + ".weight"], sd.get(name + ".bias"))
+    return LINEAR(x, sd[name + ".weight"], sd.get(name + ".bias"))
 
 
 def self_attention(x, freqs, sd, pre, num_heads, eps):
