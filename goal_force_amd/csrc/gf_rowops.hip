@@ -161,7 +161,8 @@ __global__ __launch_bounds__(ROW_THREADS) void quant_fp8_rowscale_kernel(const u
     if ((tid & 63) == 0) red[tid >> 6] = mx;
     __syncthreads();
     mx = fmaxf(red[0], red[1]);
-    const float sc = fmaxf(mx / 448.0f, 1.0f);
+    // x_max is a bf16 tensor in the reference, so x_max / 448 is rounded to bf16 before clamp(min=1).float()
+    const float sc = fmaxf(rbf(mx / 448.0f), 1.0f);
     if (tid == 0) scale[row] = sc;
     const float den = sc + 1e-8f;
     unsigned char* orow = out + row * out_stride;

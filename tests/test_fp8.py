@@ -102,7 +102,9 @@ def test_hip_fp8_dit_block_vs_fp8_oracle_block():
         wo.LINEAR = old
     e = rel_l2(got.float(), ref.float())
     e_q = rel_l2(ref.float(), exact)
-    assert e < 1e-2, f"HIP fp8 block vs fp8 oracle block {e:.3e} (fp8 contract itself is {e_q:.3e} from fp32 math)"
+    # bf16-level differences between the two paths flip individual e4m3 roundings, so they differ by a fraction
+    # of the fp8 contract's own quantisation noise e_q; bar: < 0.5 * e_q
+    assert e < 0.5 * e_q, f"HIP fp8 block vs fp8 oracle block {e:.3e} (fp8 contract itself is {e_q:.3e} from fp32 math)"
     # turning fp8 off restores the bf16 path
     enable_fp8(blk, False)
     got_bf = blk(x.cuda(), ctx.cuda(), t_mod.cuda(), rope).cpu()

@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmarks at the production shapes (random data, events on the launch stream).
+    python3 tools/microbench.py attn [--iters 10]     self-attention S=32760, 40 heads, d=128
+    python3 tools/microbench.py gemm [--iters 10]     the four GEMM shapes of a DiT block (+fp8 variants with --fp8)
+    python3 tools/microbench.py rows                  LayerNorm+modulate / RMSNorm+RoPE HBM rates
+Used for A/B-ing kernel changes in ONE process and as the target command of rocprofv3 PMC passes."""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from goal_force_amd import ops
+
+S, D, H, F = 32760, 5120, 40, 13824
+BF = torch.bfloat16
+
+
+def timeit(fn, iters, warm=2):
+    for _ in range(warm):
+        fn()
+    evs = []
+    for _ in range(iters):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        evs.append((a, b))
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in evs)
+    return ts[len(ts) // 2], ts[0]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", choices=["attn", "gemm", "rows", "cross"])
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--fp8", action="store_true")
+    ap.add_argument("--s", type=int, default=S)
+    a = ap.parse_args()
+    torch.manual_seed(0)
+    s = a.s
+    if a.what in ("attn", "cross"):
+        skv = s if a.what == "attn" else 512
+        q = torch.randn((s, D), device="cuda").to(BF)
+        k = torch.randn((skv, D), device="cuda").to(BF)
+        v = torch.randn((skv, D), device="cuda").to(BF)
+        o = torch.empty_like(q)
+        med, mn = timeit(lambda: ops.flash_attn(q, k, v, H, out=o), a.iters)
+        fl = 4.0 * s * skv * D
+        print(f"flash_attn S={s} Skv={skv} H={H}: median {med:.3f} ms ({fl / med / 1e9:.1f} TFLOP/s), min {mn:.3f} ms ({fl / mn / 1e9:.1f} TFLOP/s)")
+    elif a.what == "gemm":
+        x = torch.randn((s, D), device="cuda").to(BF)
+        xf = torch.randn((s, F), device="cuda").to(BF)
+        for name, (inp, n, k) in {"D->D": (x, D, D), "D->F (ffn1)": (x, F, D), "F->D (ffn2)": (xf, D, F)}.items():
+            w = (torch.randn((n, k), device="cuda") / k ** 0.5).to(BF)
+            b = torch.randn((n,), device="cuda").to(BF)
+            out = torch.empty((s, n), device="cuda", dtype=BF)
+            fl = 2.0 * s * n * k
+            med, mn = timeit(lambda: ops.gemm(inp, w, b, out=out), a.iters)
+            print(f"gemm bf16 {name}: median {med:.3f} ms ({fl / med / 1e9:.1f} TFLOP/s), min {mn:.3f} ms")
+            if a.fp8:
+                w8 = ops.cast_fp8(w)
+                x8, sc = ops.quant_fp8_rowscale(inp)
+                med, mn = timeit(lambda: ops.gemm_fp8(x8, sc, w8, b, out=out), a.iters)
+                medq, _ = timeit(lambda: ops.quant_fp8_rowscale(inp), a.iters)
+                print(f"gemm fp8  {name}: median {med:.3f} ms ({fl / med / 1e9:.1f} TFLOP/s), quantise {medq:.3f} ms")
+    else:
+        x = torch.randn((s, D), device="cuda").to(BF)
+        sc = torch.randn((D,), device="cuda").to(BF)
+        out = torch.empty_like(x)
+        med, _ = timeit(lambda: ops.layernorm_modulate(x, scale1p=sc, shift=sc, out=out), a.iters)
+        print(f"layernorm_modulate: {med:.3f} ms = {2 * x.numel() * 2 / med / 1e9:.2f} TB/s")
+        cos = torch.randn((s, 64), device="cuda")
+        med, _ = timeit(lambda: ops.rmsnorm_rope(x, sc, cos, cos), a.iters)
+        print(f"rmsnorm_rope: {med:.3f} ms = {(2 * x.numel() * 2 + 2 * cos.numel() * 4) / med / 1e9:.2f} TB/s")
+
+
+if __name__ == "__main__":
+    main()
