@@ -18,7 +18,7 @@ SYMBOLS = (
     "gf_modulation", "gf_layernorm_modulate", "gf_rmsnorm_rope", "gf_gemm_bf16", "gf_flash_attn_fwd",
     "gf_patchify_im2col", "gf_unpatchify", "gf_cfg_euler_step", "gf_act", "gf_add_bf16",
     "gf_force_map",
-    "gf_vae_prep_latent", "gf_vae_im2col", "gf_vae_rmsnorm_silu", "gf_softmax_rows", "gf_transpose_pad",
+    "gf_vae_prep_latent", "gf_vae_im2col", "gf_vae_finish_latent", "gf_vae_rmsnorm_silu", "gf_softmax_rows", "gf_transpose_pad",
     "gf_vae_tile_blend", "gf_vae_tile_finalize",
     "gf_quant_fp8_rowscale", "gf_cast_fp8", "gf_gemm_fp8",
 )
@@ -55,13 +55,14 @@ def _declare(lib):
         "gf_act": [_vp, _vp, _i64, _int, _vp],
         "gf_add_bf16": [_vp, _vp, _vp, _i64, _vp],
         "gf_vae_prep_latent": [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp],
-        "gf_vae_im2col": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _int, _i64, _vp],
+        "gf_vae_im2col": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _int, _i64, _i64, _i64, _vp],
+        "gf_vae_finish_latent": [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp],
         "gf_vae_rmsnorm_silu": [_vp, _vp, _vp, _i64, _i64, _int, _vp],
         "gf_softmax_rows": [_vp, _i64, _vp, _i64, _i64, _i64, _f32, _vp],
         "gf_transpose_pad": [_vp, _i64, _vp, _i64, _i64, _i64, _vp],
-        "gf_vae_tile_blend": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _int, _int, _int, _int,
+        "gf_vae_tile_blend": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _int, _int, _int, _int,
                               _i64, _i64, _vp],
-        "gf_vae_tile_finalize": [_vp, _vp, _i64, _i64, _vp],
+        "gf_vae_tile_finalize": [_vp, _vp, _i64, _i64, _int, _vp],
         "gf_quant_fp8_rowscale": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp],
         "gf_cast_fp8": [_vp, _vp, _i64, _vp],
         "gf_gemm_fp8": [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _i64, _vp, _vp],

@@ -45,17 +45,23 @@ __global__ __launch_bounds__(VT) void prep_latent_kernel(const u16* __restrict__
     }
 }
 
-// Patch gather for conv-as-GEMM.  out[(t, Y, X), ((dt*ks + dy)*ks + dx)*C + c] with zero fill for spatial
-// padding, temporal history from `cache` (2 frames) and the K padding columns.  up2: the conv runs on the
-// nearest-2x-upsampled image (source pixel = (Y', X') >> 1).  One thread per 16-byte chunk (8 channels).
+// Patch gather for conv-as-GEMM.  out[(j, Y, X), ((dt*ks + dy)*ks + dx)*C + c] with zero fill for spatial
+// padding, temporal history from `cache` (2 frames) and the K padding columns.  Output frame j is the
+// causal conv evaluated at input frame t = t_off + j*t_stride (taps t-kt+1 .. t).
+// mode 0: stride 1, symmetric zero padding ks/2.
+// mode 1: the conv runs on the nearest-2x-upsampled image (source pixel = (Y', X') >> 1)  [Resample upsample*].
+// mode 2: stride 2 with ZeroPad2d((0,1,0,1)) — taps (2Y+dy, 2X+dx), zero past the bottom/right edge
+//         [Resample downsample*, VAE:101-112].
+// One thread per 16-byte chunk (8 channels).
 __global__ __launch_bounds__(VT) void im2col_kernel(const u16* __restrict__ src, const u16* __restrict__ cache,
-                                                    u16* __restrict__ out, int T, int H, int W, int C, int kt, int ks,
-                                                    int up2, int kpad) {
-    const int Ho = up2 ? 2 * H : H, Wo = up2 ? 2 * W : W;
+                                                    u16* __restrict__ out, int T_out, int H, int W, int C, int kt,
+                                                    int ks, int mode, int t_stride, int t_off, int kpad) {
+    const int Ho = mode == 1 ? 2 * H : (mode == 2 ? H / 2 : H);
+    const int Wo = mode == 1 ? 2 * W : (mode == 2 ? W / 2 : W);
     const int cpc = C >> 3;                  // chunks per tap
     const int kchunks = kpad >> 3;           // chunks per output row
     const int taps = kt * ks * ks;
-    const long rows = (long)T * Ho * Wo;
+    const long rows = (long)T_out * Ho * Wo;
     const long total = rows * kchunks;
     const long frame = (long)H * W * C;
     const int half = ks >> 1;
@@ -70,16 +76,40 @@ __global__ __launch_bounds__(VT) void im2col_kernel(const u16* __restrict__ src,
             const int dx = tap % ks, dy = (tap / ks) % ks, dt = tap / (ks * ks);
             const int X = (int)(row % Wo);
             const int Y = (int)((row / Wo) % Ho);
-            const int t = (int)(row / ((long)Wo * Ho));
-            const int yy = Y + dy - half, xx = X + dx - half;
-            if (yy >= 0 && yy < Ho && xx >= 0 && xx < Wo) {
-                const int sy = up2 ? (yy >> 1) : yy, sx = up2 ? (xx >> 1) : xx;
-                const int f = t - (kt - 1) + dt;  // causal: taps reach kt-1 frames into the past
+            const int j = (int)(row / ((long)Wo * Ho));
+            int sy, sx;
+            bool ok;
+            if (mode == 2) {
+                sy = 2 * Y + dy;
+                sx = 2 * X + dx;
+                ok = sy < H && sx < W;
+            } else {
+                const int yy = Y + dy - half, xx = X + dx - half;
+                ok = yy >= 0 && yy < Ho && xx >= 0 && xx < Wo;
+                sy = mode == 1 ? (yy >> 1) : yy;
+                sx = mode == 1 ? (xx >> 1) : xx;
+            }
+            if (ok) {
+                const int f = t_off + j * t_stride - (kt - 1) + dt;  // causal: taps reach kt-1 frames into the past
                 const u16* base = (f >= 0) ? (src + (long)f * frame) : (cache + (long)(2 + f) * frame);
                 v = *reinterpret_cast<const u16x8*>(base + ((long)sy * W + sx) * C + (c8 << 3));
             }
         }
         *reinterpret_cast<u16x8*>(out + row * kpad + ((long)kc << 3)) = v;
+    }
+}
+
+// Encoder tail (VideoVAE_.encode VAE:1002-1010): mu = first C channels of the conv1 output; out = bf16(bf16(mu - mean) * inv_std),
+// channels-last [rows, C] -> [rows, C].
+__global__ __launch_bounds__(VT) void finish_latent_kernel(const u16* __restrict__ x, long ldx, const u16* __restrict__ mean,
+                                                           const u16* __restrict__ inv_std, u16* __restrict__ out,
+                                                           long rows, int C) {
+    const long total = rows * C;
+    const long stride = (long)gridDim.x * VT;
+    for (long i = (long)blockIdx.x * VT + threadIdx.x; i < total; i += stride) {
+        const int c = (int)(i % C);
+        const long r = i / C;
+        out[i] = f2bf(rbf(bf2f(x[r * ldx + c]) - bf2f(mean[c])) * bf2f(inv_std[c]));
     }
 }
 
@@ -165,9 +195,9 @@ __global__ __launch_bounds__(VT) void transpose_pad_kernel(const u16* __restrict
 //   values[c,t,Y,X] += tile[t,y,x,c] * mask(y,x);  weight[Y,X] += mask(y,x)
 // mask = min(ramp_h(y), ramp_w(x)) with ramps (i+1)/border on non-boundary sides (build_mask VAE:1081-1100).
 __global__ __launch_bounds__(VT) void tile_blend_kernel(u16* __restrict__ values, u16* __restrict__ weight,
-                                                        const u16* __restrict__ tile, int T, int th, int tw, int tc,
-                                                        int H, int W, int y0, int x0, int top, int bottom, int left,
-                                                        int right, int bh, int bw) {
+                                                        const u16* __restrict__ tile, int nch, int T, int th, int tw,
+                                                        int tc, int H, int W, int y0, int x0, int top, int bottom,
+                                                        int left, int right, int bh, int bw) {
     const long total = (long)T * th * tw;
     const long stride = (long)gridDim.x * VT;
     for (long i = (long)blockIdx.x * VT + threadIdx.x; i < total; i += stride) {
@@ -181,8 +211,7 @@ __global__ __launch_bounds__(VT) void tile_blend_kernel(u16* __restrict__ values
         if (!right && x >= tw - bw) mw = (float)(tw - x) / (float)bw;
         const float m = rbf(fminf(mh, mw));  // mask.to(bf16)
         const long pix = (long)(y0 + y) * W + (x0 + x);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
+        for (int c = 0; c < nch; ++c) {
             u16* vp = values + ((long)c * T + t) * H * W + pix;
             *vp = f2bf(bf2f(*vp) + rbf(bf2f(tile[i * tc + c]) * m));
         }
@@ -192,12 +221,12 @@ __global__ __launch_bounds__(VT) void tile_blend_kernel(u16* __restrict__ values
 
 // values = clamp(values / weight, -1, 1)   (VAE:1149-1151)
 __global__ __launch_bounds__(VT) void tile_finalize_kernel(u16* __restrict__ values, const u16* __restrict__ weight,
-                                                           long planes, long hw) {
+                                                           long planes, long hw, int clamp1) {
     const long total = planes * hw;
     const long stride = (long)gridDim.x * VT;
     for (long i = (long)blockIdx.x * VT + threadIdx.x; i < total; i += stride) {
         const float v = rbf(bf2f(values[i]) / bf2f(weight[i % hw]));
-        values[i] = f2bf(fminf(fmaxf(v, -1.f), 1.f));
+        values[i] = f2bf(clamp1 ? fminf(fmaxf(v, -1.f), 1.f) : v);
     }
 }
 
@@ -215,20 +244,33 @@ extern "C" GF_API int gf_vae_prep_latent(const void* z, int64_t sc, int64_t st, 
     return GF_OK;
 }
 
-extern "C" GF_API int gf_vae_im2col(const void* src, const void* cache, void* out, int64_t T, int64_t H, int64_t W,
-                                    int64_t C, int64_t kt, int64_t ks, int upsample2x, int64_t kpad, void* stream) {
-    GF_CHECK_ARG(src && out && T > 0 && H > 0 && W > 0, "gf_vae_im2col: bad arguments");
+extern "C" GF_API int gf_vae_im2col(const void* src, const void* cache, void* out, int64_t T_out, int64_t H, int64_t W,
+                                    int64_t C, int64_t kt, int64_t ks, int mode, int64_t t_stride, int64_t t_off,
+                                    int64_t kpad, void* stream) {
+    GF_CHECK_ARG(src && out && T_out > 0 && H > 0 && W > 0, "gf_vae_im2col: bad arguments");
     GF_CHECK_ARG(C > 0 && C % 8 == 0 && kpad % 8 == 0 && kpad >= kt * ks * ks * C,
                  "gf_vae_im2col: C=%ld must be a multiple of 8 and kpad=%ld >= taps*C", (long)C, (long)kpad);
     GF_CHECK_ARG((kt == 1 || kt == 3) && (ks == 1 || ks == 3), "gf_vae_im2col: kernel must be 1 or 3 per axis");
+    GF_CHECK_ARG(mode >= 0 && mode <= 2 && t_stride >= 1 && t_off >= 0, "gf_vae_im2col: bad mode / temporal stride");
+    GF_CHECK_ARG(mode != 2 || (H % 2 == 0 && W % 2 == 0 && ks == 3), "gf_vae_im2col: downsample mode needs even H, W and ks=3");
     GF_CHECK_ARG(kt == 1 || cache, "gf_vae_im2col: a temporal kernel needs the 2-frame cache (zeros = no history)");
     GF_CHECK_ARG(gf_aligned16(src) && gf_aligned16(out) && (!cache || gf_aligned16(cache)),
                  "gf_vae_im2col: 16-byte alignment required");
-    const long rows = T * H * W * (upsample2x ? 4 : 1);
+    const long rows = mode == 1 ? T_out * H * W * 4 : (mode == 2 ? T_out * (H / 2) * (W / 2) : T_out * H * W);
     hipLaunchKernelGGL(im2col_kernel, dim3(vgrid(rows * (kpad / 8))), dim3(VT), 0, (hipStream_t)stream,
-                       (const u16*)src, (const u16*)cache, (u16*)out, (int)T, (int)H, (int)W, (int)C, (int)kt, (int)ks,
-                       upsample2x ? 1 : 0, (int)kpad);
+                       (const u16*)src, (const u16*)cache, (u16*)out, (int)T_out, (int)H, (int)W, (int)C, (int)kt, (int)ks,
+                       mode, (int)t_stride, (int)t_off, (int)kpad);
     GF_CHECK_LAUNCH("gf_vae_im2col");
+    return GF_OK;
+}
+
+extern "C" GF_API int gf_vae_finish_latent(const void* x, int64_t ldx, const void* mean, const void* inv_std, void* out,
+                                           int64_t rows, int64_t C, void* stream) {
+    GF_CHECK_ARG(x && mean && inv_std && out && rows >= 0 && C > 0 && ldx >= C, "gf_vae_finish_latent: bad arguments");
+    if (rows == 0) return GF_OK;
+    hipLaunchKernelGGL(finish_latent_kernel, dim3(vgrid(rows * C)), dim3(VT), 0, (hipStream_t)stream, (const u16*)x,
+                       (long)ldx, (const u16*)mean, (const u16*)inv_std, (u16*)out, (long)rows, (int)C);
+    GF_CHECK_LAUNCH("gf_vae_finish_latent");
     return GF_OK;
 }
 
@@ -263,23 +305,26 @@ extern "C" GF_API int gf_transpose_pad(const void* src, int64_t ld_src, void* ds
     return GF_OK;
 }
 
-extern "C" GF_API int gf_vae_tile_blend(void* values, void* weight, const void* tile, int64_t T, int64_t th, int64_t tw,
-                                        int64_t tc, int64_t H, int64_t W, int64_t y0, int64_t x0, int top, int bottom,
-                                        int left, int right, int64_t border_h, int64_t border_w, void* stream) {
-    GF_CHECK_ARG(values && weight && tile && T > 0 && th > 0 && tw > 0 && tc >= 3, "gf_vae_tile_blend: bad arguments");
+extern "C" GF_API int gf_vae_tile_blend(void* values, void* weight, const void* tile, int64_t nch, int64_t T, int64_t th,
+                                        int64_t tw, int64_t tc, int64_t H, int64_t W, int64_t y0, int64_t x0, int top,
+                                        int bottom, int left, int right, int64_t border_h, int64_t border_w,
+                                        void* stream) {
+    GF_CHECK_ARG(values && weight && tile && T > 0 && th > 0 && tw > 0 && nch > 0 && tc >= nch,
+                 "gf_vae_tile_blend: bad arguments");
     GF_CHECK_ARG(y0 >= 0 && x0 >= 0 && y0 + th <= H && x0 + tw <= W, "gf_vae_tile_blend: tile outside the frame");
     GF_CHECK_ARG(border_h > 0 && border_w > 0, "gf_vae_tile_blend: borders must be positive");
     hipLaunchKernelGGL(tile_blend_kernel, dim3(vgrid(T * th * tw)), dim3(VT), 0, (hipStream_t)stream, (u16*)values,
-                       (u16*)weight, (const u16*)tile, (int)T, (int)th, (int)tw, (int)tc, (int)H, (int)W, (int)y0,
-                       (int)x0, top, bottom, left, right, (int)border_h, (int)border_w);
+                       (u16*)weight, (const u16*)tile, (int)nch, (int)T, (int)th, (int)tw, (int)tc, (int)H, (int)W,
+                       (int)y0, (int)x0, top, bottom, left, right, (int)border_h, (int)border_w);
     GF_CHECK_LAUNCH("gf_vae_tile_blend");
     return GF_OK;
 }
 
-extern "C" GF_API int gf_vae_tile_finalize(void* values, const void* weight, int64_t planes, int64_t hw, void* stream) {
+extern "C" GF_API int gf_vae_tile_finalize(void* values, const void* weight, int64_t planes, int64_t hw, int clamp1,
+                                           void* stream) {
     GF_CHECK_ARG(values && weight && planes > 0 && hw > 0, "gf_vae_tile_finalize: bad arguments");
     hipLaunchKernelGGL(tile_finalize_kernel, dim3(vgrid(planes * hw)), dim3(VT), 0, (hipStream_t)stream, (u16*)values,
-                       (const u16*)weight, (long)planes, (long)hw);
+                       (const u16*)weight, (long)planes, (long)hw, clamp1 ? 1 : 0);
     GF_CHECK_LAUNCH("gf_vae_tile_finalize");
     return GF_OK;
 }

@@ -264,8 +264,8 @@ def vae_prep_latent(z_slice, mean, inv_std, cpad=64):
     return out
 
 
-def vae_im2col(src, cache, kt, ks, kpad, upsample2x=False):
-    """src [T,H,W,C] (+cache [2,H,W,C]) -> [T*Ho*Wo, kpad] patch matrix."""
+def vae_im2col(src, cache, kt, ks, kpad, upsample2x=False, downsample2=False, t_stride=1, t_off=0, t_out=None):
+    """src [T,H,W,C] (+cache [2,H,W,C]) -> [T_out*Ho*Wo, kpad] patch matrix (modes: see gf_vae_im2col)."""
     _req(src, "vae_im2col.src")
     if not src.is_contiguous():
         raise GoalForceError("vae_im2col.src must be contiguous [T,H,W,C]")
@@ -274,10 +274,26 @@ def vae_im2col(src, cache, kt, ks, kpad, upsample2x=False):
         _req(cache, "vae_im2col.cache")
         if tuple(cache.shape) != (2, H, W, C) or not cache.is_contiguous():
             raise GoalForceError(f"vae_im2col.cache must be contiguous [2,{H},{W},{C}]")
-    rows = T * H * W * (4 if upsample2x else 1)
-    out = torch.empty((rows, kpad), dtype=_BF16, device=src.device)
-    _lib.check(_lib.load().gf_vae_im2col(_ptr(src), _ptr(cache), _ptr(out), T, H, W, C, kt, ks, 1 if upsample2x else 0,
+    mode = 1 if upsample2x else (2 if downsample2 else 0)
+    if t_out is None:
+        t_out = (T - t_off + t_stride - 1) // t_stride
+    if t_off + (t_out - 1) * t_stride >= T:
+        raise GoalForceError("vae_im2col: temporal window exceeds the source")
+    px = H * W * 4 if mode == 1 else ((H // 2) * (W // 2) if mode == 2 else H * W)
+    out = torch.empty((t_out * px, kpad), dtype=_BF16, device=src.device)
+    _lib.check(_lib.load().gf_vae_im2col(_ptr(src), _ptr(cache), _ptr(out), t_out, H, W, C, kt, ks, mode, t_stride, t_off,
                                          kpad, _stream(src)), "gf_vae_im2col")
+    return out
+
+
+def vae_finish_latent(x, mean, inv_std, C):
+    """x [rows, >=C] (conv1 output, channels-last) -> [rows, C] normalised mu."""
+    _req(x, "vae_finish_latent.x")
+    if x.dim() != 2 or x.stride(1) != 1:
+        raise GoalForceError("vae_finish_latent.x must be 2-D with contiguous rows")
+    out = torch.empty((x.shape[0], C), dtype=_BF16, device=x.device)
+    _lib.check(_lib.load().gf_vae_finish_latent(_ptr(x), x.stride(0), _ptr(mean), _ptr(inv_std), _ptr(out), x.shape[0], C,
+                                                _stream(x)), "gf_vae_finish_latent")
     return out
 
 
@@ -315,23 +331,23 @@ def transpose_pad(x, rpad):
 
 
 def vae_tile_blend(values, weight, tile, y0, x0, bounds, border):
-    """values [3,T,H,W], weight [H,W], tile [T,th,tw,tc] channels-last; bounds=(top,bottom,left,right)."""
+    """values [nch,T,H,W], weight [H,W], tile [T,th,tw,tc>=nch] channels-last; bounds=(top,bottom,left,right)."""
     for n, t in (("values", values), ("weight", weight), ("tile", tile)):
         _req(t, f"vae_tile_blend.{n}")
         if not t.is_contiguous():
             raise GoalForceError(f"vae_tile_blend.{n} must be contiguous")
-    _, T, H, W = values.shape
+    nch, T, H, W = values.shape
     Tt, th, tw, tc = tile.shape
     if Tt != T or tuple(weight.shape) != (H, W):
         raise GoalForceError("vae_tile_blend: shape mismatch")
-    _lib.check(_lib.load().gf_vae_tile_blend(_ptr(values), _ptr(weight), _ptr(tile), T, th, tw, tc, H, W, y0, x0,
+    _lib.check(_lib.load().gf_vae_tile_blend(_ptr(values), _ptr(weight), _ptr(tile), nch, T, th, tw, tc, H, W, y0, x0,
                                              int(bounds[0]), int(bounds[1]), int(bounds[2]), int(bounds[3]),
                                              border[0], border[1], _stream(values)), "gf_vae_tile_blend")
 
 
-def vae_tile_finalize(values, weight):
+def vae_tile_finalize(values, weight, clamp=True):
     _lib.check(_lib.load().gf_vae_tile_finalize(_ptr(values), _ptr(weight), values.shape[0] * values.shape[1],
-                                                weight.numel(), _stream(values)), "gf_vae_tile_finalize")
+                                                weight.numel(), 1 if clamp else 0, _stream(values)), "gf_vae_tile_finalize")
     return values
 
 

@@ -281,13 +281,33 @@ class WanVideoPipeline:
         video = self.vae.decode(latents, device=self.device, tiled=tiled, tile_size=tile_size, tile_stride=tile_stride)
         return video if output_type == "pt" else self.vae_output_to_video(video)
 
-    # pre-loop conditioning that needs the VAE encoder ('next' row)
+    # ---------------------------------------------------------------- pre-loop units that use the VAE encoder
+    def preprocess_image(self, image, min_value=-1, max_value=1):
+        """UTIL:60-66 — PIL -> bf16 [1,3,H,W] in [-1,1] (arithmetic in bf16 like the reference)."""
+        t = torch.Tensor(np.array(image, dtype=np.float32)).to(dtype=self.torch_dtype, device=self.device)
+        t = t * ((max_value - min_value) / 255) + min_value
+        return t.permute(2, 0, 1).unsqueeze(0)
+
     def embed_image(self, input_image, num_frames, height, width, tiled, tile_size, tile_stride):
-        raise NotImplementedError("ImageEmbedderVAE (GF:887-917) needs the VAE encoder: pass `y` pre-computed")
+        """WanVideoUnit_ImageEmbedderVAE (GF:887-917): y = cat(mask[4,f,h,w], vae.encode([image, zeros x (F-1)]))."""
+        if self.vae is None:
+            raise GoalForceError("embed_image needs pipe.vae")
+        image = self.preprocess_image(input_image.resize((width, height)))
+        msk = torch.ones(1, num_frames, height // 8, width // 8, device=self.device)
+        msk[:, 1:] = 0
+        vae_input = torch.concat([image.transpose(0, 1),
+                                  torch.zeros(3, num_frames - 1, height, width, device=self.device, dtype=self.torch_dtype)], dim=1)
+        msk = torch.concat([torch.repeat_interleave(msk[:, 0:1], repeats=4, dim=1), msk[:, 1:]], dim=1)
+        msk = msk.view(1, msk.shape[1] // 4, 4, height // 8, width // 8).transpose(1, 2)[0]
+        y = self.vae.encode([vae_input], device=self.device, tiled=tiled, tile_size=tile_size, tile_stride=tile_stride)[0]
+        return torch.concat([msk.to(self.torch_dtype), y.to(self.torch_dtype)]).unsqueeze(0)
 
     def embed_control_video(self, control_signal_video, tiled, tile_size, tile_stride):
-        raise NotImplementedError("ControlVideoEmbedder (GF:791-805) needs the VAE encoder: pass "
-                                  "`control_signal_video_latents` pre-computed")
+        """WanVideoUnit_ControlVideoEmbedder (GF:791-805): 'f h w c -> 1 c f h w' then vae.encode (un-rescaled [0,1])."""
+        if self.vae is None:
+            raise GoalForceError("embed_control_video needs pipe.vae")
+        v = control_signal_video.to(dtype=self.torch_dtype, device=self.device).permute(3, 0, 1, 2)   # view, no copy
+        return self.vae.encode([v], device=self.device, tiled=tiled, tile_size=tile_size, tile_stride=tile_stride)
 
 
 def build_random_expert(cfg=None, seed=0, device="cuda", std=0.02):

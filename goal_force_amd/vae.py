@@ -2,8 +2,8 @@
 
 Drop-in surface: `WanVideoVAE.decode(hidden_states, device, tiled, tile_size,
 tile_stride) -> [B,3,T,H,W]` in [-1,1], `.upsampling_factor = 8`, `.model.z_dim = 16`, state_dict keys of the
-reference (`model.decoder.*`, `model.conv2.*`; diffsynth/models/wan_video_vae.py, "VAE").  The encoder
-(`model.encoder.*`, `model.conv1.*`) is a 'next' row — its keys are accepted and ignored on load.
+reference (`model.encoder.*`, `model.conv1.*`, `model.conv2.*`, `model.decoder.*`; diffsynth/models/wan_video_vae.py,
+"VAE").  `encode` (used by the pre-loop units GF:791-805, 887-917) runs on the same kernels.
 
 How the reference's algorithm maps here
   * VideoVAE_.decode (VAE:1011-1034) decodes latent frame by latent frame through Decoder3d with a per-conv
@@ -94,6 +94,58 @@ def decoder_layout(dim=96, z_dim=16, dim_mult=(1, 2, 4, 4), num_res_blocks=2, te
     return plan, shapes
 
 
+def encoder_layout(dim=96, z_dim=16, dim_mult=(1, 2, 4, 4), num_res_blocks=2, temperal_downsample=(False, True, True)):
+    """Encoder3d structure (VAE:517-566) + VideoVAE_.conv1 as (plan, parameter shapes)."""
+    dims = [dim * u for u in [1] + list(dim_mult)]
+    shapes: Dict[str, Tuple[int, ...]] = {}
+    plan: List[tuple] = []
+
+    def conv3(name, cin, cout, k=(3, 3, 3)):
+        shapes[name + ".weight"] = (cout, cin) + tuple(k)
+        shapes[name + ".bias"] = (cout,)
+
+    def res(name, cin, cout):
+        shapes[f"{name}.residual.0.gamma"] = (cin, 1, 1, 1)
+        conv3(f"{name}.residual.2", cin, cout)
+        shapes[f"{name}.residual.3.gamma"] = (cout, 1, 1, 1)
+        conv3(f"{name}.residual.6", cout, cout)
+        if cin != cout:
+            conv3(f"{name}.shortcut", cin, cout, (1, 1, 1))
+        plan.append(("res", name, cin, cout))
+
+    conv3("encoder.conv1", 3, dims[0])
+    plan.append(("conv1", "encoder.conv1", 3, dims[0]))
+    idx = 0
+    out_dim = dims[0]
+    for i, (in_dim, out_dim) in enumerate(zip(dims[:-1], dims[1:])):
+        for _ in range(num_res_blocks):
+            res(f"encoder.downsamples.{idx}", in_dim, out_dim)
+            idx += 1
+            in_dim = out_dim
+        if i != len(dim_mult) - 1:
+            name = f"encoder.downsamples.{idx}"
+            shapes[name + ".resample.1.weight"] = (out_dim, out_dim, 3, 3)
+            shapes[name + ".resample.1.bias"] = (out_dim,)
+            t3 = bool(temperal_downsample[i])
+            if t3:
+                conv3(name + ".time_conv", out_dim, out_dim, (3, 1, 1))
+            plan.append(("down", name, out_dim, t3))
+            idx += 1
+    res("encoder.middle.0", out_dim, out_dim)
+    shapes["encoder.middle.1.norm.gamma"] = (out_dim, 1, 1)
+    shapes["encoder.middle.1.to_qkv.weight"] = (out_dim * 3, out_dim, 1, 1)
+    shapes["encoder.middle.1.to_qkv.bias"] = (out_dim * 3,)
+    shapes["encoder.middle.1.proj.weight"] = (out_dim, out_dim, 1, 1)
+    shapes["encoder.middle.1.proj.bias"] = (out_dim,)
+    plan.append(("attn", "encoder.middle.1", out_dim))
+    res("encoder.middle.2", out_dim, out_dim)
+    shapes["encoder.head.0.gamma"] = (out_dim, 1, 1, 1)
+    conv3("encoder.head.2", out_dim, z_dim * 2)
+    plan.append(("head", "encoder.head", out_dim))
+    conv3("conv1", z_dim * 2, z_dim * 2, (1, 1, 1))
+    return plan, shapes
+
+
 class _ParamTree(nn.Module):
     """nn.Module whose parameters are registered under dotted names so state_dict() keys equal the
     reference's (e.g. 'decoder.upsamples.4.shortcut.weight')."""
@@ -115,12 +167,14 @@ class _ParamTree(nn.Module):
 
 
 class VideoVAE_(_ParamTree):
-    """Parameter container for VideoVAE_ (VAE:951-977): decoder + conv2 (dim 96, z 16)."""
+    """Parameter container for VideoVAE_ (VAE:951-977): encoder + conv1 + conv2 + decoder (dim 96, z 16)."""
 
     def __init__(self, dim=96, z_dim=16):
         super().__init__()
         self.dim, self.z_dim = dim, z_dim
         self.plan, self.shapes = decoder_layout(dim, z_dim)
+        self.enc_plan, enc_shapes = encoder_layout(dim, z_dim)
+        self.shapes = {**enc_shapes, **self.shapes}
         for name, shp in self.shapes.items():
             if name.endswith("gamma"):
                 t = torch.ones(shp)
@@ -146,10 +200,8 @@ class WanVideoVAE(nn.Module):
 
     # ---------------------------------------------------------------- state dict
     def load_state_dict(self, state_dict, strict=True, **kw):
-        """Encoder keys (model.encoder.*, model.conv1.*) are accepted and ignored: the encoder is a 'next' row."""
-        sd = {k: v for k, v in state_dict.items() if not (k.startswith("model.encoder.") or k.startswith("model.conv1."))}
         self._prepared = None
-        return super().load_state_dict(sd, strict=strict, **kw)
+        return super().load_state_dict(state_dict, strict=strict, **kw)
 
     def _apply(self, fn, *a, **k):
         self._prepared = None
@@ -160,6 +212,11 @@ class WanVideoVAE(nn.Module):
         w = self.model.get(name + ".weight")
         b = self.model.get(name + ".bias")
         cout, cin = w.shape[0], w.shape[1]
+        if cin % 8:  # RGB input is stored channels-last padded to 8 channels
+            cpad = _pad_to(cin, 8)
+            wz = torch.zeros((cout, cpad) + tuple(w.shape[2:]), dtype=w.dtype, device=w.device)
+            wz[:, :cin] = w
+            w, cin = wz, cpad
         if w.dim() == 5:
             kt, ks = w.shape[2], w.shape[3]
             wm = w.permute(0, 2, 3, 4, 1).reshape(cout, -1)
@@ -184,13 +241,15 @@ class WanVideoVAE(nn.Module):
         for name in self.model.shapes:
             if name.endswith(".weight"):
                 base = name[:-len(".weight")]
-                P[base] = self._prep_conv(base)
+                P[base] = self._prep_conv(base, cout_pad_to=64 if base == "encoder.head.2" else 8)
         # conv2 consumes the 64-channel padded latent: K padded from 16 to 64 already by _prep_conv
         for name in self.model.shapes:
             if name.endswith("gamma"):
                 P[name] = self.model.get(name).reshape(-1).contiguous()
         P["mean"] = self.mean.to(dev, torch.bfloat16)
         P["inv_std"] = (1.0 / self.std).to(dev, torch.bfloat16)
+        P["zero3"] = torch.zeros(3, dtype=torch.bfloat16, device=dev)
+        P["one3"] = torch.ones(3, dtype=torch.bfloat16, device=dev)
         self._prepared = P
         return P
 
@@ -291,6 +350,112 @@ class WanVideoVAE(nn.Module):
         self._cache = {}
         return torch.cat(frames, dim=0)
 
+    # ---------------------------------------------------------------- encoder (VAE:517-617, 988-1010)
+    def _downsample(self, P, name, x, C, temporal):
+        """Resample downsample2d / downsample3d (VAE:101-112, 159-174)."""
+        T, H, W, _ = x.shape
+        rc = P[name + ".resample.1"]
+        cols = ops.vae_im2col(x, None, 1, 3, rc["kpad"], downsample2=True)
+        x = ops.gemm(cols, rc["w"], rc["b"]).view(T, H // 2, W // 2, -1)
+        if temporal:
+            key = name + ".time_conv"
+            prev = self._cache.get(key)
+            if prev is None:   # first chunk: remember the frame, no temporal conv (VAE:162-164)
+                self._cache[key] = torch.cat([torch.zeros_like(x[-1:]), x[-1:]], dim=0).contiguous()
+            else:              # conv over [prev_last, x_0..x_{T-1}], kernel 3, stride 2, no padding (VAE:166-170)
+                tc = P[key]
+                cols = ops.vae_im2col(x, prev, 3, 1, tc["kpad"], t_stride=2, t_off=1, t_out=T // 2)
+                self._cache[key] = torch.cat([prev, x], dim=0)[-CACHE_T:].contiguous()
+                x = ops.gemm(cols, tc["w"], tc["b"]).view(T // 2, H // 2, W // 2, -1)
+        return x
+
+    def _encode_chunk(self, P, x):
+        """Encoder3d.forward on one chunk of frames (VAE:568-617).  x [T,H,W,8] -> [T', H/8, W/8, 64 (32 used)]."""
+        for step in self.model.enc_plan:
+            kind, name = step[0], step[1]
+            if kind == "conv1":
+                x = self._causal_conv(P, name, x)
+            elif kind == "res":
+                x = self._res_block(P, name, x, step[2], step[3])
+            elif kind == "attn":
+                x = self._attention(P, name, x, step[2])
+            elif kind == "down":
+                x = self._downsample(P, name, x, step[2], step[3])
+            elif kind == "head":
+                x = ops.vae_rmsnorm_silu(x, P[name + ".0.gamma"], silu=True)
+                x = self._causal_conv(P, name + ".2", x)
+        return x
+
+    def encode_tile_channels_last(self, video_slice: torch.Tensor) -> torch.Tensor:
+        """VideoVAE_.encode (VAE:988-1010) for one [3,T,H,W] slice (any strides) -> normalised mu [T', H/8, W/8, 16]."""
+        P = self._prepare()
+        self._cache = {}
+        T = video_slice.shape[1]
+        xin = ops.vae_prep_latent(video_slice, P["zero3"], P["one3"], cpad=8)    # channels-last, RGB padded to 8
+        n_iter = 1 + (T - 1) // 4
+        outs = []
+        for i in range(n_iter):
+            chunk = xin[:1] if i == 0 else xin[1 + 4 * (i - 1):1 + 4 * i]
+            outs.append(self._encode_chunk(P, chunk.contiguous()))
+        self._cache = {}
+        h = torch.cat(outs, dim=0)                                               # [T', h, w, 64]
+        Tl, hh, ww, _ = h.shape
+        c1 = P["conv1"]
+        y = ops.gemm(h.reshape(Tl * hh * ww, -1), c1["w"], c1["b"])              # 1x1x1 conv1, [.., 32] = (mu, log_var)
+        mu = ops.vae_finish_latent(y, P["mean"], P["inv_std"], self.z_dim)       # (mu - mean) * (1/std)
+        return mu.view(Tl, hh, ww, self.z_dim)
+
+    def tiled_encode(self, video, device, tile_size, tile_stride):
+        """WanVideoVAE.tiled_encode (VAE:1155-1203); sizes in pixels; video [1,3,T,H,W]."""
+        _, _, T, H, W = video.shape
+        size_h, size_w = tile_size
+        stride_h, stride_w = tile_stride
+        tasks = []
+        for h in range(0, H, stride_h):
+            if h - stride_h >= 0 and h - stride_h + size_h >= H:
+                continue
+            for w in range(0, W, stride_w):
+                if w - stride_w >= 0 and w - stride_w + size_w >= W:
+                    continue
+                tasks.append((h, h + size_h, w, w + size_w))
+        u = self.upsampling_factor
+        out_T = (T + 3) // 4
+        values = torch.zeros((self.z_dim, out_T, H // u, W // u), dtype=torch.bfloat16, device=video.device)
+        weight = torch.zeros((H // u, W // u), dtype=torch.bfloat16, device=video.device)
+        for (h, h_, w, w_) in tasks:
+            tile = self.encode_tile_channels_last(video[0, :, :, h:h_, w:w_])
+            ops.vae_tile_blend(values, weight, tile.contiguous(), h // u, w // u,
+                               bounds=(h == 0, h_ >= H, w == 0, w_ >= W),
+                               border=((size_h - stride_h) // u, (size_w - stride_w) // u))
+        ops.vae_tile_finalize(values, weight, clamp=False)
+        return values.unsqueeze(0)
+
+    def single_encode(self, video, device):
+        tile = self.encode_tile_channels_last(video[0])
+        Tl, hh, ww, _ = tile.shape
+        values = torch.zeros((self.z_dim, Tl, hh, ww), dtype=torch.bfloat16, device=video.device)
+        weight = torch.zeros((hh, ww), dtype=torch.bfloat16, device=video.device)
+        ops.vae_tile_blend(values, weight, tile.contiguous(), 0, 0, bounds=(True, True, True, True), border=(1, 1))
+        ops.vae_tile_finalize(values, weight, clamp=False)
+        return values.unsqueeze(0)
+
+    @torch.no_grad()
+    def encode(self, videos, device=None, tiled=False, tile_size=(34, 34), tile_stride=(18, 16)):
+        """videos: iterable of [3,T,H,W] bf16 in [-1,1] (any strides) -> [B,16,(T+3)//4,H/8,W/8] normalised latents
+        (VAE:1218-1232).  Tile sizes are given in latent units like the reference and scaled by 8 here."""
+        u = self.upsampling_factor
+        outs = []
+        for v in videos:
+            v = v.unsqueeze(0)
+            if not v.is_cuda:
+                v = v.to(device or "cuda")
+            if tiled:
+                z = self.tiled_encode(v, device, (tile_size[0] * u, tile_size[1] * u), (tile_stride[0] * u, tile_stride[1] * u))
+            else:
+                z = self.single_encode(v, device)
+            outs.append(z.squeeze(0))
+        return torch.stack(outs)
+
     # ---------------------------------------------------------------- public API (VAE:1103-1152, 1211-1247)
     def tiled_decode(self, hidden_states, device, tile_size, tile_stride):
         _, _, T, H, W = hidden_states.shape
@@ -338,5 +503,3 @@ class WanVideoVAE(nn.Module):
             videos.append(v.squeeze(0))
         return torch.stack(videos)
 
-    def encode(self, videos, device=None, tiled=False, tile_size=(34, 34), tile_stride=(18, 16)):
-        raise NotImplementedError("VAE encoder is a 'next' row (SURVEY §8f rank 1); pass pre-computed latents")

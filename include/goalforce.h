@@ -202,12 +202,21 @@ GF_API int gf_vae_prep_latent(const void* z, int64_t sc, int64_t st, int64_t sy,
                               int64_t C, int64_t T, int64_t H, int64_t W, int64_t cpad, void* stream);
 
 /* gf_vae_im2col — patch gather for CausalConv3d (VAE:33-52; kt in {1,3}, ks in {1,3},
- * zero spatial padding ks/2, causal temporal padding kt-1 taken from `cache`
- * [2,H,W,C] = the reference's feat_cache entry, all-zero when there is no history)
- * and for Resample's Upsample(nearest-exact 2x)+Conv2d(3x3) when upsample2x != 0
- * (VAE:91-99).  src [T,H,W,C] -> out [T*Ho*Wo, kpad], column ((dt*ks+dy)*ks+dx)*C+c. */
-GF_API int gf_vae_im2col(const void* src, const void* cache, void* out, int64_t T, int64_t H, int64_t W,
-                         int64_t C, int64_t kt, int64_t ks, int upsample2x, int64_t kpad, void* stream);
+ * causal temporal padding kt-1 taken from `cache` [2,H,W,C] = the reference's
+ * feat_cache entry, all-zero when there is no history).  Output frame j is the conv at
+ * input frame t_off + j*t_stride (t_stride 2 = the encoder's strided time_conv, VAE:107-112, 160-170).
+ *   mode 0: zero spatial padding ks/2, stride 1;
+ *   mode 1: Upsample(nearest-exact 2x) folded into a 3x3 conv (decoder Resample, VAE:91-99);
+ *   mode 2: ZeroPad2d((0,1,0,1)) + 3x3 conv stride 2 (encoder Resample, VAE:101-106).
+ * src [T,H,W,C] -> out [T_out*Ho*Wo, kpad], column ((dt*ks+dy)*ks+dx)*C+c. */
+GF_API int gf_vae_im2col(const void* src, const void* cache, void* out, int64_t T_out, int64_t H, int64_t W,
+                         int64_t C, int64_t kt, int64_t ks, int mode, int64_t t_stride, int64_t t_off,
+                         int64_t kpad, void* stream);
+
+/* gf_vae_finish_latent — encoder tail: out[r,c] = bf16(bf16(x[r,c] - mean[c]) * inv_std[c]) for the first C
+ * (mu) channels of the 1x1x1 conv1 output (VideoVAE_.encode, VAE:1002-1010). */
+GF_API int gf_vae_finish_latent(const void* x, int64_t ldx, const void* mean, const void* inv_std, void* out,
+                                int64_t rows, int64_t C, void* stream);
 
 /* gf_vae_rmsnorm_silu — RMS_norm over channels (F.normalize * sqrt(C) * gamma, bf16
  * rounding after each eager op, VAE:55-70) optionally followed by SiLU
@@ -228,13 +237,14 @@ GF_API int gf_transpose_pad(const void* src, int64_t ld_src, void* dst, int64_t 
 /* gf_vae_tile_blend / gf_vae_tile_finalize — WanVideoVAE.tiled_decode's weighted tile
  * accumulation (VAE:1128-1150, build_mask VAE:1081-1100) with bf16 accumulators:
  *   values[c,t,y0+y,x0+x] += tile[t,y,x,c]*mask(y,x); weight[y0+y,x0+x] += mask(y,x)
- * then values = clamp(values/weight, -1, 1).  tile is channels-last [T,th,tw,tc>=3];
+ * then values = clamp(values/weight, -1, 1).  tile is channels-last [T,th,tw,tc>=nch] (nch = 3 RGB / 16 latent);
  * top/bottom/left/right = the tile touches that frame border (no ramp on that side).   */
-GF_API int gf_vae_tile_blend(void* values, void* weight, const void* tile, int64_t T, int64_t th, int64_t tw,
-                             int64_t tc, int64_t H, int64_t W, int64_t y0, int64_t x0,
+GF_API int gf_vae_tile_blend(void* values, void* weight, const void* tile, int64_t nch, int64_t T, int64_t th,
+                             int64_t tw, int64_t tc, int64_t H, int64_t W, int64_t y0, int64_t x0,
                              int top, int bottom, int left, int right, int64_t border_h, int64_t border_w,
                              void* stream);
-GF_API int gf_vae_tile_finalize(void* values, const void* weight, int64_t planes, int64_t hw, void* stream);
+/* clamp1 != 0: clamp to [-1,1] (decode); 0: no clamp (tiled_encode, VAE:1155-1203). */
+GF_API int gf_vae_tile_finalize(void* values, const void* weight, int64_t planes, int64_t hw, int clamp1, void* stream);
 
 /* ========================================================================
  * fp8 Linear — the contract of AutoWrappedLinear.fp8_linear (VRAM:115-151):

@@ -106,6 +106,81 @@ def decode(z, sd):
     return torch.cat(outs, dim=2)
 
 
+def _down(x, sd, name, st):
+    """Resample downsample2d/3d (VAE:101-112, 159-174)."""
+    b, c, t, h, w = x.shape
+    y = x.permute(0, 2, 1, 3, 4).reshape(b * t, c, h, w)
+    y = F.conv2d(F.pad(y, (0, 1, 0, 1)), sd[name + ".resample.1.weight"], sd[name + ".resample.1.bias"], stride=2)
+    x = y.reshape(b, t, c, h // 2, w // 2).permute(0, 2, 1, 3, 4)
+    if (name + ".time_conv.weight") in sd:
+        prev = st.hist.get(name + ".time_conv")
+        st.hist[name + ".time_conv"] = x[:, :, -1:].clone()
+        if prev is not None:
+            x = F.conv3d(torch.cat([prev, x], 2), sd[name + ".time_conv.weight"], sd[name + ".time_conv.bias"],
+                         stride=(2, 1, 1))
+    return x
+
+
+def _encoder_chunk(x, sd, st):
+    x = _causal_conv(x, sd, "encoder.conv1", st)
+    i = 0
+    while True:
+        n = f"encoder.downsamples.{i}"
+        if (n + ".residual.0.gamma") in sd:
+            x = _res(x, sd, n, st)
+        elif (n + ".resample.1.weight") in sd:
+            x = _down(x, sd, n, st)
+        else:
+            break
+        i += 1
+    x = _res(x, sd, "encoder.middle.0", st)
+    x = _attn(x, sd, "encoder.middle.1")
+    x = _res(x, sd, "encoder.middle.2", st)
+    x = F.silu(_rms(x, sd["encoder.head.0.gamma"]))
+    return _causal_conv(x, sd, "encoder.head.2", st)
+
+
+def encode(video, sd):
+    """VideoVAE_.encode (VAE:988-1010): video [1,3,T,H,W] in [-1,1] -> normalised mu [1,16,1+(T-1)//4,H/8,W/8]."""
+    st = _State()
+    t = video.shape[2]
+    outs = []
+    for i in range(1 + (t - 1) // 4):
+        chunk = video[:, :, :1] if i == 0 else video[:, :, 1 + 4 * (i - 1):1 + 4 * i]
+        outs.append(_encoder_chunk(chunk, sd, st))
+    out = torch.cat(outs, 2)
+    mu, _ = F.conv3d(out, sd["conv1.weight"], sd["conv1.bias"]).chunk(2, dim=1)
+    mean = torch.tensor(MEAN).to(mu.dtype).view(1, -1, 1, 1, 1)
+    inv_std = (1.0 / torch.tensor(STD)).to(mu.dtype).view(1, -1, 1, 1, 1)
+    return (mu - mean) * inv_std
+
+
+def tiled_encode(video, sd, tile_size, tile_stride, up=8):
+    """WanVideoVAE.tiled_encode (VAE:1155-1203); sizes in pixels."""
+    _, _, T, H, W = video.shape
+    (sh, sw), (th, tw) = tile_size, tile_stride
+    tasks = []
+    for h in range(0, H, th):
+        if h - th >= 0 and h - th + sh >= H:
+            continue
+        for w in range(0, W, tw):
+            if w - tw >= 0 and w - tw + sw >= W:
+                continue
+            tasks.append((h, h + sh, w, w + sw))
+    oT = (T + 3) // 4
+    weight = torch.zeros((1, 1, oT, H // up, W // up), dtype=video.dtype)
+    values = torch.zeros((1, 16, oT, H // up, W // up), dtype=video.dtype)
+    for h, h_, w, w_ in tasks:
+        tile = encode(video[:, :, :, h:h_, w:w_], sd)
+        mh = _ramp(tile.shape[3], h == 0, h_ >= H, (sh - th) // up)
+        mw = _ramp(tile.shape[4], w == 0, w_ >= W, (sw - tw) // up)
+        mask = torch.minimum(mh[:, None].expand(-1, tile.shape[4]), mw[None, :].expand(tile.shape[3], -1))
+        mask = mask.view(1, 1, 1, *mask.shape).to(video.dtype)
+        values[:, :, :, h // up:h // up + tile.shape[3], w // up:w // up + tile.shape[4]] += tile * mask
+        weight[:, :, :, h // up:h // up + tile.shape[3], w // up:w // up + tile.shape[4]] += mask
+    return values / weight
+
+
 def _ramp(length, left_bound, right_bound, border):
     x = torch.ones((length,))
     if not left_bound:

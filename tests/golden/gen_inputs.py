@@ -115,8 +115,8 @@ def block_inputs(dim, tokens, ctx_len, seed, dtype=torch.bfloat16):
 
 
 def vae_decoder_sd(names, shapes, seed, dtype=torch.bfloat16):
-    """Seeded random weights for the VAE decoder + conv2; `names`/`shapes` come from the fixture (they were read
-    from the reference's own state_dict, in its order)."""
+    """Seeded random weights for the whole VAE (encoder, conv1, conv2, decoder); `names`/`shapes` come from the
+    fixture (they were read from the reference's own state_dict, in its order)."""
     g = torch.Generator().manual_seed(seed)
     sd = {}
     for n, shp in zip(names, shapes):

@@ -21,18 +21,22 @@ def _fixture():
     gen = torch.Generator().manual_seed(62)
     z1 = torch.randn((1, 16, 3, 8, 8), generator=gen).to(BF)
     z2 = torch.randn((1, 16, 2, 12, 16), generator=gen).to(BF)
-    assert gi.same_checksum(gi.checksum(sd), g["ck_weights"]) and gi.same_checksum(gi.checksum([z1, z2]), g["ck_inputs"])
+    v1 = (torch.rand((1, 3, 9, 64, 64), generator=gen) * 2 - 1).to(BF)
+    v2 = (torch.rand((1, 3, 5, 96, 128), generator=gen) * 2 - 1).to(BF)
+    assert gi.same_checksum(gi.checksum(sd), g["ck_weights"]) and gi.same_checksum(gi.checksum([z1, z2, v1, v2]), g["ck_inputs"])
+    _fixture.videos = (v1, v2)
     return g, sd, z1, z2
 
 
 def test_decoder_layout_matches_reference_state_dict():
     from goal_force_amd.vae import WanVideoVAE, decoder_layout
     g = np.load(os.path.join(GOLDEN, "g6_vae.npz"))
-    _, shapes = decoder_layout()
+    from goal_force_amd.vae import encoder_layout
+    shapes = {**encoder_layout()[1], **decoder_layout()[1]}
     ref = {n: tuple(int(v) for v in s if int(v) > 0) for n, s in zip(g["names"], g["shapes"])}
     assert ref == {k: tuple(v) for k, v in shapes.items()}
     assert sorted(WanVideoVAE().state_dict().keys()) == sorted("model." + n for n in ref)
-    assert sum(int(np.prod(s)) for s in ref.values()) == 73_295_603 - 0  # decoder + conv2 params of the reference
+    assert sum(int(np.prod(s)) for s in ref.values()) == 126_892_531   # every parameter of the reference VAE
 
 
 def test_oracle_decode_matches_reference():
@@ -50,6 +54,15 @@ def test_oracle_tiled_decode_matches_reference():
     assert torch.equal(got, gi.from_u16(g["tiled_bf16"]))
     sd32 = {k: v.float() for k, v in sd.items()}
     assert rel_l2(vo.tiled_decode(z2.float(), sd32, (8, 8), (4, 4)), torch.from_numpy(g["tiled_f32"])) < 1e-5
+
+
+def test_oracle_encode_matches_reference():
+    g, sd, z1, z2 = _fixture()
+    v1, v2 = _fixture.videos
+    assert torch.equal(vo.encode(v1, sd), gi.from_u16(g["encode_bf16"]))
+    assert torch.equal(vo.tiled_encode(v2, sd, (64, 64), (32, 32)), gi.from_u16(g["encode_tiled_bf16"]))
+    sd32 = {k: v.float() for k, v in sd.items()}
+    assert rel_l2(vo.encode(v1.float(), sd32), torch.from_numpy(g["encode_f32"])) < 1e-5
 
 
 def _gpu_vae(sd):
@@ -152,3 +165,22 @@ def test_hip_tile_blend_exact_against_oracle_arithmetic():
     ops.vae_tile_finalize(values, weight)
     ref = (ref_v / ref_w).clamp_(-1, 1)
     assert torch.equal(values.cpu()[None], ref)
+
+
+@pytest.mark.gpu
+def test_hip_vae_encode_vs_reference_golden():
+    g, sd, z1, z2 = _fixture()
+    v1, v2 = _fixture.videos
+    vae = _gpu_vae(sd)
+    for key, got in (("encode", vae.encode(v1.cuda(), tiled=False).cpu()),
+                     ("encode_tiled", vae.encode(v2.cuda(), tiled=True, tile_size=(8, 8), tile_stride=(4, 4)).cpu())):
+        f32 = torch.from_numpy(g[f"{key}_f32"])
+        ref_bf = gi.from_u16(g[f"{key}_bf16"]).float()
+        e, e_ref = rel_l2(got.float(), f32), rel_l2(ref_bf, f32)
+        assert tuple(got.shape) == tuple(f32.shape)
+        assert e < max(1.5e-2, 1.5 * e_ref), f"{key}: vs fp32 {e:.3e} (reference bf16 {e_ref:.3e})"
+    # a [F,H,W,3] control video handed over as a permuted view (GF:800) encodes without a copy
+    cv = torch.rand((9, 64, 64, 3)).to(BF)
+    a = vae.encode([cv.cuda().permute(3, 0, 1, 2)], tiled=False)
+    b = vae.encode([cv.permute(3, 0, 1, 2).contiguous().cuda()], tiled=False)
+    assert torch.equal(a, b) and tuple(a.shape) == (1, 16, 3, 8, 8)
