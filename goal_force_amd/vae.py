@@ -264,7 +264,7 @@ class WanVideoVAE(nn.Module):
                 cache = torch.zeros((CACHE_T, H, W, C), dtype=x.dtype, device=x.device)
             cols = ops.vae_im2col(x, cache, 3, c["ks"], c["kpad"])
             self._cache[name] = torch.cat([cache, x], dim=0)[-CACHE_T:].contiguous()
-        elif c["ks"] == 1:
+        elif c["ks"] == 1 and c["kpad"] == C:
             cols = x.reshape(T * H * W, C)
         else:
             cols = ops.vae_im2col(x, None, 1, c["ks"], c["kpad"])
