@@ -10,11 +10,14 @@
 //     MFMA (k order of the accumulator layout), and V^T fragments come from the row-major V tile by
 //     ds_read_b64_tr_b16 (hardware transpose).  O^T keeps the query on the lane, so the online
 //     softmax rescale is a per-lane scalar multiply.
-//   * K and V tiles (64 keys x 128 d, 16 KiB each) are double buffered in LDS in ONE image,
+//   * K and V tiles (64 keys x 128 d, 16 KiB each) are triple buffered in LDS in ONE image,
 //     off(row,ch) = 256*row + 16*(ch ^ (((row&3)<<2) | ((row>>2)&3))), which is conflict-free for both
 //     the ds_read_b128 row reads (K) and the transposed reads (V).  Global->register loads of tile
 //     t+1 are issued before the MFMAs of tile t and written to LDS after them (latency hidden
 //     under the matrix work); one barrier per tile.
+//   * the two waves of a SIMD (w, w+4) run rotated by one phase: waves 4-7 defer each tile's PV product to the next
+//     iteration, so one partner's MFMA phase runs beside the other's softmax (VALU/transcendental) phase instead
+//     of both contending for the matrix pipe and then for the VALU in lockstep.
 //   * blockIdx -> (head, q-block) is XCD-aware: the 32 CUs of an XCD work on the same head at the
 //     same time so its K/V stream (16.8 MB at S=32760) is shared through that XCD's L2.
 //   * softmax in fp32 with exp2 and the scale folded into one FMA; lazy rescale (skip the O
@@ -29,7 +32,7 @@ constexpr int KVB = 64;          // keys per tile
 constexpr int HD = 128;          // head dim
 constexpr int KV_TILE_BYTES = KVB * HD * 2;        // 16 KiB
 constexpr int AT_STAGE_BYTES = 2 * KV_TILE_BYTES;  // K + V
-constexpr int AT_LDS = 2 * AT_STAGE_BYTES;         // 64 KiB
+constexpr int AT_LDS = 3 * AT_STAGE_BYTES;         // 96 KiB (three stages)
 
 __device__ __forceinline__ int kv_off(int row, int ch) {
     return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
@@ -129,19 +132,11 @@ __global__ __launch_bounds__(AT_THREADS, 2) void flash_attn_fwd_kernel(const Att
     float m_run = -1.0e30f;  // running max (raw score units)
     float l_run = 0.f;       // partial row sum of this lane's 32 keys per tile
     const float c = p.scale_log2e;
-
     const int nt = (p.kv_len + KVB - 1) / KVB;
-    load_tile(0);
-    write_tile(0);
-    __syncthreads();
+    bf16x8 pf[2][2];  // P^T fragments of the tile whose PV product is pending
 
-    for (int t = 0; t < nt; ++t) {
-        const int buf = t & 1;
-        GF_LDS char* kb = lds + buf * AT_STAGE_BYTES;
-        GF_LDS char* vb = kb + KV_TILE_BYTES;
-        if (t + 1 < nt) load_tile(t + 1);  // global -> registers, consumed after the MFMAs below
-
-        // ---- S^T = K · Q^T ---------------------------------------------------------------------
+    // ---- S^T = K · Q^T for the tile in stage `kb`, online softmax, P^T fragments into pf -------------
+    auto scores_softmax = [&](GF_LDS char* kb, int t) {
         f32x16 s0, s1;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -157,7 +152,6 @@ __global__ __launch_bounds__(AT_THREADS, 2) void flash_attn_fwd_kernel(const Att
             s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1f, qf[kd], s1, 0, 0, 0);
         }
         // s{kt}[e] = score(key = 64t + 32kt + (e&3) + 8*(e>>2) + 4h, query q0 + r)
-
         if (t == nt - 1 && (p.kv_len & (KVB - 1)) != 0) {  // mask the ragged tail (wave-uniform branch)
             const int kbase_i = t * KVB + 4 * h;
 #pragma unroll
@@ -167,16 +161,15 @@ __global__ __launch_bounds__(AT_THREADS, 2) void flash_attn_fwd_kernel(const Att
                 if (key + 32 >= p.kv_len) s1[e] = -INFINITY;
             }
         }
-
-        // ---- online softmax --------------------------------------------------------------------
         float mx = s0[0];
 #pragma unroll
         for (int e = 1; e < 16; ++e) mx = fmaxf(mx, s0[e]);
 #pragma unroll
         for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s1[e]);
         mx = fmaxf(mx, __shfl_xor(mx, 32));
-        // lazy rescale: keep the old max while no row of the wave grew by more than THR (raw units
-        // scaled: (mx - m)*c <= 6 -> p <= 2^6, harmless for bf16 P and fp32 sums)
+        // lazy rescale: keep the old max while no row of the wave grew by more than 2^6 (p <= 64: harmless for
+        // bf16 P and fp32 sums; exact in exact arithmetic).  Everything still at the old scale (O, l) is rescaled
+        // exactly once; P of this tile is exponentiated after the decision.
         if (!__all((mx - m_run) * c <= 6.0f)) {
             const float m_new = fmaxf(m_run, mx);
             const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
@@ -196,9 +189,7 @@ __global__ __launch_bounds__(AT_THREADS, 2) void flash_attn_fwd_kernel(const Att
             rs += s0[e] + s1[e];
         }
         l_run += rs;
-
         // P^T fragments (B operand of O^T = V^T P^T): k-step s of subtile kt = registers 8s..8s+7
-        bf16x8 pf[2][2];
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -206,8 +197,10 @@ __global__ __launch_bounds__(AT_THREADS, 2) void flash_attn_fwd_kernel(const Att
                 pf[0][s][e] = (__bf16)s0[8 * s + e];
                 pf[1][s][e] = (__bf16)s1[8 * s + e];
             }
+    };
 
-        // ---- O^T += V^T · P^T ------------------------------------------------------------------
+    // ---- O^T += V^T · P^T for the V tile in stage `vb` and the pending pf ------------------------------
+    auto pv = [&](GF_LDS char* vb) {
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -226,9 +219,44 @@ __global__ __launch_bounds__(AT_THREADS, 2) void flash_attn_fwd_kernel(const Att
                                                                       oacc[d], 0, 0, 0);
                 }
             }
+    };
 
-        if (t + 1 < nt) write_tile(buf ^ 1);  // other buffer: last read in iteration t-1, fenced by its barrier
-        __syncthreads();
+    load_tile(0);
+    write_tile(0);
+    __syncthreads();
+
+    // Three LDS stages; tile t lives in stage t % 3.  The two waves that share a SIMD (w and w+4) run the same
+    // work rotated by one phase so that one's MFMA phase meets the other's softmax (VALU) phase:
+    //   waves 0-3:  [QK^T(t), softmax(t)]  [PV(t)]                 | barrier
+    //   waves 4-7:  [PV(t-1)]              [QK^T(t), softmax(t)]   | barrier      (+ PV(nt-1) after the loop)
+    // Tile t+1 is written into stage (t+1)%3 at the end of iteration t; its previous tenant (tile t-2) was last read
+    // by waves 4-7 in iteration t-1, which the barrier of t-1 fences.
+    int cur = 0, prev = 2, nxt = 1;
+    if (wave < 4) {
+        for (int t = 0; t < nt; ++t) {
+            GF_LDS char* kb = lds + cur * AT_STAGE_BYTES;
+            if (t + 1 < nt) load_tile(t + 1);  // global -> registers, consumed after the MFMAs below
+            scores_softmax(kb, t);
+            pv(kb + KV_TILE_BYTES);
+            if (t + 1 < nt) write_tile(nxt);
+            __syncthreads();
+            prev = cur;
+            cur = nxt;
+            nxt = (nxt == 2) ? 0 : nxt + 1;
+        }
+    } else {
+        for (int t = 0; t < nt; ++t) {
+            GF_LDS char* kb = lds + cur * AT_STAGE_BYTES;
+            if (t + 1 < nt) load_tile(t + 1);
+            if (t > 0) pv(lds + prev * AT_STAGE_BYTES + KV_TILE_BYTES);
+            scores_softmax(kb, t);
+            if (t + 1 < nt) write_tile(nxt);
+            __syncthreads();
+            prev = cur;
+            cur = nxt;
+            nxt = (nxt == 2) ? 0 : nxt + 1;
+        }
+        pv(lds + prev * AT_STAGE_BYTES + KV_TILE_BYTES);  // stage of tile nt-1: nobody writes after the loop
     }
 
     // ---- epilogue: O = O^T / l ----------------------------------------------------------------------
