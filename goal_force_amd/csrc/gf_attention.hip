@@ -89,14 +89,27 @@ __global__ __launch_bounds__(AT_THREADS, 2) void flash_attn_fwd_kernel(const Att
     const int st_off0 = kv_off(st_row, st_ch);
     const int st_off1 = kv_off(st_row + 32, st_ch);
     u32x4 kreg0, kreg1, vreg0, vreg1;
+    // 32-bit element offsets of this thread's two rows inside tile 0 (host guarantees kv_len*stride < 2^31); a full
+    // tile t adds the wave-uniform t*64*stride, only the ragged last tile needs the per-lane clamp.
+    const unsigned ko0 = (unsigned)st_row * (unsigned)p.k_stride, ko1 = (unsigned)(st_row + 32) * (unsigned)p.k_stride;
+    const unsigned vo0 = (unsigned)st_row * (unsigned)p.v_stride, vo1 = (unsigned)(st_row + 32) * (unsigned)p.v_stride;
+    const unsigned kstep = KVB * (unsigned)p.k_stride, vstep = KVB * (unsigned)p.v_stride;
     auto load_tile = [&](int t) {
-        const int k0 = t * KVB;
-        const long r0 = min(k0 + st_row, p.kv_len - 1);
-        const long r1 = min(k0 + st_row + 32, p.kv_len - 1);
-        kreg0 = *reinterpret_cast<const u32x4*>(kbase + r0 * p.k_stride);
-        kreg1 = *reinterpret_cast<const u32x4*>(kbase + r1 * p.k_stride);
-        vreg0 = *reinterpret_cast<const u32x4*>(vbase + r0 * p.v_stride);
-        vreg1 = *reinterpret_cast<const u32x4*>(vbase + r1 * p.v_stride);
+        if ((t + 1) * KVB <= p.kv_len) {
+            const unsigned tk = (unsigned)t * kstep, tv = (unsigned)t * vstep;   // scalar
+            kreg0 = *reinterpret_cast<const u32x4*>(kbase + (ko0 + tk));
+            kreg1 = *reinterpret_cast<const u32x4*>(kbase + (ko1 + tk));
+            vreg0 = *reinterpret_cast<const u32x4*>(vbase + (vo0 + tv));
+            vreg1 = *reinterpret_cast<const u32x4*>(vbase + (vo1 + tv));
+        } else {
+            const int k0 = t * KVB;
+            const long r0 = min(k0 + st_row, p.kv_len - 1);
+            const long r1 = min(k0 + st_row + 32, p.kv_len - 1);
+            kreg0 = *reinterpret_cast<const u32x4*>(kbase + r0 * p.k_stride);
+            kreg1 = *reinterpret_cast<const u32x4*>(kbase + r1 * p.k_stride);
+            vreg0 = *reinterpret_cast<const u32x4*>(vbase + r0 * p.v_stride);
+            vreg1 = *reinterpret_cast<const u32x4*>(vbase + r1 * p.v_stride);
+        }
     };
     auto write_tile = [&](int buf) {
         GF_LDS char* kb = lds + buf * AT_STAGE_BYTES;
@@ -297,6 +310,8 @@ extern "C" GF_API int gf_flash_attn_fwd(const void* q, const void* k, const void
     GF_CHECK_ARG(gf_aligned16(q) && gf_aligned16(k) && gf_aligned16(v) && gf_aligned16(o),
                  "gf_flash_attn_fwd: 16-byte alignment required");
     GF_CHECK_ARG(q_len < (1 << 30) && kv_len < (1 << 30), "gf_flash_attn_fwd: sequence too long");
+    GF_CHECK_ARG((kv_len + 64) * k_stride < (1LL << 31) && (kv_len + 64) * v_stride < (1LL << 31),
+                 "gf_flash_attn_fwd: kv_len*stride must stay below 2^31 elements");
     if (q_len == 0) return GF_OK;
     static bool attr_set = false;
     if (!attr_set) {
