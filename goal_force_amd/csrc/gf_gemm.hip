@@ -21,6 +21,7 @@
 //     A/W panels through that XCD's L2.
 //   * M and N tails: loads clamp the row index, stores are masked.
 #include "gf_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -239,20 +240,290 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmArgs p)
     }
 }
 
+// ================================================================================================
+// Phased kernel (the one that ships): same 256x256 tile / 8 waves / 128-byte-row LDS image, but the K loop is cut
+// into 4 phases per K-tile and the operand tiles into four 16 KiB HALF-TILES per K-tile
+//     A0 = rows   0..127, A1 = rows 128..255 of the A tile;   B0 / B1 likewise for the W tile,
+// laid out per double-buffer as [A0 | A1 | B0 | B1] (64 KiB) x 2 = 128 KiB.
+//
+//   * wave (wr, wc) owns four C quadrants (a, b): 64 rows [wr*64, +64) of A-half a  x  32 columns [wc*32, +32) of
+//     B-half b.  Phase p of a K-tile multiplies ONE quadrant over the whole K-step (16 MFMAs bf16 / 8 MFMAs fp8):
+//        p0: read A-sub0 + B-sub0, quadrant (0,0)      p1: read B-sub1, quadrant (0,1)
+//        p2: read A-sub1,          quadrant (1,1)      p3: no LDS read,  quadrant (1,0)   (B-sub0 kept in registers)
+//   * half-tiles stream through LDS-DMA in the fixed order  A0,B0,B1,A1 | A0,B0,...  exactly one per phase, SIX phases
+//     ahead of the phase that first reads it; `s_waitcnt vmcnt(8)` (4 half-tiles x 2 DMA instructions stay in flight)
+//     retires what the NEXT phase reads, so HBM/L2 latency is covered by >= 5 phases of matrix work and the DMA
+//     stays in flight across barriers (raw s_barrier, never __syncthreads).  A region is re-staged >= 2 phases after
+//     its last ds_read.
+//   * the two waves that share a SIMD (w and w+4 = wave rows 0 and 1) run offset by half a phase: each phase is
+//     [L: issue DMA + ds_reads] barrier [M: MFMA cluster at raised priority] barrier, and wave row 1 starts one
+//     barrier late — one partner feeds the matrix pipe while the other feeds LDS.
+//   * epilogue: all waves park their bf16 quadrants in one swizzled 256x256 LDS image, then every wave writes full
+//     512-byte rows (16 B per lane), reading residual / gate / bias in the same coalesced pattern.
+template <int EPI, bool FP8>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs p) {
+    constexpr int ESZ = FP8 ? 1 : 2;
+    constexpr int BKE = 128 / ESZ;
+    constexpr int HALF_BYTES = 128 * 128;  // 16 KiB
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    GF_LDS char* lds = (GF_LDS char*)smem;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    int v;
+    {
+        const int pid = blockIdx.x;
+        const int xcd = pid & 7, local = pid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    }
+    const int per_group = GROUP_M * p.tiles_n;
+    const int group = v / per_group;
+    const int first_m = group * GROUP_M;
+    const int gsz = min(p.tiles_m - first_m, GROUP_M);
+    const int in_group = v - group * per_group;
+    const int m0 = (first_m + in_group % gsz) * BM, n0 = (in_group / gsz) * BN;
+
+    // ---- DMA sources: wave w fills row-groups 2w, 2w+1 (8 rows x 128 B each) of every half-tile -------------------
+    const int srow = lane >> 3;
+    const int schunk = (lane & 7) ^ srow;
+    const char* srcp[4][2];  // [kind: A0, B0, B1, A1][i]
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave * 2 + i) * 8 + srow;  // 0..127 inside the half-tile
+        const long a0 = min(m0 + row, p.M - 1), a1 = min(m0 + 128 + row, p.M - 1);
+        const long b0 = min(n0 + row, p.N - 1), b1 = min(n0 + 128 + row, p.N - 1);
+        srcp[0][i] = (const char*)p.A + (a0 * p.lda) * ESZ + schunk * 16;
+        srcp[3][i] = (const char*)p.A + (a1 * p.lda) * ESZ + schunk * 16;
+        srcp[1][i] = (const char*)p.W + (b0 * p.ldw) * ESZ + schunk * 16;
+        srcp[2][i] = (const char*)p.W + (b1 * p.ldw) * ESZ + schunk * 16;
+    }
+    const int nk = p.K / BKE;
+    // region byte offsets inside one double-buffer, indexed by kind
+    auto region = [](int kind) { return kind == 0 ? 0 : (kind == 3 ? HALF_BYTES : (kind == 1 ? 2 * HALF_BYTES : 3 * HALF_BYTES)); };
+    auto stage = [&](int tile, int kind) {  // issue the 2 DMA instructions of half-tile (tile, kind)
+        GF_LDS char* dst = lds + (tile & 1) * STAGE_BYTES + region(kind) + wave * 2048;
+        const long koff = (long)tile * 128;
+        glds16(srcp[kind][0] + koff, dst);
+        glds16(srcp[kind][1] + koff, dst + 1024);
+    };
+
+    // ---- fragment read offsets -----------------------------------------------------------------------------------
+    const int frow = lane & 15, fq = lane >> 4, sw = frow & 7;
+    const int a_off = (wr * 64 + frow) * 128;   // + i*2048, i < 4
+    const int b_off = (wc * 32 + frow) * 128;   // + j*2048, j < 2
+    int chb[4];                                 // swizzled 16-byte chunk offsets of this lane
+    if constexpr (!FP8) {
+        chb[0] = ((0 + fq) ^ sw) << 4;          // k-substep 0
+        chb[1] = ((4 + fq) ^ sw) << 4;          // k-substep 1
+        chb[2] = chb[3] = 0;
+    } else {
+        chb[0] = ((2 * fq) ^ sw) << 4;          // bytes [32fq, 32fq+16)
+        chb[1] = ((2 * fq + 1) ^ sw) << 4;      // bytes [32fq+16, 32fq+32)
+        chb[2] = chb[3] = 0;
+    }
+    typedef u32x4 frag_t[2];                    // bf16: [ksub] 8 bf16 each; fp8: 32 bytes = one K=128 operand
+    frag_t afr[4], bfr[2][2];                   // afr[i], bfr[b][j]
+    auto read_a = [&](GF_LDS char* buf, int a) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            afr[i][0] = *(GF_LDS u32x4*)(buf + region(a ? 3 : 0) + a_off + i * 2048 + chb[0]);
+            afr[i][1] = *(GF_LDS u32x4*)(buf + region(a ? 3 : 0) + a_off + i * 2048 + chb[1]);
+        }
+    };
+    auto read_b = [&](GF_LDS char* buf, int b) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            bfr[b][j][0] = *(GF_LDS u32x4*)(buf + region(b ? 2 : 1) + b_off + j * 2048 + chb[0]);
+            bfr[b][j][1] = *(GF_LDS u32x4*)(buf + region(b ? 2 : 1) + b_off + j * 2048 + chb[1]);
+        }
+    };
+
+    f32x4 acc[2][2][4][2];  // [a][b][i][j]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto mma = [&](int a, int b) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if constexpr (!FP8) {
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+                        acc[a][b][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8, bfr[b][j][ks]), __builtin_bit_cast(bf16x8, afr[i][ks]),
+                            acc[a][b][i][j], 0, 0, 0);
+                } else {
+                    const i32x8 bw = i32x8{(int)bfr[b][j][0][0], (int)bfr[b][j][0][1], (int)bfr[b][j][0][2], (int)bfr[b][j][0][3],
+                                           (int)bfr[b][j][1][0], (int)bfr[b][j][1][1], (int)bfr[b][j][1][2], (int)bfr[b][j][1][3]};
+                    const i32x8 aw = i32x8{(int)afr[i][0][0], (int)afr[i][0][1], (int)afr[i][0][2], (int)afr[i][0][3],
+                                           (int)afr[i][1][0], (int)afr[i][1][1], (int)afr[i][1][2], (int)afr[i][1][3]};
+                    acc[a][b][i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bw, aw, acc[a][b][i][j], 0, 0, 0,
+                                                                                         0x7F7F7F7F, 0, 0x7F7F7F7F);
+                }
+            }
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // ---- prologue: half-tiles seq 0..5 = (t0: A0 B0 B1 A1) (t1: A0 B0) ------------------------------------------------
+    const int total = 4 * nk;  // half-tiles in the stream
+    {
+        stage(0, 0);
+        stage(0, 1);
+        stage(0, 2);
+        stage(0, 3);
+        if (nk > 1) {
+            stage(1, 0);
+            stage(1, 1);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // seq 0,1 landed
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+    }
+    if (wr == 1) __builtin_amdgcn_s_barrier();  // wave row 1 runs half a phase behind wave row 0
+
+#define GF_PHASE_END(SEQ_ISSUED)                                                  \
+    if ((SEQ_ISSUED) < total) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                           \
+    __builtin_amdgcn_sched_barrier(0);                                           \
+    __builtin_amdgcn_s_barrier();
+
+    for (int c = 0; c < nk; ++c) {
+        GF_LDS char* buf = lds + (c & 1) * STAGE_BYTES;
+        const int g = 4 * c;
+        // ---- phase 0: stream B1(c+1); read A-sub0, B-sub0; quadrant (0,0)
+        if (g + 6 < total) stage(c + 1, 2);
+        read_b(buf, 0);
+        read_a(buf, 0);
+        GF_PHASE_END(g + 6)
+        mma(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 1: stream A1(c+1); read B-sub1; quadrant (0,1)
+        if (g + 7 < total) stage(c + 1, 3);
+        read_b(buf, 1);
+        GF_PHASE_END(g + 7)
+        mma(0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 2: stream A0(c+2); read A-sub1; quadrant (1,1)
+        if (g + 8 < total) stage(c + 2, 0);
+        read_a(buf, 1);
+        GF_PHASE_END(g + 8)
+        mma(1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 3: stream B0(c+2); no LDS read (B-sub0 still in registers); quadrant (1,0)
+        if (g + 9 < total) stage(c + 2, 1);
+        GF_PHASE_END(g + 9)
+        mma(1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    }
+#undef GF_PHASE_END
+    if (wr == 0) __builtin_amdgcn_s_barrier();  // pairs with wave row 1's last barrier: everyone is past its LDS reads
+
+    // ---- epilogue: bf16 quadrants -> swizzled 256 x 256 LDS image (512-byte rows) -> full-row stores ---------------------
+    // acc[a][b][i][j][r] = C[m0 + a*128 + wr*64 + i*16 + frow][n0 + b*128 + wc*32 + j*16 + fq*4 + r]
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ncol = b * 128 + wc * 32 + j * 16 + fq * 4;  // column inside the tile
+            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias && n0 + ncol < p.N) {
+                const u16x4 b4 = *reinterpret_cast<const u16x4*>(p.bias + n0 + ncol);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bv[r] = bf2f(b4[r]);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = a * 128 + wr * 64 + i * 16 + frow;
+                    float rs = 1.0f;
+                    if constexpr (FP8) rs = p.row_scale[min(m0 + row, p.M - 1)];
+                    float y[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        y[r] = rbf(acc[a][b][i][j][r] * rs + bv[r]);  // the Linear's own bf16 output
+                        if (EPI == GF_EPI_BIAS_GELU_TANH) y[r] = gelu_tanh_f(y[r]);
+                        if (EPI == GF_EPI_BIAS_SILU) y[r] = y[r] / (1.0f + expf(-y[r]));
+                    }
+                    u32x2 pk;
+                    pk[0] = pack2bf(y[0], y[1]);
+                    pk[1] = pack2bf(y[2], y[3]);
+                    const int slot = (ncol >> 2) ^ ((row & 15) << 1);  // 8-byte slot (64 per row); 16-byte pairs stay together
+                    *(GF_LDS u32x2*)(lds + row * 512 + slot * 8) = pk;
+                }
+        }
+    __syncthreads();
+    {
+        const int cc = lane & 31;                 // 16-byte chunk of the row
+        const int n = n0 + cc * 8;
+        const bool n_ok = n < p.N;
+        u16x8 g8;
+        if (EPI == GF_EPI_BIAS_GATE_RESID && n_ok) g8 = *reinterpret_cast<const u16x8*>(p.gate + n);
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int row = wave * 32 + it * 2 + (lane >> 5);
+            const int m = m0 + row;
+            const u16x8 yv = *(GF_LDS u16x8*)(lds + row * 512 + ((cc ^ (row & 15)) << 4));
+            if (m < p.M && n_ok) {
+                u16x8 o = yv;
+                if (EPI == GF_EPI_BIAS_GATE_RESID || EPI == GF_EPI_BIAS_RESID) {
+                    const u16x8 r8 = *reinterpret_cast<const u16x8*>(p.R + (long)m * p.ldr + n);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float t = bf2f(yv[e]);
+                        if (EPI == GF_EPI_BIAS_GATE_RESID) t = rbf(bf2f(g8[e]) * t);  // gate * residual
+                        o[e] = f2bf(bf2f(r8[e]) + t);                                 // x + ...
+                    }
+                }
+                *reinterpret_cast<u16x8*>(p.C + (long)m * p.ldc + n) = o;
+            }
+        }
+    }
+}
+
 template <int EPI, bool FP8>
 int launch_gemm(const GemmArgs& a, hipStream_t stream) {
     static bool attr_set = false;  // per-instantiation; benign race (idempotent call)
+    static bool use_v1 = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<EPI, FP8>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+        // bf16 ships the phased kernel (+5..11 % at the DiT shapes); fp8 ships the one-barrier-per-K-tile kernel (at 254
+        // VGPRs the phased fp8 variant measured 10-15 % slower).  GF_GEMM_V1=0/1 overrides for A/B tuning.
+        const char* ev = getenv("GF_GEMM_V1");
+        use_v1 = ev ? (ev[0] == '1') : FP8;
+        const void* fn = use_v1 ? reinterpret_cast<const void*>(gemm_kernel<EPI, FP8>)
+                                : reinterpret_cast<const void*>(gemm_ph_kernel<EPI, FP8>);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
         if (e != hipSuccess) {
             gf_set_error("gf_gemm: hipFuncSetAttribute(%d B LDS) failed: %s", GEMM_LDS, hipGetErrorString(e));
             return GF_ERR_LAUNCH;
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<EPI, FP8>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(GEMM_THREADS), GEMM_LDS,
-                       stream, a);
+    if (use_v1)
+        hipLaunchKernelGGL((gemm_kernel<EPI, FP8>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(GEMM_THREADS), GEMM_LDS,
+                           stream, a);
+    else
+        hipLaunchKernelGGL((gemm_ph_kernel<EPI, FP8>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(GEMM_THREADS), GEMM_LDS,
+                           stream, a);
     GF_CHECK_LAUNCH(FP8 ? "gf_gemm_fp8" : "gf_gemm_bf16");
     return GF_OK;
 }
