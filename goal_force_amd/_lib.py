@@ -23,7 +23,7 @@ SYMBOLS = (
     "gf_quant_fp8_rowscale", "gf_cast_fp8", "gf_gemm_fp8",
 )
 
-EPI_BIAS, EPI_BIAS_GELU_TANH, EPI_BIAS_GATE_RESID, EPI_BIAS_RESID, EPI_BIAS_SILU = range(5)
+EPI_BIAS, EPI_BIAS_GELU_TANH, EPI_BIAS_GATE_RESID, EPI_BIAS_RESID, EPI_BIAS_SILU, EPI_BIAS_MUL = range(6)
 
 
 class GoalForceError(RuntimeError):
@@ -58,7 +58,7 @@ def _declare(lib):
         "gf_vae_im2col": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _int, _i64, _i64, _i64, _vp],
         "gf_vae_finish_latent": [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp],
         "gf_vae_rmsnorm_silu": [_vp, _vp, _vp, _i64, _i64, _int, _vp],
-        "gf_softmax_rows": [_vp, _i64, _vp, _i64, _i64, _i64, _f32, _vp],
+        "gf_softmax_rows": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _f32, _vp],
         "gf_transpose_pad": [_vp, _i64, _vp, _i64, _i64, _i64, _vp],
         "gf_vae_tile_blend": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _int, _int, _int, _int,
                               _i64, _i64, _vp],

@@ -225,13 +225,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmArgs p)
             const u16x8 yv = *(GF_LDS u16x8*)(ep + row * 128 + ((cc ^ (row & 7)) << 4));
             if (m < p.M && n_ok) {
                 u16x8 o = yv;
-                if (EPI == GF_EPI_BIAS_GATE_RESID || EPI == GF_EPI_BIAS_RESID) {
+                if (EPI == GF_EPI_BIAS_GATE_RESID || EPI == GF_EPI_BIAS_RESID || EPI == GF_EPI_BIAS_MUL) {
                     const u16x8 r8 = *reinterpret_cast<const u16x8*>(p.R + (long)m * p.ldr + n);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         float t = bf2f(yv[e]);
                         if (EPI == GF_EPI_BIAS_GATE_RESID) t = rbf(bf2f(g8[e]) * t);  // gate * residual
-                        o[e] = f2bf(bf2f(r8[e]) + t);                                 // x + ...
+                        o[e] = (EPI == GF_EPI_BIAS_MUL) ? f2bf(t * bf2f(r8[e]))       // fc1(x) * gelu(gate(x))
+                                                        : f2bf(bf2f(r8[e]) + t);      // x + ...
                     }
                 }
                 *reinterpret_cast<u16x8*>(p.C + (long)m * p.ldc + n) = o;
@@ -485,13 +486,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs
             const u16x8 yv = *(GF_LDS u16x8*)(lds + row * 512 + ((cc ^ (row & 15)) << 4));
             if (m < p.M && n_ok) {
                 u16x8 o = yv;
-                if (EPI == GF_EPI_BIAS_GATE_RESID || EPI == GF_EPI_BIAS_RESID) {
+                if (EPI == GF_EPI_BIAS_GATE_RESID || EPI == GF_EPI_BIAS_RESID || EPI == GF_EPI_BIAS_MUL) {
                     const u16x8 r8 = *reinterpret_cast<const u16x8*>(p.R + (long)m * p.ldr + n);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         float t = bf2f(yv[e]);
                         if (EPI == GF_EPI_BIAS_GATE_RESID) t = rbf(bf2f(g8[e]) * t);  // gate * residual
-                        o[e] = f2bf(bf2f(r8[e]) + t);                                 // x + ...
+                        o[e] = (EPI == GF_EPI_BIAS_MUL) ? f2bf(t * bf2f(r8[e]))       // fc1(x) * gelu(gate(x))
+                                                        : f2bf(bf2f(r8[e]) + t);      // x + ...
                     }
                 }
                 *reinterpret_cast<u16x8*>(p.C + (long)m * p.ldc + n) = o;
@@ -545,7 +547,7 @@ static int gemm_dispatch(bool fp8, const void* A, int64_t lda, const void* W, in
                  "%s: 16-byte alignment required", fn);
     GF_CHECK_ARG(M < (1 << 30) && N < (1 << 30), "%s: M/N too large", fn);
     GF_CHECK_ARG(!fp8 || row_scale, "%s: row_scale is required", fn);
-    const bool need_r = epilogue == GF_EPI_BIAS_GATE_RESID || epilogue == GF_EPI_BIAS_RESID;
+    const bool need_r = epilogue == GF_EPI_BIAS_GATE_RESID || epilogue == GF_EPI_BIAS_RESID || epilogue == GF_EPI_BIAS_MUL;
     GF_CHECK_ARG(!need_r || (resid && ldr % 8 == 0 && ldr >= N && gf_aligned16(resid)),
                  "%s: residual epilogue needs an aligned resid with ldr >= N", fn);
     GF_CHECK_ARG(epilogue != GF_EPI_BIAS_GATE_RESID || (gate && gf_aligned16(gate)),
@@ -576,6 +578,7 @@ static int gemm_dispatch(bool fp8, const void* A, int64_t lda, const void* W, in
         GF_GEMM_CASE(GF_EPI_BIAS_GATE_RESID)
         GF_GEMM_CASE(GF_EPI_BIAS_RESID)
         GF_GEMM_CASE(GF_EPI_BIAS_SILU)
+        GF_GEMM_CASE(GF_EPI_BIAS_MUL)
         default:
             gf_set_error("%s: unknown epilogue %d", fn, epilogue);
             return GF_ERR_INVALID_ARG;

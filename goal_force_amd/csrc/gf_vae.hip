@@ -151,27 +151,36 @@ __global__ __launch_bounds__(VT) void rmsnorm_silu_kernel(const u16* __restrict_
     }
 }
 
-// out[r, :ncols] = softmax(x[r, :ncols] * scale) (fp32 math, bf16 out), out[r, ncols:ldo] = 0.
-// One workgroup per row.  (AttentionBlock's single-head SDPA over h*w tokens, VAE:326-333.)
-__global__ __launch_bounds__(VT) void softmax_rows_kernel(const u16* __restrict__ x, long ldx, u16* __restrict__ out,
-                                                          long ldo, int ncols, float scale) {
+// out[r, :ncols] = softmax(bf16(x[r, :] * scale + bias[r, :])) over the first nvalid columns (columns >= nvalid get
+// probability 0 = the reference's masked_fill(finfo.min)), fp32 math, bf16 out; out[r, ncols:ldo] = 0.
+// One workgroup per row.  Used by the VAE AttentionBlock (VAE:326-333; no bias) and by the umT5 attention
+// (wan_video_text_encoder.py:72-84: scores + position bias (+ key mask), softmax in fp32, no scaling).
+__global__ __launch_bounds__(VT) void softmax_rows_kernel(const u16* __restrict__ x, long ldx, const u16* __restrict__ bias,
+                                                          long ldb, u16* __restrict__ out, long ldo, int ncols, int nvalid,
+                                                          float scale) {
     __shared__ float red[VT / 64];
     const long row = blockIdx.x;
     const u16* xr = x + row * ldx;
+    const u16* br = bias ? bias + row * ldb : nullptr;
+    auto val = [&](int c) {
+        float v = bf2f(xr[c]) * scale;
+        if (br) v = rbf(v + bf2f(br[c]));   // attn = scores + attn_bias, a bf16 tensor
+        return v;
+    };
     float mx = -INFINITY;
-    for (int c = threadIdx.x; c < ncols; c += VT) mx = fmaxf(mx, bf2f(xr[c]) * scale);
+    for (int c = threadIdx.x; c < nvalid; c += VT) mx = fmaxf(mx, val(c));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
     __syncthreads();
     mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     float s = 0.f;
-    for (int c = threadIdx.x; c < ncols; c += VT) s += expf(bf2f(xr[c]) * scale - mx);
+    for (int c = threadIdx.x; c < nvalid; c += VT) s += expf(val(c) - mx);
     const float tot = block_sum<VT>(s, red);
     const float inv = 1.0f / tot;
     u16* orow = out + row * ldo;
     for (int c = threadIdx.x; c < (int)ldo; c += VT)
-        orow[c] = c < ncols ? f2bf(expf(bf2f(xr[c]) * scale - mx) * inv) : (u16)0;
+        orow[c] = c < nvalid ? f2bf(expf(val(c) - mx) * inv) : (u16)0;
 }
 
 // dst[c, r] = src[r, c] for r < R (zero for R <= r < rpad); 32x32 tiles through LDS.
@@ -286,12 +295,13 @@ extern "C" GF_API int gf_vae_rmsnorm_silu(const void* x, const void* gamma, void
     return GF_OK;
 }
 
-extern "C" GF_API int gf_softmax_rows(const void* x, int64_t ldx, void* out, int64_t ldo, int64_t rows, int64_t ncols,
-                                      float scale, void* stream) {
+extern "C" GF_API int gf_softmax_rows(const void* x, int64_t ldx, const void* bias, int64_t ldb, void* out, int64_t ldo,
+                                      int64_t rows, int64_t ncols, int64_t nvalid, float scale, void* stream) {
     GF_CHECK_ARG(x && out && rows >= 0 && ncols > 0 && ldx >= ncols && ldo >= ncols, "gf_softmax_rows: bad arguments");
+    GF_CHECK_ARG(nvalid > 0 && nvalid <= ncols && (!bias || ldb >= ncols), "gf_softmax_rows: bad nvalid / bias stride");
     if (rows == 0) return GF_OK;
     hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(VT), 0, (hipStream_t)stream, (const u16*)x,
-                       (long)ldx, (u16*)out, (long)ldo, (int)ncols, scale);
+                       (long)ldx, (const u16*)bias, (long)ldb, (u16*)out, (long)ldo, (int)ncols, (int)nvalid, scale);
     GF_CHECK_LAUNCH("gf_softmax_rows");
     return GF_OK;
 }

@@ -11,13 +11,13 @@ import math
 import torch
 
 from . import _lib
-from ._lib import (EPI_BIAS, EPI_BIAS_GATE_RESID, EPI_BIAS_GELU_TANH, EPI_BIAS_RESID, EPI_BIAS_SILU,
+from ._lib import (EPI_BIAS, EPI_BIAS_GATE_RESID, EPI_BIAS_GELU_TANH, EPI_BIAS_MUL, EPI_BIAS_RESID, EPI_BIAS_SILU,
                    GoalForceError)
 
 __all__ = [
     "modulation", "layernorm_modulate", "rmsnorm_rope", "gemm", "flash_attn", "patchify_im2col", "unpatchify",
     "cfg_euler_step", "act", "add", "force_map",
-    "EPI_BIAS", "EPI_BIAS_GELU_TANH", "EPI_BIAS_GATE_RESID", "EPI_BIAS_RESID", "EPI_BIAS_SILU",
+    "EPI_BIAS", "EPI_BIAS_GELU_TANH", "EPI_BIAS_GATE_RESID", "EPI_BIAS_RESID", "EPI_BIAS_SILU", "EPI_BIAS_MUL",
 ]
 
 _BF16 = torch.bfloat16
@@ -310,13 +310,21 @@ def vae_rmsnorm_silu(x, gamma, silu=True):
     return out
 
 
-def softmax_rows(x, scale, ldo):
+def softmax_rows(x, scale, ldo, bias=None, nvalid=None):
+    """out[r,:] = softmax(bf16(x[r,:]*scale + bias[r,:])) over the first nvalid columns; zero-padded to ldo columns."""
     _req(x, "softmax_rows.x")
     if x.dim() != 2 or x.stride(1) != 1:
         raise GoalForceError("softmax_rows.x must be 2-D with contiguous rows")
+    ldb = 0
+    if bias is not None:
+        _req(bias, "softmax_rows.bias")
+        if bias.shape != x.shape or bias.stride(1) != 1:
+            raise GoalForceError("softmax_rows.bias must match x with contiguous rows")
+        ldb = bias.stride(0)
     out = torch.empty((x.shape[0], ldo), dtype=_BF16, device=x.device)
-    _lib.check(_lib.load().gf_softmax_rows(_ptr(x), x.stride(0), _ptr(out), ldo, x.shape[0], x.shape[1], float(scale),
-                                           _stream(x)), "gf_softmax_rows")
+    _lib.check(_lib.load().gf_softmax_rows(_ptr(x), x.stride(0), _ptr(bias), ldb, _ptr(out), ldo, x.shape[0], x.shape[1],
+                                           x.shape[1] if nvalid is None else int(nvalid), float(scale), _stream(x)),
+               "gf_softmax_rows")
     return out
 
 

@@ -7,8 +7,8 @@ accepted no-op (the fp32-LayerNorm numerics it switches on in the reference are 
 LayerNorm kernel always computes).  The denoising loop is `denoise()`: two model_fn calls per step
 (cond / uncond), CFG + Euler update fused in one kernel, expert switch by pointer swap.
 
-Pre-loop conditioning that needs models outside the hot path (umT5 text encoder, VAE *encoder*:
-SURVEY.md §8f 'next' rows) can be supplied pre-computed: `context_posi`, `context_nega`, `y`,
+Pre-loop conditioning (umT5 text encoder, VAE encoder — the SURVEY.md §8f rows, also on the HIP kernels) runs when
+the models are attached; it can also be supplied pre-computed: `context_posi`, `context_nega`, `y`,
 `control_signal_video_latents`.
 """
 from __future__ import annotations
@@ -64,6 +64,8 @@ class WanVideoPipeline:
         self.height_division_factor, self.width_division_factor = 16, 16
         self.time_division_factor, self.time_division_remainder = 4, 1
         self.scheduler = FlowMatchScheduler(shift=5, sigma_min=0.0, extra_one_step=True)  # GF:127
+        from .text_encoder import WanPrompter
+        self.prompter = WanPrompter(tokenizer_path=tokenizer_path)   # GF:128
         self.text_encoder = None
         self.image_encoder = None
         self.dit: Optional[WanModel] = None
@@ -258,11 +260,12 @@ class WanVideoPipeline:
         length = (num_frames - 1) // 4 + 1
         noise = self.generate_noise((1, 16, length, height // 8, width // 8), seed=seed, rand_device=rand_device)
         if context_posi is None or (cfg_scale != 1.0 and context_nega is None):
-            if self.text_encoder is None:
-                raise NotImplementedError("no text encoder loaded: pass context_posi/context_nega "
-                                          "([1,512,4096] umT5 embeddings); the encoder is a 'next' row (SURVEY §8f)")
-            context_posi = self.text_encoder.encode_prompt(prompt, device=self.device)
-            context_nega = self.text_encoder.encode_prompt(negative_prompt, device=self.device)
+            if self.text_encoder is None or self.prompter.tokenizer is None:
+                raise GoalForceError("no text encoder / tokenizer loaded: attach pipe.text_encoder (WanTextEncoder) and "
+                                     "pipe.prompter.fetch_tokenizer(path), or pass context_posi/context_nega")
+            self.prompter.fetch_models(self.text_encoder)
+            context_posi = self.prompter.encode_prompt(prompt, positive=True, device=self.device)      # GF:808-822
+            context_nega = self.prompter.encode_prompt(negative_prompt, positive=False, device=self.device)
         if y is None and input_image is not None:
             y = self.embed_image(input_image, num_frames, height, width, tiled, tile_size, tile_stride)
         if controlnet and control_signal_video_latents is None:

@@ -108,7 +108,9 @@ typedef enum {
     GF_EPI_BIAS_GELU_TANH = 1, /* bf16(gelu_tanh(bf16(acc + bias)))              */
     GF_EPI_BIAS_GATE_RESID = 2,/* bf16(resid + bf16(gate * bf16(acc + bias)))    */
     GF_EPI_BIAS_RESID = 3,     /* bf16(resid + bf16(acc + bias))                 */
-    GF_EPI_BIAS_SILU = 4       /* bf16(silu(bf16(acc + bias)))                   */
+    GF_EPI_BIAS_SILU = 4,      /* bf16(silu(bf16(acc + bias)))                   */
+    GF_EPI_BIAS_MUL = 5        /* bf16(bf16(acc + bias) * resid)  — GEGLU: fc1(x) * gelu(gate(x)),
+                                  wan_video_text_encoder.py:106                  */
 } gf_epilogue;
 
 GF_API int gf_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias,
@@ -224,10 +226,12 @@ GF_API int gf_vae_finish_latent(const void* x, int64_t ldx, const void* mean, co
 GF_API int gf_vae_rmsnorm_silu(const void* x, const void* gamma, void* out, int64_t rows, int64_t C,
                                int silu, void* stream);
 
-/* gf_softmax_rows — out[r,:ncols] = softmax(x[r,:ncols]*scale), out[r,ncols:ldo] = 0
- * (the single-head SDPA of AttentionBlock, VAE:326-333, between its two GEMMs).      */
-GF_API int gf_softmax_rows(const void* x, int64_t ldx, void* out, int64_t ldo, int64_t rows, int64_t ncols,
-                           float scale, void* stream);
+/* gf_softmax_rows — out[r,:ncols] = softmax(bf16(x[r,:]*scale + bias[r,:])) over the first nvalid columns
+ * (columns >= nvalid: probability 0, = masked_fill(finfo.min)), out[r,ncols:ldo] = 0; bias may be NULL.
+ * The single-head SDPA of the VAE AttentionBlock (VAE:326-333) and the umT5 attention with its relative
+ * position bias and key mask (wan_video_text_encoder.py:72-84), between their two GEMMs.                  */
+GF_API int gf_softmax_rows(const void* x, int64_t ldx, const void* bias, int64_t ldb, void* out, int64_t ldo,
+                           int64_t rows, int64_t ncols, int64_t nvalid, float scale, void* stream);
 
 /* gf_transpose_pad — dst[c, r] = src[r, c], r >= R zero-filled up to rpad (V^T operand
  * of the AttentionBlock's P·V GEMM).                                                   */

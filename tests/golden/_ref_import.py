@@ -52,6 +52,7 @@ def load_reference(with_pipeline=True, with_dataset=True):
     out.vae = importlib.import_module("diffsynth.models.wan_video_vae")
     out.fm = importlib.import_module("diffsynth.schedulers.flow_match")
     out.vram = importlib.import_module("diffsynth.vram_management.layers")
+    out.t5 = importlib.import_module("diffsynth.models.wan_video_text_encoder")
     if with_pipeline:
         # wan_video_new.py needs names at import time only; all uses are at call time
         _stub("modelscope", snapshot_download=_Anything())

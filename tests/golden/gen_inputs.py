@@ -131,6 +131,26 @@ def vae_decoder_sd(names, shapes, seed, dtype=torch.bfloat16):
     return sd
 
 
+T5_TINY = dict(vocab=100, dim=256, dim_attn=256, dim_ffn=512, num_heads=4, num_layers=2, num_buckets=32, shared_pos=False)
+
+
+def t5_sd(cfg, seed, dtype=torch.bfloat16):
+    """Seeded weights with the reference WanTextEncoder's key names (wan_video_text_encoder.py:209-243)."""
+    g = torch.Generator().manual_seed(seed)
+    d, da, df = cfg["dim"], cfg["dim_attn"], cfg["dim_ffn"]
+    sd = {"token_embedding.weight": _randn(g, (cfg["vocab"], d)), "norm.weight": 1.0 + _randn(g, (d,), 0.1)}
+    for i in range(cfg["num_layers"]):
+        p = f"blocks.{i}."
+        sd[p + "norm1.weight"] = 1.0 + _randn(g, (d,), 0.1)
+        sd[p + "norm2.weight"] = 1.0 + _randn(g, (d,), 0.1)
+        for n, shp, std in (("attn.q", (da, d), d ** -0.5), ("attn.k", (da, d), d ** -0.5), ("attn.v", (da, d), d ** -0.5),
+                            ("attn.o", (d, da), da ** -0.5), ("ffn.gate.0", (df, d), d ** -0.5), ("ffn.fc1", (df, d), d ** -0.5),
+                            ("ffn.fc2", (d, df), df ** -0.5)):
+            sd[p + n + ".weight"] = _randn(g, shp, std)
+        sd[p + "pos_embedding.embedding.weight"] = _randn(g, (cfg["num_buckets"], cfg["num_heads"]), 0.5)
+    return {k: v.to(dtype) for k, v in sd.items()}
+
+
 def checksum(tensors) -> float:
     """Order-dependent fp64 checksum of a dict/list of tensors (detects RNG / generation drift)."""
     items = tensors.items() if isinstance(tensors, dict) else enumerate(tensors)

@@ -1,0 +1,85 @@
+"""umT5 text encoder: CPU oracle pinned to the reference WanTextEncoder; HIP encoder vs the same goldens."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import gen_inputs as gi
+from conftest import GOLDEN, rel_l2
+from oracle import t5_oracle as to
+
+BF = torch.bfloat16
+torch.set_grad_enabled(False)
+
+
+def _fix():
+    g = np.load(os.path.join(GOLDEN, "g8_text_encoder.npz"))
+    sd = gi.t5_sd(gi.T5_TINY, seed=81)
+    assert gi.same_checksum(gi.checksum(sd), g["ck_weights"])
+    return g, sd, torch.from_numpy(g["ids"]), torch.from_numpy(g["mask"])
+
+
+def test_oracle_matches_reference():
+    g, sd, ids, mask = _fix()
+    cfg = gi.T5_TINY
+    assert torch.equal(to.encode(ids, mask, sd, cfg["num_heads"], cfg["num_layers"]), gi.from_u16(g["encode_bf16"]))
+    assert torch.equal(to.encode_prompt_ids(ids, mask, sd, cfg["num_heads"], cfg["num_layers"]),
+                       gi.from_u16(g["prompt_emb_bf16"]))
+    sd32 = {k: v.float() for k, v in sd.items()}
+    assert rel_l2(to.encode(ids, mask, sd32, cfg["num_heads"], cfg["num_layers"]), torch.from_numpy(g["encode_f32"])) < 1e-5
+
+
+def test_state_dict_names_match_reference():
+    from goal_force_amd.text_encoder import WanTextEncoder
+    cfg = gi.T5_TINY
+    m = WanTextEncoder(**cfg)
+    sd = gi.t5_sd(cfg, seed=81)   # these keys were loaded strict=True into the reference class
+    assert sorted(m.state_dict().keys()) == sorted(sd.keys())
+    m.load_state_dict(sd, strict=True)
+    # bucket table equals the oracle's restatement of T5:165-190
+    b = m.blocks[0].pos_embedding(24, 24)
+    assert torch.equal(b[None], to.rel_bias(sd["blocks.0.pos_embedding.embedding.weight"].float(), 24, 24))
+
+
+@pytest.mark.gpu
+def test_hip_text_encoder_vs_reference_golden():
+    from goal_force_amd.text_encoder import WanPrompter, WanTextEncoder
+    g, sd, ids, mask = _fix()
+    enc = WanTextEncoder(**gi.T5_TINY)
+    enc.load_state_dict(sd, strict=True)
+    enc = enc.to(BF).cuda()
+    got = enc(ids.cuda(), mask.cuda()).cpu()
+    f32 = torch.from_numpy(g["encode_f32"])
+    ref_bf = gi.from_u16(g["encode_bf16"]).float()
+    nv = int(mask.sum())
+    # rows past the prompt length are zeroed by the prompter; compare the real tokens
+    e, e_ref = rel_l2(got.float()[:, :nv], f32[:, :nv]), rel_l2(ref_bf[:, :nv], f32[:, :nv])
+    assert e < max(5e-3, 1.5 * e_ref), f"vs fp32 {e:.3e} (reference bf16 {e_ref:.3e})"
+    pr = WanPrompter()
+    pr.fetch_models(enc)
+    emb = pr.encode_ids(ids, mask).cpu()
+    assert float(emb[:, nv:].abs().sum()) == 0
+    assert rel_l2(emb.float(), torch.from_numpy(g["prompt_emb_f32"])) < max(5e-3, 1.5 * e_ref)
+    # no mask == all keys valid
+    full = enc(ids.cuda()).cpu()
+    ref_full = to.encode(ids, None, {k: v.float() for k, v in sd.items()}, 4, 2)
+    assert rel_l2(full.float(), ref_full) < 5e-3
+
+
+@pytest.mark.gpu
+def test_gemm_mul_epilogue_and_biased_softmax():
+    import torch.nn.functional as F
+    from goal_force_amd import ops
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn((300, 256), generator=g).to(BF)
+    w = (torch.randn((512, 256), generator=g) / 16).to(BF)
+    r = torch.randn((300, 512), generator=g).to(BF)
+    got = ops.gemm(x.cuda(), w.cuda(), epilogue=ops.EPI_BIAS_MUL, resid=r.cuda()).cpu()
+    ref = F.linear(x.float(), w.float()).to(BF) * r
+    assert rel_l2(got.float(), ref.float()) < 2e-3
+    s = (torch.randn((40, 48), generator=g) * 3).to(BF)
+    b = torch.randn((40, 48), generator=g).to(BF)
+    p = ops.softmax_rows(s.cuda(), 1.0, 64, bias=b.cuda(), nvalid=33).cpu()
+    refp = torch.softmax((s + b)[:, :33].float(), -1)
+    assert rel_l2(p[:, :33].float(), refp) < 3e-3 and float(p[:, 33:].abs().sum()) == 0
