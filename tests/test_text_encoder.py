@@ -64,7 +64,9 @@ def test_hip_text_encoder_vs_reference_golden():
     # no mask == all keys valid
     full = enc(ids.cuda()).cpu()
     ref_full = to.encode(ids, None, {k: v.float() for k, v in sd.items()}, 4, 2)
-    assert rel_l2(full.float(), ref_full) < 5e-3
+    e_ref_full = rel_l2(to.encode(ids, None, sd, 4, 2).float(), ref_full)   # the bf16 arithmetic's own noise (unscaled logits)
+    e_full = rel_l2(full.float(), ref_full)
+    assert e_full < max(5e-3, 1.5 * e_ref_full), f"unmasked: vs fp32 {e_full:.3e} (bf16 oracle {e_ref_full:.3e})"
 
 
 @pytest.mark.gpu
