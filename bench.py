@@ -194,9 +194,15 @@ def main():
             "denoise_step_ms_high_noise": sum(hi) / len(hi) if hi else None,
             "denoise_step_ms_low_noise": sum(lo) / len(lo) if lo else None,
             "step_mfma_frac": (sum(step_flops) / elapsed / 1e12) / PEAK_BF16_TFLOPS,
+            "frames_per_sec_schedule_weighted": (videos * 81.0 / ((21 * sum(hi) / len(hi) + 29 * sum(lo) / len(lo)) / 1e3 + vae_s)
+                                                 if hi and lo else None),
             "roofline": {"bound": "mfma", "kernel": "flash_attn_fwd_kernel (self-attention, S=32760, 40 heads, d=128)",
                          "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": None if achieved is None else achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                         "frac": None if achieved is None else achieved / PEAK_BF16_TFLOPS,
+                         # HBM bytes per launch from rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes over
+                         # tools/microbench.py attn, profiles/r01/pmc/): (2 x FETCH_SIZE [gfx950 reports half of a 16-B/lane
+                         # stream] + WRITE_SIZE) KiB -> bytes.  Not collected live: PMC needs the profiler.
+                         "traffic": (2 * 1484500 + 327600) * 1024, "traffic_source": "profiles/r01/pmc/attn_{FETCH,WRITE}_SIZE_counter_collection.csv",
                          "launches": len(self_att), "avg_launch_ms": att_ms if self_att else None,
                          "algorithmic_flops_per_launch": att_flops},
         }
