@@ -13,8 +13,8 @@
 //   * K and V tiles (64 keys x 128 d, 16 KiB each) are triple buffered in LDS in ONE image,
 //     off(row,ch) = 256*row + 16*(ch ^ (((row&3)<<2) | ((row>>2)&3))), which is conflict-free for both
 //     the ds_read_b128 row reads (K) and the transposed reads (V).  Global->register loads of tile
-//     t+1 are issued before the MFMAs of tile t and written to LDS after them (latency hidden
-//     under the matrix work); one barrier per tile.
+//     t+1 go straight into the next LDS stage by LDS-DMA (global_load_lds_dwordx4, swizzle applied to the per-lane
+//     source chunk) at the top of tile t and are waited for at its end; one barrier per tile.
 //   * the two waves of a SIMD (w, w+4) run rotated by one phase: waves 4-7 defer each tile's PV product to the next
 //     iteration, so one partner's MFMA phase runs beside the other's softmax (VALU/transcendental) phase instead
 //     of both contending for the matrix pipe and then for the VALU in lockstep.
@@ -23,6 +23,35 @@
 //   * softmax in fp32 with exp2 and the scale folded into one FMA; lazy rescale (skip the O
 //     rescale while the running max grows by less than 2^THR_LOG2; exact in exact arithmetic).
 #include "gf_common.h"
+#include <type_traits>
+
+#ifndef GF_ATTN_SCHED
+#define GF_ATTN_SCHED 1
+#endif
+#ifndef GF_ATTN_LATE_PRIO
+#define GF_ATTN_LATE_PRIO 1
+#endif
+
+// GF_ATTN_STAMP: diagnostic build only (tools/attn_stamps.py) — per-segment s_memtime sums of waves 0 and 4 of
+// workgroup 0, written to a debug buffer; the shipped library is built without it.
+#ifndef GF_ATTN_STAMP
+#define GF_ATTN_STAMP 0
+#endif
+#if GF_ATTN_STAMP
+static unsigned long long* g_attn_dbg = nullptr;
+extern "C" GF_API void gf_debug_set_attn_buffer(void* p) { g_attn_dbg = (unsigned long long*)p; }
+#define STAMP(i)                                                                            \
+    {                                                                                       \
+        unsigned long long t_;                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        seg[i] += t_ - tprev;                                                               \
+        tprev = t_;                                                                         \
+    }
+#else
+#define STAMP(i)
+#endif
 
 namespace {
 
@@ -31,8 +60,9 @@ constexpr int QB = 256;          // query rows per workgroup
 constexpr int KVB = 64;          // keys per tile
 constexpr int HD = 128;          // head dim
 constexpr int KV_TILE_BYTES = KVB * HD * 2;        // 16 KiB
-constexpr int AT_STAGE_BYTES = 2 * KV_TILE_BYTES;  // K + V
-constexpr int AT_LDS = 3 * AT_STAGE_BYTES;         // 96 KiB (three stages)
+constexpr int AT_STAGES = 3;
+constexpr int AT_V_BASE = AT_STAGES * KV_TILE_BYTES;   // K stages at [0, 48K), V stages at [48K, 96K)
+constexpr int AT_LDS = 2 * AT_STAGES * KV_TILE_BYTES;  // 96 KiB
 
 __device__ __forceinline__ int kv_off(int row, int ch) {
     return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
@@ -46,6 +76,7 @@ struct AttnArgs {
     int q_len, kv_len, heads, n_qblocks;
     long q_stride, k_stride, v_stride, o_stride;
     float scale_log2e;  // softmax scale * log2(e)
+    unsigned long long* dbg;
 };
 
 __global__ __launch_bounds__(AT_THREADS, 2) void flash_attn_fwd_kernel(const AttnArgs p) {
@@ -82,60 +113,78 @@ __global__ __launch_bounds__(AT_THREADS, 2) void flash_attn_fwd_kernel(const Att
         for (int kd = 0; kd < 8; ++kd) qf[kd] = *reinterpret_cast<const bf16x8*>(qp + 16 * kd);
     }
 
-    // ---- K/V staging: thread handles 16-byte chunk (row = tid>>4 [+32], ch = tid&15) -------------
-    const int st_row = tid >> 4, st_ch = tid & 15;
-    const u16* kbase = p.k + head * HD + st_ch * 8;
-    const u16* vbase = p.v + head * HD + st_ch * 8;
-    const int st_off0 = kv_off(st_row, st_ch);
-    const int st_off1 = kv_off(st_row + 32, st_ch);
-    u32x4 kreg0, kreg1, vreg0, vreg1;
-    // 32-bit element offsets of this thread's two rows inside tile 0 (host guarantees kv_len*stride < 2^31); a full
-    // tile t adds the wave-uniform t*64*stride, only the ragged last tile needs the per-lane clamp.
-    const unsigned ko0 = (unsigned)st_row * (unsigned)p.k_stride, ko1 = (unsigned)(st_row + 32) * (unsigned)p.k_stride;
-    const unsigned vo0 = (unsigned)st_row * (unsigned)p.v_stride, vo1 = (unsigned)(st_row + 32) * (unsigned)p.v_stride;
+    // ---- K/V staging by LDS-DMA (global_load_lds_dwordx4): one wave instruction fills 4 rows x 256 B of a tile image;
+    // wave w issues row-groups j = 2w, 2w+1 of the K tile and of the V tile (4 DMAs per wave per tile, no VGPRs, no
+    // ds_write).  The DMA writes lane-linear, so the image's chunk swizzle is applied to the per-lane SOURCE chunk:
+    // lane i fills physical chunk (i&15) of row 4j+(i>>4), which must hold logical chunk (i&15) ^ swz(row).
+    const int dma_r = lane >> 4;  // row inside the 4-row group ( = row & 3 )
+    unsigned dma_off[2][2];       // [jj][K/V] element offset of this lane's 16-byte piece inside tile 0
+    int dma_row[2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const int j = 2 * wave + jj;
+        const int row = 4 * j + dma_r;
+        const int lch = (lane & 15) ^ ((dma_r << 2) | (j & 3));
+        dma_row[jj] = row;
+        dma_off[jj][0] = (unsigned)row * (unsigned)p.k_stride + head * HD + lch * 8;
+        dma_off[jj][1] = (unsigned)row * (unsigned)p.v_stride + head * HD + lch * 8;
+    }
     const unsigned kstep = KVB * (unsigned)p.k_stride, vstep = KVB * (unsigned)p.v_stride;
-    auto load_tile = [&](int t) {
+    // The DMA is issued from inline asm: hipcc otherwise treats every outstanding LDS-DMA as a possible alias of the
+    // ds_read_b64_tr_b16 reads and puts `s_waitcnt vmcnt(0)` in front of them (the whole HBM latency, every tile).
+    // M0 (LDS destination) is written in the same statement that uses it and restored; completion is waited for by
+    // hand (vmcnt(0) before the tile's closing barrier).
+    auto dma16 = [&](const u16* g, GF_LDS char* l) {
+        unsigned keep;
+        const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)l);
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(g), "s"(dst)
+                     : "memory");
+    };
+    auto stage_tile = [&](int t, int stg) {
+        GF_LDS char* kb = lds + stg * KV_TILE_BYTES + wave * 2048;
+        GF_LDS char* vb = kb + AT_V_BASE;
         if ((t + 1) * KVB <= p.kv_len) {
-            const unsigned tk = (unsigned)t * kstep, tv = (unsigned)t * vstep;   // scalar
-            kreg0 = *reinterpret_cast<const u32x4*>(kbase + (ko0 + tk));
-            kreg1 = *reinterpret_cast<const u32x4*>(kbase + (ko1 + tk));
-            vreg0 = *reinterpret_cast<const u32x4*>(vbase + (vo0 + tv));
-            vreg1 = *reinterpret_cast<const u32x4*>(vbase + (vo1 + tv));
-        } else {
-            const int k0 = t * KVB;
-            const long r0 = min(k0 + st_row, p.kv_len - 1);
-            const long r1 = min(k0 + st_row + 32, p.kv_len - 1);
-            kreg0 = *reinterpret_cast<const u32x4*>(kbase + r0 * p.k_stride);
-            kreg1 = *reinterpret_cast<const u32x4*>(kbase + r1 * p.k_stride);
-            vreg0 = *reinterpret_cast<const u32x4*>(vbase + r0 * p.v_stride);
-            vreg1 = *reinterpret_cast<const u32x4*>(vbase + r1 * p.v_stride);
+            const unsigned tk = (unsigned)t * kstep, tv = (unsigned)t * vstep;  // scalar
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                dma16(p.k + (dma_off[jj][0] + tk), kb + jj * 1024);
+                dma16(p.v + (dma_off[jj][1] + tv), vb + jj * 1024);
+            }
+        } else {  // ragged last tile: clamp the key row (the scores of the padding keys are masked)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const long rr = min(t * KVB + dma_row[jj], p.kv_len - 1);
+                const int j = 2 * wave + jj;
+                const int lch = (lane & 15) ^ ((dma_r << 2) | (j & 3));
+                dma16(p.k + rr * p.k_stride + head * HD + lch * 8, kb + jj * 1024);
+                dma16(p.v + rr * p.v_stride + head * HD + lch * 8, vb + jj * 1024);
+            }
         }
     };
-    auto write_tile = [&](int buf) {
-        GF_LDS char* kb = lds + buf * AT_STAGE_BYTES;
-        GF_LDS char* vb = kb + KV_TILE_BYTES;
-        *(GF_LDS u32x4*)(kb + st_off0) = kreg0;
-        *(GF_LDS u32x4*)(kb + st_off1) = kreg1;
-        *(GF_LDS u32x4*)(vb + st_off0) = vreg0;
-        *(GF_LDS u32x4*)(vb + st_off1) = vreg1;
-    };
 
-    // ---- per-lane LDS read offsets ----------------------------------------------------------------
-    // K row read for subtile kt, d-step kd: row = 32*kt + r, chunk = 2*kd + h
-    //   off = 256*row + 16*((2kd+h) ^ sK), sK = ((r&3)<<2)|((r>>2)&3)   (32*kt does not change row&3, (row>>2)&3)
-    const int sK = ((r & 3) << 2) | ((r >> 2) & 3);
-    const int k_row_off = 256 * r;
-    // V transposed read (ds_read_b64_tr_b16): 16-lane group g = lane>>4, i = lane&15, qd = i>>2, pp = i&3.
-    //   rows key0 + qd with key0 = 32kt + 16s + 4h (+8 for the second half of the fragment),
-    //   chunk = 4*dblk + 2*(g&1) + (pp>>1), byte +8*(pp&1)
-    const int g1 = (lane >> 4) & 1;
-    const int qd = (lane & 15) >> 2, pp = lane & 3;
-    // row = 32kt + 16s + 8*half + 4h + qd : row&3 = qd, (row>>2)&3 = (2*half + h) & 3 -> depends on half
-    const int v_row_base = 4 * h + qd;  // + 32kt + 16s + 8*half
-    const int v_ch_lo = 2 * g1 + (pp >> 1);  // + 4*dblk
-    const int v_byte = 8 * (pp & 1);
-    const int sV0 = (qd << 2) | ((0 * 2 + h) & 3);  // half 0
-    const int sV1 = (qd << 2) | ((1 * 2 + h) & 3);  // half 1
+    // ---- per-lane LDS read offsets, all lane-dependent parts precomputed so every read is base register + immediate ----
+    // K row read (subtile kt, d-step kd): row = 32kt + r, logical chunk 2kd + h:
+    //   koff[kd] = 256 r + 16 ((2kd + h) ^ sK), sK = ((r&3)<<2) | ((r>>2)&3);   + stage*16K + kt*8K as immediate
+    // V transposed read (ds_read_b64_tr_b16; 16-lane group g, i = lane&15, qd = i>>2, pp = i&3), fragment half hf:
+    //   row = 32kt + 16s + 8hf + 4h + qd, logical chunk 4d + 2(g&1) + (pp>>1), byte + 8 (pp&1)
+    //   voff[hf][d] = 48K + 256 (8hf + 4h + qd) + 16 ((4d + vcl) ^ sV[hf]) + 8 (pp&1);   + stage*16K + 256 (32kt + 16s) immediate
+    int koff[8], voff[2][4];
+    {
+        const int sK = ((r & 3) << 2) | ((r >> 2) & 3);
+#pragma unroll
+        for (int kd = 0; kd < 8; ++kd) koff[kd] = 256 * r + 16 * ((2 * kd + h) ^ sK);
+        const int qd = (lane & 15) >> 2, pp = lane & 3;
+        const int vcl = 2 * ((lane >> 4) & 1) + (pp >> 1);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int sV = (qd << 2) | ((2 * hf + h) & 3);
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+                voff[hf][d] = AT_V_BASE + 256 * (8 * hf + 4 * h + qd) + 16 * ((4 * d + vcl) ^ sV) + 8 * (pp & 1);
+        }
+    }
 
     f32x16 oacc[4];
 #pragma unroll
@@ -147,9 +196,13 @@ __global__ __launch_bounds__(AT_THREADS, 2) void flash_attn_fwd_kernel(const Att
     const float c = p.scale_log2e;
     const int nt = (p.kv_len + KVB - 1) / KVB;
     bf16x8 pf[2][2];  // P^T fragments of the tile whose PV product is pending
+#if GF_ATTN_STAMP
+    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+#endif
 
     // ---- S^T = K · Q^T for the tile in stage `kb`, online softmax, P^T fragments into pf -------------
-    auto scores_softmax = [&](GF_LDS char* kb, int t) {
+    auto scores_softmax = [&](auto stg_c, int t) {
+        constexpr int STG = decltype(stg_c)::value;
         f32x16 s0, s1;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -158,12 +211,21 @@ __global__ __launch_bounds__(AT_THREADS, 2) void flash_attn_fwd_kernel(const Att
         }
 #pragma unroll
         for (int kd = 0; kd < 8; ++kd) {
-            const int off = k_row_off + 16 * ((2 * kd + h) ^ sK);
-            const bf16x8 k0f = *(GF_LDS bf16x8*)(kb + off);
-            const bf16x8 k1f = *(GF_LDS bf16x8*)(kb + off + 32 * 256);
+            const bf16x8 k0f = *(GF_LDS bf16x8*)(lds + koff[kd] + STG * KV_TILE_BYTES);
+            const bf16x8 k1f = *(GF_LDS bf16x8*)(lds + koff[kd] + STG * KV_TILE_BYTES + 32 * 256);
             s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0f, qf[kd], s0, 0, 0, 0);
             s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1f, qf[kd], s1, 0, 0, 0);
         }
+#if GF_ATTN_SCHED
+        // software-pipeline the K fragment reads two d-steps (4 ds_read_b128) ahead of the MFMAs that consume them
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+#endif
         // s{kt}[e] = score(key = 64t + 32kt + (e&3) + 8*(e>>2) + 4h, query q0 + r)
         if (t == nt - 1 && (p.kv_len & (KVB - 1)) != 0) {  // mask the ragged tail (wave-uniform branch)
             const int kbase_i = t * KVB + 4 * h;
@@ -174,6 +236,7 @@ __global__ __launch_bounds__(AT_THREADS, 2) void flash_attn_fwd_kernel(const Att
                 if (key + 32 >= p.kv_len) s1[e] = -INFINITY;
             }
         }
+        STAMP(1)
         float mx = s0[0];
 #pragma unroll
         for (int e = 1; e < 16; ++e) mx = fmaxf(mx, s0[e]);
@@ -193,6 +256,7 @@ __global__ __launch_bounds__(AT_THREADS, 2) void flash_attn_fwd_kernel(const Att
 #pragma unroll
                 for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
         }
+        STAMP(2)
         const float mc = m_run * c;
         float rs = 0.f;
 #pragma unroll
@@ -210,32 +274,43 @@ __global__ __launch_bounds__(AT_THREADS, 2) void flash_attn_fwd_kernel(const Att
                 pf[0][s][e] = (__bf16)s0[8 * s + e];
                 pf[1][s][e] = (__bf16)s1[8 * s + e];
             }
+        STAMP(3)
     };
 
     // ---- O^T += V^T · P^T for the V tile in stage `vb` and the pending pf ------------------------------
-    auto pv = [&](GF_LDS char* vb) {
+    auto pv = [&](auto stg_c) {
+        constexpr int STG = decltype(stg_c)::value;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const int rowa = 32 * kt + 16 * s + v_row_base;  // half 0; half 1 = +8
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int imm = STG * KV_TILE_BYTES + 256 * (32 * kt + 16 * s);
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
-                    const int ch = 4 * d + v_ch_lo;
-                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (GF_LDS s16x4*)(vb + 256 * rowa + 16 * (ch ^ sV0) + v_byte));
-                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (GF_LDS s16x4*)(vb + 256 * (rowa + 8) + 16 * (ch ^ sV1) + v_byte));
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GF_LDS s16x4*)(lds + voff[0][d] + imm));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GF_LDS s16x4*)(lds + voff[1][d] + imm));
                     typedef __attribute__((ext_vector_type(8))) short s16x8;
                     const s16x8 vv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                     oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf[kt][s],
                                                                       oacc[d], 0, 0, 0);
                 }
             }
+#if GF_ATTN_SCHED
+        // V^T fragment reads (2 ds_read_b64_tr_b16 per MFMA) run two MFMAs ahead
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 1);
+#pragma unroll
+        for (int i = 0; i < 14; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 1);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 1);
+#endif
     };
 
-    load_tile(0);
-    write_tile(0);
+    stage_tile(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     // Three LDS stages; tile t lives in stage t % 3.  The two waves that share a SIMD (w and w+4) run the same
@@ -244,34 +319,58 @@ __global__ __launch_bounds__(AT_THREADS, 2) void flash_attn_fwd_kernel(const Att
     //   waves 4-7:  [PV(t-1)]              [QK^T(t), softmax(t)]   | barrier      (+ PV(nt-1) after the loop)
     // Tile t+1 is written into stage (t+1)%3 at the end of iteration t; its previous tenant (tile t-2) was last read
     // by waves 4-7 in iteration t-1, which the barrier of t-1 fences.
-    int cur = 0, prev = 2, nxt = 1;
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, 1> S1;
+    typedef std::integral_constant<int, 2> S2;
+    // the second-dispatched half of the workgroup loses every issue arbitration to its older SIMD partner (priority,
+    // then age); one static priority raise lets its deferred PV product run beside the partner's softmax
+    if (wave >= 4) __builtin_amdgcn_s_setprio(GF_ATTN_LATE_PRIO);
+    // The tile loop is unrolled by the three stages so that the stage offset is an immediate of every ds_read.
     if (wave < 4) {
-        for (int t = 0; t < nt; ++t) {
-            GF_LDS char* kb = lds + cur * AT_STAGE_BYTES;
-            if (t + 1 < nt) load_tile(t + 1);  // global -> registers, consumed after the MFMAs below
-            scores_softmax(kb, t);
-            pv(kb + KV_TILE_BYTES);
-            if (t + 1 < nt) write_tile(nxt);
+        auto iter = [&](auto cur_c, auto nxt_c, int t) {
+            STAMP(0)
+            if (t + 1 < nt) stage_tile(t + 1, decltype(nxt_c)::value);  // DMA in flight during this tile's matrix work
+            scores_softmax(cur_c, t);
+            pv(cur_c);
+            STAMP(4)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            STAMP(5)
             __syncthreads();
-            prev = cur;
-            cur = nxt;
-            nxt = (nxt == 2) ? 0 : nxt + 1;
+            STAMP(6)
+        };
+        for (int t = 0; t < nt; t += 3) {
+            iter(S0{}, S1{}, t);
+            if (t + 1 < nt) iter(S1{}, S2{}, t + 1);
+            if (t + 2 < nt) iter(S2{}, S0{}, t + 2);
         }
     } else {
-        for (int t = 0; t < nt; ++t) {
-            GF_LDS char* kb = lds + cur * AT_STAGE_BYTES;
-            if (t + 1 < nt) load_tile(t + 1);
-            if (t > 0) pv(lds + prev * AT_STAGE_BYTES + KV_TILE_BYTES);
-            scores_softmax(kb, t);
-            if (t + 1 < nt) write_tile(nxt);
+        auto iter = [&](auto cur_c, auto prev_c, auto nxt_c, int t) {
+            STAMP(0)
+            if (t + 1 < nt) stage_tile(t + 1, decltype(nxt_c)::value);
+            if (t > 0) pv(prev_c);
+            STAMP(4)
+            scores_softmax(cur_c, t);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            STAMP(5)
             __syncthreads();
-            prev = cur;
-            cur = nxt;
-            nxt = (nxt == 2) ? 0 : nxt + 1;
+            STAMP(6)
+        };
+        for (int t = 0; t < nt; t += 3) {
+            iter(S0{}, S2{}, S1{}, t);
+            if (t + 1 < nt) iter(S1{}, S0{}, S2{}, t + 1);
+            if (t + 2 < nt) iter(S2{}, S1{}, S0{}, t + 2);
         }
-        pv(lds + prev * AT_STAGE_BYTES + KV_TILE_BYTES);  // stage of tile nt-1: nobody writes after the loop
+        // the deferred product of the last tile (its stage is not written after the loop)
+        const int last = (nt - 1) % 3;
+        if (last == 0) pv(S0{});
+        else if (last == 1) pv(S1{});
+        else pv(S2{});
     }
 
+#if GF_ATTN_STAMP
+    if (p.dbg && blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0)
+        for (int i = 0; i < 8; ++i) p.dbg[(wave >> 2) * 8 + i] = seg[i];
+#endif
     // ---- epilogue: O = O^T / l ----------------------------------------------------------------------
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
@@ -337,6 +436,11 @@ extern "C" GF_API int gf_flash_attn_fwd(const void* q, const void* k, const void
     a.v_stride = v_stride;
     a.o_stride = o_stride;
     a.scale_log2e = scale * 1.4426950408889634f;
+#if GF_ATTN_STAMP
+    a.dbg = g_attn_dbg;
+#else
+    a.dbg = nullptr;
+#endif
     hipLaunchKernelGGL(flash_attn_fwd_kernel, dim3((unsigned)(a.n_qblocks * a.heads)), dim3(AT_THREADS), AT_LDS,
                        (hipStream_t)stream, a);
     GF_CHECK_LAUNCH("gf_flash_attn_fwd");
