@@ -23,6 +23,7 @@
 //   * softmax in fp32 with exp2 and the scale folded into one FMA; lazy rescale (skip the O
 //     rescale while the running max grows by less than 2^THR_LOG2; exact in exact arithmetic).
 #include "gf_common.h"
+#include <cstdlib>
 #include <type_traits>
 
 #ifndef GF_ATTN_SCHED
@@ -390,6 +391,386 @@ __global__ __launch_bounds__(AT_THREADS, 2) void flash_attn_fwd_kernel(const Att
     }
 }
 
+
+// ================================================================================================================
+// Kernel 2: same workgroup shape as kernel 1 (8 waves x 32 query rows, two waves per SIMD), but every wave runs a
+// tile-level software pipeline inside ONE instruction stream.  Phase p of a wave:
+//     matrix stream :  O^T += V(p-1)^T P(p-1)^T   (16 MFMAs)   then   S(p+1)^T = K(p+1) Q^T   (16 MFMAs)
+//     VALU stream   :  softmax of S(p)  ->  P(p)  (row max, 32 exp2, row sum, bf16 pack)
+// tools/issue_probe.py (profiles/r01/issue_probe.txt) measured what bounds this loop on gfx950: a wave issues serially
+// (MFMA 4, VALU ~5, v_exp_f32 ~12.5, ds_read ~6.7 cycles each) against 32 cycles per 32x32x16 MFMA, so a wave that runs
+// its matrix phase and its softmax phase one after the other leaves the matrix pipe idle half the time and two such
+// waves only help when they happen to be out of phase.  Here each 64-cycle slot (two waves share the pipe) carries
+// one MFMA, its operand reads for three slots ahead and ONE score's softmax work, pinned in that order: both waves
+// of a SIMD present the same steady mix of matrix / VALU / LDS work all the time.
+//   * S is double buffered in registers (tile parity), P needs one buffer: PV(p-1) reads fragment (kt, s) in slots
+//     4(2kt+s)..+3, the softmax of tile p rewrites it from slot 5 + 8(2kt+s) on.
+//   * lazy rescale is deferred by one phase: a new running max found in phase p scales l at once and P(p) is taken
+//     against it, but O (still receiving PV(p-1), which is in the OLD scale) is multiplied at the top of phase p+1.
+//   * K and V tiles are staged separately by LDS-DMA, two buffers each (64 KiB): K(p+2) and V(p) are issued at the top
+//     of phase p and waited for at its closing barrier (K(j) is consumed in phase j-1, V(j) in phase j+1).
+constexpr int AT2_THREADS = 512;
+constexpr int AT2_V_BASE = 2 * KV_TILE_BYTES;
+constexpr int AT2_LDS = 4 * KV_TILE_BYTES;
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+__device__ __forceinline__ void mfma32(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(AT2_THREADS, 2) void flash_attn_fwd_kernel2(const AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    GF_LDS char* lds = (GF_LDS char*)smem;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    int head, qb;
+    {
+        const int pid = blockIdx.x;
+        if ((p.heads & 7) == 0) {
+            const int xcd = pid & 7, idx = pid >> 3;
+            head = xcd + 8 * (idx / p.n_qblocks);
+            qb = idx % p.n_qblocks;
+        } else {
+            head = pid / p.n_qblocks;
+            qb = pid % p.n_qblocks;
+        }
+    }
+    const int q0 = qb * QB + wave * 32;
+
+    bf16x8 qf[8];
+    {
+        const int qr = min(q0 + r, p.q_len - 1);
+        const u16* qp = p.q + (long)qr * p.q_stride + head * HD + 8 * h;
+#pragma unroll
+        for (int kd = 0; kd < 8; ++kd) qf[kd] = *reinterpret_cast<const bf16x8*>(qp + 16 * kd);
+    }
+
+    // ---- DMA staging: wave w fills row-groups j = 2w, 2w+1 (4 rows x 256 B each) of a K or V tile
+    const int dma_r = lane >> 4;
+    unsigned dma_off[2][2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const int j = 2 * wave + jj;
+        const int row = 4 * j + dma_r;
+        const int lch = (lane & 15) ^ ((dma_r << 2) | (j & 3));
+        dma_off[jj][0] = (unsigned)row * (unsigned)p.k_stride + head * HD + lch * 8;
+        dma_off[jj][1] = (unsigned)row * (unsigned)p.v_stride + head * HD + lch * 8;
+    }
+    const unsigned kstep = KVB * (unsigned)p.k_stride, vstep = KVB * (unsigned)p.v_stride;
+    auto dma16 = [&](const u16* g, GF_LDS char* l) {
+        unsigned keep;
+        const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)l);
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(g), "s"(dst)
+                     : "memory");
+    };
+    // which = 0: K tile t -> K buffer buf;  which = 1: V tile t -> V buffer buf
+    auto stage = [&](int which, int t, int buf) {
+        GF_LDS char* base = lds + which * AT2_V_BASE + buf * KV_TILE_BYTES + wave * 2048;
+        const u16* g = which ? p.v : p.k;
+        if ((t + 1) * KVB <= p.kv_len) {
+            const unsigned tt = (unsigned)t * (which ? vstep : kstep);
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) dma16(g + (dma_off[jj][which] + tt), base + jj * 1024);
+        } else {   // ragged last tile: clamp the row (masked later), 64-bit addressing
+            const long stride = which ? p.v_stride : p.k_stride;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int j = 2 * wave + jj;
+                const long rr = min(t * KVB + 4 * j + dma_r, p.kv_len - 1);
+                const int lch = (lane & 15) ^ ((dma_r << 2) | (j & 3));
+                dma16(g + rr * stride + head * HD + lch * 8, base + jj * 1024);
+            }
+        }
+    };
+
+    int koff[8], voff[2][4];
+    {
+        const int sK = ((r & 3) << 2) | ((r >> 2) & 3);
+#pragma unroll
+        for (int kd = 0; kd < 8; ++kd) koff[kd] = 256 * r + 16 * ((2 * kd + h) ^ sK);
+        const int qd = (lane & 15) >> 2, pp = lane & 3;
+        const int vcl = 2 * ((lane >> 4) & 1) + (pp >> 1);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int sV = (qd << 2) | ((2 * hf + h) & 3);
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+                voff[hf][d] = AT2_V_BASE + 256 * (8 * hf + 4 * h + qd) + 16 * ((4 * d + vcl) ^ sV) + 8 * (pp & 1);
+        }
+    }
+
+    f32x16 oacc[4], sc[2][2];   // sc[tile parity][key half]
+    bf16x8 pf[2][2];            // P fragments [kt][s]
+    float m_run = -1.0e30f, l_run = 0.f, alpha_pend = 1.f;
+    bool pend = false;          // wave-uniform: O still has to be multiplied by alpha_pend
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
+    const float c = p.scale_log2e;
+    const int nt = (p.kv_len + KVB - 1) / KVB;
+    const bool ragged = (p.kv_len & (KVB - 1)) != 0;
+
+    typedef std::integral_constant<int, 0> C0;
+    typedef std::integral_constant<int, 1> C1;
+
+    // ---- unpipelined building blocks (prologue, first and last phase)
+    auto qk_plain = [&](auto par_c) {   // S(par) = K(buffer par) Q^T
+        constexpr int PAR = decltype(par_c)::value;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            sc[PAR][0][e] = 0.f;
+            sc[PAR][1][e] = 0.f;
+        }
+#pragma unroll
+        for (int kd = 0; kd < 8; ++kd) {
+            const bf16x8 k0f = *(GF_LDS bf16x8*)(lds + koff[kd] + PAR * KV_TILE_BYTES);
+            const bf16x8 k1f = *(GF_LDS bf16x8*)(lds + koff[kd] + PAR * KV_TILE_BYTES + 32 * 256);
+            mfma32(sc[PAR][0], k0f, qf[kd]);
+            mfma32(sc[PAR][1], k1f, qf[kd]);
+        }
+    };
+    auto pv_plain = [&](auto buf_c) {   // O^T += V(buffer)^T P^T
+        constexpr int BUF = decltype(buf_c)::value;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int imm = BUF * KV_TILE_BYTES + 256 * (32 * kt + 16 * s);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GF_LDS s16x4*)(lds + voff[0][d] + imm));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GF_LDS s16x4*)(lds + voff[1][d] + imm));
+                    typedef __attribute__((ext_vector_type(8))) short s16x8;
+                    const s16x8 vv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    mfma32(oacc[d], __builtin_bit_cast(bf16x8, vv), pf[kt][s]);
+                }
+            }
+    };
+    auto apply_pending = [&]() {
+        if (pend) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha_pend;
+            pend = false;
+        }
+    };
+    // new running max of tile scores `mx` (already exchanged between the lane halves): rare
+    auto new_max = [&](float mx) {
+        if (!__all((mx - m_run) * c <= 6.0f)) {
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+            m_run = m_new;
+            l_run *= alpha;
+            alpha_pend = alpha;   // at most one outstanding: applied at the top of the next phase
+            pend = true;
+        }
+    };
+    auto softmax_plain = [&](auto par_c, int t) {
+        constexpr int PAR = decltype(par_c)::value;
+        if (ragged && t == nt - 1) {
+            const int kbase_i = t * KVB + 4 * h;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key = kbase_i + (e & 3) + 8 * (e >> 2);
+                if (key >= p.kv_len) sc[PAR][0][e] = -INFINITY;
+                if (key + 32 >= p.kv_len) sc[PAR][1][e] = -INFINITY;
+            }
+        }
+        float mx = sc[PAR][0][0];
+#pragma unroll
+        for (int e = 1; e < 16; ++e) mx = fmaxf(mx, sc[PAR][0][e]);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sc[PAR][1][e]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        new_max(mx);
+        const float mc = m_run * c;
+        float rs = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            sc[PAR][0][e] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[PAR][0][e], c, -mc));
+            sc[PAR][1][e] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[PAR][1][e], c, -mc));
+            rs += sc[PAR][0][e] + sc[PAR][1][e];
+        }
+        l_run += rs;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                pf[0][s][e] = (__bf16)sc[PAR][0][8 * s + e];
+                pf[1][s][e] = (__bf16)sc[PAR][1][8 * s + e];
+            }
+    };
+
+    // ---- the steady phase p (1 <= p <= nt-2), PAR = p & 1:  matrix ops g = 0..31
+    //   g <  16: PV(p-1)   kt = g>>3, s = (g>>2)&1, d = g&3;  V^T fragment from V buffer 1-PAR (two transposed reads)
+    //   g >= 16: QK(p+1)   kd = (g-16)>>1, half = (g-16)&1;   K fragment from K buffer 1-PAR (one row read) -> sc[1-PAR]
+    // The A operand of op g is read in slot g-3 into ring entry g&3 (ops 0..2 at the top of the phase: their tiles
+    // only land at the closing barrier of the phase before); hipcc counts lgkmcnt itself.  sched_barrier(0) after every
+    // slot pins the written order; the empty volatile asms pin each score's VALU work INTO its slot (instruction
+    // selection would otherwise hoist all 32 exps to the top of the phase).
+    bf16x8 fr[4];
+    auto frag_load = [&](auto g_c, auto par_c) {
+        constexpr int G = decltype(g_c)::value, PAR = decltype(par_c)::value;
+        if constexpr (G < 16) {
+            constexpr int kt = G >> 3, sq = (G >> 2) & 1, d = G & 3;
+            constexpr int imm = (1 - PAR) * KV_TILE_BYTES + 256 * (32 * kt + 16 * sq);
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GF_LDS s16x4*)(lds + voff[0][d] + imm));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GF_LDS s16x4*)(lds + voff[1][d] + imm));
+            typedef __attribute__((ext_vector_type(8))) short s16x8;
+            const s16x8 vv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            fr[G & 3] = __builtin_bit_cast(bf16x8, vv);
+        } else if constexpr (G < 32) {
+            constexpr int kd = (G - 16) >> 1, half = (G - 16) & 1;
+            fr[G & 3] = *(GF_LDS bf16x8*)(lds + koff[kd] + (1 - PAR) * KV_TILE_BYTES + half * 32 * 256);
+        }
+    };
+    auto mfma_op = [&](auto g_c, auto par_c) {
+        constexpr int G = decltype(g_c)::value, PAR = decltype(par_c)::value;
+        if constexpr (G < 16) {
+            constexpr int kt = G >> 3, sq = (G >> 2) & 1, d = G & 3;
+            mfma32(oacc[d], fr[G & 3], pf[kt][sq]);
+        } else {
+            constexpr int kd = (G - 16) >> 1, half = (G - 16) & 1;
+            if constexpr (kd == 0) {
+                const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                sc[1 - PAR][half] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[G & 3], qf[kd], zero, 0, 0, 0);
+            } else {
+                mfma32(sc[1 - PAR][half], fr[G & 3], qf[kd]);
+            }
+        }
+    };
+    auto phase = [&](auto par_c, int pidx) {
+        constexpr int PAR = decltype(par_c)::value;
+        if (pidx + 2 < nt) stage(0, pidx + 2, PAR);
+        stage(1, pidx, PAR);
+        apply_pending();
+        frag_load(std::integral_constant<int, 0>{}, par_c);
+        frag_load(std::integral_constant<int, 1>{}, par_c);
+        frag_load(std::integral_constant<int, 2>{}, par_c);
+        float mx = -INFINITY, mo = 0.f;
+        static_for<0, 4>([&](auto i_c) {
+            constexpr int G = decltype(i_c)::value;
+            mfma_op(i_c, par_c);
+            frag_load(std::integral_constant<int, G + 3>{}, par_c);
+            if constexpr (G == 1) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sc[PAR][0][e]);
+            } else if constexpr (G == 2) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sc[PAR][1][e]);
+                mo = __shfl_xor(mx, 32);
+            } else if constexpr (G == 3) {
+                mx = fmaxf(mx, mo);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        new_max(mx);
+        const float mc = m_run * c;
+        float rs = 0.f, pe[2];
+        static_for<4, 32>([&](auto i_c) {
+            constexpr int G = decltype(i_c)::value;
+            mfma_op(i_c, par_c);
+            frag_load(std::integral_constant<int, G + 3>{}, par_c);
+            // scores 0..7 two per slot in slots 4-7, scores 8..31 one per slot in slots 8-31
+            constexpr int n_el = (G < 8) ? 2 : 1;
+            constexpr int el0 = (G < 8) ? 2 * (G - 4) : G;
+            static_for<0, n_el>([&](auto k_c) {
+                constexpr int el = el0 + decltype(k_c)::value, half = el >> 4, e = el & 15;
+                float sv = sc[PAR][half][e];
+                asm volatile("" : "+v"(sv));
+                pe[el & 1] = __builtin_amdgcn_exp2f(__builtin_fmaf(sv, c, -mc));
+                rs += pe[el & 1];
+                if constexpr (el & 1) {
+                    asm volatile("" : "+v"(pe[0]), "+v"(pe[1]), "+v"(rs));
+                    pf[half][e >> 3][(e & 7) - 1] = (__bf16)pe[0];
+                    pf[half][e >> 3][e & 7] = (__bf16)pe[1];
+                }
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        l_run += rs;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+
+    // ---- prologue: K(0), K(1) staged; S(0)
+    stage(0, 0, 0);
+    if (nt > 1) stage(0, 1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    qk_plain(C0{});
+    __syncthreads();   // every wave has read K(0) before K(2) overwrites its buffer
+    // ---- phase 0 (no PV yet): K(2), V(0) in flight; S(1); softmax(0)
+    if (nt > 2) stage(0, 2, 0);
+    stage(1, 0, 0);
+    if (nt > 1) qk_plain(C1{});
+    softmax_plain(C0{}, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // ---- steady phases 1 .. nt-2
+    int pi = 1;
+    for (; pi + 1 <= nt - 2; pi += 2) {
+        phase(C1{}, pi);
+        phase(C0{}, pi + 1);
+    }
+    if (pi <= nt - 2) {
+        phase(C1{}, pi);
+        ++pi;
+    }
+    // ---- last phase p = nt-1 (nt >= 2): V(nt-1) in flight; PV(nt-2); softmax(nt-1)
+    if (nt >= 2) {
+        const int par = (nt - 1) & 1;
+        stage(1, nt - 1, par);
+        apply_pending();
+        if (par) {
+            pv_plain(C0{});
+            softmax_plain(C1{}, nt - 1);
+        } else {
+            pv_plain(C1{});
+            softmax_plain(C0{}, nt - 1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    // ---- PV(nt-1)
+    apply_pending();
+    if ((nt - 1) & 1)
+        pv_plain(C1{});
+    else
+        pv_plain(C0{});
+
+    // ---- epilogue
+    {
+        const float l_tot = l_run + __shfl_xor(l_run, 32);
+        const float inv = 1.0f / l_tot;
+        const int qrow = q0 + r;
+        if (qrow < p.q_len) {
+            u16* op = p.o + (long)qrow * p.o_stride + head * HD + 4 * h;
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    u32x2 pk;
+                    pk[0] = pack2bf(oacc[d][4 * rg + 0] * inv, oacc[d][4 * rg + 1] * inv);
+                    pk[1] = pack2bf(oacc[d][4 * rg + 2] * inv, oacc[d][4 * rg + 3] * inv);
+                    *reinterpret_cast<u32x2*>(op + 32 * d + 8 * rg) = pk;
+                }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" GF_API int gf_flash_attn_fwd(const void* q, const void* k, const void* v, void* o, int64_t q_len, int64_t kv_len,
@@ -413,9 +794,13 @@ extern "C" GF_API int gf_flash_attn_fwd(const void* q, const void* k, const void
                  "gf_flash_attn_fwd: kv_len*stride must stay below 2^31 elements");
     if (q_len == 0) return GF_OK;
     static bool attr_set = false;
+    static bool use_k2 = true;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_fwd_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, AT_LDS);
+        const char* ev = getenv("GF_ATTN_KERNEL");   // tuning switch: 1 = the phase-serial kernel, 2 = the slot-pipelined kernel
+        use_k2 = !(ev && ev[0] == '1');
+        hipError_t e = hipFuncSetAttribute(use_k2 ? reinterpret_cast<const void*>(flash_attn_fwd_kernel2)
+                                                  : reinterpret_cast<const void*>(flash_attn_fwd_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, use_k2 ? AT2_LDS : AT_LDS);
         if (e != hipSuccess) {
             gf_set_error("gf_flash_attn_fwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
             return GF_ERR_LAUNCH;
@@ -441,8 +826,12 @@ extern "C" GF_API int gf_flash_attn_fwd(const void* q, const void* k, const void
 #else
     a.dbg = nullptr;
 #endif
-    hipLaunchKernelGGL(flash_attn_fwd_kernel, dim3((unsigned)(a.n_qblocks * a.heads)), dim3(AT_THREADS), AT_LDS,
-                       (hipStream_t)stream, a);
+    if (use_k2)
+        hipLaunchKernelGGL(flash_attn_fwd_kernel2, dim3((unsigned)(a.n_qblocks * a.heads)), dim3(AT2_THREADS), AT2_LDS,
+                           (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(flash_attn_fwd_kernel, dim3((unsigned)(a.n_qblocks * a.heads)), dim3(AT_THREADS), AT_LDS,
+                           (hipStream_t)stream, a);
     GF_CHECK_LAUNCH("gf_flash_attn_fwd");
     return GF_OK;
 }
