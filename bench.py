@@ -196,7 +196,7 @@ def main():
             "step_mfma_frac": (sum(step_flops) / elapsed / 1e12) / PEAK_BF16_TFLOPS,
             "frames_per_sec_schedule_weighted": (videos * 81.0 / ((21 * sum(hi) / len(hi) + 29 * sum(lo) / len(lo)) / 1e3 + vae_s)
                                                  if hi and lo else None),
-            "roofline": {"bound": "mfma", "kernel": "flash_attn_fwd_kernel (self-attention, S=32760, 40 heads, d=128)",
+            "roofline": {"bound": "mfma", "kernel": "flash_attn_fwd_kernel2 (self-attention, S=32760, 40 heads, d=128)",
                          "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": None if achieved is None else achieved / PEAK_BF16_TFLOPS,
                          # HBM bytes per launch from rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes over

@@ -11,6 +11,8 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgoalforce_hip.so")
+# GOALFORCE_HIP_LIB: A/B a differently built libgoalforce_hip.so (kernel tuning); it is still the HIP library, never a fallback
+LIB_PATH = os.environ.get("GOALFORCE_HIP_LIB", LIB_PATH)
 
 # every symbol include/goalforce.h declares (tests check the .so exports exactly these)
 SYMBOLS = (

@@ -34,6 +34,18 @@ MIXES = [
     ("pkfma", dict(pk=1)),
     ("lds_tr", dict(lds=1)),
     ("lds_b128", dict(ldsq=1)),
+    ("lds_b128_lin16", dict(ldsq=1, addr="lin16")),
+    ("lds_b128_kpattern", dict(ldsq=1, addr="kpat")),
+    ("lds_tr_vpattern", dict(lds=1, addr="vpat")),
+    ("mfma+1lds_b128_k", dict(m=1, ldsq=1, addr="kpat")),
+    ("mfma+2lds_tr_v", dict(m=1, lds=2, addr="vpat")),
+    ("mfmaV (acc in VGPRs)", dict(mv=1)),
+    ("mfmaV+2lds_tr_v", dict(mv=1, lds=2, addr="vpat")),
+    ("mfmaV+1exp+3fma", dict(mv=1, exp=1, fma=3)),
+    ("mfmaV+1exp+3fma+2lds", dict(mv=1, exp=1, fma=3, lds=2, addr="vpat")),
+    ("mfma+1exp+3fma+2lds_v", dict(m=1, exp=1, fma=3, lds=2, addr="vpat")),
+    ("mfma+1exp+2fma+1cvt+2lds+wait", dict(m=1, exp=1, fma=2, cvt=1, lds=2, addr="vpat", wait=1)),
+    ("mfmaV+1exp+2fma+1cvt+2lds+wait", dict(mv=1, exp=1, fma=2, cvt=1, lds=2, addr="vpat", wait=1)),
     ("mfma16", dict(m16=1)),
     ("mfma+2pk+1exp", dict(m=1, pk=2, exp=1)),
 ]
@@ -45,15 +57,18 @@ def body(mix):
         a0 = 16 * (s % 4)
         if mix.get("m"):
             lines.append(f"v_mfma_f32_32x32x16_bf16 a[{a0}:{a0+15}], v[8:11], v[12:15], a[{a0}:{a0+15}]")
+        if mix.get("mv"):
+            v0 = 120 + 16 * (s % 4)
+            lines.append(f"v_mfma_f32_32x32x16_bf16 v[{v0}:{v0+15}], v[8:11], v[12:15], v[{v0}:{v0+15}]")
         if mix.get("m16"):
             a4 = 4 * (s % 8)
             lines.append(f"v_mfma_f32_16x16x32_bf16 a[{a4}:{a4+3}], v[8:11], v[12:15], a[{a4}:{a4+3}]")
         for k in range(mix.get("lds", 0)):
             r = 52 + 2 * ((2 * s + k) % 16)
-            lines.append(f"ds_read_b64_tr_b16 v[{r}:{r+1}], v16 offset:{512 * ((2 * s + k) % 16)}")
+            lines.append(f"ds_read_b64_tr_b16 v[{r}:{r+1}], v16 offset:{4096 * ((2 * s + k) % 4)}")
         for k in range(mix.get("ldsq", 0)):
             r = 52 + 4 * (s % 8)
-            lines.append(f"ds_read_b128 v[{r}:{r+3}], v16 offset:{1024 * s}")
+            lines.append(f"ds_read_b128 v[{r}:{r+3}], v16 offset:{8192 * (s % 4)}")
         for k in range(mix.get("exp", 0)):
             lines.append(f"v_exp_f32 v{20 + (4 * s + k) % 32}, v17")
         for k in range(mix.get("fma", 0)):
@@ -61,6 +76,10 @@ def body(mix):
         for k in range(mix.get("pk", 0)):
             r = 84 + 2 * ((8 * s + k) % 16)
             lines.append(f"v_pk_fma_f32 v[{r}:{r+1}], v[8:9], v[10:11], v[12:13]")
+        for k in range(mix.get("cvt", 0)):
+            lines.append(f"v_cvt_pk_bf16_f32 v{116 + (s % 4)}, v17, v18")
+        if mix.get("wait"):
+            lines.append("s_waitcnt lgkmcnt(6)")
         for k in range(mix.get("salu", 0)):
             lines.append(f"s_add_u32 s{24 + k}, s{24 + k}, 1")
         if mix.get("lds") or mix.get("ldsq"):
@@ -72,7 +91,7 @@ def body(mix):
 def gen():
     out = ['#include <hip/hip_runtime.h>', '#include <cstdio>', '#include <cstdlib>', '#include <cstring>',
            'extern __shared__ char smem[];']
-    clob = ",".join([f'"v{i}"' for i in range(8, 120)] + [f'"a{i}"' for i in range(64)] +
+    clob = ",".join([f'"v{i}"' for i in range(8, 184)] + [f'"a{i}"' for i in range(64)] +
                     [f'"s{i}"' for i in range(20, 30)] + ['"scc"', '"memory"'])
     for idx, (name, mix) in enumerate(MIXES):
         asm = ["v_mov_b32 v16, %1", "v_mov_b32 v17, 0x3f000000", "v_mov_b32 v18, 0x3f800000", "v_mov_b32 v19, 0",
@@ -82,8 +101,13 @@ def gen():
         asm += ["s_nop 7", "1:"] + body(mix) + ["s_sub_u32 s20, s20, 1", "s_cmp_lg_u32 s20, 0", "s_cbranch_scc1 1b",
                                               "s_waitcnt lgkmcnt(0)", "s_nop 15"]
         text = "\\n\\t".join(asm)
+        addr = {"lin8": "lane * 8", "lin16": "lane * 16",
+                "kpat": "256 * (lane & 31) + 16 * ((lane >> 5) ^ (((lane & 3) << 2) | ((lane >> 2) & 3)))",
+                "vpat": "256 * (4 * (lane >> 5) + ((lane & 15) >> 2)) + 16 * ((2 * ((lane >> 4) & 1) + ((lane & 3) >> 1)) ^ ((((lane & 15) >> 2) << 2) | (lane >> 5))) + 8 * (lane & 1)",
+                }[mix.get("addr", "lin8")]
         out.append(f'__global__ void probe{idx}(int n, float* o) {{\n'
-                   f'  int off = (threadIdx.x & 63) * 8;\n'
+                   f'  int lane = threadIdx.x & 63;\n'
+                   f'  int off = {addr};\n'
                    f'  asm volatile("{text}" :: "s"(n), "v"(off) : {clob});\n'
                    f'  if (o) o[threadIdx.x] = 0.f;\n}}')
     out.append("typedef void (*kfn)(int, float*);")
