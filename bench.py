@@ -202,7 +202,7 @@ def main():
                          # HBM bytes per launch from rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes over
                          # tools/microbench.py attn, profiles/r01/pmc/): (2 x FETCH_SIZE [gfx950 reports half of a 16-B/lane
                          # stream] + WRITE_SIZE) KiB -> bytes.  Not collected live: PMC needs the profiler.
-                         "traffic": (2 * 1484500 + 327600) * 1024, "traffic_source": "profiles/r01/pmc/attn_{FETCH,WRITE}_SIZE_counter_collection.csv",
+                         "traffic": (2 * 1753460 + 409524) * 1024, "traffic_source": "profiles/r01/pmc/attn_k2_{FETCH,WRITE}_SIZE_counter_collection.csv",
                          "launches": len(self_att), "avg_launch_ms": att_ms if self_att else None,
                          "algorithmic_flops_per_launch": att_flops},
         }

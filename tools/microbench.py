@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--fp8", action="store_true")
     ap.add_argument("--s", type=int, default=S)
+    ap.add_argument("--ref", action="store_true", help="also time torch F.linear (hipBLASLt) on the same shapes: a yardstick, not a product path")
     a = ap.parse_args()
     torch.manual_seed(0)
     s = a.s
@@ -60,6 +61,9 @@ def main():
             fl = 2.0 * s * n * k
             med, mn = timeit(lambda: ops.gemm(inp, w, b, out=out), a.iters)
             print(f"gemm bf16 {name}: median {med:.3f} ms ({fl / med / 1e9:.1f} TFLOP/s), min {mn:.3f} ms")
+            if a.ref:
+                med, mn = timeit(lambda: torch.nn.functional.linear(inp, w, b), a.iters)
+                print(f"   torch F.linear {name}: median {med:.3f} ms ({fl / med / 1e9:.1f} TFLOP/s), min {mn:.3f} ms")
             if a.fp8:
                 w8 = ops.cast_fp8(w)
                 x8, sc = ops.quant_fp8_rowscale(inp)
