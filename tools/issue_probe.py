@@ -46,6 +46,13 @@ MIXES = [
     ("mfma+1exp+3fma+2lds_v", dict(m=1, exp=1, fma=3, lds=2, addr="vpat")),
     ("mfma+1exp+2fma+1cvt+2lds+wait", dict(m=1, exp=1, fma=2, cvt=1, lds=2, addr="vpat", wait=1)),
     ("mfmaV+1exp+2fma+1cvt+2lds+wait", dict(mv=1, exp=1, fma=2, cvt=1, lds=2, addr="vpat", wait=1)),
+    ("lds_b128 gemm frag 16 rows x 4 chunks", dict(ldsq=1, addr="g16")),
+    ("lds_b128 gemm frag 32 rows x 2 chunks", dict(ldsq=1, addr="g32")),
+    ("lds_b128 gemm frag 32 rows, pair swizzle", dict(ldsq=1, addr="g32s")),
+    ("lds_b128 gemm frag 32 rows, pair swizzle ks=1", dict(ldsq=1, addr="g32s1")),
+    ("lds_b128 gemm frag 32 rows, swz (row>>1)&7", dict(ldsq=1, addr="g32t")),
+    ("mfma 1 accumulator chain", dict(m=1, nacc=1)),
+    ("mfma 2 accumulator chains", dict(m=1, nacc=2)),
     ("mfma16", dict(m16=1)),
     ("mfma+2pk+1exp", dict(m=1, pk=2, exp=1)),
 ]
@@ -54,7 +61,7 @@ MIXES = [
 def body(mix):
     lines = []
     for s in range(8):
-        a0 = 16 * (s % 4)
+        a0 = 16 * (s % mix.get("nacc", 4))
         if mix.get("m"):
             lines.append(f"v_mfma_f32_32x32x16_bf16 a[{a0}:{a0+15}], v[8:11], v[12:15], a[{a0}:{a0+15}]")
         if mix.get("mv"):
@@ -103,6 +110,11 @@ def gen():
         text = "\\n\\t".join(asm)
         addr = {"lin8": "lane * 8", "lin16": "lane * 16",
                 "kpat": "256 * (lane & 31) + 16 * ((lane >> 5) ^ (((lane & 3) << 2) | ((lane >> 2) & 3)))",
+                "g16": "128 * (lane & 15) + 16 * ((lane >> 4) ^ (lane & 7))",
+                "g32": "128 * (lane & 31) + 16 * ((lane >> 5) ^ (lane & 7))",
+                "g32s": "256 * ((lane & 31) >> 1) + 16 * ((((lane & 1) * 8) + (lane >> 5)) ^ ((lane & 31) >> 1))",
+                "g32s1": "256 * ((lane & 31) >> 1) + 16 * ((((lane & 1) * 8) + 2 + (lane >> 5)) ^ ((lane & 31) >> 1))",
+                "g32t": "128 * (lane & 31) + 16 * ((lane >> 5) ^ ((lane >> 1) & 7))",
                 "vpat": "256 * (4 * (lane >> 5) + ((lane & 15) >> 2)) + 16 * ((2 * ((lane >> 4) & 1) + ((lane & 3) >> 1)) ^ ((((lane & 15) >> 2) << 2) | (lane >> 5))) + 8 * (lane & 1)",
                 }[mix.get("addr", "lin8")]
         out.append(f'__global__ void probe{idx}(int n, float* o) {{\n'
