@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fp8", action="store_true", help="BASELINE config 5: block Linears on the fp8_linear contract (e4m3 MFMA)")
+    ap.add_argument("--sp", type=int, default=1, help="head-parallel (Ulysses) degree inside each forward: world = videos x 2 x sp "
+                    "(latency mode; the default 1 is the CFG-pair x sample layout the driver's scaling runs use)")
     ap.add_argument("--layers", type=int, default=40, help=argparse.SUPPRESS)  # debugging only; 40 = the real model
     args = ap.parse_args()
 
@@ -89,7 +91,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    cfgp = CfgPairParallel(rank, world) if world > 1 else None
+    if args.sp > 1 and world % (2 * args.sp):
+        raise SystemExit(f"--sp {args.sp} needs --gpus = videos x 2 x sp")
+    cfgp = CfgPairParallel(rank, world, sp_size=args.sp) if world > 1 else None
+    seqp = None if cfgp is None else cfgp.sequence_parallel()
     sample = 0 if cfgp is None else cfgp.sample
 
     cfg = dict(A14B_CONFIG)
@@ -131,7 +136,8 @@ def main():
 
     def run(ids, record=False):
         return pipe.denoise(latents, ctx_p, ctx_n, y, control, num_inference_steps=n_sched, cfg_scale=5.0,
-                            controlnet=True, step_ids=ids, cfg_parallel=cfgp, record_step_times=record)
+                            controlnet=True, step_ids=ids, cfg_parallel=cfgp, record_step_times=record,
+                            sequence_parallel=seqp)
 
     if warm_ids:
         run(warm_ids)
@@ -162,7 +168,7 @@ def main():
 
     if rank == 0:
         sec_per_step = elapsed / k
-        videos = 1 if world == 1 else world // 2
+        videos = 1 if world == 1 else world // (2 * args.sp)
         loop_s = n_sched * sec_per_step
         value = videos * 81.0 / (loop_s + vae_s)
         hi = [ms for ms, low in pipe.last_step_ms if not low]
@@ -170,9 +176,9 @@ def main():
         # dominant kernel: self-attention flash-attention launches (q_len == kv_len == S)
         self_att = [(a.elapsed_time(b)) for a, b, sq, skv, _ in prof if sq == skv == S_TOK]
         att_ms = sum(self_att) / max(1, len(self_att))
-        att_flops = 4.0 * S_TOK * S_TOK * DIM
+        att_flops = 4.0 * S_TOK * S_TOK * DIM / args.sp   # a launch covers 40/sp heads under head parallelism
         achieved = att_flops / (att_ms * 1e-3) / 1e12 if self_att else None
-        fwd_per_step = 2 if world == 1 else 1
+        fwd_per_step = 2 if world == 1 else 1.0 / args.sp   # forwards computed by ONE rank per step
         n_hi = sum(1 for i in step_ids if i < 21)
         step_flops = [(forward_flops(True) if i < 21 else forward_flops(False)) * fwd_per_step for i in step_ids]
         out = {
@@ -186,7 +192,8 @@ def main():
                        "schedule": f"FlowMatch 50 steps shift 5, boundary 0.875; timed step ids {step_ids} "
                                    f"({n_hi} high-noise with ControlNet, {k - n_hi} low-noise with the all-zero ControlNet2 elided)",
                        "layers": args.layers,
-                       "parallelism": "1 GPU: sequential CFG" if world == 1 else f"{videos} video(s) x CFG pair, RCCL all-gather of noise_pred per step",
+                       "parallelism": "1 GPU: sequential CFG" if world == 1 else f"{videos} video(s) x CFG pair, RCCL all-gather of noise_pred per step"
+                                      + (f"; head-parallel attention degree {args.sp} (RCCL all-to-all over xGMI)" if args.sp > 1 else ""),
                        "vae_decode": "tiled (30,52)/(15,26) decode of [1,16,21,60,104] on the HIP kernels, measured after the "
                                      "timed steps and included in value: frames/s = videos*81 / (50*s_per_step + vae_s)"},
             "vae_decode_s": vae_s, "denoise_loop_s_50_steps": loop_s,

@@ -8,7 +8,9 @@ The path shards along two independent axes:
     (src/goal_force/wan_video_new.py:710-716): ONE exchange of the 4.2 MB noise prediction per step
     inside a 2-rank group, after which both ranks apply the identical CFG + Euler update, so the
     latents stay bit-identical on both without a broadcast.
-Layout for world size W >= 2 (even): rank r -> sample r // 2, branch r % 2 (0 = cond, 1 = uncond).
+  * heads     — (optional, degree P) Ulysses attention inside one forward: sequence_parallel.py.
+Layout for world size W = samples x 2 x P: rank r -> sp_rank r % P, branch (r // P) % 2 (0 = cond, 1 = uncond),
+sample r // 2P; with P = 1: sample r // 2, branch r % 2.
 At the end the decoded frames of all samples are all-gathered over the world group.
 """
 from __future__ import annotations
@@ -30,21 +32,44 @@ def split_list_across_devices_contiguous(items: list, world_size: int, device_id
 
 
 class CfgPairParallel:
-    """Communication plan for CFG-pair x sample sharding."""
+    """Communication plan for (samples) x (CFG pair) x (sequence-parallel degree P) sharding.
 
-    def __init__(self, rank: int, world_size: int):
-        if world_size < 2 or world_size % 2:
-            raise ValueError("CFG-pair sharding needs an even world size >= 2")
-        self.rank, self.world_size = rank, world_size
-        self.sample = rank // 2
-        self.branch = rank % 2          # 0 = cond (positive prompt), 1 = uncond
-        self.num_samples = world_size // 2
+    rank r -> sp_rank = r % P, branch = (r // P) % 2, sample = r // (2 P).  The P ranks of one (sample, branch) are
+    consecutive: they form the sequence-parallel group (head all-to-alls between neighbouring GPUs); the CFG exchange
+    runs between the two ranks with equal sp_rank of a sample (each holds the whole noise prediction after the token
+    all-gather).  P = 1 is the plain CFG-pair layout: rank r -> sample r // 2, branch r % 2."""
+
+    def __init__(self, rank: int, world_size: int, sp_size: int = 1):
+        if sp_size < 1 or world_size < 2 * sp_size or world_size % (2 * sp_size):
+            raise ValueError("CFG-pair sharding needs world_size = samples x 2 x sp_size")
+        self.rank, self.world_size, self.sp_size = rank, world_size, sp_size
+        self.sp_rank = rank % sp_size
+        self.branch = (rank // sp_size) % 2          # 0 = cond (positive prompt), 1 = uncond
+        self.sample = rank // (2 * sp_size)
+        self.num_samples = world_size // (2 * sp_size)
         self.pair_group = None
+        self.sp_group = None
         # every rank must create every group, in the same order
         for s in range(self.num_samples):
-            g = dist.new_group(ranks=[2 * s, 2 * s + 1])
-            if s == self.sample:
-                self.pair_group = g
+            base = 2 * sp_size * s
+            for i in range(sp_size):
+                g = dist.new_group(ranks=[base + i, base + sp_size + i])
+                if s == self.sample and i == self.sp_rank:
+                    self.pair_group = g
+        if sp_size > 1:
+            for s in range(self.num_samples):
+                for b in range(2):
+                    base = 2 * sp_size * s + sp_size * b
+                    g = dist.new_group(ranks=list(range(base, base + sp_size)))
+                    if s == self.sample and b == self.branch:
+                        self.sp_group = g
+
+    def sequence_parallel(self):
+        """The SequenceParallel object of this rank's (sample, branch), or None when P = 1."""
+        if self.sp_size == 1:
+            return None
+        from .sequence_parallel import SequenceParallel
+        return SequenceParallel(self.sp_group)
 
     def exchange(self, noise_pred: torch.Tensor):
         """all-gather of this rank's noise prediction inside its CFG pair -> (posi, nega)."""
@@ -53,12 +78,13 @@ class CfgPairParallel:
         return buf[0], buf[1]
 
     def gather_frames(self, frames: Optional[torch.Tensor], shape, dtype, device) -> List[torch.Tensor]:
-        """World all-gather of decoded frames; branch-0 ranks contribute their sample, branch-1 ranks a
-        zero tensor that is dropped.  Returns one tensor per sample (on every rank)."""
-        mine = frames if (self.branch == 0 and frames is not None) else torch.zeros(shape, dtype=dtype, device=device)
+        """World all-gather of decoded frames; the (branch 0, sp_rank 0) rank of a sample contributes it, every other
+        rank a zero tensor that is dropped.  Returns one tensor per sample (on every rank)."""
+        lead = self.branch == 0 and self.sp_rank == 0
+        mine = frames if (lead and frames is not None) else torch.zeros(shape, dtype=dtype, device=device)
         out = [torch.empty(shape, dtype=dtype, device=device) for _ in range(self.world_size)]
         dist.all_gather(out, mine.contiguous())
-        return [out[2 * s] for s in range(self.num_samples)]
+        return [out[2 * self.sp_size * s] for s in range(self.num_samples)]
 
 
 def init_from_env(backend: Optional[str] = None):

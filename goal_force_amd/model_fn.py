@@ -2,7 +2,7 @@
 `pipe.model_fn`, src/goal_force/wan_video_new.py:161, 1349-1591), rebuilt on the HIP kernels.
 
 Same keyword interface as the reference; branches the Goal-Force inference scripts never take
-(S2V, VACE, camera/motion control, TeaCache, sliding window, USP, reference latents, cfg-merged batches)
+(S2V, VACE, camera/motion control, TeaCache, sliding window, reference latents, cfg-merged batches)
 raise NotImplementedError instead of silently doing something else.
 
 Differences that do not change results:
@@ -12,6 +12,8 @@ Differences that do not change results:
   * zero-conv + residual add is one GEMM epilogue;
   * a ControlNet whose zero-convs are all exactly zero is skipped (x + 0 == x bitwise) unless
     `elide_zero_controlnet=False`;
+  * `use_unified_sequence_parallel` / `sequence_parallel=` run the blocks on this rank's token chunk with head-parallel
+    attention (sequence_parallel.py); unlike the reference's USP path the ControlNet tokens are sharded too;
   * `context_cache` (optional) memoises text_embedding(context) and the per-block cross-attention K/V,
     which are constant over the denoising steps for one (expert, prompt).
 """
@@ -72,6 +74,7 @@ def model_fn_wan_video(
     controlnet=None,
     context_cache: Optional[ContextCache] = None,
     elide_zero_controlnet: bool = True,
+    sequence_parallel=None,
     **kwargs,
 ):
     for name, val in (("motion_controller", motion_controller), ("vace", vace), ("reference_latents", reference_latents),
@@ -80,8 +83,12 @@ def model_fn_wan_video(
                       ("control_camera_latents_input", control_camera_latents_input),
                       ("clip_feature", clip_feature if dit.require_clip_embedding else None)):
         _unsupported(name, val)
-    if use_unified_sequence_parallel:
-        raise NotImplementedError("USP (xfuser Ulysses) is not wired for the ControlNet path in the reference either")
+    sp = sequence_parallel
+    if use_unified_sequence_parallel and sp is None:
+        from .sequence_parallel import SequenceParallel
+        sp = SequenceParallel()          # the reference's flag: Ulysses over the whole world group (GF:1422-1426)
+    if sp is not None and sp.size == 1:
+        sp = None
     if cfg_merge or latents.shape[0] != 1 or context.shape[0] != 1:
         raise NotImplementedError("cfg_merge / batch > 1: run the cond and uncond forwards separately (GF:710-716)")
     if dit.seperated_timestep and fuse_vae_embedding_in_latents:
@@ -106,6 +113,9 @@ def model_fn_wan_video(
     x, (f, h, w) = dit.patchify(latents, extra=y if (y is not None and dit.require_vae_embedding) else None)
     x = x[0]
     rope = dit.rope_table(f, h, w, latents.device)
+    if sp is not None:                      # GF:1526-1531: contiguous token chunks; RoPE of the chunk (xdit:36-37)
+        x = sp.shard_tokens(x).contiguous()
+        rope = dit.rope_table_shard(f, h, w, latents.device, sp)
 
     run_cn = use_controlnet and not (elide_zero_controlnet and controlnet.all_zero())
     c = None
@@ -116,6 +126,8 @@ def model_fn_wan_video(
         if control_latents is None:
             raise GoalForceError("controlnet given but control_signal_video_latents missing")
         c = controlnet.controlnet_patch_embedding(control_latents)[0]      # GF:1493
+        if sp is not None:
+            c = sp.shard_tokens(c).contiguous()   # ControlNet tokens follow the DiT's chunking (injection stays local)
         n_cn = controlnet.controlnet_dit.num_layers
     else:
         n_cn = 0
@@ -131,12 +143,16 @@ def model_fn_wan_video(
     for block_id, block in enumerate(dit.blocks):
         if block_id < n_cn:
             cb = controlnet.controlnet_dit.blocks[block_id]
-            c = cb(c, ctx, t_mod, rope, context_kv=kv_for(context_cache.cn_kv if context_cache else None, cb, block_id))
-        x = block(x, ctx, t_mod, rope, context_kv=kv_for(context_cache.dit_kv if context_cache else None, block, block_id))
+            c = cb(c, ctx, t_mod, rope, context_kv=kv_for(context_cache.cn_kv if context_cache else None, cb, block_id),
+                   sp=sp)
+        x = block(x, ctx, t_mod, rope, context_kv=kv_for(context_cache.dit_kv if context_cache else None, block, block_id),
+                  sp=sp)
         if block_id < n_cn:
             # x = x + zero_conv(state)   (GF:1565-1570) — Conv1d(k=1) == Linear, fused residual epilogue
             ops.gemm(c, controlnet.zero_conv_weight(block_id), controlnet.controlnet_zero_convs_after[block_id].bias,
                      epilogue=ops.EPI_BIAS_RESID, resid=x, out=x)
 
     x = dit.head(x.unsqueeze(0), t)          # GF:1581
+    if sp is not None:
+        x = sp.gather_tokens(x[0]).unsqueeze(0)   # GF:1582-1585
     return dit.unpatchify(x, (f, h, w))      # GF:1590

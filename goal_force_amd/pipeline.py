@@ -91,8 +91,8 @@ class WanVideoPipeline:
         """GF:483-595.  Loads local Wan2.2-I2V-A14B expert checkpoints (high-noise first, then low-noise);
         ControlNet blocks are initialised as copies of DiT blocks 0..N-1 of the matching expert and
         controlnet2 is a copy made before any ControlNet weights are loaded (GF:559-568)."""
-        if use_usp or apply_strided_controlnet:
-            raise NotImplementedError("USP / strided ControlNet are not part of the Goal-Force sampling path")
+        if apply_strided_controlnet:
+            raise NotImplementedError("strided ControlNet is not part of the Goal-Force sampling path")
         pipe = WanVideoPipeline(device=device, torch_dtype=torch_dtype, controlnet=controlnet,
                                 controlnet_num_layers=controlnet_num_layers, controlnet_stride=controlnet_stride)
         dits = []
@@ -107,6 +107,9 @@ class WanVideoPipeline:
             else:
                 raise NotImplementedError(f"checkpoint {mc.path}: only Wan DiT experts are loaded here; text encoder "
                                           "and VAE-encoder weights belong to the 'next' rows (SURVEY §8f)")
+        # GF:516/594 `use_usp`: head-parallel attention over the whole process group (sequence_parallel.py); the
+        # pipeline's __call__ / denoise then pass use_unified_sequence_parallel to model_fn (GF:1107-1109)
+        pipe.use_unified_sequence_parallel = bool(use_usp)
         if dits:
             pipe.dit = dits[0]
             pipe.dit2 = dits[1] if len(dits) > 1 else None
@@ -177,11 +180,14 @@ class WanVideoPipeline:
     @torch.no_grad()
     def denoise(self, latents, context_posi, context_nega, y, control_signal_video_latents, num_inference_steps=50,
                 cfg_scale=5.0, switch_DiT_boundary=0.875, sigma_shift=5.0, denoising_strength=1.0, controlnet=True,
-                progress_bar_cmd=None, record_step_times=False, step_ids=None, cfg_parallel=None):
+                progress_bar_cmd=None, record_step_times=False, step_ids=None, cfg_parallel=None,
+                sequence_parallel=None):
         """GF:663 + GF:697-723.  Returns the final latents [1,16,f,H/8,W/8] (a new tensor).
         `step_ids` (optional) restricts the loop to a sub-range of the schedule (benchmarks).
         `cfg_parallel` (distributed.CfgPairParallel): this rank computes only its branch of the CFG pair and
-        exchanges the noise prediction with its partner once per step (RCCL all-gather, 4.2 MB)."""
+        exchanges the noise prediction with its partner once per step (RCCL all-gather, 4.2 MB).
+        `sequence_parallel` (sequence_parallel.SequenceParallel): every forward runs on this rank's token chunk with
+        head-parallel attention; the noise prediction comes back whole on every rank of the group."""
         self.scheduler.set_timesteps(num_inference_steps, denoising_strength=denoising_strength, shift=sigma_shift)
         latents = latents.clone()
         models = {"dit": self.dit, "controlnet": self.controlnet if controlnet else None}
@@ -206,6 +212,10 @@ class WanVideoPipeline:
                 ev0.record()
             shared = dict(latents=latents, timestep=ts, y=y, control_signal_video_latents=control_signal_video_latents,
                           elide_zero_controlnet=self.elide_zero_controlnet)
+            if sequence_parallel is not None:
+                shared["sequence_parallel"] = sequence_parallel
+            elif getattr(self, "use_unified_sequence_parallel", False):
+                shared["use_unified_sequence_parallel"] = True          # GF:1107-1109
             if cfg_parallel is not None and cfg_scale != 1.0:
                 b = cfg_parallel.branch
                 mine = self.model_fn(**models, **shared, context=context_nega if b else context_posi,
