@@ -23,6 +23,7 @@ SYMBOLS = (
     "gf_vae_prep_latent", "gf_vae_im2col", "gf_vae_finish_latent", "gf_vae_rmsnorm_silu", "gf_softmax_rows", "gf_transpose_pad",
     "gf_vae_tile_blend", "gf_vae_tile_finalize",
     "gf_quant_fp8_rowscale", "gf_cast_fp8", "gf_gemm_fp8",
+    "gf_flash_attn_fwd_lse", "gf_flash_attn_bwd",
 )
 
 EPI_BIAS, EPI_BIAS_GELU_TANH, EPI_BIAS_GATE_RESID, EPI_BIAS_RESID, EPI_BIAS_SILU, EPI_BIAS_MUL = range(6)
@@ -51,6 +52,8 @@ def _declare(lib):
         "gf_rmsnorm_rope": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _vp],
         "gf_gemm_bf16": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _i64, _vp, _vp],
         "gf_flash_attn_fwd": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _vp],
+        "gf_flash_attn_fwd_lse": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _vp],
+        "gf_flash_attn_bwd": [_vp] * 10 + [_i64] * 12 + [_f32, _vp],
         "gf_patchify_im2col": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp],
         "gf_unpatchify": [_vp, _vp, _i64, _i64, _i64, _i64, _vp],
         "gf_cfg_euler_step": [_vp, _vp, _vp, _f32, _f32, _i64, _vp],

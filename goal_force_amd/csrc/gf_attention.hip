@@ -78,6 +78,7 @@ struct AttnArgs {
     long q_stride, k_stride, v_stride, o_stride;
     float scale_log2e;  // softmax scale * log2(e)
     unsigned long long* dbg;
+    float* lse;         // optional [q_len, heads] fp32: log2-domain log-sum-exp of the scaled scores (training backward)
 };
 
 __global__ __launch_bounds__(AT_THREADS, 2) void flash_attn_fwd_kernel(const AttnArgs p) {
@@ -376,6 +377,7 @@ __global__ __launch_bounds__(AT_THREADS, 2) void flash_attn_fwd_kernel(const Att
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
     const int qrow = q0 + r;
+    if (p.lse && h == 0 && qrow < p.q_len) p.lse[(long)qrow * p.heads + head] = m_run * c + __builtin_amdgcn_logf(l_tot);
     if (qrow < p.q_len) {
         u16* op = p.o + (long)qrow * p.o_stride + head * HD + 4 * h;
 #pragma unroll
@@ -756,6 +758,8 @@ __global__ __launch_bounds__(AT2_THREADS, 2) void flash_attn_fwd_kernel2(const A
         const float l_tot = l_run + __shfl_xor(l_run, 32);
         const float inv = 1.0f / l_tot;
         const int qrow = q0 + r;
+        // P = exp2(c S - lse) is the softmax row: what the backward kernels rebuild the probabilities from
+        if (p.lse && h == 0 && qrow < p.q_len) p.lse[(long)qrow * p.heads + head] = m_run * c + __builtin_amdgcn_logf(l_tot);
         if (qrow < p.q_len) {
             u16* op = p.o + (long)qrow * p.o_stride + head * HD + 4 * h;
 #pragma unroll
@@ -773,9 +777,9 @@ __global__ __launch_bounds__(AT2_THREADS, 2) void flash_attn_fwd_kernel2(const A
 
 }  // namespace
 
-extern "C" GF_API int gf_flash_attn_fwd(const void* q, const void* k, const void* v, void* o, int64_t q_len, int64_t kv_len,
-                                 int64_t heads, int64_t head_dim, int64_t q_stride, int64_t k_stride,
-                                 int64_t v_stride, int64_t o_stride, float scale, void* stream) {
+static int flash_attn_fwd_impl(const void* q, const void* k, const void* v, void* o, float* lse, int64_t q_len, int64_t kv_len,
+                               int64_t heads, int64_t head_dim, int64_t q_stride, int64_t k_stride,
+                               int64_t v_stride, int64_t o_stride, float scale, void* stream) {
     GF_CHECK_ARG(q && k && v && o, "gf_flash_attn_fwd: null pointer");
     if (head_dim != HD) {
         gf_set_error("gf_flash_attn_fwd: head_dim=%ld unsupported (kernel is built for 128)", (long)head_dim);
@@ -821,6 +825,7 @@ extern "C" GF_API int gf_flash_attn_fwd(const void* q, const void* k, const void
     a.v_stride = v_stride;
     a.o_stride = o_stride;
     a.scale_log2e = scale * 1.4426950408889634f;
+    a.lse = lse;
 #if GF_ATTN_STAMP
     a.dbg = g_attn_dbg;
 #else
@@ -834,4 +839,19 @@ extern "C" GF_API int gf_flash_attn_fwd(const void* q, const void* k, const void
                            (hipStream_t)stream, a);
     GF_CHECK_LAUNCH("gf_flash_attn_fwd");
     return GF_OK;
+}
+
+extern "C" GF_API int gf_flash_attn_fwd(const void* q, const void* k, const void* v, void* o, int64_t q_len, int64_t kv_len,
+                                 int64_t heads, int64_t head_dim, int64_t q_stride, int64_t k_stride,
+                                 int64_t v_stride, int64_t o_stride, float scale, void* stream) {
+    return flash_attn_fwd_impl(q, k, v, o, nullptr, q_len, kv_len, heads, head_dim, q_stride, k_stride, v_stride, o_stride, scale,
+                               stream);
+}
+
+extern "C" GF_API int gf_flash_attn_fwd_lse(const void* q, const void* k, const void* v, void* o, float* lse, int64_t q_len,
+                                     int64_t kv_len, int64_t heads, int64_t head_dim, int64_t q_stride, int64_t k_stride,
+                                     int64_t v_stride, int64_t o_stride, float scale, void* stream) {
+    GF_CHECK_ARG(lse, "gf_flash_attn_fwd_lse: null lse");
+    return flash_attn_fwd_impl(q, k, v, o, lse, q_len, kv_len, heads, head_dim, q_stride, k_stride, v_stride, o_stride, scale,
+                               stream);
 }

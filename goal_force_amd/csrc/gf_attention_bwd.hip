@@ -1,0 +1,342 @@
+// gf_attention_bwd.hip — flash-attention backward (dQ, dK, dV), head_dim 128, non-causal, bf16 in/out, fp32 accumulate.
+// Used by the ControlNet training step (reference: training_loss, src/goal_force/wan_video_new.py:180-193, whose
+// loss.backward() reaches F.scaled_dot_product_attention's backward through every DiT / ControlNet block, DIT:28-61).
+//
+// With P = softmax(scale Q K^T) rebuilt from the forward's log-sum-exp (P = exp2(c S - lse), c = scale log2 e) and
+// delta = rowsum(dO . O):   dV = P^T dO,   dP = dO V^T,   dS = P . (dP - delta),   dQ = scale dS K,   dK = scale dS^T Q.
+// Two kernels, no atomics (S and dP are recomputed in both; 7 tile products instead of the minimal 5):
+//   * attn_bwd_dq_kernel : one wave owns 32 QUERIES (on the lane, as in the forward) and walks the KV tiles;
+//   * attn_bwd_dkv_kernel: one wave owns 32 KEYS (on the lane) and walks the query tiles.
+// Same operand algebra as the forward (gf_attention.hip): swapped products with v_mfma_f32_32x32x16_bf16 so the owned
+// row is on the lane and the per-row scalars (lse, delta) are per-lane (dQ) or per-register broadcast reads (dK/dV); the
+// fp32 accumulator converted pairwise to bf16 is the B operand of the second product; row fragments by ds_read_b128
+// and transposed fragments by ds_read_b64_tr_b16 from ONE XOR-swizzled 64 x 128 tile image staged by LDS-DMA.
+// Round-1 shape: 4 waves per workgroup (one per SIMD, up to 512 registers), single-buffered tiles, two barriers per tile
+// — correct first; the forward's slot pipeline is the template for making it fast.
+#include "gf_common.h"
+
+namespace {
+
+constexpr int KVB = 64, HD = 128;
+constexpr int TILE_BYTES = KVB * HD * 2;   // 16 KiB
+constexpr int BWD_THREADS = 256;
+constexpr int BWD_ROWS = 128;              // rows (queries or keys) per workgroup
+
+struct BwdArgs {
+    const u16 *q, *k, *v, *o, *dout;
+    const float* lse;      // [q_len, heads]
+    float* delta;          // [q_len, heads] workspace
+    u16 *dq, *dk, *dv;
+    int q_len, kv_len, heads;
+    long q_stride, k_stride, v_stride, o_stride, do_stride, dq_stride, dk_stride, dv_stride;
+    float scale, scale_log2e;
+};
+
+// delta[s, h] = sum_d dO[s, h, d] * O[s, h, d]
+__global__ __launch_bounds__(256) void attn_bwd_delta_kernel(const BwdArgs p) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)p.q_len * p.heads) return;
+    const int s = (int)(idx / p.heads), h = (int)(idx % p.heads);
+    const u16* op = p.o + (long)s * p.o_stride + h * HD;
+    const u16* dp = p.dout + (long)s * p.do_stride + h * HD;
+    float acc = 0.f;
+#pragma unroll 4
+    for (int i = 0; i < HD / 8; ++i) {
+        const u16x8 a = *reinterpret_cast<const u16x8*>(op + 8 * i);
+        const u16x8 b = *reinterpret_cast<const u16x8*>(dp + 8 * i);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc += bf2f(a[e]) * bf2f(b[e]);
+    }
+    p.delta[idx] = acc;
+}
+
+__device__ __forceinline__ void dma16(const u16* g, GF_LDS char* l) {
+    unsigned keep;
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)l);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(g), "s"(dst)
+                 : "memory");
+}
+
+// 64 rows x 256 B of `base` (rows row0.., clamped to len-1; head column offset included in base) -> swizzled LDS image.
+// 4 waves: wave w fills row-groups j = 4w..4w+3 (4 rows x 256 B each); the DMA writes lane-linear, so the image's chunk
+// swizzle off(row,ch) = 256 row + 16 (ch ^ (((row&3)<<2) | ((row>>2)&3))) is applied to the per-lane SOURCE chunk.
+__device__ __forceinline__ void stage_tile(const u16* base, long stride, int row0, int len, GF_LDS char* dst, int wave, int lane) {
+    const int dma_r = lane >> 4;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const int j = 4 * wave + jj;
+        const long rr = min(row0 + 4 * j + dma_r, len - 1);
+        const int lch = (lane & 15) ^ ((dma_r << 2) | (j & 3));
+        dma16(base + rr * stride + lch * 8, dst + wave * 4096 + jj * 1024);
+    }
+}
+
+struct FragOffsets {
+    int row[8];      // row-read offsets of fragment kd (rows 0..31; +32*256 for rows 32..63)
+    int tr[2][4];    // transposed-read offsets [hf][d]
+};
+
+__device__ __forceinline__ FragOffsets frag_offsets(int lane) {
+    FragOffsets f;
+    const int r = lane & 31, h = lane >> 5;
+    const int sK = ((r & 3) << 2) | ((r >> 2) & 3);
+#pragma unroll
+    for (int kd = 0; kd < 8; ++kd) f.row[kd] = 256 * r + 16 * ((2 * kd + h) ^ sK);
+    const int qd = (lane & 15) >> 2, pp = lane & 3;
+    const int vcl = 2 * ((lane >> 4) & 1) + (pp >> 1);
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        const int sV = (qd << 2) | ((2 * hf + h) & 3);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) f.tr[hf][d] = 256 * (8 * hf + 4 * h + qd) + 16 * ((4 * d + vcl) ^ sV) + 8 * (pp & 1);
+    }
+    return f;
+}
+
+__device__ __forceinline__ bf16x8 tr_frag(GF_LDS char* buf, const FragOffsets& f, int d, int kt, int s) {
+    const int imm = 256 * (32 * kt + 16 * s);
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GF_LDS s16x4*)(buf + f.tr[0][d] + imm));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GF_LDS s16x4*)(buf + f.tr[1][d] + imm));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 vv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, vv);
+}
+
+__device__ __forceinline__ void mfma32(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ void zero16(f32x16& a) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) a[e] = 0.f;
+}
+
+// transposed accumulator acc[d][e] (lane = owned row, register e of block d = column 32d + (e&3) + 8(e>>2) + 4h) -> row of out
+__device__ __forceinline__ void store_rows(u16* rowp, const f32x16 (&acc)[4], float mul, int h) {
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            u32x2 pk;
+            pk[0] = pack2bf(acc[d][4 * rg + 0] * mul, acc[d][4 * rg + 1] * mul);
+            pk[1] = pack2bf(acc[d][4 * rg + 2] * mul, acc[d][4 * rg + 3] * mul);
+            *reinterpret_cast<u32x2*>(rowp + 4 * h + 32 * d + 8 * rg) = pk;
+        }
+}
+
+// ---- dQ: wave owns queries q0 + r ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BWD_THREADS, 1) void attn_bwd_dq_kernel(const BwdArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    GF_LDS char* lds = (GF_LDS char*)smem;
+    GF_LDS char* kbuf = lds;
+    GF_LDS char* vbuf = lds + TILE_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int nqb = (p.q_len + BWD_ROWS - 1) / BWD_ROWS;
+    const int head = blockIdx.x / nqb, qb = blockIdx.x % nqb;
+    const int q0 = qb * BWD_ROWS + wave * 32;
+    const int qr = min(q0 + r, p.q_len - 1);
+
+    bf16x8 qf[8], dof[8];
+    {
+        const u16* qp = p.q + (long)qr * p.q_stride + head * HD + 8 * h;
+        const u16* dp = p.dout + (long)qr * p.do_stride + head * HD + 8 * h;
+#pragma unroll
+        for (int kd = 0; kd < 8; ++kd) {
+            qf[kd] = *reinterpret_cast<const bf16x8*>(qp + 16 * kd);
+            dof[kd] = *reinterpret_cast<const bf16x8*>(dp + 16 * kd);
+        }
+    }
+    const float lse = p.lse[(long)qr * p.heads + head];
+    const float dl = p.delta[(long)qr * p.heads + head];
+    const float c = p.scale_log2e;
+    const FragOffsets fo = frag_offsets(lane);
+    f32x16 dq[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) zero16(dq[d]);
+
+    const int nt = (p.kv_len + KVB - 1) / KVB;
+    for (int t = 0; t < nt; ++t) {
+        __syncthreads();   // every wave is done reading the previous tile
+        stage_tile(p.k + head * HD, p.k_stride, t * KVB, p.kv_len, kbuf, wave, lane);
+        stage_tile(p.v + head * HD, p.v_stride, t * KVB, p.kv_len, vbuf, wave, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        f32x16 sc[2], dp[2];
+        zero16(sc[0]); zero16(sc[1]); zero16(dp[0]); zero16(dp[1]);
+#pragma unroll
+        for (int kd = 0; kd < 8; ++kd) {
+            const bf16x8 k0 = *(GF_LDS bf16x8*)(kbuf + fo.row[kd]);
+            const bf16x8 k1 = *(GF_LDS bf16x8*)(kbuf + fo.row[kd] + 32 * 256);
+            const bf16x8 v0 = *(GF_LDS bf16x8*)(vbuf + fo.row[kd]);
+            const bf16x8 v1 = *(GF_LDS bf16x8*)(vbuf + fo.row[kd] + 32 * 256);
+            mfma32(sc[0], k0, qf[kd]);      // S^T[key, query]
+            mfma32(sc[1], k1, qf[kd]);
+            mfma32(dp[0], v0, dof[kd]);     // dP^T[key, query] = V dO^T
+            mfma32(dp[1], v1, dof[kd]);
+        }
+        bf16x8 dsf[2][2];
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key = t * KVB + 32 * half + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const float pr = key < p.kv_len ? __builtin_amdgcn_exp2f(__builtin_fmaf(sc[half][e], c, -lse)) : 0.f;
+                dsf[half][e >> 3][e & 7] = (__bf16)(pr * (dp[half][e] - dl));
+            }
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) mfma32(dq[d], tr_frag(kbuf, fo, d, kt, s), dsf[kt][s]);   // dQ^T += K^T dS^T
+    }
+    if (q0 + r < p.q_len) store_rows(p.dq + (long)(q0 + r) * p.dq_stride + head * HD, dq, p.scale, h);
+}
+
+// ---- dK, dV: wave owns keys k0 + r -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BWD_THREADS, 1) void attn_bwd_dkv_kernel(const BwdArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    GF_LDS char* lds = (GF_LDS char*)smem;
+    GF_LDS char* qbuf = lds;
+    GF_LDS char* dobuf = lds + TILE_BYTES;
+    GF_LDS float* lse_s = (GF_LDS float*)(lds + 2 * TILE_BYTES);
+    GF_LDS float* dl_s = lse_s + KVB;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int nkb = (p.kv_len + BWD_ROWS - 1) / BWD_ROWS;
+    const int head = blockIdx.x / nkb, kb = blockIdx.x % nkb;
+    const int k0 = kb * BWD_ROWS + wave * 32;
+    const int kr = min(k0 + r, p.kv_len - 1);
+
+    bf16x8 kf[8], vf[8];
+    {
+        const u16* kp = p.k + (long)kr * p.k_stride + head * HD + 8 * h;
+        const u16* vp = p.v + (long)kr * p.v_stride + head * HD + 8 * h;
+#pragma unroll
+        for (int kd = 0; kd < 8; ++kd) {
+            kf[kd] = *reinterpret_cast<const bf16x8*>(kp + 16 * kd);
+            vf[kd] = *reinterpret_cast<const bf16x8*>(vp + 16 * kd);
+        }
+    }
+    const float c = p.scale_log2e;
+    const FragOffsets fo = frag_offsets(lane);
+    f32x16 dk[4], dv[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        zero16(dk[d]);
+        zero16(dv[d]);
+    }
+
+    const int nt = (p.q_len + KVB - 1) / KVB;
+    for (int t = 0; t < nt; ++t) {
+        __syncthreads();
+        stage_tile(p.q + head * HD, p.q_stride, t * KVB, p.q_len, qbuf, wave, lane);
+        stage_tile(p.dout + head * HD, p.do_stride, t * KVB, p.q_len, dobuf, wave, lane);
+        if (tid < KVB) {
+            const long qi = min(t * KVB + tid, p.q_len - 1);
+            lse_s[tid] = p.lse[qi * p.heads + head];
+            dl_s[tid] = p.delta[qi * p.heads + head];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        f32x16 sc[2], dp[2];
+        zero16(sc[0]); zero16(sc[1]); zero16(dp[0]); zero16(dp[1]);
+#pragma unroll
+        for (int kd = 0; kd < 8; ++kd) {
+            const bf16x8 q0f = *(GF_LDS bf16x8*)(qbuf + fo.row[kd]);
+            const bf16x8 q1f = *(GF_LDS bf16x8*)(qbuf + fo.row[kd] + 32 * 256);
+            const bf16x8 d0f = *(GF_LDS bf16x8*)(dobuf + fo.row[kd]);
+            const bf16x8 d1f = *(GF_LDS bf16x8*)(dobuf + fo.row[kd] + 32 * 256);
+            mfma32(sc[0], q0f, kf[kd]);     // S[query, key]: lane = key, registers = queries
+            mfma32(sc[1], q1f, kf[kd]);
+            mfma32(dp[0], d0f, vf[kd]);     // dP[query, key] = dO V^T
+            mfma32(dp[1], d1f, vf[kd]);
+        }
+        bf16x8 pf[2][2], dsf[2][2];
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int qi = 32 * half + 8 * g + 4 * h;      // 4 consecutive queries of registers 4g..4g+3
+                const f32x4 l4 = *(GF_LDS f32x4*)(lse_s + qi);
+                const f32x4 d4 = *(GF_LDS f32x4*)(dl_s + qi);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int e = 4 * g + i;
+                    const bool ok = t * KVB + qi + i < p.q_len;
+                    const float pr = ok ? __builtin_amdgcn_exp2f(__builtin_fmaf(sc[half][e], c, -l4[i])) : 0.f;
+                    pf[half][e >> 3][e & 7] = (__bf16)pr;
+                    dsf[half][e >> 3][e & 7] = (__bf16)(pr * (dp[half][e] - d4[i]));
+                }
+            }
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    mfma32(dv[d], tr_frag(dobuf, fo, d, kt, s), pf[kt][s]);    // dV^T += dO^T P
+                    mfma32(dk[d], tr_frag(qbuf, fo, d, kt, s), dsf[kt][s]);    // dK^T += Q^T dS
+                }
+    }
+    if (k0 + r < p.kv_len) {
+        store_rows(p.dk + (long)(k0 + r) * p.dk_stride + head * HD, dk, p.scale, h);
+        store_rows(p.dv + (long)(k0 + r) * p.dv_stride + head * HD, dv, 1.0f, h);
+    }
+}
+
+}  // namespace
+
+extern "C" GF_API int gf_flash_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,
+                                        const float* lse, float* delta_ws, void* dq, void* dk, void* dv, int64_t q_len,
+                                        int64_t kv_len, int64_t heads, int64_t head_dim, int64_t q_stride, int64_t k_stride,
+                                        int64_t v_stride, int64_t o_stride, int64_t do_stride, int64_t dq_stride,
+                                        int64_t dk_stride, int64_t dv_stride, float scale, void* stream) {
+    GF_CHECK_ARG(q && k && v && o && dout && lse && delta_ws && dq && dk && dv, "gf_flash_attn_bwd: null pointer");
+    if (head_dim != HD) {
+        gf_set_error("gf_flash_attn_bwd: head_dim=%ld unsupported (kernels are built for 128)", (long)head_dim);
+        return GF_ERR_UNSUPPORTED;
+    }
+    GF_CHECK_ARG(q_len > 0 && kv_len > 0 && heads > 0 && q_len < (1 << 30) && kv_len < (1 << 30),
+                 "gf_flash_attn_bwd: bad lengths q=%ld kv=%ld heads=%ld", (long)q_len, (long)kv_len, (long)heads);
+    const int64_t strides[8] = {q_stride, k_stride, v_stride, o_stride, do_stride, dq_stride, dk_stride, dv_stride};
+    for (int i = 0; i < 8; ++i)
+        GF_CHECK_ARG(strides[i] % 8 == 0 && strides[i] >= heads * HD, "gf_flash_attn_bwd: strides must cover heads*128 and be multiples of 8");
+    GF_CHECK_ARG(gf_aligned16(q) && gf_aligned16(k) && gf_aligned16(v) && gf_aligned16(o) && gf_aligned16(dout) &&
+                     gf_aligned16(dq) && gf_aligned16(dk) && gf_aligned16(dv),
+                 "gf_flash_attn_bwd: 16-byte alignment required");
+    static bool attr_set = false;
+    const int lds_bytes = 2 * TILE_BYTES + 2 * KVB * (int)sizeof(float);
+    if (!attr_set) {
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e1 != hipSuccess || e2 != hipSuccess) {
+            gf_set_error("gf_flash_attn_bwd: hipFuncSetAttribute failed");
+            return GF_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    BwdArgs a;
+    a.q = (const u16*)q; a.k = (const u16*)k; a.v = (const u16*)v; a.o = (const u16*)o; a.dout = (const u16*)dout;
+    a.lse = lse; a.delta = delta_ws;
+    a.dq = (u16*)dq; a.dk = (u16*)dk; a.dv = (u16*)dv;
+    a.q_len = (int)q_len; a.kv_len = (int)kv_len; a.heads = (int)heads;
+    a.q_stride = q_stride; a.k_stride = k_stride; a.v_stride = v_stride; a.o_stride = o_stride; a.do_stride = do_stride;
+    a.dq_stride = dq_stride; a.dk_stride = dk_stride; a.dv_stride = dv_stride;
+    a.scale = scale; a.scale_log2e = scale * 1.4426950408889634f;
+    hipStream_t s = (hipStream_t)stream;
+    const long nd = q_len * heads;
+    hipLaunchKernelGGL(attn_bwd_delta_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, s, a);
+    const unsigned nqb = (unsigned)((q_len + BWD_ROWS - 1) / BWD_ROWS), nkb = (unsigned)((kv_len + BWD_ROWS - 1) / BWD_ROWS);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(nqb * (unsigned)heads), dim3(BWD_THREADS), lds_bytes, s, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(nkb * (unsigned)heads), dim3(BWD_THREADS), lds_bytes, s, a);
+    GF_CHECK_LAUNCH("gf_flash_attn_bwd");
+    return GF_OK;
+}

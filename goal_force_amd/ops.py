@@ -167,6 +167,50 @@ def flash_attn(q, k, v, num_heads, out=None, scale=None):
     return out
 
 
+def flash_attn_lse(q, k, v, num_heads, scale=None):
+    """flash_attn that also returns the log2-domain log-sum-exp [Sq, H] fp32 (what flash_attn_bwd rebuilds P from)."""
+    for n, t in (("q", q), ("k", k), ("v", v)):
+        _req(t, f"flash_attn_lse.{n}")
+        if t.dim() != 2 or t.stride(1) != 1:
+            raise GoalForceError(f"flash_attn_lse.{n}: expected 2-D [len, heads*head_dim] with contiguous rows")
+    sq, hd_all = q.shape
+    skv = k.shape[0]
+    head_dim = hd_all // num_heads
+    if k.shape[1] != hd_all or v.shape != k.shape or head_dim * num_heads != hd_all:
+        raise GoalForceError("flash_attn_lse: q/k/v shape mismatch")
+    if scale is None:
+        scale = 1.0 / math.sqrt(head_dim)
+    out = torch.empty((sq, hd_all), dtype=_BF16, device=q.device)
+    lse = torch.empty((sq, num_heads), dtype=torch.float32, device=q.device)
+    _lib.check(_lib.load().gf_flash_attn_fwd_lse(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), sq, skv, num_heads, head_dim,
+                                                 q.stride(0), k.stride(0), v.stride(0), out.stride(0), float(scale),
+                                                 _stream(q)), "gf_flash_attn_fwd_lse")
+    return out, lse
+
+
+def flash_attn_bwd(q, k, v, o, dout, lse, num_heads, scale=None):
+    """Gradients of flash_attn: (dq [Sq, H*128], dk, dv [Skv, H*128]) bf16."""
+    for n, t in (("q", q), ("k", k), ("v", v), ("o", o), ("dout", dout)):
+        _req(t, f"flash_attn_bwd.{n}")
+        if t.dim() != 2 or t.stride(1) != 1:
+            raise GoalForceError(f"flash_attn_bwd.{n}: expected 2-D [len, heads*head_dim] with contiguous rows")
+    sq, hd_all = q.shape
+    skv = k.shape[0]
+    head_dim = hd_all // num_heads
+    if scale is None:
+        scale = 1.0 / math.sqrt(head_dim)
+    if lse.dtype != torch.float32 or tuple(lse.shape) != (sq, num_heads) or not lse.is_contiguous():
+        raise GoalForceError("flash_attn_bwd.lse: expected contiguous fp32 [Sq, heads]")
+    dq, dk, dv = torch.empty_like(q, memory_format=torch.contiguous_format), \
+        torch.empty((skv, hd_all), dtype=_BF16, device=q.device), torch.empty((skv, hd_all), dtype=_BF16, device=q.device)
+    delta = torch.empty((sq, num_heads), dtype=torch.float32, device=q.device)
+    _lib.check(_lib.load().gf_flash_attn_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(dout), _ptr(lse), _ptr(delta), _ptr(dq),
+                                             _ptr(dk), _ptr(dv), sq, skv, num_heads, head_dim, q.stride(0), k.stride(0),
+                                             v.stride(0), o.stride(0), dout.stride(0), dq.stride(0), dk.stride(0),
+                                             dv.stride(0), float(scale), _stream(q)), "gf_flash_attn_bwd")
+    return dq, dk, dv
+
+
 def patchify_im2col(src0, src1=None, kpad=None):
     """[c,F,H,W] (+[c1,F,H,W]) -> [F*(H/2)*(W/2), kpad] token-major patches (Conv3d weight column order)."""
     _req(src0, "patchify.src0")

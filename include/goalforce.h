@@ -131,6 +131,24 @@ GF_API int gf_flash_attn_fwd(const void* q, const void* k, const void* v, void* 
                       float scale, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Training (ControlNet training step): training_loss (GF:180-193) calls loss.backward() through
+ * F.scaled_dot_product_attention (DIT:28-61) in every block.
+ * gf_flash_attn_fwd_lse — gf_flash_attn_fwd that also returns lse [q_len, heads] fp32, the log2-domain log-sum-exp
+ *   of the scaled scores: softmax row = exp2(scale*log2(e)*S - lse).
+ * gf_flash_attn_bwd — dq, dk, dv from (q, k, v, o, dout, lse); delta_ws is a caller-owned [q_len, heads] fp32
+ *   workspace (rowsum(dout*o)).  Same layouts / strides as the forward; fp32 accumulation, bf16 results.
+ */
+GF_API int gf_flash_attn_fwd_lse(const void* q, const void* k, const void* v, void* o, float* lse,
+                          int64_t q_len, int64_t kv_len, int64_t heads, int64_t head_dim,
+                          int64_t q_stride, int64_t k_stride, int64_t v_stride, int64_t o_stride,
+                          float scale, void* stream);
+GF_API int gf_flash_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,
+                      const float* lse, float* delta_ws, void* dq, void* dk, void* dv,
+                      int64_t q_len, int64_t kv_len, int64_t heads, int64_t head_dim,
+                      int64_t q_stride, int64_t k_stride, int64_t v_stride, int64_t o_stride, int64_t do_stride,
+                      int64_t dq_stride, int64_t dk_stride, int64_t dv_stride, float scale, void* stream);
+
+/* ------------------------------------------------------------------------
  * gf_patchify_im2col — gathers the (1,2,2) patches of an NCTHW latent into a
  * token-major matrix for the patch-embedding GEMM.  Replaces the data movement
  * of WanModel.patchify (DIT:341-349) / ControlNet_PatchEmbedding.forward
