@@ -459,3 +459,103 @@ def gemm_fp8(a8, row_scale, w8, bias=None, epilogue=EPI_BIAS, resid=None, gate=N
                                        _ptr(ov), ldc, M, N, K, int(epilogue), _ptr(resid), ldr, _ptr(gate), _stream(a8)),
                "gf_gemm_fp8")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# backward / training ops (gf_backward.hip, gf_attention_bwd.hip)
+def _f32(t, name):
+    if not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise GoalForceError(f"{name}: expected a contiguous fp32 CUDA tensor")
+    return t
+
+
+def layernorm_bwd(x, dy, g=None, dg_acc=None, db_acc=None, eps=1e-6):
+    """dx of LayerNorm with y = xhat*g (+b) (g = affine weight, or 1+scale, or None); fp32 [dim] accumulators optional."""
+    _req(x, "layernorm_bwd.x")
+    _req(dy, "layernorm_bwd.dy")
+    xv, rows, dim, xs = _rows2d(x, "layernorm_bwd.x")
+    dv, _, _, ds = _rows2d(dy, "layernorm_bwd.dy")
+    dx = torch.empty((rows, dim), dtype=_BF16, device=x.device)
+    if g is not None:
+        _req(g, "layernorm_bwd.g")
+    _lib.check(_lib.load().gf_layernorm_bwd(_ptr(xv), xs, _ptr(dv), ds, _ptr(g),
+                                            _ptr(dx), dim, None if dg_acc is None else _ptr(_f32(dg_acc, "dg_acc")),
+                                            None if db_acc is None else _ptr(_f32(db_acc, "db_acc")), rows, dim, float(eps),
+                                            _stream(x)), "gf_layernorm_bwd")
+    return dx.view(x.shape)
+
+
+def rmsnorm_rope_bwd(x_pre, dy, weight, cos=None, sin=None, head_dim=128, eps=1e-6, dw_acc=None):
+    _req(x_pre, "rmsnorm_rope_bwd.x")
+    _req(dy, "rmsnorm_rope_bwd.dy")
+    xv, rows, dim, xs = _rows2d(x_pre, "rmsnorm_rope_bwd.x")
+    dv, _, _, ds = _rows2d(dy, "rmsnorm_rope_bwd.dy")
+    dx = torch.empty((rows, dim), dtype=_BF16, device=x_pre.device)
+    _req(weight, "rmsnorm_rope_bwd.weight")
+    _lib.check(_lib.load().gf_rmsnorm_rope_bwd(_ptr(xv), xs, _ptr(dv), ds, _ptr(weight),
+                                               None if cos is None else _ptr(_f32(cos, "cos")),
+                                               None if sin is None else _ptr(_f32(sin, "sin")), _ptr(dx), dim,
+                                               None if dw_acc is None else _ptr(_f32(dw_acc, "dw_acc")), rows, dim,
+                                               int(head_dim), float(eps), _stream(x_pre)), "gf_rmsnorm_rope_bwd")
+    return dx.view(x_pre.shape)
+
+
+def colsum(a, b=None, gate=None, acc=None):
+    """acc[n] += sum_r a[r,n]*(b[r,n] or 1); with `gate` also returns bf16(a*gate) (else None)."""
+    _req(a, "colsum.a")
+    av, rows, cols, lda = _rows2d(a, "colsum.a")
+    ldb, bp = 0, None
+    if b is not None:
+        _req(b, "colsum.b")
+        bv, _, _, ldb = _rows2d(b, "colsum.b")
+        bp = _ptr(bv)
+    out = None
+    if gate is not None:
+        _req(gate, "colsum.gate")
+        out = torch.empty((rows, cols), dtype=_BF16, device=a.device)
+    _lib.check(_lib.load().gf_colsum(_ptr(av), lda, bp, ldb, None if gate is None else _ptr(gate),
+                                     None if out is None else _ptr(out), cols, None if acc is None else _ptr(_f32(acc, "acc")),
+                                     rows, cols, _stream(a)), "gf_colsum")
+    return None if out is None else out.view(a.shape)
+
+
+def act_bwd(u, df, kind: str):
+    _req(u, "act_bwd.u")
+    _req(df, "act_bwd.df")
+    if not u.is_contiguous() or not df.is_contiguous() or u.numel() != df.numel():
+        raise GoalForceError("act_bwd: u/df must be contiguous and equal-sized")
+    du = torch.empty_like(u)
+    _lib.check(_lib.load().gf_act_bwd(_ptr(u), _ptr(df), _ptr(du), u.numel(), {"gelu_tanh": 0, "silu": 1}[kind], _stream(u)),
+               "gf_act_bwd")
+    return du
+
+
+def mse_loss(pred, target, weight=1.0, want_grad=True):
+    """(loss fp32 [1] = weight*mean((pred-target)^2), dpred bf16 or None)."""
+    _req(pred, "mse_loss.pred")
+    _req(target, "mse_loss.target")
+    if not pred.is_contiguous() or not target.is_contiguous() or pred.numel() != target.numel():
+        raise GoalForceError("mse_loss: pred/target must be contiguous and equal-sized")
+    loss = torch.empty((1,), dtype=torch.float32, device=pred.device)
+    dpred = torch.empty_like(pred) if want_grad else None
+    _lib.check(_lib.load().gf_mse_loss(_ptr(pred), _ptr(target), None if dpred is None else _ptr(dpred), _ptr(loss),
+                                       pred.numel(), float(weight), _stream(pred)), "gf_mse_loss")
+    return loss, dpred
+
+
+def adamw_step(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_scale=1.0):
+    _req(param, "adamw_step.param")
+    _req(grad, "adamw_step.grad")
+    if not param.is_contiguous() or not grad.is_contiguous() or grad.numel() != param.numel():
+        raise GoalForceError("adamw_step: param/grad must be contiguous and equal-sized")
+    _lib.check(_lib.load().gf_adamw_step(_ptr(param), _ptr(grad), _ptr(_f32(exp_avg, "exp_avg")),
+                                         _ptr(_f32(exp_avg_sq, "exp_avg_sq")), param.numel(), float(lr), float(betas[0]),
+                                         float(betas[1]), float(eps), float(weight_decay), int(step), float(grad_scale),
+                                         _stream(param)), "gf_adamw_step")
+
+
+def f32_to_bf16(acc):
+    _f32(acc, "f32_to_bf16.acc")
+    out = torch.empty(acc.shape, dtype=_BF16, device=acc.device)
+    _lib.check(_lib.load().gf_f32_to_bf16(_ptr(acc), _ptr(out), acc.numel(), _stream(acc)), "gf_f32_to_bf16")
+    return out

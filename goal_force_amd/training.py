@@ -1,0 +1,417 @@
+"""ControlNet training step on the HIP kernels.
+
+Reference: `WanVideoPipeline.training_loss` (src/goal_force/wan_video_new.py:180-193) — sample a timestep, noise the
+input latents, run `model_fn` with the ControlNet, MSE against `noise - latents`, weight by the scheduler's training
+weight — driven by `launch_training_task` (src/goal_force/utils.py:734-826): AdamW over the ControlNet parameters
+(`pipe.controlnet.*`: patch embedding, 10 DiT blocks, 10 zero-convs; GF:97-117), bf16 parameters, optional gradient
+clipping, checkpoints `{"pipe.controlnet.<name>": tensor}`.
+
+Design (MI355X-first, not a port of torch autograd):
+  * torch.autograd is only the tape between a few coarse Functions; every FLOP of forward and backward runs in this
+    repo's HIP kernels (GEMM, flash-attention fwd/bwd, row-op backward kernels, loss, AdamW).
+  * one Function per DiT / ControlNet BLOCK: its forward is the fused inference path (GEMM epilogues etc.) and keeps only
+    the block input; its backward re-runs the block un-fused to rebuild the intermediates, then walks them backwards
+    (block-granular activation checkpointing is built in — what the reference reaches for with
+    use_gradient_checkpointing, GF:1503-1557; at S=32760 a block's intermediates are ~6 GB, its input 335 MB).
+  * weight gradients are only formed for parameters that require them (the DiT experts are frozen: their blocks cost
+    a forward + an activation-only backward); GEMM backward reuses the forward GEMM on transposed operands
+    (dX = dY W via W^T; dW = dY^T X via dY^T, X^T padded to the K step).
+  * gradient fan-in (a tensor used twice) is summed by the HIP add kernel inside the Functions, not by autograd.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import GoalForceError
+from .dit import DiTBlock, RopeTable, WanModel, _tokens2d
+
+BF = torch.bfloat16
+
+
+def _pad64(n: int) -> int:
+    return -(-n // 64) * 64
+
+
+def _zeros_f32(dim, device):
+    return torch.zeros((dim,), dtype=torch.float32, device=device)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# GEMM backward on the forward kernel
+def linear_dx(dy: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    """dX[M,K] = dY[M,N] W[N,K]  (W^T is the GEMM's [N',K'] operand; N must be a multiple of the 64-wide K step)."""
+    n, k = weight.shape
+    if n % 64:
+        raise GoalForceError(f"linear_dx: out_features={n} must be a multiple of 64")
+    w_t = ops.transpose_pad(weight.detach(), n)              # [K, N]
+    return ops.gemm(dy, w_t, None)
+
+
+def linear_dw(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """dW[N,K] = dY[M,N]^T X[M,K]  (both operands transposed with the token dim zero-padded to a multiple of 64)."""
+    m = dy.shape[0]
+    mp = _pad64(m)
+    return ops.gemm(ops.transpose_pad(dy, mp), ops.transpose_pad(x, mp), None)
+
+
+def bias_grad(dy: torch.Tensor) -> torch.Tensor:
+    acc = _zeros_f32(dy.shape[1], dy.device)
+    ops.colsum(dy, acc=acc)
+    return ops.f32_to_bf16(acc)
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b on the MFMA GEMM, with its backward."""
+
+    @staticmethod
+    def forward(ctx, x2, weight, bias):
+        ctx.save_for_backward(x2, weight)
+        ctx.has_bias = bias is not None
+        return ops.gemm(x2, weight, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = linear_dx(dy, weight) if ctx.needs_input_grad[0] else None
+        dw = linear_dw(dy, x2) if ctx.needs_input_grad[1] else None
+        db = bias_grad(dy) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dw, db
+
+
+class PatchEmbedFn(torch.autograd.Function):
+    """ControlNet_PatchEmbedding (GF:72-94): Conv3d k=s=(1,2,2) == GEMM over the gathered patches; `cols` [S, kpad]."""
+
+    @staticmethod
+    def forward(ctx, cols, conv_weight, bias):
+        k = conv_weight.shape[1] * 4
+        wp = torch.zeros((conv_weight.shape[0], cols.shape[1]), dtype=conv_weight.dtype, device=conv_weight.device)
+        wp[:, :k] = conv_weight.detach().reshape(conv_weight.shape[0], k)
+        ctx.save_for_backward(cols)
+        ctx.wshape, ctx.k = conv_weight.shape, k
+        return ops.gemm(cols, wp, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (cols,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dw = linear_dw(dy, cols)[:, :ctx.k].reshape(ctx.wshape).contiguous() if ctx.needs_input_grad[1] else None
+        db = bias_grad(dy) if ctx.needs_input_grad[2] else None
+        return None, dw, db
+
+
+class LayerNormModFn(torch.autograd.Function):
+    """LayerNorm (no affine) * scale1p + shift (Head.forward, DIT:253-269); no parameter gradients needed there."""
+
+    @staticmethod
+    def forward(ctx, x2, scale1p, shift, eps):
+        ctx.save_for_backward(x2, scale1p)
+        ctx.eps = eps
+        return ops.layernorm_modulate(x2, scale1p=scale1p, shift=shift, eps=eps)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, scale1p = ctx.saved_tensors
+        return ops.layernorm_bwd(x2, dy.contiguous(), g=scale1p, eps=ctx.eps), None, None, None
+
+
+class InjectFn(torch.autograd.Function):
+    """x + zero_conv(state)  (GF:1565-1570; Conv1d(k=1) == Linear): one GEMM with the residual epilogue."""
+
+    @staticmethod
+    def forward(ctx, x2, state, weight2d, bias):
+        ctx.save_for_backward(state, weight2d)
+        return ops.gemm(state, weight2d, bias, epilogue=ops.EPI_BIAS_RESID, resid=x2)
+
+    @staticmethod
+    def backward(ctx, dout):
+        state, w = ctx.saved_tensors
+        dout = dout.contiguous()
+        dstate = linear_dx(dout, w) if ctx.needs_input_grad[1] else None
+        dw = linear_dw(dout, state) if ctx.needs_input_grad[2] else None
+        db = bias_grad(dout) if ctx.needs_input_grad[3] else None
+        return dout, dstate, dw, db
+
+
+class FanoutFn(torch.autograd.Function):
+    """A tensor consumed twice: the two gradients are summed by the HIP add kernel."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        if g1 is None:
+            return g2
+        if g2 is None:
+            return g1
+        return ops.add(g1.contiguous(), g2.contiguous())
+
+
+class UnpatchifyFn(torch.autograd.Function):
+    """'b (f h w) (x y z c) -> b c (f x) (h y) (w z)' (DIT:351-356); backward is the inverse data movement."""
+
+    @staticmethod
+    def forward(ctx, tokens, c, f, h, w):
+        ctx.dims = (c, f, h, w)
+        return ops.unpatchify(tokens.contiguous(), c, f, h, w)
+
+    @staticmethod
+    def backward(ctx, dout):
+        c, f, h, w = ctx.dims
+        g = dout.reshape(c, f, h, 2, w, 2).permute(1, 2, 4, 3, 5, 0)      # f h w y z c
+        return g.reshape(f * h * w, 4 * c).contiguous(), None, None, None, None
+
+
+class MseLossFn(torch.autograd.Function):
+    """weight * F.mse_loss(pred.float(), target.float())  (GF:190-191)."""
+
+    @staticmethod
+    def forward(ctx, pred, target, weight):
+        loss, dpred = ops.mse_loss(pred.contiguous(), target.contiguous(), weight=weight, want_grad=True)
+        ctx.save_for_backward(dpred)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dpred,) = ctx.saved_tensors
+        if float(g) != 1.0:
+            dpred = (dpred.float() * float(g)).to(BF)
+        return dpred, None, None
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# one DiT / ControlNet block
+_PARAM_NAMES = (
+    "modulation",
+    "self_attn.q.weight", "self_attn.q.bias", "self_attn.k.weight", "self_attn.k.bias", "self_attn.v.weight",
+    "self_attn.v.bias", "self_attn.o.weight", "self_attn.o.bias", "self_attn.norm_q.weight", "self_attn.norm_k.weight",
+    "norm3.weight", "norm3.bias",
+    "cross_attn.q.weight", "cross_attn.q.bias", "cross_attn.k.weight", "cross_attn.k.bias", "cross_attn.v.weight",
+    "cross_attn.v.bias", "cross_attn.o.weight", "cross_attn.o.bias", "cross_attn.norm_q.weight", "cross_attn.norm_k.weight",
+    "ffn.0.weight", "ffn.0.bias", "ffn.2.weight", "ffn.2.bias",
+)
+
+
+def _block_params(block: DiTBlock):
+    named = dict(block.named_parameters())
+    return [named[n] for n in _PARAM_NAMES]
+
+
+class DiTBlockFn(torch.autograd.Function):
+    """DiTBlock.forward (DIT:197-230) with a hand-written backward; inputs x2 [S,D], ctx2 [L,D], t_mod [1,6,D]."""
+
+    @staticmethod
+    def forward(ctx, block, rope, x2, ctx2, t_mod, *params):
+        ctx.block, ctx.rope = block, rope
+        ctx.save_for_backward(x2, ctx2, t_mod)
+        ctx.param_needs = [p.requires_grad for p in params]
+        with torch.no_grad():
+            return block(x2, ctx2, t_mod, rope)
+
+    @staticmethod
+    def backward(ctx, dout):
+        block, rope = ctx.block, ctx.rope
+        x, c2, t_mod = ctx.saved_tensors
+        need = dict(zip(_PARAM_NAMES, ctx.param_needs))
+        any_param = any(ctx.param_needs)
+        eps, dev, d = block.eps, x.device, block.dim
+        sa, ca, heads, hd = block.self_attn, block.cross_attn, block.num_heads, block.dim // block.num_heads
+        dout = dout.contiguous()
+        g = {}                                              # parameter gradients by name
+
+        def lin(xin, layer):
+            return ops.gemm(xin, layer.weight, layer.bias)
+
+        def lin_bwd(dy, xin, layer, prefix, want_dx=True):
+            if need[prefix + ".weight"]:
+                g[prefix + ".weight"] = linear_dw(dy, xin)
+            if need[prefix + ".bias"]:
+                g[prefix + ".bias"] = bias_grad(dy)
+            return linear_dx(dy, layer.weight) if want_dx else None
+
+        # ---- recompute the forward, un-fused, keeping the intermediates (DIT:218-229)
+        mod = ops.modulation(block.modulation, t_mod.contiguous(), onep_mask=0b010010)
+        h1 = ops.layernorm_modulate(x, scale1p=mod[1], shift=mod[0], eps=eps)
+        qp, kp, vv = lin(h1, sa.q), lin(h1, sa.k), lin(h1, sa.v)
+        qn, kn = qp.clone(), kp.clone()
+        ops.rmsnorm_rope(qn, sa.norm_q.weight, rope.cos, rope.sin, hd, sa.norm_q.eps)
+        ops.rmsnorm_rope(kn, sa.norm_k.weight, rope.cos, rope.sin, hd, sa.norm_k.eps)
+        a, lse = ops.flash_attn_lse(qn, kn, vv, heads)
+        o = lin(a, sa.o)
+        x1 = ops.add(x, ops.colsum(o, gate=mod[2]))                                  # x + gate_msa * o
+        h2 = ops.layernorm_modulate(x1, weight=block.norm3.weight, bias=block.norm3.bias, eps=eps)
+        q2p, k2p, v2 = lin(h2, ca.q), lin(c2, ca.k), lin(c2, ca.v)
+        q2n, k2n = q2p.clone(), k2p.clone()
+        ops.rmsnorm_rope(q2n, ca.norm_q.weight, None, None, hd, ca.norm_q.eps)
+        ops.rmsnorm_rope(k2n, ca.norm_k.weight, None, None, hd, ca.norm_k.eps)
+        a2, lse2 = ops.flash_attn_lse(q2n, k2n, v2, heads)
+        x2b = ops.gemm(a2, ca.o.weight, ca.o.bias, epilogue=ops.EPI_BIAS_RESID, resid=x1)
+        h3 = ops.layernorm_modulate(x2b, scale1p=mod[4], shift=mod[3], eps=eps)
+        u = lin(h3, block.ffn[0])
+        f = ops.act(u, "gelu_tanh")
+        y = lin(f, block.ffn[2])
+
+        def acc():
+            return _zeros_f32(d, dev) if need["modulation"] else None
+
+        # ---- FFN branch: x3 = x2b + gate_mlp * y
+        dgate2 = acc()
+        dy = ops.colsum(dout, b=y, gate=mod[5], acc=dgate2)
+        df = lin_bwd(dy, f, block.ffn[2], "ffn.2")
+        du = ops.act_bwd(u, df, "gelu_tanh")
+        dh3 = lin_bwd(du, h3, block.ffn[0], "ffn.0")
+        dscale2, dshift2 = acc(), acc()
+        d_x2b = ops.add(dout, ops.layernorm_bwd(x2b, dh3, g=mod[4], dg_acc=dscale2, db_acc=dshift2, eps=eps))
+        del dy, df, du, dh3, u, f, y, h3
+        # ---- cross-attention branch: x2b = x1 + o2
+        da2 = lin_bwd(d_x2b, a2, ca.o, "cross_attn.o")
+        dq2n, dk2n, dv2 = ops.flash_attn_bwd(q2n, k2n, v2, a2, da2, lse2, heads)
+        wq_acc = _zeros_f32(d, dev) if need["cross_attn.norm_q.weight"] else None
+        wk_acc = _zeros_f32(d, dev) if need["cross_attn.norm_k.weight"] else None
+        dq2p = ops.rmsnorm_rope_bwd(q2p, dq2n, ca.norm_q.weight, None, None, hd, ca.norm_q.eps, dw_acc=wq_acc)
+        dh2 = lin_bwd(dq2p, h2, ca.q, "cross_attn.q")
+        if any_param:                                        # the context side only feeds parameter gradients
+            dk2p = ops.rmsnorm_rope_bwd(k2p, dk2n, ca.norm_k.weight, None, None, hd, ca.norm_k.eps, dw_acc=wk_acc)
+            lin_bwd(dk2p, c2, ca.k, "cross_attn.k", want_dx=False)
+            lin_bwd(dv2, c2, ca.v, "cross_attn.v", want_dx=False)
+        if wq_acc is not None:
+            g["cross_attn.norm_q.weight"] = ops.f32_to_bf16(wq_acc)
+        if wk_acc is not None:
+            g["cross_attn.norm_k.weight"] = ops.f32_to_bf16(wk_acc)
+        n3w = _zeros_f32(d, dev) if need["norm3.weight"] else None
+        n3b = _zeros_f32(d, dev) if need["norm3.bias"] else None
+        d_x1 = ops.add(d_x2b, ops.layernorm_bwd(x1, dh2, g=block.norm3.weight, dg_acc=n3w, db_acc=n3b, eps=eps))
+        if n3w is not None:
+            g["norm3.weight"] = ops.f32_to_bf16(n3w)
+        if n3b is not None:
+            g["norm3.bias"] = ops.f32_to_bf16(n3b)
+        del da2, dq2n, dk2n, dv2, dq2p, dh2, d_x2b, a2, q2n, k2n, v2, q2p, k2p, h2, x2b
+        # ---- self-attention branch: x1 = x + gate_msa * o
+        dgate1 = acc()
+        do = ops.colsum(d_x1, b=o, gate=mod[2], acc=dgate1)
+        da = lin_bwd(do, a, sa.o, "self_attn.o")
+        dqn, dkn, dvv = ops.flash_attn_bwd(qn, kn, vv, a, da, lse, heads)
+        wq_acc = _zeros_f32(d, dev) if need["self_attn.norm_q.weight"] else None
+        wk_acc = _zeros_f32(d, dev) if need["self_attn.norm_k.weight"] else None
+        dqp = ops.rmsnorm_rope_bwd(qp, dqn, sa.norm_q.weight, rope.cos, rope.sin, hd, sa.norm_q.eps, dw_acc=wq_acc)
+        dkp = ops.rmsnorm_rope_bwd(kp, dkn, sa.norm_k.weight, rope.cos, rope.sin, hd, sa.norm_k.eps, dw_acc=wk_acc)
+        if wq_acc is not None:
+            g["self_attn.norm_q.weight"] = ops.f32_to_bf16(wq_acc)
+        if wk_acc is not None:
+            g["self_attn.norm_k.weight"] = ops.f32_to_bf16(wk_acc)
+        dh1 = lin_bwd(dqp, h1, sa.q, "self_attn.q")
+        dh1 = ops.add(dh1, lin_bwd(dkp, h1, sa.k, "self_attn.k"))
+        dh1 = ops.add(dh1, lin_bwd(dvv, h1, sa.v, "self_attn.v"))
+        dscale1, dshift1 = acc(), acc()
+        dx = ops.add(d_x1, ops.layernorm_bwd(x, dh1, g=mod[1], dg_acc=dscale1, db_acc=dshift1, eps=eps))
+        if need["modulation"]:    # rows: shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp (d(1+s) = ds)
+            rows = torch.stack([dshift1, dscale1, dgate1, dshift2, dscale2, dgate2]).contiguous()
+            g["modulation"] = ops.f32_to_bf16(rows).view(block.modulation.shape)
+        grads = [g.get(n) if nd else None for n, nd in zip(_PARAM_NAMES, ctx.param_needs)]
+        return (None, None, dx, None, None, *grads)
+
+
+def block_forward(block: DiTBlock, x2, ctx2, t_mod, rope: RopeTable):
+    return DiTBlockFn.apply(block, rope, x2, ctx2, t_mod, *_block_params(block))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# model_fn with a tape, loss, optimiser
+def model_fn_train(dit: WanModel, controlnet, latents, timestep, context, y, control_signal_video_latents):
+    """model_fn_wan_video (GF:1349-1591) with gradients to the ControlNet parameters.  The DiT expert is frozen: its
+    embeddings run without a tape, its blocks back-propagate activations only."""
+    with torch.no_grad():
+        t, t_mod = dit.time_embed(timestep)
+        ctx2 = dit.embed_text(context)[0]
+        x, (f, h, w) = dit.patchify(latents, extra=y if (y is not None and dit.require_vae_embedding) else None)
+        rope = dit.rope_table(f, h, w, latents.device)
+        pe = controlnet.controlnet_patch_embedding
+        kpad = _pad64(pe.patch_embedding.weight.shape[1] * 4)
+        cols = ops.patchify_im2col(control_signal_video_latents[0].contiguous(), None, kpad=kpad)
+        hmod = ops.modulation(dit.head.modulation, t.contiguous(), onep_mask=0b10)
+    x = x[0]
+    c = PatchEmbedFn.apply(cols, pe.patch_embedding.weight, pe.patch_embedding.bias)
+    n_cn = controlnet.controlnet_dit.num_layers
+    for i, block in enumerate(dit.blocks):
+        if i < n_cn:
+            c = block_forward(controlnet.controlnet_dit.blocks[i], c, ctx2, t_mod, rope)
+            zc = controlnet.controlnet_zero_convs_after[i]
+            if i + 1 < n_cn:
+                c, c_inj = FanoutFn.apply(c)            # the state feeds the next ControlNet block AND the injection
+            else:
+                c_inj = c
+        x = block_forward(block, x, ctx2, t_mod, rope)
+        if i < n_cn:
+            x = InjectFn.apply(x, c_inj, zc.weight.view(zc.weight.shape[0], -1), zc.bias)
+    hx = LayerNormModFn.apply(x, hmod[1], hmod[0], dit.head.eps)
+    tok = LinearFn.apply(hx, dit.head.head.weight, dit.head.head.bias)
+    return UnpatchifyFn.apply(tok, dit.out_dim, f, h, w).unsqueeze(0)
+
+
+def training_loss(pipe, *, input_latents, noise, context, y, control_signal_video_latents, timestep_id=None,
+                  max_timestep_boundary=1.0, min_timestep_boundary=0.0, dit=None, controlnet=None):
+    """GF:180-193.  The scheduler must be in training mode (`set_timesteps(1000, training=True)`, as the reference's
+    training entry point does).  `timestep_id` pins the random draw (tests)."""
+    sch = pipe.scheduler
+    if timestep_id is None:
+        lo = int(min_timestep_boundary * sch.num_train_timesteps)
+        hi = int(max_timestep_boundary * sch.num_train_timesteps)
+        timestep_id = int(torch.randint(lo, hi, (1,)))
+    timestep = sch.timesteps[timestep_id:timestep_id + 1].to(dtype=pipe.torch_dtype, device=pipe.device)
+    latents = sch.add_noise(input_latents, noise, timestep)
+    target = sch.training_target(input_latents, noise, timestep)
+    pred = model_fn_train(dit or pipe.dit, controlnet or pipe.controlnet, latents, timestep, context, y,
+                          control_signal_video_latents)
+    return MseLossFn.apply(pred[0], target[0].contiguous(), float(sch.training_weight(timestep)))
+
+
+class AdamW:
+    """torch.optim.AdamW(params, lr, weight_decay) of launch_training_task (utils.py:755) on the HIP kernel: bf16
+    parameters, fp32 moments (the reference's moments inherit the parameters' bf16; fp32 is strictly more precise)."""
+
+    def __init__(self, params, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        self.params = [p for p in params if p.requires_grad]
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.step_count = 0
+        self.state = {}
+
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None
+
+    def grad_norm(self) -> float:
+        sq = torch.zeros((), dtype=torch.float32, device=self.params[0].device)
+        for p in self.params:
+            if p.grad is not None:
+                sq += p.grad.float().pow(2).sum()
+        return float(sq.sqrt())
+
+    @torch.no_grad()
+    def step(self, max_grad_norm: Optional[float] = None):
+        """One update; `max_grad_norm` > 0 applies accelerator.clip_grad_norm_ (utils.py:806-808) as a gradient scale."""
+        self.step_count += 1
+        scale = 1.0
+        if max_grad_norm is not None and max_grad_norm > 0:
+            n = self.grad_norm()
+            scale = min(1.0, max_grad_norm / (n + 1e-6))
+        for p in self.params:
+            if p.grad is None:
+                continue
+            st = self.state.get(p)
+            if st is None:
+                st = self.state[p] = (torch.zeros(p.shape, dtype=torch.float32, device=p.device),
+                                      torch.zeros(p.shape, dtype=torch.float32, device=p.device))
+            ops.adamw_step(p.data, p.grad.contiguous(), st[0], st[1], self.step_count, self.lr, self.betas, self.eps,
+                           self.weight_decay, grad_scale=scale)
+
+
+def controlnet_state_dict(controlnet: nn.Module) -> dict:
+    """Checkpoint layout of the reference's ModelLogger (remove_prefix 'pipe.controlnet.' on load, GF:176-178)."""
+    return {"pipe.controlnet." + k: v.detach().cpu() for k, v in controlnet.state_dict().items()}

@@ -148,6 +148,32 @@ GF_API int gf_flash_attn_bwd(const void* q, const void* k, const void* v, const 
                       int64_t q_stride, int64_t k_stride, int64_t v_stride, int64_t o_stride, int64_t do_stride,
                       int64_t dq_stride, int64_t dk_stride, int64_t dv_stride, float scale, void* stream);
 
+/* Backward of the row / elementwise ops of a block and the loss / optimiser of the training step (gf_backward.hip).
+ * Gradients: fp32 math on the bf16 forward operands, one rounding to bf16.  *_acc are caller-zeroed fp32 [dim] column
+ * accumulators (parameter gradients summed over the token rows; NULL = not wanted).
+ * gf_layernorm_bwd   — LayerNorm (DIT:206-208, VRAM:78-92) with y = xhat*g (+b): g = affine weight or (1+scale) or NULL;
+ *                      dx; dg_acc += dy*xhat, db_acc += dy.
+ * gf_rmsnorm_rope_bwd — RMSNorm (DIT:100-111) (+ RoPE DIT:92-97): x is the PRE-norm tensor; dx; dw_acc.
+ * gf_colsum          — acc[n] += sum_r a[r,n]*(b ? b[r,n] : 1); optionally out[r,n] = bf16(a[r,n]*gate[n]) (bias gradients;
+ *                      the gated residual out = resid + gate*y: a = dout, b = y gives dgate and dy in one pass).
+ * gf_act_bwd         — du = df * act'(u), kind 0 = GELU-tanh (DIT:209), 1 = SiLU.
+ * gf_mse_loss        — loss[0] = weight * mean((pred-target)^2), dpred = weight*2(pred-target)/n  (GF:190-191).
+ * gf_adamw_step      — torch.optim.AdamW update of a bf16 parameter with fp32 moments (utils.py:755); grad_scale
+ *                      multiplies the gradient first (gradient clipping).
+ * gf_f32_to_bf16     — rounds an accumulator buffer to the bf16 gradient.                                             */
+GF_API int gf_layernorm_bwd(const void* x, int64_t x_stride, const void* dy, int64_t dy_stride, const void* g, void* dx,
+                            int64_t dx_stride, float* dg_acc, float* db_acc, int64_t rows, int64_t dim, float eps, void* stream);
+GF_API int gf_rmsnorm_rope_bwd(const void* x, int64_t x_stride, const void* dy, int64_t dy_stride, const void* weight,
+                               const float* cos_tab, const float* sin_tab, void* dx, int64_t dx_stride, float* dw_acc,
+                               int64_t rows, int64_t dim, int64_t head_dim, float eps, void* stream);
+GF_API int gf_colsum(const void* a, int64_t lda, const void* b, int64_t ldb, const void* gate, void* out, int64_t ldo,
+                     float* acc, int64_t rows, int64_t cols, void* stream);
+GF_API int gf_act_bwd(const void* u, const void* df, void* du, int64_t n, int kind, void* stream);
+GF_API int gf_mse_loss(const void* pred, const void* target, void* dpred, float* loss, int64_t n, float weight, void* stream);
+GF_API int gf_adamw_step(void* param, const void* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                         float beta2, float eps, float weight_decay, int64_t step, float grad_scale, void* stream);
+GF_API int gf_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+
 /* ------------------------------------------------------------------------
  * gf_patchify_im2col — gathers the (1,2,2) patches of an NCTHW latent into a
  * token-major matrix for the patch-embedding GEMM.  Replaces the data movement

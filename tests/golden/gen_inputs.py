@@ -151,6 +151,32 @@ def t5_sd(cfg, seed, dtype=torch.bfloat16):
     return {k: v.to(dtype) for k, v in sd.items()}
 
 
+TRAIN_TIMESTEP_ID = 137     # the pinned "random" draw of training_loss (GF:183) in the training golden
+
+
+def train_inputs(seed=77, dtype=torch.bfloat16):
+    """Inputs of one training_loss call at the tiny size (GF:180-193): clean latents, noise, prompt embedding, image
+    conditioning y (mask channels {0,1}), control latents."""
+    g = torch.Generator().manual_seed(seed)
+    b, c, f, h, w = TINY_LATENT
+    y = _randn(g, (b, 20, f, h, w))
+    y[:, :4] = (y[:, :4] > 0).float()
+    return dict(input_latents=_randn(g, (b, c, f, h, w)).to(dtype), noise=_randn(g, (b, c, f, h, w)).to(dtype),
+                context=_randn(g, (1, TINY_CTX_LEN, TINY["text_dim"])).to(dtype), y=y.to(dtype),
+                control=_randn(g, (b, 16, f, h, w)).to(dtype))
+
+
+def grad_probes(n: int, seed: int, k: int = 4) -> torch.Tensor:
+    """k seeded unit-variance probe vectors [k, n] (fp64): projections of a gradient pin the whole tensor cheaply."""
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn((k, n), generator=g, dtype=torch.float64)
+
+
+def grad_sample_index(n: int, seed: int, k: int = 256) -> torch.Tensor:
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(0, n, (k,), generator=g)
+
+
 def checksum(tensors) -> float:
     """Order-dependent fp64 checksum of a dict/list of tensors (detects RNG / generation drift)."""
     items = tensors.items() if isinstance(tensors, dict) else enumerate(tensors)

@@ -1,0 +1,83 @@
+"""Training-step oracle against the reference-generated golden (tests/golden/g9_training.npz: the reference's scheduler,
+model_fn_wan_video and modules run through training_loss + loss.backward(), GF:180-193)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import gen_inputs as gi
+from conftest import GOLDEN
+from oracle import train_oracle as to
+
+
+@pytest.fixture(autouse=True)
+def _grad_enabled():
+    """Other test modules switch autograd off process-wide at import; the training tests need the tape."""
+    with torch.enable_grad():
+        yield
+
+
+def _g():
+    return np.load(os.path.join(GOLDEN, "g9_training.npz"))
+
+
+def test_training_schedule_matches_reference():
+    g = _g()
+    sig, ts, w = to.training_schedule(1000, 5.0)
+    ids = g["sched_ids"]
+    assert np.array_equal(sig[ids].numpy(), g["sched_sigmas"])
+    assert np.array_equal(ts[ids].numpy(), g["sched_timesteps"])
+    assert np.allclose(w[ids].numpy(), g["sched_weights"], rtol=1e-6, atol=0)
+
+
+def test_product_scheduler_training_mode_matches_reference():
+    from goal_force_amd.scheduler import FlowMatchScheduler
+    g = _g()
+    sch = FlowMatchScheduler(shift=5, sigma_min=0.0, extra_one_step=True)
+    sch.set_timesteps(1000, training=True)
+    ids = g["sched_ids"]
+    assert np.array_equal(sch.sigmas[ids].numpy(), g["sched_sigmas"])
+    assert np.array_equal(sch.timesteps[ids].numpy(), g["sched_timesteps"])
+    assert np.allclose(sch.linear_timesteps_weights[ids].numpy(), g["sched_weights"], rtol=1e-6, atol=0)
+    # training_weight looks the bf16-rounded timestep up again by nearest neighbour (FM:108-111): id 137 -> 968.0
+    t = sch.timesteps[137:138].to(torch.bfloat16)
+    sig, ts, w = to.training_schedule(1000, 5.0)
+    tid = int(torch.argmin((ts - t.float()).abs()))
+    assert float(sch.training_weight(t)) == float(w[tid])
+    assert float(sch.add_noise(torch.zeros(1), torch.ones(1), t)) == float(sig[tid])
+
+
+def _check(grads, g, mode, rtol):
+    names = [str(n) for n in g["names"]]
+    assert sorted(grads) == names
+    for i, n in enumerate(names):
+        gf = grads[n].double().flatten()
+        nrm = float(g[f"norm_{mode}"][i])
+        assert abs(float(gf.norm()) - nrm) <= rtol * nrm + 1e-12, n
+        pr = gi.grad_probes(gf.numel(), seed=1000 + i) @ gf
+        scale = nrm * np.sqrt(gf.numel()) + 1e-30                      # std of a projection of a vector of that norm
+        assert float((pr - torch.from_numpy(g[f"proj_{mode}"][i])).abs().max()) <= rtol * scale, n
+        smp = gf[gi.grad_sample_index(gf.numel(), seed=2000 + i)]
+        ref = torch.from_numpy(g[f"sample_{mode}"][i])
+        assert float((smp - ref).norm()) <= rtol * float(ref.norm()) + 1e-12, n
+
+
+def test_oracle_training_step_fp32_matches_reference():
+    g = _g()
+    inp = gi.train_inputs()
+    assert gi.same_checksum(gi.checksum(inp), g["ck_inputs"])
+    cfg = gi.TINY
+    loss, grads = to.loss_and_grads(gi.dit_sd(cfg, seed=41), gi.controlnet_sd(cfg, gi.TINY_CONTROLNET_LAYERS, seed=42), cfg,
+                                    gi.TINY_CONTROLNET_LAYERS, inp, gi.TRAIN_TIMESTEP_ID, dtype=torch.float32)
+    assert abs(float(loss) - float(g["loss_f32"])) < 1e-5 * float(g["loss_f32"])
+    _check(grads, g, "f32", rtol=2e-4)
+
+
+def test_oracle_training_step_bf16_matches_reference():
+    g = _g()
+    cfg = gi.TINY
+    loss, grads = to.loss_and_grads(gi.dit_sd(cfg, seed=41), gi.controlnet_sd(cfg, gi.TINY_CONTROLNET_LAYERS, seed=42), cfg,
+                                    gi.TINY_CONTROLNET_LAYERS, gi.train_inputs(), gi.TRAIN_TIMESTEP_ID, dtype=torch.bfloat16)
+    assert abs(float(loss) - float(g["loss_bf16"])) < 2e-2 * float(g["loss_bf16"])
+    _check(grads, g, "bf16", rtol=5e-2)       # same ops, same dtype; the oracle's LayerNorm is the fp32-autocast variant

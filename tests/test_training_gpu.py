@@ -13,6 +13,13 @@ BF = torch.bfloat16
 HD = 128
 
 
+@pytest.fixture(autouse=True)
+def _grad_enabled():
+    """Other test modules switch autograd off process-wide at import; the training tests need the tape."""
+    with torch.enable_grad():
+        yield
+
+
 def _ref_attention_grads(q, k, v, dout, heads):
     qf, kf, vf = (t.float().cpu().requires_grad_(True) for t in (q, k, v))
     sq, skv = q.shape[0], k.shape[0]
@@ -58,3 +65,236 @@ def test_flash_attn_backward_strided_inputs():
     dq, dk, dv = ops.flash_attn_bwd(q, k, v, o, dout, lse, heads)
     dq2, dk2, dv2 = ops.flash_attn_bwd(q.contiguous(), k.contiguous(), v.contiguous(), o, dout, lse, heads)
     assert torch.equal(dq, dq2) and torch.equal(dk, dk2) and torch.equal(dv, dv2)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# row / elementwise backward kernels, loss, optimiser
+def _bf(t):
+    return t.to(BF).cuda()
+
+
+def test_layernorm_backward_modulate_and_affine():
+    from goal_force_amd import ops
+    g = torch.Generator().manual_seed(1)
+    rows, dim = 75, 256
+    x, dy = torch.randn((rows, dim), generator=g).to(BF), torch.randn((rows, dim), generator=g).to(BF)
+    gmul = (1 + 0.1 * torch.randn((dim,), generator=g)).to(BF)
+    shift = (0.1 * torch.randn((dim,), generator=g)).to(BF)
+    xf, gf, bf_ = x.float().requires_grad_(True), gmul.float().requires_grad_(True), shift.float().requires_grad_(True)
+    y = torch.nn.functional.layer_norm(xf, (dim,), None, None, 1e-6) * gf + bf_
+    y.backward(dy.float())
+    dg, db = torch.zeros(dim, device="cuda"), torch.zeros(dim, device="cuda")
+    dx = ops.layernorm_bwd(_bf(x), _bf(dy), g=_bf(gmul), dg_acc=dg, db_acc=db, eps=1e-6)
+    assert rel_l2(dx.float().cpu(), xf.grad) < 6e-3
+    assert rel_l2(dg.cpu(), gf.grad) < 2e-3 and rel_l2(db.cpu(), bf_.grad) < 1e-5
+    # no multiplier, no accumulators
+    xf2 = x.float().requires_grad_(True)
+    torch.nn.functional.layer_norm(xf2, (dim,), None, None, 1e-6).backward(dy.float())
+    assert rel_l2(ops.layernorm_bwd(_bf(x), _bf(dy)).float().cpu(), xf2.grad) < 6e-3
+
+
+@pytest.mark.parametrize("rope", [True, False])
+def test_rmsnorm_rope_backward(rope):
+    from goal_force_amd import ops
+    from oracle import wan_oracle as wo
+    g = torch.Generator().manual_seed(2)
+    rows, heads, hd = 72, 2, 128
+    dim = heads * hd
+    x, dy = torch.randn((rows, dim), generator=g).to(BF), torch.randn((rows, dim), generator=g).to(BF)
+    w = (1 + 0.1 * torch.randn((dim,), generator=g)).to(BF)
+    freqs = wo.rope_freqs_3d(hd, 3, 4, 6)                                  # [72, 64] complex
+    xf, wf = x.float().requires_grad_(True), w.float().requires_grad_(True)
+    y = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6) * wf
+    if rope:
+        yc = torch.view_as_complex(y.double().reshape(rows, heads, hd // 2, 2)) * freqs[:, None, :]
+        y = torch.view_as_real(yc).flatten(1).float()
+    y.backward(dy.float())
+    cos = freqs.real.float().contiguous().cuda() if rope else None
+    sin = freqs.imag.float().contiguous().cuda() if rope else None
+    dw = torch.zeros(dim, device="cuda")
+    dx = ops.rmsnorm_rope_bwd(_bf(x), _bf(dy), _bf(w), cos, sin, hd, 1e-6, dw_acc=dw)
+    assert rel_l2(dx.float().cpu(), xf.grad) < 6e-3
+    assert rel_l2(dw.cpu(), wf.grad) < 2e-3
+
+
+def test_colsum_gate_act_bwd_mse_adamw():
+    from goal_force_amd import ops
+    g = torch.Generator().manual_seed(4)
+    rows, dim = 130, 512
+    a, b = torch.randn((rows, dim), generator=g).to(BF), torch.randn((rows, dim), generator=g).to(BF)
+    gate = torch.randn((dim,), generator=g).to(BF)
+    acc = torch.zeros(dim, device="cuda")
+    out = ops.colsum(_bf(a), b=_bf(b), gate=_bf(gate), acc=acc)
+    assert rel_l2(acc.cpu(), (a.float() * b.float()).sum(0)) < 1e-5
+    assert torch.equal(out.cpu(), (a.float() * gate.float()).to(BF))
+    acc2 = torch.zeros(dim, device="cuda")
+    assert ops.colsum(_bf(a), acc=acc2) is None and rel_l2(acc2.cpu(), a.float().sum(0)) < 1e-5
+    # activations
+    for kind, fn in (("gelu_tanh", lambda t: torch.nn.functional.gelu(t, approximate="tanh")), ("silu", torch.nn.functional.silu)):
+        uf = a.float().requires_grad_(True)
+        fn(uf).backward(b.float())
+        assert rel_l2(ops.act_bwd(_bf(a), _bf(b), kind).float().cpu(), uf.grad) < 4e-3
+    # loss
+    pf = a.float().requires_grad_(True)
+    l_ref = torch.nn.functional.mse_loss(pf, b.float()) * 0.37
+    l_ref.backward()
+    loss, dpred = ops.mse_loss(_bf(a), _bf(b), weight=0.37)
+    assert abs(float(loss) - float(l_ref.detach())) < 1e-5 * float(l_ref.detach())
+    assert rel_l2(dpred.float().cpu(), pf.grad) < 4e-3
+    # AdamW against torch.optim.AdamW on fp32 copies (3 steps)
+    p0, grads = torch.randn((1000,), generator=g).to(BF), [torch.randn((1000,), generator=g).to(BF) for _ in range(3)]
+    pr = torch.nn.Parameter(p0.float().clone())
+    opt = torch.optim.AdamW([pr], lr=1e-2, weight_decay=1e-2)
+    p, m, v = _bf(p0), torch.zeros(1000, device="cuda"), torch.zeros(1000, device="cuda")
+    for i, gr in enumerate(grads):
+        pr.grad = gr.float()
+        opt.step()
+        ops.adamw_step(p, _bf(gr), m, v, i + 1, lr=1e-2, weight_decay=1e-2)
+    # bf16 parameter storage: up to half an ulp (2^-9 relative) of rounding per step on top of the fp32 trajectory
+    assert bool(((p.float().cpu() - pr.detach()).abs() <= 3 * 2.0 ** -8 * pr.detach().abs() + 1e-3).all())
+    assert rel_l2(m.cpu(), opt.state[pr]["exp_avg"]) < 1e-5 and rel_l2(v.cpu(), opt.state[pr]["exp_avg_sq"]) < 1e-4
+
+
+def test_linear_backward():
+    from goal_force_amd.training import LinearFn
+    g = torch.Generator().manual_seed(5)
+    m, k, n = 72, 256, 512
+    x, w, b = torch.randn((m, k), generator=g).to(BF), (torch.randn((n, k), generator=g) / 16).to(BF), torch.randn((n,), generator=g).to(BF)
+    dy = torch.randn((m, n), generator=g).to(BF)
+    xf, wf, bf_ = (t.float().requires_grad_(True) for t in (x, w, b))
+    torch.nn.functional.linear(xf, wf, bf_).backward(dy.float())
+    xc, wc, bc = (_bf(t).requires_grad_(True) for t in (x, w, b))
+    LinearFn.apply(xc, wc, bc).backward(_bf(dy))
+    for got, want in ((xc.grad, xf.grad), (wc.grad, wf.grad), (bc.grad, bf_.grad)):
+        assert rel_l2(got.float().cpu(), want) < 4e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# block and full training step against the oracle / the reference golden
+def _oracle_block_grads(cfg, sd, x, ctx, t_mod, dout):
+    from oracle import wan_oracle as wo
+    sdf = {k: v.float().requires_grad_(True) for k, v in sd.items()}
+    xf = x.float().requires_grad_(True)
+    freqs = wo.rope_freqs_3d(cfg["dim"] // cfg["num_heads"], 3, 4, 6)
+    y = wo.dit_block(xf, ctx.float(), t_mod.float(), freqs, sdf, "", cfg["num_heads"], cfg["eps"])
+    y.backward(dout.float())
+    return xf.grad, {k: v.grad for k, v in sdf.items()}
+
+
+def test_dit_block_backward_vs_oracle():
+    import gen_inputs as gi
+    from goal_force_amd.dit import DiTBlock, RopeTable, precompute_freqs_cis_3d
+    from goal_force_amd.training import block_forward
+    cfg = gi.TINY
+    sd = gi.block_sd(torch.Generator().manual_seed(9), cfg["dim"], cfg["ffn_dim"], "", BF)
+    x, ctx, t_mod = gi.block_inputs(cfg["dim"], 72, gi.TINY_CTX_LEN, seed=12)
+    dout = torch.randn(x.shape, generator=torch.Generator().manual_seed(13)).to(BF)
+    dx_ref, g_ref = _oracle_block_grads(cfg, sd, x, ctx, t_mod, dout)
+    blk = DiTBlock(False, cfg["dim"], cfg["num_heads"], cfg["ffn_dim"], cfg["eps"])
+    blk.load_state_dict(sd, strict=True)
+    blk = blk.to(BF).cuda()
+    rope = RopeTable.from_grid(precompute_freqs_cis_3d(cfg["dim"] // cfg["num_heads"]), 3, 4, 6, "cuda")
+    xc = x[0].cuda().requires_grad_(True)
+    with torch.enable_grad():
+        y = block_forward(blk, xc, ctx[0].cuda(), t_mod.cuda(), rope)
+        y.backward(dout[0].cuda())
+    assert rel_l2(xc.grad.float().cpu(), dx_ref[0]) < 1.5e-2, "dx"
+    named = dict(blk.named_parameters())
+    worst = 0.0
+    for n, want in g_ref.items():
+        got = named[n].grad
+        assert got is not None, n
+        e = rel_l2(got.float().cpu().reshape(want.shape), want)
+        worst = max(worst, e)
+        # a bias on the keys shifts every score of a query by the same amount, to which softmax is blind: what is left of
+        # that gradient comes through the RMSNorm only and is cancellation-dominated (its own bf16 noise is ~5e-2)
+        bar = 8e-2 if n.endswith("attn.k.bias") else 2.5e-2
+        assert e < bar, f"{n}: rel_l2={e:.3e}"
+    # a frozen block back-propagates activations only and gives the same dx
+    for p_ in blk.parameters():
+        p_.requires_grad_(False)
+        p_.grad = None
+    xc2 = x[0].cuda().requires_grad_(True)
+    with torch.enable_grad():
+        block_forward(blk, xc2, ctx[0].cuda(), t_mod.cuda(), rope).backward(dout[0].cuda())
+    assert torch.equal(xc2.grad, xc.grad) and all(p_.grad is None for p_ in blk.parameters())
+
+
+def _tiny_train_models():
+    import gen_inputs as gi
+    from goal_force_amd.controlnet import ControlNet
+    from goal_force_amd.dit import WanModel
+    cfg = gi.TINY
+    dit = WanModel(has_image_input=False, require_clip_embedding=False, **cfg)
+    dit.load_state_dict(gi.dit_sd(cfg, seed=41), strict=True)
+    cn = ControlNet(gi.TINY_CONTROLNET_LAYERS, dim=cfg["dim"], num_heads=cfg["num_heads"], ffn_dim=cfg["ffn_dim"])
+    cn.load_state_dict(gi.controlnet_sd(cfg, gi.TINY_CONTROLNET_LAYERS, seed=42), strict=True)
+    dit, cn = dit.to(BF).cuda(), cn.to(BF).cuda()
+    for p_ in dit.parameters():
+        p_.requires_grad_(False)
+    return dit, cn
+
+
+def _tiny_train_pipe(dit, cn):
+    from goal_force_amd.pipeline import WanVideoPipeline
+    pipe = WanVideoPipeline.from_modules(dit, None, cn, None, device="cuda")
+    pipe.scheduler.set_timesteps(1000, training=True)                  # utils.py:560
+    return pipe
+
+
+def test_training_step_vs_reference_golden():
+    """loss and every ControlNet gradient of one training_loss call against the reference's own run (g9_training.npz):
+    bar = 2x the reference-bf16's own distance from its fp32 run, floor 2e-2."""
+    import os
+    import numpy as np
+    import gen_inputs as gi
+    from conftest import GOLDEN
+    from goal_force_amd import training as tr
+    g = np.load(os.path.join(GOLDEN, "g9_training.npz"))
+    dit, cn = _tiny_train_models()
+    pipe = _tiny_train_pipe(dit, cn)
+    inp = {k: v.cuda() for k, v in gi.train_inputs().items()}
+    with torch.enable_grad():
+        loss = tr.training_loss(pipe, input_latents=inp["input_latents"], noise=inp["noise"], context=inp["context"],
+                                y=inp["y"], control_signal_video_latents=inp["control"], timestep_id=gi.TRAIN_TIMESTEP_ID)
+        loss.backward()
+    lf, lb = float(g["loss_f32"]), float(g["loss_bf16"])
+    lv = float(loss.detach())
+    assert abs(lv - lf) <= 2 * abs(lb - lf) + 1e-2 * lf, f"loss {lv} vs fp32 {lf} (reference bf16 {lb})"
+    named = dict(cn.named_parameters())
+    names = [str(n) for n in g["names"]]
+    assert sorted(named) == names
+    assert all(p_.grad is None for p_ in dit.parameters())
+    for i, n in enumerate(names):
+        gr = named[n].grad
+        assert gr is not None and gr.dtype == BF and gr.shape == named[n].shape, n
+        gf = gr.double().cpu().flatten()
+        idx = gi.grad_sample_index(gf.numel(), seed=2000 + i)
+        s32, s16 = torch.from_numpy(g["sample_f32"][i]), torch.from_numpy(g["sample_bf16"][i])
+        e_ref = float((s16 - s32).norm() / s32.norm())
+        e = float((gf[idx] - s32).norm() / s32.norm())
+        assert e <= 2 * e_ref + 2e-2, f"{n}: sample rel err {e:.3e} (reference bf16 {e_ref:.3e})"
+        nrm = float(g["norm_f32"][i])
+        assert abs(float(gf.norm()) - nrm) <= (2 * abs(float(g["norm_bf16"][i]) - nrm) + 3e-2 * nrm), n
+
+
+def test_training_steps_reduce_the_loss():
+    """launch_training_task's inner loop (utils.py:797-812): zero_grad, loss, backward, clip, AdamW step."""
+    import gen_inputs as gi
+    from goal_force_amd import training as tr
+    dit, cn = _tiny_train_models()
+    pipe = _tiny_train_pipe(dit, cn)
+    inp = {k: v.cuda() for k, v in gi.train_inputs().items()}
+    opt = tr.AdamW(cn.parameters(), lr=2e-4, weight_decay=1e-2)
+    losses = []
+    for _ in range(4):
+        opt.zero_grad()
+        with torch.enable_grad():
+            loss = tr.training_loss(pipe, input_latents=inp["input_latents"], noise=inp["noise"], context=inp["context"],
+                                    y=inp["y"], control_signal_video_latents=inp["control"], timestep_id=gi.TRAIN_TIMESTEP_ID)
+            loss.backward()
+        opt.step(max_grad_norm=1.0)
+        losses.append(float(loss.detach()))
+    assert losses[-1] < losses[0], losses
+    sd = tr.controlnet_state_dict(cn)
+    assert all(k.startswith("pipe.controlnet.") for k in sd) and len(sd) == len(cn.state_dict())
