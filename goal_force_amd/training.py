@@ -412,6 +412,41 @@ class AdamW:
                            self.weight_decay, grad_scale=scale)
 
 
+def allreduce_gradients(params, group=None, bucket_bytes: int = 512 << 20):
+    """Data-parallel gradient averaging (the reference trains under Accelerate's DistributedDataParallel,
+    utils.py:756-760): gradients are packed into flat bf16 buckets and all-reduced over RCCL.  xGMI is point to point, so a
+    ring all-reduce moves 2(N-1)/N of each bucket over every link; 512 MB buckets (the ControlNet has 7.5 GB of bf16
+    gradients -> 15 collectives) keep the per-collective launch latency negligible against the ~25 ms a bucket takes at
+    ~40 GB/s per direction and link pair, and the whole exchange (~0.4 s) is small against the 9 s backward it follows.
+    Called after backward(), before the optimiser step; every rank must hold the same set of gradients."""
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    world = dist.get_world_size(group)
+    grads = [p.grad for p in params if p.requires_grad and p.grad is not None]
+    bucket, size = [], 0
+
+    def flush():
+        nonlocal bucket, size
+        if not bucket:
+            return
+        flat = torch.cat([g.reshape(-1) for g in bucket])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat = (flat.float() / world).to(bucket[0].dtype)          # mean, rounded once
+        off = 0
+        for g in bucket:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+        bucket, size = [], 0
+
+    for g in grads:
+        bucket.append(g)
+        size += g.numel() * g.element_size()
+        if size >= bucket_bytes:
+            flush()
+    flush()
+
+
 def controlnet_state_dict(controlnet: nn.Module) -> dict:
     """Checkpoint layout of the reference's ModelLogger (remove_prefix 'pipe.controlnet.' on load, GF:176-178)."""
     return {"pipe.controlnet." + k: v.detach().cpu() for k, v in controlnet.state_dict().items()}

@@ -119,3 +119,29 @@ def test_layout_rejects_bad_world():
         CfgPairParallel(0, 6, sp_size=2)
     with pytest.raises(ValueError):
         CfgPairParallel(0, 2, sp_size=2)
+
+
+def _ddp_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from goal_force_amd.training import allreduce_gradients
+        g = torch.Generator().manual_seed(11)
+        params = [torch.nn.Parameter(torch.randn(shape, generator=g).to(BF)) for shape in ((7, 5), (33,), (4, 4, 2))]
+        frozen = torch.nn.Parameter(torch.ones(3).to(BF), requires_grad=False)
+        for i, p in enumerate(params):
+            p.grad = torch.full(p.shape, float(rank + 1 + i)).to(BF)
+        allreduce_gradients(params + [frozen], bucket_bytes=64)          # several buckets
+        for i, p in enumerate(params):
+            want = sum(float(r + 1 + i) for r in range(world)) / world
+            assert torch.equal(p.grad, torch.full(p.shape, want).to(BF)), (i, p.grad.flatten()[:3])
+        assert frozen.grad is None
+        open(os.path.join(out, f"ddp{rank}"), "w").close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_gradient_average(tmp_path):
+    world = 2
+    mp.spawn(_ddp_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(os.path.join(tmp_path, f"ddp{r}")) for r in range(world))

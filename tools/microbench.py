@@ -34,7 +34,7 @@ def timeit(fn, iters, warm=2):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["attn", "gemm", "rows", "cross"])
+    ap.add_argument("what", choices=["attn", "gemm", "rows", "cross", "attnbwd"])
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--fp8", action="store_true")
     ap.add_argument("--s", type=int, default=S)
@@ -51,6 +51,16 @@ def main():
         med, mn = timeit(lambda: ops.flash_attn(q, k, v, H, out=o), a.iters)
         fl = 4.0 * s * skv * D
         print(f"flash_attn S={s} Skv={skv} H={H}: median {med:.3f} ms ({fl / med / 1e9:.1f} TFLOP/s), min {mn:.3f} ms ({fl / mn / 1e9:.1f} TFLOP/s)")
+    elif a.what == "attnbwd":
+        q = torch.randn((s, D), device="cuda").to(BF)
+        k = torch.randn((s, D), device="cuda").to(BF)
+        v = torch.randn((s, D), device="cuda").to(BF)
+        do = torch.randn((s, D), device="cuda").to(BF)
+        o, lse = ops.flash_attn_lse(q, k, v, H)
+        med, mn = timeit(lambda: ops.flash_attn_bwd(q, k, v, o, do, lse, H), a.iters)
+        fl = 10.0 * s * s * D       # the 5 necessary products (the two-kernel form computes 7)
+        print(f"flash_attn_bwd S={s} H={H}: median {med:.3f} ms ({fl / med / 1e9:.1f} TFLOP/s algorithmic, "
+              f"{1.4 * fl / med / 1e9:.1f} executed)")
     elif a.what == "gemm":
         x = torch.randn((s, D), device="cuda").to(BF)
         xf = torch.randn((s, F), device="cuda").to(BF)
