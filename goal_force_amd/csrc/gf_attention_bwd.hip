@@ -11,16 +11,17 @@
 // row is on the lane and the per-row scalars (lse, delta) are per-lane (dQ) or per-register broadcast reads (dK/dV); the
 // fp32 accumulator converted pairwise to bf16 is the B operand of the second product; row fragments by ds_read_b128
 // and transposed fragments by ds_read_b64_tr_b16 from ONE XOR-swizzled 64 x 128 tile image staged by LDS-DMA.
-// Round-1 shape: 4 waves per workgroup (one per SIMD, up to 512 registers), single-buffered tiles, two barriers per tile
-// — correct first; the forward's slot pipeline is the template for making it fast.
+// Round-1 shape: tiles double buffered (the DMA of tile t+1 flies during the products of tile t, one barrier per tile),
+// plain per-tile product order — the forward's slot pipeline is the template for the next step.
 #include "gf_common.h"
 
 namespace {
 
 constexpr int KVB = 64, HD = 128;
 constexpr int TILE_BYTES = KVB * HD * 2;   // 16 KiB
-constexpr int BWD_THREADS = 256;
-constexpr int BWD_ROWS = 128;              // rows (queries or keys) per workgroup
+constexpr int DQ_THREADS = 512, DQ_ROWS = 256;     // dQ: 8 waves x 32 queries, two waves per SIMD (<= 256 registers)
+constexpr int DKV_THREADS = 256, DKV_ROWS = 128;   // dK/dV: 4 waves x 32 keys, one wave per SIMD (~300 registers)
+constexpr int BWD_LDS = 4 * TILE_BYTES + 4 * KVB * (int)sizeof(float);   // two stages of (two tiles + lse + delta)
 
 struct BwdArgs {
     const u16 *q, *k, *v, *o, *dout;
@@ -60,16 +61,18 @@ __device__ __forceinline__ void dma16(const u16* g, GF_LDS char* l) {
 }
 
 // 64 rows x 256 B of `base` (rows row0.., clamped to len-1; head column offset included in base) -> swizzled LDS image.
-// 4 waves: wave w fills row-groups j = 4w..4w+3 (4 rows x 256 B each); the DMA writes lane-linear, so the image's chunk
+// NW waves: wave w fills row-groups j = (16/NW) w .. (4 rows x 256 B each); the DMA writes lane-linear, so the image's chunk
 // swizzle off(row,ch) = 256 row + 16 (ch ^ (((row&3)<<2) | ((row>>2)&3))) is applied to the per-lane SOURCE chunk.
+template <int NW>
 __device__ __forceinline__ void stage_tile(const u16* base, long stride, int row0, int len, GF_LDS char* dst, int wave, int lane) {
+    constexpr int PER = 16 / NW;
     const int dma_r = lane >> 4;
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-        const int j = 4 * wave + jj;
+    for (int jj = 0; jj < PER; ++jj) {
+        const int j = PER * wave + jj;
         const long rr = min(row0 + 4 * j + dma_r, len - 1);
         const int lch = (lane & 15) ^ ((dma_r << 2) | (j & 3));
-        dma16(base + rr * stride + lch * 8, dst + wave * 4096 + jj * 1024);
+        dma16(base + rr * stride + lch * 8, dst + j * 1024);
     }
 }
 
@@ -127,17 +130,15 @@ __device__ __forceinline__ void store_rows(u16* rowp, const f32x16 (&acc)[4], fl
 }
 
 // ---- dQ: wave owns queries q0 + r ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BWD_THREADS, 1) void attn_bwd_dq_kernel(const BwdArgs p) {
+__global__ __launch_bounds__(DQ_THREADS, 2) void attn_bwd_dq_kernel(const BwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     GF_LDS char* lds = (GF_LDS char*)smem;
-    GF_LDS char* kbuf = lds;
-    GF_LDS char* vbuf = lds + TILE_BYTES;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int nqb = (p.q_len + BWD_ROWS - 1) / BWD_ROWS;
+    const int nqb = (p.q_len + DQ_ROWS - 1) / DQ_ROWS;
     const int head = blockIdx.x / nqb, qb = blockIdx.x % nqb;
-    const int q0 = qb * BWD_ROWS + wave * 32;
+    const int q0 = qb * DQ_ROWS + wave * 32;
     const int qr = min(q0 + r, p.q_len - 1);
 
     bf16x8 qf[8], dof[8];
@@ -159,12 +160,18 @@ __global__ __launch_bounds__(BWD_THREADS, 1) void attn_bwd_dq_kernel(const BwdAr
     for (int d = 0; d < 4; ++d) zero16(dq[d]);
 
     const int nt = (p.kv_len + KVB - 1) / KVB;
+    auto stage = [&](int t) {   // stage s = t & 1: K at s*32K, V at s*32K + 16K
+        GF_LDS char* b = lds + (t & 1) * 2 * TILE_BYTES;
+        stage_tile<8>(p.k + head * HD, p.k_stride, t * KVB, p.kv_len, b, wave, lane);
+        stage_tile<8>(p.v + head * HD, p.v_stride, t * KVB, p.kv_len, b + TILE_BYTES, wave, lane);
+    };
+    stage(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     for (int t = 0; t < nt; ++t) {
-        __syncthreads();   // every wave is done reading the previous tile
-        stage_tile(p.k + head * HD, p.k_stride, t * KVB, p.kv_len, kbuf, wave, lane);
-        stage_tile(p.v + head * HD, p.v_stride, t * KVB, p.kv_len, vbuf, wave, lane);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (t + 1 < nt) stage(t + 1);          // lands while this tile is multiplied; its buffer was released by the last barrier
+        GF_LDS char* kbuf = lds + (t & 1) * 2 * TILE_BYTES;
+        GF_LDS char* vbuf = kbuf + TILE_BYTES;
         f32x16 sc[2], dp[2];
         zero16(sc[0]); zero16(sc[1]); zero16(dp[0]); zero16(dp[1]);
 #pragma unroll
@@ -193,24 +200,23 @@ __global__ __launch_bounds__(BWD_THREADS, 1) void attn_bwd_dq_kernel(const BwdAr
             for (int s = 0; s < 2; ++s)
 #pragma unroll
                 for (int d = 0; d < 4; ++d) mfma32(dq[d], tr_frag(kbuf, fo, d, kt, s), dsf[kt][s]);   // dQ^T += K^T dS^T
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
     }
     if (q0 + r < p.q_len) store_rows(p.dq + (long)(q0 + r) * p.dq_stride + head * HD, dq, p.scale, h);
 }
 
 // ---- dK, dV: wave owns keys k0 + r -------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BWD_THREADS, 1) void attn_bwd_dkv_kernel(const BwdArgs p) {
+__global__ __launch_bounds__(DKV_THREADS, 1) void attn_bwd_dkv_kernel(const BwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     GF_LDS char* lds = (GF_LDS char*)smem;
-    GF_LDS char* qbuf = lds;
-    GF_LDS char* dobuf = lds + TILE_BYTES;
-    GF_LDS float* lse_s = (GF_LDS float*)(lds + 2 * TILE_BYTES);
-    GF_LDS float* dl_s = lse_s + KVB;
+    GF_LDS float* scal = (GF_LDS float*)(lds + 4 * TILE_BYTES);    // [stage][lse 64 | delta 64]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int nkb = (p.kv_len + BWD_ROWS - 1) / BWD_ROWS;
+    const int nkb = (p.kv_len + DKV_ROWS - 1) / DKV_ROWS;
     const int head = blockIdx.x / nkb, kb = blockIdx.x % nkb;
-    const int k0 = kb * BWD_ROWS + wave * 32;
+    const int k0 = kb * DKV_ROWS + wave * 32;
     const int kr = min(k0 + r, p.kv_len - 1);
 
     bf16x8 kf[8], vf[8];
@@ -233,17 +239,25 @@ __global__ __launch_bounds__(BWD_THREADS, 1) void attn_bwd_dkv_kernel(const BwdA
     }
 
     const int nt = (p.q_len + KVB - 1) / KVB;
-    for (int t = 0; t < nt; ++t) {
-        __syncthreads();
-        stage_tile(p.q + head * HD, p.q_stride, t * KVB, p.q_len, qbuf, wave, lane);
-        stage_tile(p.dout + head * HD, p.do_stride, t * KVB, p.q_len, dobuf, wave, lane);
-        if (tid < KVB) {
+    auto stage = [&](int t) {   // stage s = t & 1: Q at s*32K, dO at s*32K + 16K, lse/delta at scal + s*128
+        GF_LDS char* b = lds + (t & 1) * 2 * TILE_BYTES;
+        if (tid < KVB) {   // before the DMA pieces: the wait for these two loads must not cover the tiles in flight
             const long qi = min(t * KVB + tid, p.q_len - 1);
-            lse_s[tid] = p.lse[qi * p.heads + head];
-            dl_s[tid] = p.delta[qi * p.heads + head];
+            scal[(t & 1) * 2 * KVB + tid] = p.lse[qi * p.heads + head];
+            scal[(t & 1) * 2 * KVB + KVB + tid] = p.delta[qi * p.heads + head];
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        stage_tile<4>(p.q + head * HD, p.q_stride, t * KVB, p.q_len, b, wave, lane);
+        stage_tile<4>(p.dout + head * HD, p.do_stride, t * KVB, p.q_len, b + TILE_BYTES, wave, lane);
+    };
+    stage(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        if (t + 1 < nt) stage(t + 1);
+        GF_LDS char* qbuf = lds + (t & 1) * 2 * TILE_BYTES;
+        GF_LDS char* dobuf = qbuf + TILE_BYTES;
+        GF_LDS float* lse_s = scal + (t & 1) * 2 * KVB;
+        GF_LDS float* dl_s = lse_s + KVB;
         f32x16 sc[2], dp[2];
         zero16(sc[0]); zero16(sc[1]); zero16(dp[0]); zero16(dp[1]);
 #pragma unroll
@@ -283,6 +297,8 @@ __global__ __launch_bounds__(BWD_THREADS, 1) void attn_bwd_dkv_kernel(const BwdA
                     mfma32(dv[d], tr_frag(dobuf, fo, d, kt, s), pf[kt][s]);    // dV^T += dO^T P
                     mfma32(dk[d], tr_frag(qbuf, fo, d, kt, s), dsf[kt][s]);    // dK^T += Q^T dS
                 }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
     }
     if (k0 + r < p.kv_len) {
         store_rows(p.dk + (long)(k0 + r) * p.dk_stride + head * HD, dk, p.scale, h);
@@ -311,7 +327,7 @@ extern "C" GF_API int gf_flash_attn_bwd(const void* q, const void* k, const void
                      gf_aligned16(dq) && gf_aligned16(dk) && gf_aligned16(dv),
                  "gf_flash_attn_bwd: 16-byte alignment required");
     static bool attr_set = false;
-    const int lds_bytes = 2 * TILE_BYTES + 2 * KVB * (int)sizeof(float);
+    const int lds_bytes = BWD_LDS;
     if (!attr_set) {
         hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -334,9 +350,9 @@ extern "C" GF_API int gf_flash_attn_bwd(const void* q, const void* k, const void
     hipStream_t s = (hipStream_t)stream;
     const long nd = q_len * heads;
     hipLaunchKernelGGL(attn_bwd_delta_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, s, a);
-    const unsigned nqb = (unsigned)((q_len + BWD_ROWS - 1) / BWD_ROWS), nkb = (unsigned)((kv_len + BWD_ROWS - 1) / BWD_ROWS);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(nqb * (unsigned)heads), dim3(BWD_THREADS), lds_bytes, s, a);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(nkb * (unsigned)heads), dim3(BWD_THREADS), lds_bytes, s, a);
+    const unsigned nqb = (unsigned)((q_len + DQ_ROWS - 1) / DQ_ROWS), nkb = (unsigned)((kv_len + DKV_ROWS - 1) / DKV_ROWS);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(nqb * (unsigned)heads), dim3(DQ_THREADS), lds_bytes, s, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(nkb * (unsigned)heads), dim3(DKV_THREADS), lds_bytes, s, a);
     GF_CHECK_LAUNCH("gf_flash_attn_bwd");
     return GF_OK;
 }

@@ -95,12 +95,18 @@ def init_from_env(backend: Optional[str] = None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # GF_DIST_BACKEND=gloo: several ranks sharing one GPU (RCCL wants one device per rank) — used to exercise the
+            # N>1 code path on a single-GPU box; gloo carries device tensors through host memory
+            backend = os.environ.get("GF_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        if torch.cuda.is_available():
+            local = local % max(1, torch.cuda.device_count())
         if backend == "nccl":
             torch.cuda.set_device(local)
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    if torch.cuda.is_available():
+        local = local % max(1, torch.cuda.device_count())
     return rank, local, world
