@@ -23,6 +23,27 @@
 #include "gf_common.h"
 #include <cstdlib>
 
+// GF_GEMM_STAMP: diagnostic build only (tools/gemm_stamps.py) — per-segment s_memtime sums of waves 0 and 4 of
+// workgroup 0 of the phased kernel, written to a debug buffer; the shipped library is built without it.
+#ifndef GF_GEMM_STAMP
+#define GF_GEMM_STAMP 0
+#endif
+#if GF_GEMM_STAMP
+static unsigned long long* g_gemm_dbg = nullptr;
+extern "C" GF_API void gf_debug_set_gemm_buffer(void* p) { g_gemm_dbg = (unsigned long long*)p; }
+#define GSTAMP(i)                                                                           \
+    {                                                                                       \
+        unsigned long long t_;                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        seg[i] += t_ - tprev;                                                               \
+        tprev = t_;                                                                         \
+    }
+#else
+#define GSTAMP(i)
+#endif
+
 namespace {
 
 constexpr int BM = 256, BN = 256, BK = 64;
@@ -43,6 +64,7 @@ struct GemmArgs {
     int M, N, K;
     long lda, ldw, ldc, ldr;
     int tiles_m, tiles_n;
+    unsigned long long* dbg;
 };
 
 __device__ __forceinline__ void glds16(const void* g, GF_LDS char* l) {
@@ -354,6 +376,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // (Tried and measured: issuing the phase's two DMA pieces inside this burst instead of in the load segment — the
+    // stamps of tools/gemm_stamps.py put the load segment at 527 cycles against a 340-cycle burst — ran 4 % SLOWER: the two
+    // waves of a SIMD share one issue budget, moving work between them does not net.)
     auto mma = [&](int a, int b) {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -397,44 +422,62 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs
     if (wr == 1) __builtin_amdgcn_s_barrier();  // wave row 1 runs half a phase behind wave row 0
 
 #define GF_PHASE_END(SEQ_ISSUED)                                                  \
+    GSTAMP(1)                                                                    \
     if ((SEQ_ISSUED) < total) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   \
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        \
+    GSTAMP(2)                                                                    \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                           \
+    GSTAMP(3)                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                           \
-    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();                                                \
+    GSTAMP(4)
 
+#if GF_GEMM_STAMP
+    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
+#endif
+#define GF_AFTER_MMA                       \
+    GSTAMP(5)                              \
+    __builtin_amdgcn_sched_barrier(0);     \
+    __builtin_amdgcn_s_barrier();          \
+    GSTAMP(6)
     for (int c = 0; c < nk; ++c) {
         GF_LDS char* buf = lds + (c & 1) * STAGE_BYTES;
         const int g = 4 * c;
         // ---- phase 0: stream B1(c+1); read A-sub0, B-sub0; quadrant (0,0)
         if (g + 6 < total) stage(c + 1, 2);
+        GSTAMP(0)
         read_b(buf, 0);
         read_a(buf, 0);
         GF_PHASE_END(g + 6)
         mma(0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        GF_AFTER_MMA
         // ---- phase 1: stream A1(c+1); read B-sub1; quadrant (0,1)
         if (g + 7 < total) stage(c + 1, 3);
+        GSTAMP(0)
         read_b(buf, 1);
         GF_PHASE_END(g + 7)
         mma(0, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        GF_AFTER_MMA
         // ---- phase 2: stream A0(c+2); read A-sub1; quadrant (1,1)
         if (g + 8 < total) stage(c + 2, 0);
+        GSTAMP(0)
         read_a(buf, 1);
         GF_PHASE_END(g + 8)
         mma(1, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        GF_AFTER_MMA
         // ---- phase 3: stream B0(c+2); no LDS read (B-sub0 still in registers); quadrant (1,0)
         if (g + 9 < total) stage(c + 2, 1);
+        GSTAMP(0)
         GF_PHASE_END(g + 9)
         mma(1, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        GF_AFTER_MMA
     }
+#undef GF_AFTER_MMA
+#if GF_GEMM_STAMP
+    if (p.dbg && blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0)
+        for (int i = 0; i < 8; ++i) p.dbg[(wave >> 2) * 8 + i] = seg[i];
+#endif
 #undef GF_PHASE_END
     if (wr == 0) __builtin_amdgcn_s_barrier();  // pairs with wave row 1's last barrier: everyone is past its LDS reads
 
@@ -570,6 +613,11 @@ static int gemm_dispatch(bool fp8, const void* A, int64_t lda, const void* W, in
     a.ldr = ldr;
     a.tiles_m = (int)((M + BM - 1) / BM);
     a.tiles_n = (int)((N + BN - 1) / BN);
+#if GF_GEMM_STAMP
+    a.dbg = g_gemm_dbg;
+#else
+    a.dbg = nullptr;
+#endif
     hipStream_t s = (hipStream_t)stream;
 #define GF_GEMM_CASE(E) case E: return fp8 ? launch_gemm<E, true>(a, s) : launch_gemm<E, false>(a, s);
     switch (epilogue) {
