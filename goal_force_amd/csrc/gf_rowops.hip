@@ -132,6 +132,113 @@ __global__ __launch_bounds__(ROW_THREADS) void rmsnorm_rope_kernel(
     }
 }
 
+// ---- one WAVE per row (dim = NCH * 512): the row lives in one wave's registers, both reductions are wave shuffles, no LDS,
+// no barrier, no ragged-chunk predicates; 4 rows per 256-thread workgroup.  Used for the DiT widths (5120, 4096, 1536);
+// the 128-thread kernels above stay for every other width.
+constexpr int WROWS = 4;
+
+template <int NCH>
+__global__ __launch_bounds__(64 * WROWS) void layernorm_modulate_wave_kernel(
+    const u16* __restrict__ x, u16* __restrict__ out, const u16* __restrict__ weight, const u16* __restrict__ bias,
+    const u16* __restrict__ scale1p, const u16* __restrict__ shift, long rows, long x_stride, long out_stride, float eps) {
+    constexpr int DIM = NCH * 512;
+    const long row = (long)blockIdx.x * WROWS + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const u16* xr = x + row * x_stride + lane * 8;
+    u16x8 v[NCH];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        v[i] = *reinterpret_cast<const u16x8*>(xr + i * 512);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += bf2f(v[i][j]);
+    }
+    const float mean = wave_sum(s) * (1.0f / DIM);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float d = bf2f(v[i][j]) - mean;
+            q += d * d;
+        }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / DIM) + eps);
+    u16* orow = out + row * out_stride + lane * 8;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c0 = i * 512 + lane * 8;
+        u16x8 w8, b8, sc8, sh8, o;
+        if (weight) w8 = *reinterpret_cast<const u16x8*>(weight + c0);
+        if (bias) b8 = *reinterpret_cast<const u16x8*>(bias + c0);
+        if (scale1p) sc8 = *reinterpret_cast<const u16x8*>(scale1p + c0);
+        if (shift) sh8 = *reinterpret_cast<const u16x8*>(shift + c0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float y = (bf2f(v[i][j]) - mean) * rstd;
+            if (weight) y = y * bf2f(w8[j]);
+            if (bias) y = y + bf2f(b8[j]);
+            y = rbf(y);                                   // .type_as(x)
+            if (scale1p) y = rbf(y * bf2f(sc8[j]));       // x * (1 + scale)
+            if (shift) y = rbf(y + bf2f(sh8[j]));         // + shift
+            o[j] = f2bf(y);
+        }
+        *reinterpret_cast<u16x8*>(orow + i * 512) = o;
+    }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(64 * WROWS) void rmsnorm_rope_wave_kernel(u16* __restrict__ x, const u16* __restrict__ weight,
+                                                                         const float* __restrict__ cos_tab,
+                                                                         const float* __restrict__ sin_tab, long rows,
+                                                                         int head_dim, long x_stride, float eps) {
+    constexpr int DIM = NCH * 512;
+    const long row = (long)blockIdx.x * WROWS + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    u16* xr = x + row * x_stride + lane * 8;
+    u16x8 v[NCH];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        v[i] = *reinterpret_cast<const u16x8*>(xr + i * 512);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float f = bf2f(v[i][j]);
+            s += f * f;
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(s) * (1.0f / DIM) + eps);
+    const int half = head_dim >> 1;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c0 = i * 512 + lane * 8;
+        const u16x8 w8 = *reinterpret_cast<const u16x8*>(weight + c0);
+        float y[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float n = rbf(bf2f(v[i][j]) * rstd);  // norm(x.float()).to(dtype)
+            y[j] = rbf(n * bf2f(w8[j]));                // * weight (bf16 multiply)
+        }
+        u16x8 o;
+        if (cos_tab) {
+            const int p0 = (c0 % head_dim) >> 1;        // first complex pair of this chunk
+            const f32x4 cs = *reinterpret_cast<const f32x4*>(cos_tab + row * half + p0);
+            const f32x4 sn = *reinterpret_cast<const f32x4*>(sin_tab + row * half + p0);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const float a = y[2 * p], b = y[2 * p + 1];
+                o[2 * p] = f2bf(a * cs[p] - b * sn[p]);
+                o[2 * p + 1] = f2bf(a * sn[p] + b * cs[p]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = f2bf(y[j]);
+        }
+        *reinterpret_cast<u16x8*>(xr + i * 512) = o;
+    }
+}
+
 // fp8 activation quantisation of AutoWrappedLinear.fp8_linear (VRAM:115-140):
 //   scale_a = clamp(rowmax|x| / 448, min=1)  (fp32);   x8 = e4m3(float(x) / (scale_a + 1e-8))
 // OCP e4m3fn on gfx950 (not MI300's fnuz).  One workgroup per row, row kept in registers.
@@ -238,6 +345,17 @@ extern "C" GF_API int gf_layernorm_modulate(const void* x, void* out, const void
                      (!scale1p || gf_aligned16(scale1p)) && (!shift || gf_aligned16(shift)),
                  "gf_layernorm_modulate: vectors must be 16-byte aligned");
     if (rows == 0) return GF_OK;
+#define GF_LN_WAVE(NCH)                                                                                                  \
+    if (dim == NCH * 512) {                                                                                              \
+        hipLaunchKernelGGL(layernorm_modulate_wave_kernel<NCH>, dim3((unsigned)((rows + WROWS - 1) / WROWS)),            \
+                           dim3(64 * WROWS), 0, (hipStream_t)stream, (const u16*)x, (u16*)out, (const u16*)weight,       \
+                           (const u16*)bias, (const u16*)scale1p, (const u16*)shift, (long)rows, (long)x_stride,        \
+                           (long)out_stride, eps);                                                                       \
+        GF_CHECK_LAUNCH("gf_layernorm_modulate");                                                                        \
+        return GF_OK;                                                                                                    \
+    }
+    GF_LN_WAVE(10) GF_LN_WAVE(8) GF_LN_WAVE(3)
+#undef GF_LN_WAVE
     hipLaunchKernelGGL(layernorm_modulate_kernel, dim3((unsigned)rows), dim3(ROW_THREADS), 0,
                        (hipStream_t)stream, (const u16*)x, (u16*)out, (const u16*)weight, (const u16*)bias,
                        (const u16*)scale1p, (const u16*)shift, (int)dim, (long)x_stride, (long)out_stride, eps);
@@ -259,6 +377,16 @@ extern "C" GF_API int gf_rmsnorm_rope(void* x, const void* weight, const float* 
                      (!cos_tab || (gf_aligned16(cos_tab) && gf_aligned16(sin_tab))),
                  "gf_rmsnorm_rope: 16-byte alignment required");
     if (rows == 0) return GF_OK;
+#define GF_RMS_WAVE(NCH)                                                                                                 \
+    if (dim == NCH * 512) {                                                                                              \
+        hipLaunchKernelGGL(rmsnorm_rope_wave_kernel<NCH>, dim3((unsigned)((rows + WROWS - 1) / WROWS)), dim3(64 * WROWS), \
+                           0, (hipStream_t)stream, (u16*)x, (const u16*)weight, cos_tab, sin_tab, (long)rows,            \
+                           (int)head_dim, (long)x_stride, eps);                                                          \
+        GF_CHECK_LAUNCH("gf_rmsnorm_rope");                                                                              \
+        return GF_OK;                                                                                                    \
+    }
+    GF_RMS_WAVE(10) GF_RMS_WAVE(8) GF_RMS_WAVE(3)
+#undef GF_RMS_WAVE
     hipLaunchKernelGGL(rmsnorm_rope_kernel, dim3((unsigned)rows), dim3(ROW_THREADS), 0, (hipStream_t)stream,
                        (u16*)x, (const u16*)weight, cos_tab, sin_tab, (int)dim, (int)head_dim, (long)x_stride, eps);
     GF_CHECK_LAUNCH("gf_rmsnorm_rope");
