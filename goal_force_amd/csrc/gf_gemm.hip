@@ -22,6 +22,7 @@
 //   * M and N tails: loads clamp the row index, stores are masked.
 #include "gf_common.h"
 #include <cstdlib>
+#include <type_traits>
 
 // GF_GEMM_STAMP: diagnostic build only (tools/gemm_stamps.py) — per-segment s_memtime sums of waves 0 and 4 of
 // workgroup 0 of the phased kernel, written to a debug buffer; the shipped library is built without it.
@@ -545,8 +546,261 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs
     }
 }
 
+// ================================================================================================================
+// EXPERIMENTAL, NOT THE SHIPPED PATH (GF_GEMM_KERNEL=sl selects it; parity-tested): measured 1.07 / 1.22 / 1.20 PFLOP/s
+// against the phased kernel's 1.18 / 1.34 / 1.35.  What-if builds: without its DMA instructions the same loop runs at
+// 1.85 PFLOP/s, without its barrier and waits still at 1.22 — with ONE wave per SIMD the LDS-DMA issue back-pressure
+// (misses queue in the vector memory path; tools/issue_probe.py shows the mix at full rate only on cached sources)
+// stalls the wave's MFMAs too, while the phased kernel's second wave per SIMD computes through those stalls.
+// gemm_sl_kernel — slot-scheduled bf16 GEMM: 4 waves per workgroup (ONE per SIMD, up to 512 registers), 256x256 tile,
+// 128x128 per wave on v_mfma_f32_32x32x16_bf16 with the 256 fp32 accumulators in AGPRs.
+// Why: tools/gemm_stamps.py shows the phased kernel issue-bound on its coarse structure (a load segment of 2 DMA pieces
+// + 8-12 ds_read + waits is longer than the MFMA burst it is paired with), while tools/issue_probe.py shows the SAME
+// instruction mix finely interleaved — per 8 MFMAs 4 ds_read_b128 and 2 LDS-DMA pieces — running at 32.5 cycles per
+// 32x32x16 MFMA, i.e. at the matrix pipe's rate.  So here every wave runs one software pipeline:
+//   * K-step 32 per stage, NST = 4 stages of (256 x 64 B of A + 256 x 64 B of W) = 128 KiB; tile t+3 streams in by
+//     LDS-DMA while tile t is multiplied; ONE barrier per K-tile, placed between its two 16-k halves;
+//   * half h of tile t = 16 MFMAs (4 x 4 accumulator tiles) on the fragment set read during the previous half; its 16
+//     slots carry, pinned in order, the 8 fragment reads of the next half (even slots) and 4 of the 8 DMA pieces of
+//     tile t+3 (slots 1, 5, 9, 13);
+//   * LDS image: 64-byte rows, 16-byte chunk index XOR ((row >> 2) & 3) — conflict-free for the 32-row x 2-chunk
+//     fragment read of the 32x32x16 form (16 consecutive lanes cover one 256-byte bank period);
+//   * DMA in the saddr form (SGPR base + 32-bit VGPR offset): advancing K is one scalar add per operand and tile;
+//   * same swapped-operand / whole-tile LDS epilogue and fused epilogues as the phased kernel.
+constexpr int SL_THREADS = 256;
+constexpr int SL_BK = 32;
+constexpr int SL_NST = 4;
+constexpr int SL_STAGE = 2 * 256 * SL_BK * 2;      // 32 KiB: A then W
+constexpr int SL_LDS = SL_NST * SL_STAGE;          // 128 KiB (the epilogue's 256 x 512 B image reuses it)
+
+__device__ __forceinline__ void sl_dma(const void* base, unsigned off, GF_LDS char* l) {
+    unsigned keep;
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)l);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(off), "s"(base), "s"(dst)
+                 : "memory");
+}
+
+template <int EPI>
+__global__ __launch_bounds__(SL_THREADS, 1) void gemm_sl_kernel(const GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    GF_LDS char* lds = (GF_LDS char*)smem;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    int v;
+    {
+        const int pid = blockIdx.x;
+        const int xcd = pid & 7, local = pid >> 3;
+        const int q = nwg >> 3, rr = nwg & 7;
+        v = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + local;
+    }
+    const int per_group = GROUP_M * p.tiles_n;
+    const int group = v / per_group;
+    const int first_m = group * GROUP_M;
+    const int gsz = min(p.tiles_m - first_m, GROUP_M);
+    const int in_group = v - group * per_group;
+    const int m0 = (first_m + in_group % gsz) * BM, n0 = (in_group / gsz) * BN;
+
+    // ---- DMA: a piece = 16 rows x 64 B; wave w stages pieces 4w..4w+3 of A (rows 64w..) and of W.  Lane L fills physical
+    // chunk L&3 of row L>>2, which holds logical chunk (L&3) ^ ((row>>2)&3).
+    unsigned offA[4], offB[4];
+    {
+        const int prow = lane >> 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (4 * wave + i) * 16 + prow;                     // 0..255 inside the tile
+            const int lch = (lane & 3) ^ ((row >> 2) & 3);
+            const long ra = min(m0 + row, p.M - 1), rb = min(n0 + row, p.N - 1);
+            offA[i] = (unsigned)((ra * p.lda + lch * 8) * 2);
+            offB[i] = (unsigned)((rb * p.ldw + lch * 8) * 2);
+        }
+    }
+    const int nk = p.K / SL_BK;
+    // piece 0..3: A, 4..7: W of the tile whose operand bases are (ta, tw) and whose stage starts at byte `stage_off`
+    auto dma_piece = [&](const char* ta, const char* tw, int stage_off, int piece) {
+        GF_LDS char* dst = lds + stage_off + (piece >> 2) * (SL_STAGE / 2) + (4 * wave + (piece & 3)) * 1024;
+        sl_dma(piece < 4 ? ta : tw, piece < 4 ? offA[piece & 3] : offB[piece & 3], dst);
+    };
+    // ---- fragment addresses (without the stage base): rows wr*128 + 32 i + r (A) / wc*128 + 32 j + r (W), chunk (2 ks + h)
+    const int key = (r >> 2) & 3;
+    int a_rd[2], b_rd[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        a_rd[ks] = (wr * 128 + r) * 64 + (((2 * ks + h) ^ key) << 4);
+        b_rd[ks] = SL_STAGE / 2 + (wc * 128 + r) * 64 + (((2 * ks + h) ^ key) << 4);
+    }
+    bf16x8 fa[2][4], fb[2][4];                 // [fragment set][row tile / column tile]
+    auto read_frag = [&](int set, int idx, int stage_off, int ks) {   // idx 0..3: A row tile, 4..7: W column tile
+        if (idx < 4) fa[set][idx] = *(GF_LDS bf16x8*)(lds + stage_off + a_rd[ks] + idx * 2048);
+        else fb[set][idx - 4] = *(GF_LDS bf16x8*)(lds + stage_off + b_rd[ks] + (idx - 4) * 2048);
+    };
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // one half: 16 MFMAs on fragment set CUR; slot m also carries read m/2 of the next set (even m) and one DMA piece (m = 1,
+    // 5, 9, 13; skipped behind a uniform branch once nothing is left to stream).  sched_barrier(0) after every slot pins
+    // the written order (MFMA and DMA are volatile asms).  ONE loop body for every tile: the accumulators keep their
+    // registers — hipcc does not know the asm MFMAs' latency and must never be given a reason to copy them in the loop.
+    auto half = [&](auto cur_c, int next_stage_off, int next_ks, bool stream, const char* ta, const char* tw, int dma_stage_off,
+                    int dma_piece0) {
+        constexpr int CUR = decltype(cur_c)::value;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const int i = m >> 2, j = m & 3;
+            // The 256 accumulators would fill the AGPR file to the last register (hipcc then spills, and scratch traffic
+            // counts in the same vmcnt as the DMA): rows 0-2 of the accumulator grid are pinned to AGPRs, row 3 to VGPRs.
+            if (i < 3) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fb[CUR][j]), "v"(fa[CUR][i]));
+            else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(fb[CUR][j]), "v"(fa[CUR][i]));
+            // next set: the four W fragments first (every MFMA of a half needs one of them at once), then the A fragments
+            // (row tile i is first used by MFMA 4 i): the youngest reads are the ones needed last
+            if ((m & 1) == 0) read_frag(1 - CUR, ((m >> 1) + 4) & 7, next_stage_off, next_ks);
+            if ((m & 3) == 1 && stream) dma_piece(ta, tw, dma_stage_off, dma_piece0 + (m >> 2));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    typedef std::integral_constant<int, 0> C0;
+    typedef std::integral_constant<int, 1> C1;
+    auto handoff = [&](int outstanding) {   // own pieces of the next tile landed, own fragment reads done, then the barrier
+        if (outstanding == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (outstanding == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (outstanding == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // no lgkmcnt wait: the reads in flight belong to tile t's stage, which is only refilled after the NEXT barrier, and
+        // by then the second half's MFMAs have consumed them
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- prologue: tiles 0..2 in flight, tile 0 landed, fragment set 0 = (tile 0, k-half 0)
+    const char* const a0p = (const char*)p.A;
+    const char* const w0p = (const char*)p.W;
+#pragma unroll 1
+    for (int t = 0; t < SL_NST - 1 && t < nk; ++t)
+#pragma unroll
+        for (int pc = 0; pc < 8; ++pc) dma_piece(a0p + (long)t * (SL_BK * 2), w0p + (long)t * (SL_BK * 2), t * SL_STAGE, pc);
+    handoff(nk >= 3 ? 16 : (nk == 2 ? 8 : 0));
+#pragma unroll
+    for (int idx = 0; idx < 8; ++idx) read_frag(0, (idx + 4) & 7, 0, 0);
+
+    // tile t+3 streams in while tile t is multiplied (its stage was released by the barrier inside tile t-1); past the end
+    // the fragment prefetch reads a stale stage (harmless) and the DMA slots are skipped
+#pragma unroll 1
+    for (int t = 0; t < nk; ++t) {
+        const int st = (t & (SL_NST - 1)) * SL_STAGE, stn = ((t + 1) & (SL_NST - 1)) * SL_STAGE;
+        const int std_ = ((t + 3) & (SL_NST - 1)) * SL_STAGE;
+        const bool stream = t + 3 < nk;
+        const char* ta = a0p + (long)(t + 3) * (SL_BK * 2);
+        const char* tw = w0p + (long)(t + 3) * (SL_BK * 2);
+        half(C0{}, st, 1, stream, ta, tw, std_, 0);     // (t, k 0..15); reads (t, k 16..31); A pieces of t+3
+        handoff(stream ? 12 : (t + 2 < nk ? 8 : 0));    // tile t+1 complete in LDS; nobody reads tile t's first half any more
+        half(C1{}, stn, 0, stream, ta, tw, std_, 4);    // (t, k 16..31); reads (t+1, k 0..15); W pieces of t+3
+    }
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results before anything else reads them
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();   // every wave is past its LDS reads: the stages become the epilogue image
+
+    // ---- epilogue: bf16 tile -> swizzled 256 x 256 LDS image (512-byte rows) -> full-row stores
+    // acc[i][j][4g + q] = C[m0 + wr*128 + 32 i + r][n0 + wc*128 + 32 j + 8 g + 4 h + q]
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int ncol = wc * 128 + j * 32 + g * 8 + h * 4;
+            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias && n0 + ncol < p.N) {
+                const u16x4 b4 = *reinterpret_cast<const u16x4*>(p.bias + n0 + ncol);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bv[q] = bf2f(b4[q]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = wr * 128 + i * 32 + r;
+                float y[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    y[q] = rbf(acc[i][j][4 * g + q] + bv[q]);  // the Linear's own bf16 output
+                    if (EPI == GF_EPI_BIAS_GELU_TANH) y[q] = gelu_tanh_f(y[q]);
+                    if (EPI == GF_EPI_BIAS_SILU) y[q] = y[q] / (1.0f + expf(-y[q]));
+                }
+                u32x2 pk;
+                pk[0] = pack2bf(y[0], y[1]);
+                pk[1] = pack2bf(y[2], y[3]);
+                const int slot = (ncol >> 2) ^ ((row & 31) << 1);  // 8-byte slot (64 per row); 16-byte pairs stay together
+                *(GF_LDS u32x2*)(lds + row * 512 + slot * 8) = pk;
+            }
+        }
+    __syncthreads();
+    {
+        const int cc = lane & 31;                 // 16-byte chunk of the row
+        const int n = n0 + cc * 8;
+        const bool n_ok = n < p.N;
+        u16x8 g8;
+        if (EPI == GF_EPI_BIAS_GATE_RESID && n_ok) g8 = *reinterpret_cast<const u16x8*>(p.gate + n);
+#pragma unroll 4
+        for (int it = 0; it < 32; ++it) {
+            const int row = wave * 64 + it * 2 + (lane >> 5);
+            const int m = m0 + row;
+            const u16x8 yv = *(GF_LDS u16x8*)(lds + row * 512 + ((cc ^ (row & 31)) << 4));
+            if (m < p.M && n_ok) {
+                u16x8 o = yv;
+                if (EPI == GF_EPI_BIAS_GATE_RESID || EPI == GF_EPI_BIAS_RESID || EPI == GF_EPI_BIAS_MUL) {
+                    const u16x8 r8 = *reinterpret_cast<const u16x8*>(p.R + (long)m * p.ldr + n);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float t = bf2f(yv[e]);
+                        if (EPI == GF_EPI_BIAS_GATE_RESID) t = rbf(bf2f(g8[e]) * t);  // gate * residual
+                        o[e] = (EPI == GF_EPI_BIAS_MUL) ? f2bf(t * bf2f(r8[e]))       // fc1(x) * gelu(gate(x))
+                                                        : f2bf(bf2f(r8[e]) + t);      // x + ...
+                    }
+                }
+                *reinterpret_cast<u16x8*>(p.C + (long)m * p.ldc + n) = o;
+            }
+        }
+    }
+}
+
+template <int EPI>
+int launch_gemm_sl(const GemmArgs& a, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sl_kernel<EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, SL_LDS);
+        if (e != hipSuccess) {
+            gf_set_error("gf_gemm: hipFuncSetAttribute(%d B LDS) failed: %s", SL_LDS, hipGetErrorString(e));
+            return GF_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_sl_kernel<EPI>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(SL_THREADS), SL_LDS, stream, a);
+    GF_CHECK_LAUNCH("gf_gemm_bf16");
+    return GF_OK;
+}
+
 template <int EPI, bool FP8>
 int launch_gemm(const GemmArgs& a, hipStream_t stream) {
+    if constexpr (!FP8) {
+        // bf16: GF_GEMM_KERNEL=sl selects the experimental slot-scheduled kernel (A/B); its DMA offsets are 32-bit byte
+        // offsets from the operand base
+        static int use_sl = -1;
+        if (use_sl < 0) {
+            const char* ek = getenv("GF_GEMM_KERNEL");
+            use_sl = (ek && ek[0] == 's') ? 1 : 0;
+        }
+        if (use_sl && (long)a.M * a.lda < (1L << 31) && (long)a.N * a.ldw < (1L << 31)) return launch_gemm_sl<EPI>(a, stream);
+    }
     static bool attr_set = false;  // per-instantiation; benign race (idempotent call)
     static bool use_v1 = false;
     if (!attr_set) {

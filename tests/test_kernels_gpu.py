@@ -308,3 +308,30 @@ def test_abi_error_channel(ops):
     q = torch.zeros((8, 2 * 64), dtype=BF, device="cuda")
     with pytest.raises(_lib.GoalForceError, match="head_dim"):
         ops.flash_attn(q, q, q, 2)
+
+
+def test_gemm_experimental_slot_kernel_in_subprocess():
+    """GF_GEMM_KERNEL=sl (read once per process) selects the one-wave-per-SIMD slot-scheduled kernel: keep it correct."""
+    import subprocess
+    import sys
+    code = r'''
+import math, torch
+import torch.nn.functional as F
+from goal_force_amd import ops
+torch.manual_seed(3)
+for (M, N, K) in ((256, 256, 64), (300, 520, 192), (1000, 768, 1024)):
+    a = torch.randn((M, K), device="cuda").to(torch.bfloat16)
+    w = (torch.randn((N, K), device="cuda") / math.sqrt(K)).to(torch.bfloat16)
+    b = torch.randn((N,), device="cuda").to(torch.bfloat16)
+    r = torch.randn((M, N), device="cuda").to(torch.bfloat16)
+    g = torch.randn((N,), device="cuda").to(torch.bfloat16)
+    ref = F.linear(a.float(), w.float(), b.float())
+    def rel(x, y): return float((x.float() - y).norm() / y.norm())
+    assert rel(ops.gemm(a, w, b), ref) < 2e-3
+    assert rel(ops.gemm(a, w, b, epilogue=ops.EPI_BIAS_GELU_TANH), F.gelu(ref.to(torch.bfloat16).float(), approximate="tanh")) < 3e-3
+    assert rel(ops.gemm(a, w, b, epilogue=ops.EPI_BIAS_GATE_RESID, resid=r, gate=g), r.float() + g.float() * ref) < 3e-3
+print("ok")
+'''
+    env = dict(os.environ, GF_GEMM_KERNEL="sl", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]

@@ -53,6 +53,16 @@ MIXES = [
     ("lds_b128 gemm frag 32 rows, swz (row>>1)&7", dict(ldsq=1, addr="g32t")),
     ("mfma 1 accumulator chain", dict(m=1, nacc=1)),
     ("mfma 2 accumulator chains", dict(m=1, nacc=2)),
+    ("GEMM-X: 8 mfma32 + 4 ldsq + 2 dma / trip", dict(m=1, ldsq_every=2, dma_trip=2, addr="lin16")),
+    ("GEMM-X: 8 mfma32 + 4 ldsq + 1 dma / trip", dict(m=1, ldsq_every=2, dma_trip=1, addr="lin16")),
+    ("GEMM-X: 8 mfma32 + 4 ldsq (no dma)", dict(m=1, ldsq_every=2, addr="lin16")),
+    ("GEMM-X: 8 mfma32 + 2 dma (no lds)", dict(m=1, dma_trip=2, addr="lin16")),
+    ("GEMM-ph: 8 mfma16 + 3 ldsq + 1 dma / trip", dict(m16=1, ldsq_trip=3, dma_trip=1, addr="lin16")),
+    ("dma only (2 / trip)", dict(dma_trip=2, addr="lin16")),
+    ("dma only, 8 rows x 128 B", dict(dma_trip=2, addr="lin16", gaddr="r8")),
+    ("dma only, 16 rows x 64 B", dict(dma_trip=2, addr="lin16", gaddr="r16")),
+    ("GEMM-X mix, dma 8 rows x 128 B", dict(m=1, ldsq_every=2, dma_trip=2, addr="lin16", gaddr="r8")),
+    ("GEMM-X mix, dma 16 rows x 64 B", dict(m=1, ldsq_every=2, dma_trip=2, addr="lin16", gaddr="r16")),
     ("mfma16", dict(m16=1)),
     ("mfma+2pk+1exp", dict(m=1, pk=2, exp=1)),
 ]
@@ -73,7 +83,16 @@ def body(mix):
         for k in range(mix.get("lds", 0)):
             r = 52 + 2 * ((2 * s + k) % 16)
             lines.append(f"ds_read_b64_tr_b16 v[{r}:{r+1}], v16 offset:{4096 * ((2 * s + k) % 4)}")
-        for k in range(mix.get("ldsq", 0)):
+        nq = mix.get("ldsq", 0)
+        if mix.get("ldsq_every") and s % mix["ldsq_every"] == 0:
+            nq = 1
+        if mix.get("ldsq_trip") and s < mix["ldsq_trip"]:
+            nq = 1
+        if mix.get("dma_trip") and s in ((1, 5)[:mix["dma_trip"]]):
+            lines.append(f"s_mov_b32 m0, {32768 + 1024 * s}")
+            lines.append("s_nop 0")
+            lines.append("global_load_lds_dwordx4 v[2:3], off")
+        for k in range(nq):
             r = 52 + 4 * (s % 8)
             lines.append(f"ds_read_b128 v[{r}:{r+3}], v16 offset:{8192 * (s % 4)}")
         for k in range(mix.get("exp", 0)):
@@ -89,9 +108,11 @@ def body(mix):
             lines.append("s_waitcnt lgkmcnt(6)")
         for k in range(mix.get("salu", 0)):
             lines.append(f"s_add_u32 s{24 + k}, s{24 + k}, 1")
-        if mix.get("lds") or mix.get("ldsq"):
+        if mix.get("lds") or mix.get("ldsq") or mix.get("ldsq_every") or mix.get("ldsq_trip"):
             if s % 4 == 3:
                 lines.append("s_waitcnt lgkmcnt(4)")
+        if mix.get("dma_trip") and s == 7:
+            lines.append("s_waitcnt vmcnt(4)")
     return lines
 
 
@@ -99,10 +120,10 @@ def gen():
     out = ['#include <hip/hip_runtime.h>', '#include <cstdio>', '#include <cstdlib>', '#include <cstring>',
            'extern __shared__ char smem[];']
     clob = ",".join([f'"v{i}"' for i in range(8, 184)] + [f'"a{i}"' for i in range(64)] +
-                    [f'"s{i}"' for i in range(20, 30)] + ['"scc"', '"memory"'])
+                    [f'"s{i}"' for i in range(20, 30)] + ['"v2"', '"v3"', '"m0"', '"scc"', '"memory"'])
     for idx, (name, mix) in enumerate(MIXES):
         asm = ["v_mov_b32 v16, %1", "v_mov_b32 v17, 0x3f000000", "v_mov_b32 v18, 0x3f800000", "v_mov_b32 v19, 0",
-               "s_mov_b32 s20, %0"]
+               "s_mov_b32 s20, %0", "v_mov_b32 v2, %2", "v_mov_b32 v3, %3"]
         asm += [f"v_mov_b32 v{r}, 0" for r in range(8, 16)]
         asm += [f"v_accvgpr_write_b32 a{r}, 0" for r in range(64)]
         asm += ["s_nop 7", "1:"] + body(mix) + ["s_sub_u32 s20, s20, 1", "s_cmp_lg_u32 s20, 0", "s_cbranch_scc1 1b",
@@ -117,11 +138,15 @@ def gen():
                 "g32t": "128 * (lane & 31) + 16 * ((lane >> 5) ^ ((lane >> 1) & 7))",
                 "vpat": "256 * (4 * (lane >> 5) + ((lane & 15) >> 2)) + 16 * ((2 * ((lane >> 4) & 1) + ((lane & 3) >> 1)) ^ ((((lane & 15) >> 2) << 2) | (lane >> 5))) + 8 * (lane & 1)",
                 }[mix.get("addr", "lin8")]
+        gexpr = {"lin": "lane * 16", "r8": "(lane >> 3) * 10240 + (lane & 7) * 16",
+                 "r16": "(lane >> 2) * 10240 + (lane & 3) * 16"}[mix.get("gaddr", "lin")]
         out.append(f'__global__ void probe{idx}(int n, float* o) {{\n'
                    f'  int lane = threadIdx.x & 63;\n'
                    f'  int off = {addr};\n'
-                   f'  asm volatile("{text}" :: "s"(n), "v"(off) : {clob});\n'
-                   f'  if (o) o[threadIdx.x] = 0.f;\n}}')
+                   f'  unsigned long long ga = (unsigned long long)(o + (blockIdx.x & 255) * 4096) + {gexpr};\n'
+                   f'  unsigned galo = (unsigned)ga, gahi = (unsigned)(ga >> 32);\n'
+                   f'  asm volatile("{text}\\n\\ts_waitcnt vmcnt(0)" :: "s"(n), "v"(off), "v"(galo), "v"(gahi) : {clob});\n'
+                   f'  if (n < 0) o[threadIdx.x] = 0.f;\n}}')
     out.append("typedef void (*kfn)(int, float*);")
     out.append("static kfn fns[] = {" + ",".join(f"probe{i}" for i in range(len(MIXES))) + "};")
     out.append("static const char* names[] = {" + ",".join(f'"{n}"' for n, _ in MIXES) + "};")
@@ -129,6 +154,8 @@ def gen():
 int main() {
   const int n = 20000;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  float* gbuf = nullptr; if (hipMalloc(&gbuf, 64 << 20) != hipSuccess) { printf("malloc failed\n"); return 1; }
+  hipMemset(gbuf, 0, 64 << 20);
   for (int wps = 1; wps <= 2; ++wps) {
     double base = 0;
     for (unsigned i = 0; i < sizeof(fns) / sizeof(fns[0]); ++i) {
@@ -137,7 +164,7 @@ int main() {
       printf("waves/SIMD=%d %-28s ", wps, names[i]); fflush(stdout);
       for (int rep = 0; rep < 4; ++rep) {
         hipEventRecord(e0, 0);
-        hipLaunchKernelGGL(fns[i], dim3(256), dim3(256 * wps), 65536, 0, n, (float*)nullptr);
+        hipLaunchKernelGGL(fns[i], dim3(256), dim3(256 * wps), 65536, 0, n, gbuf);
         hipEventRecord(e1, 0);
         if (hipEventSynchronize(e1) != hipSuccess) { printf("sync error\n"); return 1; }
         float ms; hipEventElapsedTime(&ms, e0, e1); if (rep && ms < best) best = ms;
