@@ -547,8 +547,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs
 }
 
 // ================================================================================================================
-// EXPERIMENTAL, NOT THE SHIPPED PATH (GF_GEMM_KERNEL=sl selects it; parity-tested): measured 1.07 / 1.22 / 1.20 PFLOP/s
-// against the phased kernel's 1.18 / 1.34 / 1.35.  What-if builds: without its DMA instructions the same loop runs at
+// EXPERIMENTAL, NOT THE SHIPPED PATH (GF_GEMM_KERNEL=sl / sl8 select it; parity-tested): measured 1.07 / 1.22 / 1.20 PFLOP/s
+// (sl8, the two-waves-per-SIMD form: 1.07 / 1.18 / 1.17) against the phased kernel's 1.18 / 1.34 / 1.35.  What-if builds: without its DMA instructions the same loop runs at
 // 1.85 PFLOP/s, without its barrier and waits still at 1.22 — with ONE wave per SIMD the LDS-DMA issue back-pressure
 // (misses queue in the vector memory path; tools/issue_probe.py shows the mix at full rate only on cached sources)
 // stalls the wave's MFMAs too, while the phased kernel's second wave per SIMD computes through those stalls.
@@ -567,7 +567,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs
 //     fragment read of the 32x32x16 form (16 consecutive lanes cover one 256-byte bank period);
 //   * DMA in the saddr form (SGPR base + 32-bit VGPR offset): advancing K is one scalar add per operand and tile;
 //   * same swapped-operand / whole-tile LDS epilogue and fused epilogues as the phased kernel.
-constexpr int SL_THREADS = 256;
 constexpr int SL_BK = 32;
 constexpr int SL_NST = 4;
 constexpr int SL_STAGE = 2 * 256 * SL_BK * 2;      // 32 KiB: A then W
@@ -582,14 +581,20 @@ __device__ __forceinline__ void sl_dma(const void* base, unsigned off, GF_LDS ch
                  : "memory");
 }
 
-template <int EPI>
-__global__ __launch_bounds__(SL_THREADS, 1) void gemm_sl_kernel(const GemmArgs p) {
+// NW = 4: one wave per SIMD, 128x128 per wave (the design described above).  NW = 8: two waves per SIMD, 128x64 per wave (128
+// accumulators, all in AGPRs): the same slot pipeline per wave, and a partner wave whose MFMAs run through this wave's DMA
+// stalls.
+template <int EPI, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 4) void gemm_sl_kernel(const GemmArgs p) {
+    constexpr int NJ = (NW == 4) ? 4 : 2;          // 32-column accumulator tiles per wave
+    constexpr int NPC = 32 / NW;                   // DMA pieces per wave and tile (half A, half W)
+    constexpr int NMF = 4 * NJ;                    // MFMAs per half
     extern __shared__ __attribute__((aligned(16))) char smem[];
     GF_LDS char* lds = (GF_LDS char*)smem;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = (NW == 4) ? (wave >> 1) : (wave >> 2), wc = (NW == 4) ? (wave & 1) : (wave & 3);
     const int r = lane & 31, h = lane >> 5;
 
     const int nwg = p.tiles_m * p.tiles_n;
@@ -607,14 +612,14 @@ __global__ __launch_bounds__(SL_THREADS, 1) void gemm_sl_kernel(const GemmArgs p
     const int in_group = v - group * per_group;
     const int m0 = (first_m + in_group % gsz) * BM, n0 = (in_group / gsz) * BN;
 
-    // ---- DMA: a piece = 16 rows x 64 B; wave w stages pieces 4w..4w+3 of A (rows 64w..) and of W.  Lane L fills physical
+    // ---- DMA: a piece = 16 rows x 64 B; wave w stages pieces (NPC/2) w .. of A and of W.  Lane L fills physical
     // chunk L&3 of row L>>2, which holds logical chunk (L&3) ^ ((row>>2)&3).
-    unsigned offA[4], offB[4];
+    unsigned offA[NPC / 2], offB[NPC / 2];
     {
         const int prow = lane >> 2;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = (4 * wave + i) * 16 + prow;                     // 0..255 inside the tile
+        for (int i = 0; i < NPC / 2; ++i) {
+            const int row = ((NPC / 2) * wave + i) * 16 + prow;             // 0..255 inside the tile
             const int lch = (lane & 3) ^ ((row >> 2) & 3);
             const long ra = min(m0 + row, p.M - 1), rb = min(n0 + row, p.N - 1);
             offA[i] = (unsigned)((ra * p.lda + lch * 8) * 2);
@@ -622,10 +627,12 @@ __global__ __launch_bounds__(SL_THREADS, 1) void gemm_sl_kernel(const GemmArgs p
         }
     }
     const int nk = p.K / SL_BK;
-    // piece 0..3: A, 4..7: W of the tile whose operand bases are (ta, tw) and whose stage starts at byte `stage_off`
+    // piece < NPC/2: A, else W, of the tile whose operand bases are (ta, tw) and whose stage starts at byte `stage_off`
     auto dma_piece = [&](const char* ta, const char* tw, int stage_off, int piece) {
-        GF_LDS char* dst = lds + stage_off + (piece >> 2) * (SL_STAGE / 2) + (4 * wave + (piece & 3)) * 1024;
-        sl_dma(piece < 4 ? ta : tw, piece < 4 ? offA[piece & 3] : offB[piece & 3], dst);
+        const bool isw = piece >= NPC / 2;
+        const int pi = isw ? piece - NPC / 2 : piece;
+        GF_LDS char* dst = lds + stage_off + (isw ? SL_STAGE / 2 : 0) + ((NPC / 2) * wave + pi) * 1024;
+        sl_dma(isw ? tw : ta, isw ? offB[pi] : offA[pi], dst);
     };
     // ---- fragment addresses (without the stage base): rows wr*128 + 32 i + r (A) / wc*128 + 32 j + r (W), chunk (2 ks + h)
     const int key = (r >> 2) & 3;
@@ -633,19 +640,19 @@ __global__ __launch_bounds__(SL_THREADS, 1) void gemm_sl_kernel(const GemmArgs p
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
         a_rd[ks] = (wr * 128 + r) * 64 + (((2 * ks + h) ^ key) << 4);
-        b_rd[ks] = SL_STAGE / 2 + (wc * 128 + r) * 64 + (((2 * ks + h) ^ key) << 4);
+        b_rd[ks] = SL_STAGE / 2 + (wc * (32 * NJ) + r) * 64 + (((2 * ks + h) ^ key) << 4);
     }
-    bf16x8 fa[2][4], fb[2][4];                 // [fragment set][row tile / column tile]
-    auto read_frag = [&](int set, int idx, int stage_off, int ks) {   // idx 0..3: A row tile, 4..7: W column tile
-        if (idx < 4) fa[set][idx] = *(GF_LDS bf16x8*)(lds + stage_off + a_rd[ks] + idx * 2048);
-        else fb[set][idx - 4] = *(GF_LDS bf16x8*)(lds + stage_off + b_rd[ks] + (idx - 4) * 2048);
+    bf16x8 fa[2][4], fb[2][NJ];                // [fragment set][row tile / column tile]
+    auto read_frag = [&](int set, int idx, int stage_off, int ks) {   // idx < NJ: W column tile, else A row tile idx - NJ
+        if (idx < NJ) fb[set][idx] = *(GF_LDS bf16x8*)(lds + stage_off + b_rd[ks] + idx * 2048);
+        else fa[set][idx - NJ] = *(GF_LDS bf16x8*)(lds + stage_off + a_rd[ks] + (idx - NJ) * 2048);
     };
 
-    f32x16 acc[4][4];
+    f32x16 acc[4][NJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
@@ -657,25 +664,29 @@ __global__ __launch_bounds__(SL_THREADS, 1) void gemm_sl_kernel(const GemmArgs p
                     int dma_piece0) {
         constexpr int CUR = decltype(cur_c)::value;
 #pragma unroll
-        for (int m = 0; m < 16; ++m) {
-            const int i = m >> 2, j = m & 3;
-            // The 256 accumulators would fill the AGPR file to the last register (hipcc then spills, and scratch traffic
-            // counts in the same vmcnt as the DMA): rows 0-2 of the accumulator grid are pinned to AGPRs, row 3 to VGPRs.
-            if (i < 3) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fb[CUR][j]), "v"(fa[CUR][i]));
+        for (int m = 0; m < NMF; ++m) {
+            const int i = m / NJ, j = m % NJ;
+            // NW = 4: the 256 accumulators would fill the AGPR file to the last register (hipcc then spills, and scratch
+            // traffic counts in the same vmcnt as the DMA): rows 0-2 of the accumulator grid are pinned to AGPRs, row 3 to
+            // VGPRs.  NW = 8: all 128 in AGPRs.
+            if (NW == 8 || i < 3) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fb[CUR][j]), "v"(fa[CUR][i]));
             else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(fb[CUR][j]), "v"(fa[CUR][i]));
-            // next set: the four W fragments first (every MFMA of a half needs one of them at once), then the A fragments
-            // (row tile i is first used by MFMA 4 i): the youngest reads are the ones needed last
-            if ((m & 1) == 0) read_frag(1 - CUR, ((m >> 1) + 4) & 7, next_stage_off, next_ks);
-            if ((m & 3) == 1 && stream) dma_piece(ta, tw, dma_stage_off, dma_piece0 + (m >> 2));
+            // next set, one read per slot from slot 0: the W fragments first (every MFMA needs one of them at once), then the
+            // A fragments (row tile i is first used by MFMA NJ i): the youngest reads are the ones needed last
+            if (NW == 4 ? ((m & 1) == 0) : (m < 4 + NJ)) read_frag(1 - CUR, NW == 4 ? (m >> 1) : m, next_stage_off, next_ks);
+            if ((m % (NMF / (NPC / 2))) == 1 && stream) dma_piece(ta, tw, dma_stage_off, dma_piece0 + m / (NMF / (NPC / 2)));
             __builtin_amdgcn_sched_barrier(0);
         }
     };
     typedef std::integral_constant<int, 0> C0;
     typedef std::integral_constant<int, 1> C1;
-    auto handoff = [&](int outstanding) {   // own pieces of the next tile landed, own fragment reads done, then the barrier
+    auto handoff = [&](int tiles2) {   // allowed in flight: tiles2 half-tiles' worth of this wave's pieces; then the barrier
+        const int outstanding = tiles2 * (NPC / 2);
         if (outstanding == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else if (outstanding == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
         else if (outstanding == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (outstanding == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (outstanding == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // no lgkmcnt wait: the reads in flight belong to tile t's stage, which is only refilled after the NEXT barrier, and
         // by then the second half's MFMAs have consumed them
@@ -690,10 +701,10 @@ __global__ __launch_bounds__(SL_THREADS, 1) void gemm_sl_kernel(const GemmArgs p
 #pragma unroll 1
     for (int t = 0; t < SL_NST - 1 && t < nk; ++t)
 #pragma unroll
-        for (int pc = 0; pc < 8; ++pc) dma_piece(a0p + (long)t * (SL_BK * 2), w0p + (long)t * (SL_BK * 2), t * SL_STAGE, pc);
-    handoff(nk >= 3 ? 16 : (nk == 2 ? 8 : 0));
+        for (int pc = 0; pc < NPC; ++pc) dma_piece(a0p + (long)t * (SL_BK * 2), w0p + (long)t * (SL_BK * 2), t * SL_STAGE, pc);
+    handoff(nk >= 3 ? 4 : (nk == 2 ? 2 : 0));
 #pragma unroll
-    for (int idx = 0; idx < 8; ++idx) read_frag(0, (idx + 4) & 7, 0, 0);
+    for (int idx = 0; idx < 4 + NJ; ++idx) read_frag(0, idx, 0, 0);
 
     // tile t+3 streams in while tile t is multiplied (its stage was released by the barrier inside tile t-1); past the end
     // the fragment prefetch reads a stale stage (harmless) and the DMA slots are skipped
@@ -705,8 +716,8 @@ __global__ __launch_bounds__(SL_THREADS, 1) void gemm_sl_kernel(const GemmArgs p
         const char* ta = a0p + (long)(t + 3) * (SL_BK * 2);
         const char* tw = w0p + (long)(t + 3) * (SL_BK * 2);
         half(C0{}, st, 1, stream, ta, tw, std_, 0);     // (t, k 0..15); reads (t, k 16..31); A pieces of t+3
-        handoff(stream ? 12 : (t + 2 < nk ? 8 : 0));    // tile t+1 complete in LDS; nobody reads tile t's first half any more
-        half(C1{}, stn, 0, stream, ta, tw, std_, 4);    // (t, k 16..31); reads (t+1, k 0..15); W pieces of t+3
+        handoff(stream ? 3 : (t + 2 < nk ? 2 : 0));     // tile t+1 complete in LDS; nobody reads tile t's first half any more
+        half(C1{}, stn, 0, stream, ta, tw, std_, NPC / 2);   // (t, k 16..31); reads (t+1, k 0..15); W pieces of t+3
     }
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results before anything else reads them
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -715,10 +726,10 @@ __global__ __launch_bounds__(SL_THREADS, 1) void gemm_sl_kernel(const GemmArgs p
     // ---- epilogue: bf16 tile -> swizzled 256 x 256 LDS image (512-byte rows) -> full-row stores
     // acc[i][j][4g + q] = C[m0 + wr*128 + 32 i + r][n0 + wc*128 + 32 j + 8 g + 4 h + q]
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int ncol = wc * 128 + j * 32 + g * 8 + h * 4;
+            const int ncol = wc * (32 * NJ) + j * 32 + g * 8 + h * 4;
             float bv[4] = {0.f, 0.f, 0.f, 0.f};
             if (p.bias && n0 + ncol < p.N) {
                 const u16x4 b4 = *reinterpret_cast<const u16x4*>(p.bias + n0 + ncol);
@@ -750,8 +761,8 @@ __global__ __launch_bounds__(SL_THREADS, 1) void gemm_sl_kernel(const GemmArgs p
         u16x8 g8;
         if (EPI == GF_EPI_BIAS_GATE_RESID && n_ok) g8 = *reinterpret_cast<const u16x8*>(p.gate + n);
 #pragma unroll 4
-        for (int it = 0; it < 32; ++it) {
-            const int row = wave * 64 + it * 2 + (lane >> 5);
+        for (int it = 0; it < 128 / NW; ++it) {
+            const int row = wave * (256 / NW) + it * 2 + (lane >> 5);
             const int m = m0 + row;
             const u16x8 yv = *(GF_LDS u16x8*)(lds + row * 512 + ((cc ^ (row & 31)) << 4));
             if (m < p.M && n_ok) {
@@ -772,11 +783,11 @@ __global__ __launch_bounds__(SL_THREADS, 1) void gemm_sl_kernel(const GemmArgs p
     }
 }
 
-template <int EPI>
+template <int EPI, int NW>
 int launch_gemm_sl(const GemmArgs& a, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sl_kernel<EPI>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sl_kernel<EPI, NW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, SL_LDS);
         if (e != hipSuccess) {
             gf_set_error("gf_gemm: hipFuncSetAttribute(%d B LDS) failed: %s", SL_LDS, hipGetErrorString(e));
@@ -784,7 +795,7 @@ int launch_gemm_sl(const GemmArgs& a, hipStream_t stream) {
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_sl_kernel<EPI>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(SL_THREADS), SL_LDS, stream, a);
+    hipLaunchKernelGGL((gemm_sl_kernel<EPI, NW>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(64 * NW), SL_LDS, stream, a);
     GF_CHECK_LAUNCH("gf_gemm_bf16");
     return GF_OK;
 }
@@ -797,9 +808,10 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
         static int use_sl = -1;
         if (use_sl < 0) {
             const char* ek = getenv("GF_GEMM_KERNEL");
-            use_sl = (ek && ek[0] == 's') ? 1 : 0;
+            use_sl = (ek && ek[0] == 's') ? ((ek[1] == 'l' && ek[2] == '8') ? 8 : 4) : 0;   // "sl" / "sl8"
         }
-        if (use_sl && (long)a.M * a.lda < (1L << 31) && (long)a.N * a.ldw < (1L << 31)) return launch_gemm_sl<EPI>(a, stream);
+        if (use_sl && (long)a.M * a.lda < (1L << 31) && (long)a.N * a.ldw < (1L << 31))
+            return use_sl == 8 ? launch_gemm_sl<EPI, 8>(a, stream) : launch_gemm_sl<EPI, 4>(a, stream);
     }
     static bool attr_set = false;  // per-instantiation; benign race (idempotent call)
     static bool use_v1 = false;

@@ -310,8 +310,10 @@ def test_abi_error_channel(ops):
         ops.flash_attn(q, q, q, 2)
 
 
-def test_gemm_experimental_slot_kernel_in_subprocess():
-    """GF_GEMM_KERNEL=sl (read once per process) selects the one-wave-per-SIMD slot-scheduled kernel: keep it correct."""
+@pytest.mark.parametrize("variant", ["sl", "sl8"])
+def test_gemm_experimental_slot_kernel_in_subprocess(variant):
+    """GF_GEMM_KERNEL=sl / sl8 (read once per process) selects the slot-scheduled kernel with one / two waves per SIMD:
+    keep both correct."""
     import subprocess
     import sys
     code = r'''
@@ -332,6 +334,6 @@ for (M, N, K) in ((256, 256, 64), (300, 520, 192), (1000, 768, 1024)):
     assert rel(ops.gemm(a, w, b, epilogue=ops.EPI_BIAS_GATE_RESID, resid=r, gate=g), r.float() + g.float() * ref) < 3e-3
 print("ok")
 '''
-    env = dict(os.environ, GF_GEMM_KERNEL="sl", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, GF_GEMM_KERNEL=variant, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
