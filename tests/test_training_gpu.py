@@ -220,6 +220,34 @@ def test_dit_block_backward_vs_oracle():
     assert torch.equal(xc2.grad, xc.grad) and all(p_.grad is None for p_ in blk.parameters())
 
 
+def test_dit_block_backward_mid_size_vs_oracle():
+    """Wan-1.3B block shape (D=1536, 12 heads of 128, FFN 8960, 960 tokens = grid 5x12x16, 512 text tokens): widths and row
+    counts that exercise the multi-chunk row kernels, the M-padding of the weight-gradient GEMMs and 12-head attention."""
+    import gen_inputs as gi
+    from goal_force_amd.dit import DiTBlock, RopeTable, precompute_freqs_cis_3d
+    from goal_force_amd.training import block_forward
+    from oracle import wan_oracle as wo
+    cfg = gi.MID
+    sd = gi.block_sd(torch.Generator().manual_seed(21), cfg["dim"], cfg["ffn_dim"], "", BF)
+    x, ctx, t_mod = gi.block_inputs(cfg["dim"], 960, 512, seed=22)
+    dout = torch.randn(x.shape, generator=torch.Generator().manual_seed(23)).to(BF)
+    sdf = {k: v.float().requires_grad_(True) for k, v in sd.items()}
+    xf = x.float().requires_grad_(True)
+    freqs = wo.rope_freqs_3d(cfg["dim"] // cfg["num_heads"], 5, 12, 16)
+    wo.dit_block(xf, ctx.float(), t_mod.float(), freqs, sdf, "", cfg["num_heads"], cfg["eps"]).backward(dout.float())
+    blk = DiTBlock(False, cfg["dim"], cfg["num_heads"], cfg["ffn_dim"], cfg["eps"])
+    blk.load_state_dict(sd, strict=True)
+    blk = blk.to(BF).cuda()
+    rope = RopeTable.from_grid(precompute_freqs_cis_3d(cfg["dim"] // cfg["num_heads"]), 5, 12, 16, "cuda")
+    xc = x[0].cuda().requires_grad_(True)
+    block_forward(blk, xc, ctx[0].cuda(), t_mod.cuda(), rope).backward(dout[0].cuda())
+    assert rel_l2(xc.grad.float().cpu(), xf.grad[0]) < 1.5e-2, "dx"
+    named = dict(blk.named_parameters())
+    for n, v in sdf.items():
+        e = rel_l2(named[n].grad.float().cpu().reshape(v.grad.shape), v.grad)
+        assert e < (8e-2 if n.endswith("attn.k.bias") else 2.5e-2), f"{n}: rel_l2={e:.3e}"
+
+
 def _tiny_train_models():
     import gen_inputs as gi
     from goal_force_amd.controlnet import ControlNet
