@@ -64,7 +64,7 @@ def _worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_cfg_pair_parallel_matches_sequential(world, tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
