@@ -457,7 +457,11 @@ class WanVideoVAE(nn.Module):
         return torch.stack(outs)
 
     # ---------------------------------------------------------------- public API (VAE:1103-1152, 1211-1247)
-    def tiled_decode(self, hidden_states, device, tile_size, tile_stride):
+    def tiled_decode(self, hidden_states, device, tile_size, tile_stride, tile_group=None):
+        """VAE:1103-1152.  `tile_group` (a torch.distributed group whose ranks all hold the same latents, e.g. the two ranks
+        of a CFG pair): the tiles are decoded round-robin over the group's ranks, exchanged, and blended by EVERY rank in
+        the reference's task order — the blend arithmetic (bf16 accumulators) is order-dependent, so the result is
+        bit-identical to the one-GPU decode on all ranks."""
         _, _, T, H, W = hidden_states.shape
         size_h, size_w = tile_size
         stride_h, stride_w = tile_stride
@@ -473,9 +477,26 @@ class WanVideoVAE(nn.Module):
         out_T = T * 4 - 3
         values = torch.zeros((3, out_T, H * u, W * u), dtype=torch.bfloat16, device=hidden_states.device)
         weight = torch.zeros((H * u, W * u), dtype=torch.bfloat16, device=hidden_states.device)
-        for (h, h_, w, w_) in tasks:
-            tile = self.decode_tile_channels_last(hidden_states[0, :, :, h:h_, w:w_])
-            ops.vae_tile_blend(values, weight, tile.contiguous(), h * u, w * u,
+        gsize = 1
+        if tile_group is not None:
+            import torch.distributed as dist
+            gsize, grank = dist.get_world_size(tile_group), dist.get_rank(tile_group)
+        mine = {}
+        if gsize > 1:      # decode my share first (no waiting on the partner), then exchange in task order
+            for i, (h, h_, w, w_) in enumerate(tasks):
+                if i % gsize == grank:
+                    mine[i] = self.decode_tile_channels_last(hidden_states[0, :, :, h:h_, w:w_]).contiguous()
+            tc = 8                                             # channels of a decoded tile (RGB in 0..2), decode_tile_channels_last
+            assert all(t.shape[-1] == tc for t in mine.values())
+        for i, (h, h_, w, w_) in enumerate(tasks):
+            if gsize == 1:
+                tile = self.decode_tile_channels_last(hidden_states[0, :, :, h:h_, w:w_]).contiguous()
+            else:
+                owner = i % gsize
+                tile = mine.pop(i) if owner == grank else torch.empty(
+                    (out_T, (min(h_, H) - h) * u, (min(w_, W) - w) * u, tc), dtype=torch.bfloat16, device=hidden_states.device)
+                dist.broadcast(tile, src=dist.get_global_rank(tile_group, owner), group=tile_group)
+            ops.vae_tile_blend(values, weight, tile, h * u, w * u,
                                bounds=(h == 0, h_ >= H, w == 0, w_ >= W),
                                border=((size_h - stride_h) * u, (size_w - stride_w) * u))
         ops.vae_tile_finalize(values, weight)
@@ -492,14 +513,15 @@ class WanVideoVAE(nn.Module):
         return values.unsqueeze(0)
 
     @torch.no_grad()
-    def decode(self, hidden_states, device=None, tiled=False, tile_size=(34, 34), tile_stride=(18, 16)):
-        """[B,16,T,h,w] bf16 latents -> [B,3,4T-3,8h,8w] bf16 in [-1,1] (device tensor)."""
+    def decode(self, hidden_states, device=None, tiled=False, tile_size=(34, 34), tile_stride=(18, 16), tile_group=None):
+        """[B,16,T,h,w] bf16 latents -> [B,3,4T-3,8h,8w] bf16 in [-1,1] (device tensor).  tile_group: see tiled_decode."""
         videos = []
         for hs in hidden_states:
             hs = hs.unsqueeze(0)
             if not hs.is_cuda:
                 hs = hs.to(device or "cuda")
-            v = self.tiled_decode(hs, device, tile_size, tile_stride) if tiled else self.single_decode(hs, device)
+            v = (self.tiled_decode(hs, device, tile_size, tile_stride, tile_group=tile_group) if tiled
+                 else self.single_decode(hs, device))
             videos.append(v.squeeze(0))
         return torch.stack(videos)
 

@@ -90,3 +90,33 @@ def test_world_of_one_is_the_plain_path():
         assert torch.equal(sp.attention(q, q, q, 2), ops.flash_attn(q, q, q, 2))
     finally:
         dist.destroy_process_group()
+
+
+def _vae_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_grad_enabled(False)
+        from goal_force_amd.vae import WanVideoVAE
+        torch.manual_seed(7)
+        vae = WanVideoVAE().to(BF).cuda()
+        z = torch.randn((1, 16, 2, 12, 16), generator=torch.Generator().manual_seed(5)).to(BF).cuda()
+        got = vae.decode(z, tiled=True, tile_size=(8, 8), tile_stride=(4, 4), tile_group=dist.group.WORLD)
+        torch.save(got.cpu(), os.path.join(out, f"v{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_tiled_vae_decode_split_over_a_cfg_pair_is_bit_identical(tmp_path):
+    """The decoded tiles of one video split round-robin over the two ranks of a CFG pair (both hold the same latents),
+    exchanged, blended by both in the reference's task order: same bits as the one-GPU tiled decode, on both ranks."""
+    world = 2
+    mp.spawn(_vae_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    torch.set_grad_enabled(False)
+    from goal_force_amd.vae import WanVideoVAE
+    torch.manual_seed(7)
+    vae = WanVideoVAE().to(BF).cuda()
+    z = torch.randn((1, 16, 2, 12, 16), generator=torch.Generator().manual_seed(5)).to(BF).cuda()
+    want = vae.decode(z, tiled=True, tile_size=(8, 8), tile_stride=(4, 4)).cpu()
+    for r in range(world):
+        assert torch.equal(torch.load(os.path.join(tmp_path, f"v{r}.pt")), want)
