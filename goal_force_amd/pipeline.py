@@ -254,7 +254,7 @@ class WanVideoPipeline:
                  control_signal_video=None,
                  # pre-computed conditioning (outputs of the pre-loop units GF:791-917 / GF:808)
                  context_posi=None, context_nega=None, y=None, control_signal_video_latents=None,
-                 output_type="pil"):
+                 output_type="pil", cfg_parallel=None, sequence_parallel=None):
         for name, val in (("end_image", end_image), ("input_video", input_video), ("input_audio", input_audio),
                           ("audio_embeds", audio_embeds), ("s2v_pose_video", s2v_pose_video),
                           ("motion_video", motion_video), ("control_video", control_video),
@@ -286,12 +286,15 @@ class WanVideoPipeline:
                                num_inference_steps=num_inference_steps, cfg_scale=cfg_scale,
                                switch_DiT_boundary=switch_DiT_boundary, sigma_shift=sigma_shift,
                                denoising_strength=denoising_strength, controlnet=controlnet,
-                               progress_bar_cmd=progress_bar_cmd)
+                               progress_bar_cmd=progress_bar_cmd, cfg_parallel=cfg_parallel,
+                               sequence_parallel=sequence_parallel)
         if output_type == "latent":
             return latents
         if self.vae is None:
             raise GoalForceError("no VAE loaded: call with output_type='latent' or attach pipe.vae")
-        video = self.vae.decode(latents, device=self.device, tiled=tiled, tile_size=tile_size, tile_stride=tile_stride)
+        # multi-GPU (distributed.CfgPairParallel): both ranks of the CFG pair hold these latents -> they share the tiles
+        video = self.vae.decode(latents, device=self.device, tiled=tiled, tile_size=tile_size, tile_stride=tile_stride,
+                                tile_group=None if cfg_parallel is None else cfg_parallel.pair_group)
         return video if output_type == "pt" else self.vae_output_to_video(video)
 
     # ---------------------------------------------------------------- pre-loop units that use the VAE encoder
