@@ -141,6 +141,16 @@ class WanVideoPipeline:
         sd = load_state_dict(path, torch_dtype=torch_dtype)
         module.load_state_dict({k.replace("pipe.controlnet.", "", 1): v for k, v in sd.items()}, strict=True)
 
+    def training_loss(self, **inputs):
+        """GF:180-193 — same keyword inputs as the reference (`input_latents`, `noise`, `context`, `y`,
+        `control_signal_video_latents`, optional `max_timestep_boundary` / `min_timestep_boundary`); returns the loss with
+        the HIP backward behind it (goal_force_amd/training.py).  The scheduler must be in training mode
+        (`set_timesteps(1000, training=True)`, utils.py:560)."""
+        from . import training
+        keys = ("input_latents", "noise", "context", "y", "control_signal_video_latents", "max_timestep_boundary",
+                "min_timestep_boundary", "timestep_id")
+        return training.training_loss(self, **{k: inputs[k] for k in keys if k in inputs})
+
     def enable_vram_management(self, num_persistent_param_in_dit=None, vram_limit=None, vram_buffer=0.5):
         """GF:196-452 — accepted for interface parity; everything is already resident in HBM."""
         self.vram_management_enabled = True

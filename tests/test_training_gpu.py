@@ -282,9 +282,9 @@ def test_training_step_vs_reference_golden():
     dit, cn = _tiny_train_models()
     pipe = _tiny_train_pipe(dit, cn)
     inp = {k: v.cuda() for k, v in gi.train_inputs().items()}
-    with torch.enable_grad():
-        loss = tr.training_loss(pipe, input_latents=inp["input_latents"], noise=inp["noise"], context=inp["context"],
-                                y=inp["y"], control_signal_video_latents=inp["control"], timestep_id=gi.TRAIN_TIMESTEP_ID)
+    with torch.enable_grad():      # through the pipeline method, as the reference's training module calls it (GF:180)
+        loss = pipe.training_loss(input_latents=inp["input_latents"], noise=inp["noise"], context=inp["context"],
+                                  y=inp["y"], control_signal_video_latents=inp["control"], timestep_id=gi.TRAIN_TIMESTEP_ID)
         loss.backward()
     lf, lb = float(g["loss_f32"]), float(g["loss_bf16"])
     lv = float(loss.detach())
