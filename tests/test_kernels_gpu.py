@@ -337,3 +337,24 @@ print("ok")
     env = dict(os.environ, GF_GEMM_KERNEL=variant, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_flash_attn_kernel1_in_subprocess():
+    """GF_ATTN_KERNEL=1 (read once per process) selects the phase-serial predecessor kept for A/B runs: keep it correct."""
+    import subprocess
+    import sys
+    code = r'''
+import math, torch
+from goal_force_amd import ops
+torch.manual_seed(5)
+for (sq, skv, h) in ((72, 72, 2), (777, 1333, 3), (1000, 512, 4)):
+    q, k, v = (torch.randn((n, h * 128), device="cuda").to(torch.bfloat16) for n in (sq, skv, skv))
+    o = ops.flash_attn(q, k, v, h).float().cpu()
+    qh, kh, vh = (t.float().cpu().view(t.shape[0], h, 128).transpose(0, 1) for t in (q, k, v))
+    ref = (torch.softmax(qh @ kh.transpose(1, 2) / math.sqrt(128), -1) @ vh).transpose(0, 1).reshape(sq, h * 128)
+    assert float((o - ref).norm() / ref.norm()) < 4e-3
+print("ok")
+'''
+    env = dict(os.environ, GF_ATTN_KERNEL="1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
