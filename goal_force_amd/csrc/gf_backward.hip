@@ -305,6 +305,18 @@ __global__ __launch_bounds__(256) void adamw_kernel(u16* __restrict__ p, const u
     p[i] = f2bf(pv - (lr / bc1) * (mv / denom));
 }
 
+// acc[0] += sum x^2  (global gradient norm of clip_grad_norm_, utils.py:806-808)
+__global__ __launch_bounds__(256) void sumsq_kernel(const u16* __restrict__ x, float* __restrict__ acc, long n) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float v = bf2f(x[i]);
+        s += v * v;
+    }
+    const float tot = block_sum<256>(s, red);
+    if (threadIdx.x == 0) atomicAdd(acc, tot);
+}
+
 // dst = bf16(acc)  (column accumulators -> parameter gradients)
 __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ a, u16* __restrict__ o, long n) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -411,5 +423,14 @@ extern "C" GF_API int gf_f32_to_bf16(const float* src, void* dst, int64_t n, voi
     hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, (u16*)dst,
                        (long)n);
     GF_CHECK_LAUNCH("gf_f32_to_bf16");
+    return GF_OK;
+}
+
+extern "C" GF_API int gf_sumsq(const void* x, int64_t n, float* acc, void* stream) {
+    GF_CHECK_ARG(x && acc && n >= 0, "gf_sumsq: bad arguments");
+    if (n == 0) return GF_OK;
+    const unsigned blocks = (unsigned)min((long)((n + 255) / 256), 2048L);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u16*)x, acc, (long)n);
+    GF_CHECK_LAUNCH("gf_sumsq");
     return GF_OK;
 }

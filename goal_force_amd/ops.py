@@ -559,3 +559,11 @@ def f32_to_bf16(acc):
     out = torch.empty(acc.shape, dtype=_BF16, device=acc.device)
     _lib.check(_lib.load().gf_f32_to_bf16(_ptr(acc), _ptr(out), acc.numel(), _stream(acc)), "gf_f32_to_bf16")
     return out
+
+
+def sumsq(x, acc):
+    """acc[0] += sum(x^2) over a contiguous bf16 tensor (fp32 accumulate)."""
+    _req(x, "sumsq.x")
+    if not x.is_contiguous():
+        raise GoalForceError("sumsq.x must be contiguous")
+    _lib.check(_lib.load().gf_sumsq(_ptr(x), x.numel(), _ptr(_f32(acc, "sumsq.acc")), _stream(x)), "gf_sumsq")

@@ -387,11 +387,11 @@ class AdamW:
             p.grad = None
 
     def grad_norm(self) -> float:
-        sq = torch.zeros((), dtype=torch.float32, device=self.params[0].device)
+        sq = torch.zeros((1,), dtype=torch.float32, device=self.params[0].device)
         for p in self.params:
             if p.grad is not None:
-                sq += p.grad.float().pow(2).sum()
-        return float(sq.sqrt())
+                ops.sumsq(p.grad.contiguous(), sq)
+        return math.sqrt(float(sq[0]))
 
     @torch.no_grad()
     def step(self, max_grad_norm: Optional[float] = None):

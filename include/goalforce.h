@@ -173,6 +173,8 @@ GF_API int gf_mse_loss(const void* pred, const void* target, void* dpred, float*
 GF_API int gf_adamw_step(void* param, const void* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                          float beta2, float eps, float weight_decay, int64_t step, float grad_scale, void* stream);
 GF_API int gf_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+/* gf_sumsq — acc[0] += sum of squares of a bf16 buffer (fp32): the global gradient norm of clip_grad_norm_ (utils.py:806-808). */
+GF_API int gf_sumsq(const void* x, int64_t n, float* acc, void* stream);
 
 /* ------------------------------------------------------------------------
  * gf_patchify_im2col — gathers the (1,2,2) patches of an NCTHW latent into a

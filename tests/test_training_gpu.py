@@ -324,5 +324,7 @@ def test_training_steps_reduce_the_loss():
         opt.step(max_grad_norm=1.0)
         losses.append(float(loss.detach()))
     assert losses[-1] < losses[0], losses
+    want = math.sqrt(sum(float(p_.grad.float().pow(2).sum()) for p_ in cn.parameters() if p_.grad is not None))
+    assert abs(opt.grad_norm() - want) < 1e-4 * want
     sd = tr.controlnet_state_dict(cn)
     assert all(k.startswith("pipe.controlnet.") for k in sd) and len(sd) == len(cn.state_dict())
