@@ -25,6 +25,7 @@ SYMBOLS = (
     "gf_quant_fp8_rowscale", "gf_cast_fp8", "gf_gemm_fp8",
     "gf_flash_attn_fwd_lse", "gf_flash_attn_bwd",
     "gf_layernorm_bwd", "gf_rmsnorm_rope_bwd", "gf_colsum", "gf_act_bwd", "gf_mse_loss", "gf_adamw_step", "gf_f32_to_bf16", "gf_sumsq",
+    "gf_transpose_v", "gf_flash_attn_fwd_vt",
 )
 
 EPI_BIAS, EPI_BIAS_GELU_TANH, EPI_BIAS_GATE_RESID, EPI_BIAS_RESID, EPI_BIAS_SILU, EPI_BIAS_MUL = range(6)
@@ -63,6 +64,8 @@ def _declare(lib):
         "gf_adamw_step": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i64, _f32, _vp],
         "gf_f32_to_bf16": [_vp, _vp, _i64, _vp],
         "gf_sumsq": [_vp, _i64, _vp, _vp],
+        "gf_transpose_v": [_vp, _i64, _vp, _i64, _i64, _i64, _vp],
+        "gf_flash_attn_fwd_vt": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _vp],
         "gf_patchify_im2col": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp],
         "gf_unpatchify": [_vp, _vp, _i64, _i64, _i64, _i64, _vp],
         "gf_cfg_euler_step": [_vp, _vp, _vp, _f32, _f32, _i64, _vp],

@@ -79,6 +79,8 @@ struct AttnArgs {
     float scale_log2e;  // softmax scale * log2(e)
     unsigned long long* dbg;
     float* lse;         // optional [q_len, heads] fp32: log2-domain log-sum-exp of the scaled scores (training backward)
+    const u16* vt;      // kernel 2, VT form: V^T [heads][128][kv_pad] from gf_transpose_v (keys permuted inside 16-groups)
+    long kv_pad;
 };
 
 __global__ __launch_bounds__(AT_THREADS, 2) void flash_attn_fwd_kernel(const AttnArgs p) {
@@ -426,6 +428,11 @@ __device__ __forceinline__ void mfma32(f32x16& acc, const bf16x8& a, const bf16x
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
 }
 
+// VT = true: V arrives pre-transposed ([head][d][key], gf_transpose_v) so that a PV MFMA's A fragment (32 d-rows x 16
+// keys) is ONE ds_read_b128 instead of two ds_read_b64_tr_b16: one LDS instruction less per PV slot of an issue-bound loop
+// (+2.5 % in a what-if build); inside every group of 16 keys the copy stores keys 0-3, 8-11, 4-7, 12-15, the order in which a
+// lane half holds its eight scores of the 16-key step.
+template <bool VT>
 __global__ __launch_bounds__(AT2_THREADS, 2) void flash_attn_fwd_kernel2(const AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     GF_LDS char* lds = (GF_LDS char*)smem;
@@ -476,8 +483,26 @@ __global__ __launch_bounds__(AT2_THREADS, 2) void flash_attn_fwd_kernel2(const A
                      : "memory");
     };
     // which = 0: K tile t -> K buffer buf;  which = 1: V tile t -> V buffer buf
+    // VT: the V tile image is 128 d-rows x 128 B (64 keys), chunk ^ ((row >> 1) & 7); wave w stages rows 16w..16w+15 as two
+    // pieces of 8 rows (lane L: row L>>3, physical chunk L&7)
+    unsigned vt_off[2];
+    if constexpr (VT) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int row = 16 * wave + 8 * jj + (lane >> 3);
+            const int lch = (lane & 7) ^ ((row >> 1) & 7);
+            vt_off[jj] = (unsigned)(((long)head * HD + row) * p.kv_pad + lch * 8);
+        }
+    }
     auto stage = [&](int which, int t, int buf) {
         GF_LDS char* base = lds + which * AT2_V_BASE + buf * KV_TILE_BYTES + wave * 2048;
+        if constexpr (VT) {
+            if (which) {
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) dma16(p.vt + (vt_off[jj] + (unsigned)t * KVB), base + jj * 1024);
+                return;
+            }
+        }
         const u16* g = which ? p.v : p.k;
         if ((t + 1) * KVB <= p.kv_len) {
             const unsigned tt = (unsigned)t * (which ? vstep : kstep);
@@ -495,6 +520,11 @@ __global__ __launch_bounds__(AT2_THREADS, 2) void flash_attn_fwd_kernel2(const A
         }
     };
 
+    int vt_rd[4];   // VT: byte offset of this lane's 16-byte chunk of step (kt, s) inside its d-row: row r, chunk (4kt+2s+h)^key
+    if constexpr (VT) {
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) vt_rd[c4] = AT2_V_BASE + r * 128 + (((2 * c4 + h) ^ ((r >> 1) & 7)) << 4);
+    }
     int koff[8], voff[2][4];
     {
         const int sK = ((r & 3) << 2) | ((r >> 2) & 3);
@@ -551,11 +581,16 @@ __global__ __launch_bounds__(AT2_THREADS, 2) void flash_attn_fwd_kernel2(const A
                 const int imm = BUF * KV_TILE_BYTES + 256 * (32 * kt + 16 * s);
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
-                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GF_LDS s16x4*)(lds + voff[0][d] + imm));
-                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GF_LDS s16x4*)(lds + voff[1][d] + imm));
-                    typedef __attribute__((ext_vector_type(8))) short s16x8;
-                    const s16x8 vv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                    mfma32(oacc[d], __builtin_bit_cast(bf16x8, vv), pf[kt][s]);
+                    if constexpr (VT) {
+                        const bf16x8 vv = *(GF_LDS bf16x8*)(lds + vt_rd[2 * kt + s] + BUF * KV_TILE_BYTES + d * 4096);
+                        mfma32(oacc[d], vv, pf[kt][s]);
+                    } else {
+                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GF_LDS s16x4*)(lds + voff[0][d] + imm));
+                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GF_LDS s16x4*)(lds + voff[1][d] + imm));
+                        typedef __attribute__((ext_vector_type(8))) short s16x8;
+                        const s16x8 vv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                        mfma32(oacc[d], __builtin_bit_cast(bf16x8, vv), pf[kt][s]);
+                    }
                 }
             }
     };
@@ -627,12 +662,16 @@ __global__ __launch_bounds__(AT2_THREADS, 2) void flash_attn_fwd_kernel2(const A
         constexpr int G = decltype(g_c)::value, PAR = decltype(par_c)::value;
         if constexpr (G < 16) {
             constexpr int kt = G >> 3, sq = (G >> 2) & 1, d = G & 3;
-            constexpr int imm = (1 - PAR) * KV_TILE_BYTES + 256 * (32 * kt + 16 * sq);
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GF_LDS s16x4*)(lds + voff[0][d] + imm));
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GF_LDS s16x4*)(lds + voff[1][d] + imm));
-            typedef __attribute__((ext_vector_type(8))) short s16x8;
-            const s16x8 vv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-            fr[G & 3] = __builtin_bit_cast(bf16x8, vv);
+            if constexpr (VT) {
+                fr[G & 3] = *(GF_LDS bf16x8*)(lds + vt_rd[2 * kt + sq] + (1 - PAR) * KV_TILE_BYTES + d * 4096);
+            } else {
+                constexpr int imm = (1 - PAR) * KV_TILE_BYTES + 256 * (32 * kt + 16 * sq);
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GF_LDS s16x4*)(lds + voff[0][d] + imm));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GF_LDS s16x4*)(lds + voff[1][d] + imm));
+                typedef __attribute__((ext_vector_type(8))) short s16x8;
+                const s16x8 vv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                fr[G & 3] = __builtin_bit_cast(bf16x8, vv);
+            }
         } else if constexpr (G < 32) {
             constexpr int kd = (G - 16) >> 1, half = (G - 16) & 1;
             fr[G & 3] = *(GF_LDS bf16x8*)(lds + koff[kd] + (1 - PAR) * KV_TILE_BYTES + half * 32 * 256);
@@ -775,11 +814,46 @@ __global__ __launch_bounds__(AT2_THREADS, 2) void flash_attn_fwd_kernel2(const A
     }
 }
 
+// V [kv_len, heads*128] -> V^T [heads][128][kv_pad] bf16, keys >= kv_len zero; inside every group of 16 keys the order is
+// 0-3, 8-11, 4-7, 12-15 (what a lane half of the 32x32x16 B operand holds).  One workgroup per (64-key tile, head).
+__global__ __launch_bounds__(256) void transpose_v_kernel(const u16* __restrict__ v, u16* __restrict__ vt, int kv_len, long kv_pad,
+                                                          long v_stride) {
+    __shared__ u16 tile[KVB][HD + 8];
+    const int t0 = blockIdx.x * KVB, head = blockIdx.y, tid = threadIdx.x;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {                 // 64 rows x 16 chunks of 16 B
+        const int idx = it * 256 + tid, row = idx >> 4, ch = idx & 15;
+        u16x8 val = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (t0 + row < kv_len) val = *reinterpret_cast<const u16x8*>(v + (long)(t0 + row) * v_stride + head * HD + ch * 8);
+        *reinterpret_cast<u16x8*>(&tile[row][ch * 8]) = val;
+    }
+    __syncthreads();
+    const int d = tid >> 1, half = tid & 1;
+    u16* dst = vt + ((long)head * HD + d) * kv_pad + t0 + 32 * half;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {                    // 4 chunks of 8 keys
+        u16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int pos = 32 * half + 8 * c + j;   // physical position in the tile row
+            const int q16 = pos & 15;
+            const int key = (pos & ~15) | ((q16 & 3) | ((q16 & 4) << 1) | ((q16 & 8) >> 1));   // swap bits 2 and 3
+            o[j] = tile[key][d];
+        }
+        *reinterpret_cast<u16x8*>(dst + 8 * c) = o;
+    }
+}
+
 }  // namespace
 
 static int flash_attn_fwd_impl(const void* q, const void* k, const void* v, void* o, float* lse, int64_t q_len, int64_t kv_len,
                                int64_t heads, int64_t head_dim, int64_t q_stride, int64_t k_stride,
-                               int64_t v_stride, int64_t o_stride, float scale, void* stream) {
+                               int64_t v_stride, int64_t o_stride, float scale, void* stream, const void* vt = nullptr,
+                               int64_t kv_pad = 0) {
+    if (vt) {   // pre-transposed V: v itself is not read
+        v = k;
+        v_stride = k_stride;
+    }
     GF_CHECK_ARG(q && k && v && o, "gf_flash_attn_fwd: null pointer");
     if (head_dim != HD) {
         gf_set_error("gf_flash_attn_fwd: head_dim=%ld unsupported (kernel is built for 128)", (long)head_dim);
@@ -802,9 +876,12 @@ static int flash_attn_fwd_impl(const void* q, const void* k, const void* v, void
     if (!attr_set) {
         const char* ev = getenv("GF_ATTN_KERNEL");   // tuning switch: 1 = the phase-serial kernel, 2 = the slot-pipelined kernel
         use_k2 = !(ev && ev[0] == '1');
-        hipError_t e = hipFuncSetAttribute(use_k2 ? reinterpret_cast<const void*>(flash_attn_fwd_kernel2)
+        hipError_t e = hipFuncSetAttribute(use_k2 ? reinterpret_cast<const void*>(flash_attn_fwd_kernel2<false>)
                                                   : reinterpret_cast<const void*>(flash_attn_fwd_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, use_k2 ? AT2_LDS : AT_LDS);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_fwd_kernel2<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, AT2_LDS);
         if (e != hipSuccess) {
             gf_set_error("gf_flash_attn_fwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
             return GF_ERR_LAUNCH;
@@ -826,13 +903,18 @@ static int flash_attn_fwd_impl(const void* q, const void* k, const void* v, void
     a.o_stride = o_stride;
     a.scale_log2e = scale * 1.4426950408889634f;
     a.lse = lse;
+    a.vt = (const u16*)vt;
+    a.kv_pad = kv_pad;
 #if GF_ATTN_STAMP
     a.dbg = g_attn_dbg;
 #else
     a.dbg = nullptr;
 #endif
-    if (use_k2)
-        hipLaunchKernelGGL(flash_attn_fwd_kernel2, dim3((unsigned)(a.n_qblocks * a.heads)), dim3(AT2_THREADS), AT2_LDS,
+    if (vt)
+        hipLaunchKernelGGL(flash_attn_fwd_kernel2<true>, dim3((unsigned)(a.n_qblocks * a.heads)), dim3(AT2_THREADS), AT2_LDS,
+                           (hipStream_t)stream, a);
+    else if (use_k2)
+        hipLaunchKernelGGL(flash_attn_fwd_kernel2<false>, dim3((unsigned)(a.n_qblocks * a.heads)), dim3(AT2_THREADS), AT2_LDS,
                            (hipStream_t)stream, a);
     else
         hipLaunchKernelGGL(flash_attn_fwd_kernel, dim3((unsigned)(a.n_qblocks * a.heads)), dim3(AT_THREADS), AT_LDS,
@@ -854,4 +936,26 @@ extern "C" GF_API int gf_flash_attn_fwd_lse(const void* q, const void* k, const 
     GF_CHECK_ARG(lse, "gf_flash_attn_fwd_lse: null lse");
     return flash_attn_fwd_impl(q, k, v, o, lse, q_len, kv_len, heads, head_dim, q_stride, k_stride, v_stride, o_stride, scale,
                                stream);
+}
+
+extern "C" GF_API int gf_transpose_v(const void* v, int64_t v_stride, void* vt, int64_t kv_len, int64_t kv_pad, int64_t heads,
+                                     void* stream) {
+    GF_CHECK_ARG(v && vt, "gf_transpose_v: null pointer");
+    GF_CHECK_ARG(kv_len > 0 && heads > 0 && kv_pad >= kv_len && kv_pad % KVB == 0 && v_stride % 8 == 0 && v_stride >= heads * HD,
+                 "gf_transpose_v: kv_pad must be a multiple of 64 covering kv_len; v_stride must cover heads*128");
+    GF_CHECK_ARG(gf_aligned16(v) && gf_aligned16(vt), "gf_transpose_v: 16-byte alignment required");
+    GF_CHECK_ARG(heads * HD * kv_pad < (1LL << 31), "gf_transpose_v: heads*128*kv_pad must stay below 2^31 elements");
+    hipLaunchKernelGGL(transpose_v_kernel, dim3((unsigned)(kv_pad / KVB), (unsigned)heads), dim3(256), 0, (hipStream_t)stream,
+                       (const u16*)v, (u16*)vt, (int)kv_len, (long)kv_pad, (long)v_stride);
+    GF_CHECK_LAUNCH("gf_transpose_v");
+    return GF_OK;
+}
+
+extern "C" GF_API int gf_flash_attn_fwd_vt(const void* q, const void* k, const void* vt, void* o, float* lse, int64_t q_len,
+                                           int64_t kv_len, int64_t kv_pad, int64_t heads, int64_t head_dim, int64_t q_stride,
+                                           int64_t k_stride, int64_t o_stride, float scale, void* stream) {
+    GF_CHECK_ARG(vt && kv_pad >= kv_len && kv_pad % KVB == 0 && gf_aligned16(vt), "gf_flash_attn_fwd_vt: bad V^T buffer");
+    GF_CHECK_ARG(heads * HD * kv_pad < (1LL << 31), "gf_flash_attn_fwd_vt: heads*128*kv_pad must stay below 2^31 elements");
+    return flash_attn_fwd_impl(q, k, k, o, lse, q_len, kv_len, heads, head_dim, q_stride, k_stride, k_stride, o_stride, scale,
+                               stream, vt, kv_pad);
 }

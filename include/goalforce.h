@@ -130,6 +130,14 @@ GF_API int gf_flash_attn_fwd(const void* q, const void* k, const void* v, void* 
                       int64_t q_stride, int64_t k_stride, int64_t v_stride, int64_t o_stride,
                       float scale, void* stream);
 
+/* gf_transpose_v + gf_flash_attn_fwd_vt — the same attention with V handed over pre-transposed: vt [heads][128][kv_pad] bf16
+ * (kv_pad a multiple of 64, keys >= kv_len zero, keys permuted 0-3,8-11,4-7,12-15 inside every group of 16 — written by
+ * gf_transpose_v).  One LDS read per PV MFMA instead of two; what the self-attention of the DiT blocks uses.  lse may be NULL. */
+GF_API int gf_transpose_v(const void* v, int64_t v_stride, void* vt, int64_t kv_len, int64_t kv_pad, int64_t heads, void* stream);
+GF_API int gf_flash_attn_fwd_vt(const void* q, const void* k, const void* vt, void* o, float* lse,
+                         int64_t q_len, int64_t kv_len, int64_t kv_pad, int64_t heads, int64_t head_dim,
+                         int64_t q_stride, int64_t k_stride, int64_t o_stride, float scale, void* stream);
+
 /* ------------------------------------------------------------------------
  * Training (ControlNet training step): training_loss (GF:180-193) calls loss.backward() through
  * F.scaled_dot_product_attention (DIT:28-61) in every block.

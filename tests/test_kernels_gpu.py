@@ -178,6 +178,35 @@ def test_gemm_full_size_sampled_rows(ops):
 
 
 # ------------------------------------------------------------------ attention
+@pytest.mark.parametrize("skv", [64, 130, 2048, 2100, 4100])
+def test_flash_attn_pretransposed_v_matches_plain_kernel(ops, skv):
+    """gf_transpose_v + gf_flash_attn_fwd_vt (one LDS read per PV MFMA) against gf_flash_attn_fwd on the same inputs: the
+    same products in the same order, so the results are bit-identical."""
+    from goal_force_amd import _lib
+    heads, sq = 3, 300
+    g = torch.Generator().manual_seed(skv)
+    q, k, v = (dev(torch.randn((n, heads * 128), generator=g).to(BF)) for n in (sq, skv, skv))
+    lib = _lib.load()
+    plain, viavt = torch.empty_like(q), torch.empty_like(q)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.gf_flash_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), plain.data_ptr(), sq, skv, heads, 128,
+                                     q.stride(0), k.stride(0), v.stride(0), plain.stride(0), 128 ** -0.5, st), "fwd")
+    kv_pad = -(-skv // 64) * 64
+    vt = torch.full((heads * 128 * kv_pad,), float("nan"), dtype=BF, device="cuda")
+    _lib.check(lib.gf_transpose_v(v.data_ptr(), v.stride(0), vt.data_ptr(), skv, kv_pad, heads, st), "transpose")
+    vt3 = vt.view(heads, 128, kv_pad).cpu()
+    assert torch.isfinite(vt3.float()).all() and float(vt3[:, :, skv:].abs().sum()) == 0
+    perm = torch.tensor([0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15])
+    idx = (torch.arange(kv_pad) // 16) * 16 + perm[torch.arange(kv_pad) % 16]
+    vpad = torch.zeros((kv_pad, heads, 128), dtype=BF)
+    vpad[:skv] = v.cpu().view(skv, heads, 128)
+    assert torch.equal(vt3, vpad[idx].permute(1, 2, 0))
+    _lib.check(lib.gf_flash_attn_fwd_vt(q.data_ptr(), k.data_ptr(), vt.data_ptr(), viavt.data_ptr(), None, sq, skv, kv_pad,
+                                        heads, 128, q.stride(0), k.stride(0), viavt.stride(0), 128 ** -0.5, st), "fwd_vt")
+    assert torch.equal(plain, viavt)
+
+
+
 @pytest.mark.parametrize("sq,skv,heads", [(72, 72, 2), (300, 7, 2), (1000, 512, 12), (777, 1333, 3), (256, 64, 8),
                                           (4100, 4100, 8)])
 def test_flash_attn(ops, sq, skv, heads):
