@@ -54,6 +54,19 @@ constexpr int STAGE_BYTES = 2 * TILE_BYTES;   // A + B
 constexpr int GEMM_LDS = 2 * STAGE_BYTES;     // 128 KiB
 constexpr int GROUP_M = 8;
 
+// Implicit-GEMM convolution (CONV = true instantiations of the phased kernel): the A operand is never materialised — row m
+// = output pixel (j, Y, X), column k = (tap, channel) with tap = (dt*ks + dy)*ks + dx, exactly the patch matrix of
+// gf_vae.hip's im2col_kernel (same modes), and every 16-byte LDS-DMA piece (8 channels of one tap of one pixel) is fetched
+// straight from the channels-last activation [T, H, W, C] (or the 2-frame causal cache, or a zero page for padding).
+struct ConvGeom {
+    const u16* src;     // [T_in, H, W, C]
+    const u16* cache;   // [2, H, W, C]: frames -2, -1 (kt == 3)
+    const u16* zero;    // >= 16 zero bytes
+    int H, W, C, Ho, Wo, kt, ks, mode, t_stride, t_off, taps;
+    long frame;         // H*W*C
+    float inv_c, inv_ks2;
+};
+
 struct GemmArgs {
     const u16* A;
     const u16* W;
@@ -66,6 +79,7 @@ struct GemmArgs {
     long lda, ldw, ldc, ldr;
     int tiles_m, tiles_n;
     unsigned long long* dbg;
+    ConvGeom cv;
 };
 
 __device__ __forceinline__ void glds16(const void* g, GF_LDS char* l) {
@@ -284,8 +298,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmArgs p)
 //     barrier late — one partner feeds the matrix pipe while the other feeds LDS.
 //   * epilogue: all waves park their bf16 quadrants in one swizzled 256x256 LDS image, then every wave writes full
 //     512-byte rows (16 B per lane), reading residual / gate / bias in the same coalesced pattern.
-template <int EPI, bool FP8>
+template <int EPI, bool FP8, bool CONV = false>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs p) {
+    static_assert(!(CONV && FP8), "the implicit-GEMM convolution is bf16 only");
     constexpr int ESZ = FP8 ? 1 : 2;
     constexpr int BKE = 128 / ESZ;
     constexpr int HALF_BYTES = 128 * 128;  // 16 KiB
@@ -326,11 +341,63 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs
         srcp[1][i] = (const char*)p.W + (b0 * p.ldw) * ESZ + schunk * 16;
         srcp[2][i] = (const char*)p.W + (b1 * p.ldw) * ESZ + schunk * 16;
     }
+    // CONV: this lane's four A rows as output pixels: (Y << 16 | X) and the first source frame of the causal window
+    int cyx[2][2], cf[2][2];
+    if constexpr (CONV) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int m = min(m0 + a * 128 + (wave * 2 + i) * 8 + srow, p.M - 1);
+                const int X = m % p.cv.Wo, t = m / p.cv.Wo;
+                const int Y = t % p.cv.Ho, j = t / p.cv.Ho;
+                cyx[a][i] = (Y << 16) | X;
+                cf[a][i] = p.cv.t_off + j * p.cv.t_stride - (p.cv.kt - 1);
+            }
+    }
     const int nk = p.K / BKE;
     // region byte offsets inside one double-buffer, indexed by kind
     auto region = [](int kind) { return kind == 0 ? 0 : (kind == 3 ? HALF_BYTES : (kind == 1 ? 2 * HALF_BYTES : 3 * HALF_BYTES)); };
     auto stage = [&](int tile, int kind) {  // issue the 2 DMA instructions of half-tile (tile, kind)
         GF_LDS char* dst = lds + (tile & 1) * STAGE_BYTES + region(kind) + wave * 2048;
+        if constexpr (CONV) {
+            if (kind == 0 || kind == 3) {
+                const ConvGeom& g = p.cv;
+                const int a = kind == 3;
+                const int ke = tile * 64 + schunk * 8;                       // first of this lane's 8 channels along K
+                const int tap = (int)(((float)ke + 0.5f) * g.inv_c);         // exact: ke < 2^16, C <= 512
+                const int c = ke - tap * g.C;
+                const int dt = (int)(((float)tap + 0.5f) * g.inv_ks2);
+                const int rem = tap - dt * g.ks * g.ks;
+                int dy = 0, dx = 0;
+                if (g.ks == 3) {
+                    dy = (rem * 11) >> 5;                                    // rem / 3 for rem < 9
+                    dx = rem - 3 * dy;
+                }
+                const int half = g.ks >> 1;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int Y = cyx[a][i] >> 16, X = cyx[a][i] & 0xffff;
+                    int sy, sx;
+                    bool ok;
+                    if (g.mode == 2) {                                       // stride 2, zero pad on the bottom / right only
+                        sy = 2 * Y + dy;
+                        sx = 2 * X + dx;
+                        ok = sy < g.H && sx < g.W;
+                    } else {
+                        const int yy = Y + dy - half, xx = X + dx - half;
+                        ok = yy >= 0 && yy < g.Ho && xx >= 0 && xx < g.Wo;
+                        sy = g.mode == 1 ? (yy >> 1) : yy;                   // conv on the nearest-2x upsampled image
+                        sx = g.mode == 1 ? (xx >> 1) : xx;
+                    }
+                    const int f = cf[a][i] + dt;
+                    const u16* base = f >= 0 ? g.src + (long)f * g.frame : g.cache + (long)(2 + f) * g.frame;
+                    const u16* src = (ok && tap < g.taps) ? base + ((long)sy * g.W + sx) * g.C + c : g.zero;
+                    glds16(src, dst + i * 1024);
+                }
+                return;
+            }
+        }
         const long koff = (long)tile * 128;
         glds16(srcp[kind][0] + koff, dst);
         glds16(srcp[kind][1] + koff, dst + 1024);
@@ -839,6 +906,38 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
     return GF_OK;
 }
 
+template <int EPI>
+int launch_conv(const GemmArgs& a, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ph_kernel<EPI, false, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+        if (e != hipSuccess) {
+            gf_set_error("gf_conv3d: hipFuncSetAttribute(%d B LDS) failed: %s", GEMM_LDS, hipGetErrorString(e));
+            return GF_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_ph_kernel<EPI, false, true>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(GEMM_THREADS),
+                       GEMM_LDS, stream, a);
+    GF_CHECK_LAUNCH("gf_conv3d_bf16");
+    return GF_OK;
+}
+
+// 256 zero bytes per device: where the convolution's padding taps and K-padding columns are fetched from
+const u16* conv_zero_page() {
+    static const u16* page[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!page[dev]) {
+        void* z = nullptr;
+        if (hipMalloc(&z, 256) != hipSuccess) return nullptr;
+        if (hipMemset(z, 0, 256) != hipSuccess) return nullptr;
+        page[dev] = (const u16*)z;
+    }
+    return page[dev];
+}
+
 }  // namespace
 
 static int gemm_dispatch(bool fp8, const void* A, int64_t lda, const void* W, int64_t ldw, const float* row_scale,
@@ -910,4 +1009,78 @@ extern "C" GF_API int gf_gemm_fp8(const void* A8, int64_t lda, const void* W8, i
                                   const void* bias, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue,
                                   const void* resid, int64_t ldr, const void* gate, void* stream) {
     return gemm_dispatch(true, A8, lda, W8, ldw, row_scale, bias, C, ldc, M, N, K, epilogue, resid, ldr, gate, stream);
+}
+
+// Causal 3-D / 2-D convolution of the Wan VAE as ONE implicit GEMM (no patch matrix in HBM): out[(j, Y, X), n] =
+// bias[n] + sum over (dt, dy, dx, c) of in[t_off + j*t_stride - (kt-1) + dt, Y', X', c] * Wm[n, ((dt*ks + dy)*ks + dx)*C + c]
+// with the gather rules of gf_vae_im2col (mode 0 / 1 / 2), frames < 0 taken from `cache` (its 2 frames are frames -2, -1).
+// Wm is [N, ldw] bf16 with zero columns from taps*C up to K (K a multiple of 64).  Results are bit-identical to
+// gf_vae_im2col + gf_gemm_bf16 (same K order, same kernel).
+extern "C" GF_API int gf_conv3d_bf16(const void* src, const void* cache, const void* Wm, int64_t ldw, const void* bias,
+                                     void* out, int64_t ldc, int64_t T_in, int64_t T_out, int64_t H, int64_t W, int64_t C,
+                                     int kt, int ks, int mode, int t_stride, int t_off, int64_t N, int64_t K, int epilogue,
+                                     const void* resid, int64_t ldr, void* stream) {
+    GF_CHECK_ARG(src && Wm && out, "gf_conv3d_bf16: null src/W/out");
+    GF_CHECK_ARG(T_in > 0 && T_out >= 0 && H > 0 && W > 0 && H < 32768 && W < 32768, "gf_conv3d_bf16: bad frame size");
+    GF_CHECK_ARG(C > 0 && C % 8 == 0 && C <= 512, "gf_conv3d_bf16: C=%ld must be a multiple of 8 and <= 512", (long)C);
+    GF_CHECK_ARG((kt == 1 || kt == 3) && (ks == 1 || ks == 3), "gf_conv3d_bf16: kt/ks must be 1 or 3");
+    GF_CHECK_ARG(mode >= 0 && mode <= 2 && (mode == 0 || ks == 3), "gf_conv3d_bf16: bad mode");
+    GF_CHECK_ARG(mode != 2 || (H % 2 == 0 && W % 2 == 0), "gf_conv3d_bf16: stride-2 mode needs even H, W");
+    GF_CHECK_ARG(kt == 1 || cache, "gf_conv3d_bf16: a temporal kernel needs the 2-frame cache");
+    GF_CHECK_ARG(t_stride >= 1 && t_off >= 0 && (T_out == 0 || t_off + (T_out - 1) * t_stride < T_in),
+                 "gf_conv3d_bf16: output frames reach past the input");
+    const long taps = (long)kt * ks * ks;
+    GF_CHECK_ARG(K % 64 == 0 && K >= taps * C && K < 65536 && ldw >= K && ldw % 8 == 0,
+                 "gf_conv3d_bf16: K=%ld must be a multiple of 64 covering %ld taps x %ld channels", (long)K, taps, (long)C);
+    GF_CHECK_ARG(N > 0 && N % 8 == 0 && ldc >= N && ldc % 8 == 0, "gf_conv3d_bf16: N / ldc must be multiples of 8");
+    GF_CHECK_ARG(gf_aligned16(src) && gf_aligned16(Wm) && gf_aligned16(out) && (!cache || gf_aligned16(cache)) &&
+                     (!bias || gf_aligned16(bias)), "gf_conv3d_bf16: 16-byte alignment required");
+    GF_CHECK_ARG(epilogue == GF_EPI_BIAS || epilogue == GF_EPI_BIAS_RESID, "gf_conv3d_bf16: epilogue must be BIAS or BIAS_RESID");
+    GF_CHECK_ARG(epilogue != GF_EPI_BIAS_RESID || (resid && ldr % 8 == 0 && ldr >= N && gf_aligned16(resid)),
+                 "gf_conv3d_bf16: residual epilogue needs an aligned resid with ldr >= N");
+    const long Ho = mode == 1 ? 2 * H : (mode == 2 ? H / 2 : H), Wo = mode == 1 ? 2 * W : (mode == 2 ? W / 2 : W);
+    const long M = T_out * Ho * Wo;
+    GF_CHECK_ARG(M < (1L << 30), "gf_conv3d_bf16: too many output pixels");
+    if (M == 0) return GF_OK;
+    GemmArgs a;
+    a.A = nullptr;
+    a.W = (const u16*)Wm;
+    a.bias = (const u16*)bias;
+    a.C = (u16*)out;
+    a.R = (const u16*)resid;
+    a.gate = nullptr;
+    a.row_scale = nullptr;
+    a.M = (int)M;
+    a.N = (int)N;
+    a.K = (int)K;
+    a.lda = 0;
+    a.ldw = ldw;
+    a.ldc = ldc;
+    a.ldr = ldr;
+    a.tiles_m = (int)((M + BM - 1) / BM);
+    a.tiles_n = (int)((N + BN - 1) / BN);
+    a.dbg = nullptr;
+    a.cv.src = (const u16*)src;
+    a.cv.cache = (const u16*)cache;
+    a.cv.zero = conv_zero_page();
+    if (!a.cv.zero) {
+        gf_set_error("gf_conv3d_bf16: could not allocate the zero page");
+        return GF_ERR_LAUNCH;
+    }
+    a.cv.H = (int)H;
+    a.cv.W = (int)W;
+    a.cv.C = (int)C;
+    a.cv.Ho = (int)Ho;
+    a.cv.Wo = (int)Wo;
+    a.cv.kt = kt;
+    a.cv.ks = ks;
+    a.cv.mode = mode;
+    a.cv.t_stride = t_stride;
+    a.cv.t_off = t_off;
+    a.cv.taps = (int)taps;
+    a.cv.frame = (long)H * W * C;
+    a.cv.inv_c = 1.0f / (float)C;
+    a.cv.inv_ks2 = 1.0f / (float)(ks * ks);
+    hipStream_t s = (hipStream_t)stream;
+    return epilogue == GF_EPI_BIAS ? launch_conv<GF_EPI_BIAS>(a, s) : launch_conv<GF_EPI_BIAS_RESID>(a, s);
 }

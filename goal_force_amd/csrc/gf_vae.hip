@@ -114,29 +114,39 @@ __global__ __launch_bounds__(VT) void finish_latent_kernel(const u16* __restrict
 }
 
 // RMS_norm (VAE:55-70): F.normalize(x, dim=channel) * sqrt(C) * gamma, then optional SiLU; every eager op of
-// the reference rounds to bf16 and so do we.  One wave per pixel row (C <= 512), 4 rows per workgroup.
+// the reference rounds to bf16 and so do we.  LPR lanes per pixel row (16 bytes per lane, C <= 8*LPR): 64/LPR rows per wave,
+// so the decoder's widest images (C = 96: 12 chunks) keep 48 of 64 lanes busy instead of 12.  The row sum is the upper part
+// of the same descending butterfly at every LPR (the stages it skips would only add zeros): results do not depend on LPR.
+template <int LPR>
 __global__ __launch_bounds__(VT) void rmsnorm_silu_kernel(const u16* __restrict__ x, const u16* __restrict__ gamma,
                                                           u16* __restrict__ out, long rows, int C, float scale,
                                                           int silu) {
+    constexpr int RPW = 64 / LPR;                 // rows per wave
     const int lane = threadIdx.x & 63;
-    const long row0 = (long)blockIdx.x * (VT / 64) + (threadIdx.x >> 6);
-    const long rstride = (long)gridDim.x * (VT / 64);
+    const int sub = lane & (LPR - 1);
+    const long row0 = ((long)blockIdx.x * (VT / 64) + (threadIdx.x >> 6)) * RPW + lane / LPR;
+    const long rstride = (long)gridDim.x * (VT / 64) * RPW;
     const int nch = C >> 3;
-    for (long row = row0; row < rows; row += rstride) {
+    u16x8 g8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (sub < nch) g8 = *reinterpret_cast<const u16x8*>(gamma + (sub << 3));
+    // the loop bound is wave-uniform (the shuffles below need every lane): rows past the end are computed on zeros, not stored
+    for (long rb = row0 - lane / LPR; rb < rows; rb += rstride) {
+        const long row = rb + lane / LPR;
+        const bool live = sub < nch && row < rows;
         u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
         float s = 0.f;
-        if (lane < nch) {
-            v = *reinterpret_cast<const u16x8*>(x + row * C + (lane << 3));
+        if (live) {
+            v = *reinterpret_cast<const u16x8*>(x + row * C + (sub << 3));
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float f = bf2f(v[j]);
                 s += f * f;
             }
         }
-        s = wave_sum(s);
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
         const float nrm = fmaxf(rbf(sqrtf(s)), 1e-12f);  // x.norm(2, dim).clamp_min(eps), bf16 tensor
-        if (lane < nch) {
-            const u16x8 g8 = *reinterpret_cast<const u16x8*>(gamma + (lane << 3));
+        if (live) {
             u16x8 o;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -146,7 +156,7 @@ __global__ __launch_bounds__(VT) void rmsnorm_silu_kernel(const u16* __restrict_
                 if (silu) y = y / (1.0f + expf(-y));
                 o[j] = f2bf(y);
             }
-            *reinterpret_cast<u16x8*>(out + row * C + (lane << 3)) = o;
+            *reinterpret_cast<u16x8*>(out + row * C + (sub << 3)) = o;
         }
     }
 }
@@ -289,8 +299,14 @@ extern "C" GF_API int gf_vae_rmsnorm_silu(const void* x, const void* gamma, void
     GF_CHECK_ARG(C > 0 && C % 8 == 0 && C <= 512, "gf_vae_rmsnorm_silu: C=%ld must be a multiple of 8 and <= 512", (long)C);
     GF_CHECK_ARG(gf_aligned16(x) && gf_aligned16(out) && gf_aligned16(gamma), "gf_vae_rmsnorm_silu: alignment");
     if (rows == 0) return GF_OK;
-    hipLaunchKernelGGL(rmsnorm_silu_kernel, dim3(vgrid(rows * 64)), dim3(VT), 0, (hipStream_t)stream, (const u16*)x,
-                       (const u16*)gamma, (u16*)out, (long)rows, (int)C, sqrtf((float)C), silu ? 1 : 0);
+#define GF_RMS_LAUNCH(LPR)                                                                                                  \
+    hipLaunchKernelGGL(rmsnorm_silu_kernel<LPR>, dim3(vgrid(rows * LPR)), dim3(VT), 0, (hipStream_t)stream, (const u16*)x,  \
+                       (const u16*)gamma, (u16*)out, (long)rows, (int)C, sqrtf((float)C), silu ? 1 : 0)
+    if (C <= 64) GF_RMS_LAUNCH(8);
+    else if (C <= 128) GF_RMS_LAUNCH(16);
+    else if (C <= 256) GF_RMS_LAUNCH(32);
+    else GF_RMS_LAUNCH(64);
+#undef GF_RMS_LAUNCH
     GF_CHECK_LAUNCH("gf_vae_rmsnorm_silu");
     return GF_OK;
 }

@@ -356,6 +356,45 @@ def vae_im2col(src, cache, kt, ks, kpad, upsample2x=False, downsample2=False, t_
     return out
 
 
+def vae_conv3d(src, cache, w, bias, kt, ks, upsample2x=False, downsample2=False, t_stride=1, t_off=0, t_out=None,
+               resid=None, out=None):
+    """Causal conv as one implicit GEMM (gf_conv3d_bf16): src [T,H,W,C] (+cache [2,H,W,C]) x w [N, kpad] -> [T_out*Ho*Wo, N].
+    Same arguments as vae_im2col + gemm(epilogue BIAS / BIAS_RESID); bit-identical to that pair."""
+    _req(src, "vae_conv3d.src")
+    _req(w, "vae_conv3d.w")
+    if not src.is_contiguous() or src.dim() != 4:
+        raise GoalForceError("vae_conv3d.src must be contiguous [T,H,W,C]")
+    T, H, W, C = src.shape
+    if cache is not None:
+        _req(cache, "vae_conv3d.cache")
+        if tuple(cache.shape) != (2, H, W, C) or not cache.is_contiguous():
+            raise GoalForceError(f"vae_conv3d.cache must be contiguous [2,{H},{W},{C}]")
+    if w.dim() != 2 or w.stride(1) != 1:
+        raise GoalForceError("vae_conv3d.w must be [N, kpad] with contiguous rows")
+    mode = 1 if upsample2x else (2 if downsample2 else 0)
+    if t_out is None:
+        t_out = (T - t_off + t_stride - 1) // t_stride
+    px = H * W * 4 if mode == 1 else ((H // 2) * (W // 2) if mode == 2 else H * W)
+    n, k = w.shape
+    if out is None:
+        out = torch.empty((t_out * px, n), dtype=_BF16, device=src.device)
+    elif out.dim() != 2 or out.shape != (t_out * px, n) or out.stride(1) != 1:
+        raise GoalForceError("vae_conv3d.out must be [T_out*Ho*Wo, N] with contiguous rows")
+    if bias is not None:
+        _req(bias, "vae_conv3d.bias")
+    ldr = 0
+    if resid is not None:
+        _req(resid, "vae_conv3d.resid")
+        if resid.dim() != 2 or resid.shape[0] != t_out * px or resid.stride(1) != 1:
+            raise GoalForceError("vae_conv3d.resid must be [T_out*Ho*Wo, >=N] with contiguous rows")
+        ldr = resid.stride(0)
+    _lib.check(_lib.load().gf_conv3d_bf16(_ptr(src), _ptr(cache), _ptr(w), w.stride(0), _ptr(bias), _ptr(out), out.stride(0),
+                                          T, t_out, H, W, C, kt, ks, mode, t_stride, t_off, n, k,
+                                          EPI_BIAS if resid is None else EPI_BIAS_RESID, _ptr(resid), ldr, _stream(src)),
+               "gf_conv3d_bf16")
+    return out
+
+
 def vae_finish_latent(x, mean, inv_std, C):
     """x [rows, >=C] (conv1 output, channels-last) -> [rows, C] normalised mu."""
     _req(x, "vae_finish_latent.x")

@@ -22,6 +22,7 @@ How the reference's algorithm maps here
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -35,6 +36,26 @@ VAE_MEAN = [-0.7571, -0.7089, -0.9113, 0.1075, -0.1745, 0.9653, -0.1517, 1.5508,
             0.4134, -0.0715, 0.5517, -0.3632, -0.1922, -0.9497, 0.2503, -0.2921]   # VAE:1063-1066
 VAE_STD = [2.8184, 1.4541, 2.3275, 2.6558, 1.2196, 1.7708, 2.6052, 2.0743,
            3.2687, 2.1526, 2.8652, 1.5579, 1.6382, 1.1253, 2.8251, 1.9160]        # VAE:1067-1070
+
+
+# Convolutions run as ONE implicit GEMM (gf_conv3d_bf16: no patch matrix in HBM).  GF_VAE_CONV=im2col selects the first
+# version (gf_vae_im2col + gf_gemm_bf16, bit-identical results) for A/B timing and for the parity test of the two.
+IMPLICIT_CONV = os.environ.get("GF_VAE_CONV", "implicit") != "im2col"
+
+
+def _conv(x, cache, c, resid=None, **gather):
+    """One prepared conv `c` (dict of _prep_conv) on x [T,H,W,C] (+ 2-frame cache) -> [T_out*Ho*Wo, N]."""
+    if IMPLICIT_CONV:
+        return ops.vae_conv3d(x, cache, c["w"], c["b"], c["kt"], c["ks"], resid=resid, **gather)
+    cols = ops.vae_im2col(x, cache, c["kt"], c["ks"], c["kpad"], **gather)
+    return ops.gemm(cols, c["w"], c["b"], epilogue=ops.EPI_BIAS if resid is None else ops.EPI_BIAS_RESID, resid=resid)
+
+
+def _roll_cache(cache, x):
+    """The feature cache after a chunk: the last CACHE_T frames of [cache, x] (VAE:283-294) ."""
+    if x.shape[0] >= CACHE_T:
+        return x[-CACHE_T:].clone()       # a copy: a view would keep the whole group of frames alive
+    return torch.cat([cache[x.shape[0] - CACHE_T:], x], dim=0)
 
 
 def _pad_to(n, m):
@@ -197,6 +218,9 @@ class WanVideoVAE(nn.Module):
         self.z_dim = z_dim
         self._prepared = None     # GEMM-ready weights (built lazily, invalidated on load)
         self._cache: Dict[str, torch.Tensor] = {}
+        # latent frames per decoder call / 4-frame chunks per encoder call after the first frame (1 = the reference's streaming
+        # granularity; any value gives the same bits).  20 = the whole 81-frame clip of a tile: ~10 GB of activations.
+        self.frames_per_chunk = int(os.environ.get("GF_VAE_FRAMES_PER_CHUNK", "20"))
 
     # ---------------------------------------------------------------- state dict
     def load_state_dict(self, state_dict, strict=True, **kw):
@@ -258,19 +282,17 @@ class WanVideoVAE(nn.Module):
         """CausalConv3d with its feature cache (VAE:33-52 + the cache handling of VAE:283-294)."""
         c = P[name]
         T, H, W, C = x.shape
+        r2 = None if resid is None else resid.reshape(T * H * W, -1)
+        cache = None
         if c["kt"] == 3:
             cache = self._cache.get(name)
             if cache is None:
                 cache = torch.zeros((CACHE_T, H, W, C), dtype=x.dtype, device=x.device)
-            cols = ops.vae_im2col(x, cache, 3, c["ks"], c["kpad"])
-            self._cache[name] = torch.cat([cache, x], dim=0)[-CACHE_T:].contiguous()
+            self._cache[name] = _roll_cache(cache, x)
         elif c["ks"] == 1 and c["kpad"] == C:
-            cols = x.reshape(T * H * W, C)
-        else:
-            cols = ops.vae_im2col(x, None, 1, c["ks"], c["kpad"])
-        out = ops.gemm(cols, c["w"], c["b"], epilogue=ops.EPI_BIAS if resid is None else ops.EPI_BIAS_RESID,
-                       resid=None if resid is None else resid.reshape(T * H * W, -1))
-        return out.view(T, H, W, -1)
+            return ops.gemm(x.reshape(T * H * W, C), c["w"], c["b"],
+                            epilogue=ops.EPI_BIAS if resid is None else ops.EPI_BIAS_RESID, resid=r2).view(T, H, W, -1)
+        return _conv(x, cache, c, resid=r2).view(T, H, W, -1)
 
     def _res_block(self, P, name, x, cin, cout):
         """ResidualBlock (VAE:267-301)."""
@@ -308,18 +330,12 @@ class WanVideoVAE(nn.Module):
             cache = self._cache.get(name + ".time_conv")
             if cache is None:  # 'Rep': the first executed time_conv sees zero history (VAE:139-147)
                 cache = torch.zeros((CACHE_T, H, W, C), dtype=x.dtype, device=x.device)
-            cols = ops.vae_im2col(x, cache, 3, 1, tc["kpad"])
-            self._cache[name + ".time_conv"] = torch.cat([cache, x], dim=0)[-CACHE_T:].contiguous()
-            y = torch.empty((2 * T, H, W, C), dtype=x.dtype, device=x.device)
-            hw = H * W
-            for t in range(T):
-                for j in range(2):  # channels [jC,(j+1)C) of frame t become frame 2t+j (VAE:155-158)
-                    ops.gemm(cols[t * hw:(t + 1) * hw], tc["w"][j * C:(j + 1) * C], tc["b"][j * C:(j + 1) * C],
-                             out=y[2 * t + j].reshape(hw, C))
-            x, T = y, 2 * T
-        rc = P[name + ".resample.1"]
-        cols = ops.vae_im2col(x, None, 1, 3, rc["kpad"], upsample2x=True)
-        return ops.gemm(cols, rc["w"], rc["b"]).view(T, 2 * H, 2 * W, -1)
+            self._cache[name + ".time_conv"] = _roll_cache(cache, x)
+            y2 = _conv(x, cache, tc)                                  # [T*hw, 2C]
+            # channels [jC,(j+1)C) of frame t become frame 2t+j (VAE:155-158)
+            x = y2.view(T, H * W, 2, C).transpose(1, 2).contiguous().view(2 * T, H, W, C)
+            T = 2 * T
+        return _conv(x, None, P[name + ".resample.1"], upsample2x=True).view(T, 2 * H, 2 * W, -1)
 
     def _decode_chunk(self, P, x, first):
         """Decoder3d.forward on one latent frame (VAE:788-838).  x [1,h,w,16] -> [1 or 4, 8h, 8w, 8]."""
@@ -346,7 +362,13 @@ class WanVideoVAE(nn.Module):
         T, h, w, _ = zc.shape
         c2 = P["conv2"]
         x = ops.gemm(zc.reshape(T * h * w, 64), c2["w"], c2["b"]).view(T, h, w, -1)  # conv2, 1x1x1
-        frames = [self._decode_chunk(P, x[i:i + 1].contiguous(), first=(i == 0)) for i in range(T)]
+        # The reference streams one latent frame per call through the feature caches (VAE:1021-1033).  A causal conv over a
+        # GROUP of frames with the same 2-frame cache in front computes exactly the same sums, so after the first frame (which
+        # skips the temporal upsampling) the frames go through in groups: launches that fill the chip, bit-identical output.
+        frames = [self._decode_chunk(P, x[:1].contiguous(), first=True)]
+        g = max(1, int(self.frames_per_chunk))
+        for i in range(1, T, g):
+            frames.append(self._decode_chunk(P, x[i:i + g].contiguous(), first=False))
         self._cache = {}
         return torch.cat(frames, dim=0)
 
@@ -354,19 +376,15 @@ class WanVideoVAE(nn.Module):
     def _downsample(self, P, name, x, C, temporal):
         """Resample downsample2d / downsample3d (VAE:101-112, 159-174)."""
         T, H, W, _ = x.shape
-        rc = P[name + ".resample.1"]
-        cols = ops.vae_im2col(x, None, 1, 3, rc["kpad"], downsample2=True)
-        x = ops.gemm(cols, rc["w"], rc["b"]).view(T, H // 2, W // 2, -1)
+        x = _conv(x, None, P[name + ".resample.1"], downsample2=True).view(T, H // 2, W // 2, -1)
         if temporal:
             key = name + ".time_conv"
             prev = self._cache.get(key)
             if prev is None:   # first chunk: remember the frame, no temporal conv (VAE:162-164)
                 self._cache[key] = torch.cat([torch.zeros_like(x[-1:]), x[-1:]], dim=0).contiguous()
             else:              # conv over [prev_last, x_0..x_{T-1}], kernel 3, stride 2, no padding (VAE:166-170)
-                tc = P[key]
-                cols = ops.vae_im2col(x, prev, 3, 1, tc["kpad"], t_stride=2, t_off=1, t_out=T // 2)
-                self._cache[key] = torch.cat([prev, x], dim=0)[-CACHE_T:].contiguous()
-                x = ops.gemm(cols, tc["w"], tc["b"]).view(T // 2, H // 2, W // 2, -1)
+                self._cache[key] = _roll_cache(prev, x)
+                x = _conv(x, prev, P[key], t_stride=2, t_off=1, t_out=T // 2).view(T // 2, H // 2, W // 2, -1)
         return x
 
     def _encode_chunk(self, P, x):
@@ -392,11 +410,12 @@ class WanVideoVAE(nn.Module):
         self._cache = {}
         T = video_slice.shape[1]
         xin = ops.vae_prep_latent(video_slice, P["zero3"], P["one3"], cpad=8)    # channels-last, RGB padded to 8
-        n_iter = 1 + (T - 1) // 4
-        outs = []
-        for i in range(n_iter):
-            chunk = xin[:1] if i == 0 else xin[1 + 4 * (i - 1):1 + 4 * i]
-            outs.append(self._encode_chunk(P, chunk.contiguous()))
+        # frame 0 alone, then the 4-frame chunks of VAE:994-1001 in groups (same sums as one chunk at a time, see decode)
+        outs = [self._encode_chunk(P, xin[:1].contiguous())]
+        n4 = 4 * ((T - 1) // 4)
+        g = 4 * max(1, int(self.frames_per_chunk))
+        for i in range(1, 1 + n4, g):
+            outs.append(self._encode_chunk(P, xin[i:min(i + g, 1 + n4)].contiguous()))
         self._cache = {}
         h = torch.cat(outs, dim=0)                                               # [T', h, w, 64]
         Tl, hh, ww, _ = h.shape

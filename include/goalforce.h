@@ -269,6 +269,17 @@ GF_API int gf_vae_im2col(const void* src, const void* cache, void* out, int64_t 
                          int64_t C, int64_t kt, int64_t ks, int mode, int64_t t_stride, int64_t t_off,
                          int64_t kpad, void* stream);
 
+/* gf_conv3d_bf16 — the same convolution as ONE implicit GEMM: gf_vae_im2col's patch matrix is never written; the GEMM's
+ * LDS-DMA fetches every 16-byte piece (8 channels of one tap of one output pixel) straight from src / cache (padding taps
+ * and the K padding columns from a zero page).  Replaces CausalConv3d.forward (VAE:33-52) and the convs inside Resample
+ * (VAE:82-174) end to end; arguments as gf_vae_im2col (T_in = frames in src) + gf_gemm_bf16 (Wm [N, ldw] with columns
+ * ((dt*ks+dy)*ks+dx)*C+c, zero from kt*ks*ks*C up to K; K a multiple of 64; epilogue GF_EPI_BIAS or GF_EPI_BIAS_RESID).
+ * out [T_out*Ho*Wo, ldc].  Bit-identical to gf_vae_im2col + gf_gemm_bf16. */
+GF_API int gf_conv3d_bf16(const void* src, const void* cache, const void* Wm, int64_t ldw, const void* bias,
+                          void* out, int64_t ldc, int64_t T_in, int64_t T_out, int64_t H, int64_t W, int64_t C,
+                          int kt, int ks, int mode, int t_stride, int t_off, int64_t N, int64_t K, int epilogue,
+                          const void* resid, int64_t ldr, void* stream);
+
 /* gf_vae_finish_latent — encoder tail: out[r,c] = bf16(bf16(x[r,c] - mean[c]) * inv_std[c]) for the first C
  * (mu) channels of the 1x1x1 conv1 output (VideoVAE_.encode, VAE:1002-1010). */
 GF_API int gf_vae_finish_latent(const void* x, int64_t ldx, const void* mean, const void* inv_std, void* out,

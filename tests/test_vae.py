@@ -108,6 +108,71 @@ def test_hip_vae_im2col_and_norm_kernels_exact():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", [
+    # (T, H, W, C, N, kt, ks, gather kwargs, residual)
+    dict(T=2, H=5, W=6, C=16, N=24, kt=3, ks=3),                                   # causal 3x3x3, K 432 -> 448
+    dict(T=4, H=18, W=20, C=96, N=96, kt=3, ks=3, resid=True),                     # decoder top level (C=96), > 1 M tile
+    dict(T=1, H=9, W=7, C=192, N=96, kt=1, ks=3, gather=dict(upsample2x=True)),    # Resample upsample2d conv
+    dict(T=3, H=8, W=10, C=24, N=24, kt=1, ks=3, gather=dict(downsample2=True)),   # Resample downsample2d conv
+    dict(T=4, H=6, W=5, C=32, N=32, kt=3, ks=1, gather=dict(t_stride=2, t_off=1, t_out=2)),   # encoder time_conv
+    dict(T=2, H=6, W=5, C=32, N=64, kt=3, ks=1, gather=dict(t_off=1, t_out=1)),    # decoder time_conv, one frame at a time
+    dict(T=1, H=12, W=12, C=8, N=96, kt=3, ks=3),                                  # encoder conv1 on RGB padded to 8
+    dict(T=1, H=40, W=40, C=384, N=384, kt=3, ks=3, resid=True),                   # widest level: K 10368, 2 N tiles
+])
+def test_hip_implicit_conv_bit_identical_to_im2col_gemm(case):
+    """gf_conv3d_bf16 (no patch matrix) == gf_vae_im2col + gf_gemm_bf16, bit for bit, in every gather mode."""
+    from goal_force_amd import ops
+    g = torch.Generator().manual_seed(11)
+    T, H, W, C, N, kt, ks = (case[k] for k in ("T", "H", "W", "C", "N", "kt", "ks"))
+    gather = case.get("gather", {})
+    k = kt * ks * ks * C
+    kpad = -(-k // 64) * 64
+    x = torch.randn((T, H, W, C), generator=g).to(BF).cuda()
+    cache = torch.randn((2, H, W, C), generator=g).to(BF).cuda() if kt == 3 else None
+    w = torch.zeros((N, kpad), dtype=BF)
+    w[:, :k] = (torch.randn((N, k), generator=g) / k ** 0.5).to(BF)
+    w = w.cuda()
+    b = torch.randn((N,), generator=g).to(BF).cuda()
+    cols = ops.vae_im2col(x, cache, kt, ks, kpad, **gather)
+    resid = torch.randn((cols.shape[0], N), generator=g).to(BF).cuda() if case.get("resid") else None
+    ref = ops.gemm(cols, w, b, epilogue=ops.EPI_BIAS if resid is None else ops.EPI_BIAS_RESID, resid=resid)
+    got = ops.vae_conv3d(x, cache, w, b, kt, ks, resid=resid, **gather)
+    assert got.shape == ref.shape and torch.equal(got, ref)
+    assert float(ref.float().abs().max()) > 0.5                                    # not comparing zeros
+
+
+@pytest.mark.gpu
+def test_hip_implicit_conv_rejects_bad_arguments():
+    from goal_force_amd import ops
+    from goal_force_amd._lib import GoalForceError
+    x = torch.zeros((2, 4, 4, 16), dtype=BF).cuda()
+    w = torch.zeros((8, 448), dtype=BF).cuda()
+    with pytest.raises(GoalForceError):
+        ops.vae_conv3d(x, None, w, None, 3, 3)                 # temporal kernel without its cache
+    with pytest.raises(GoalForceError):
+        ops.vae_conv3d(x, None, w[:, :100], None, 1, 3)        # K not a multiple of 64 / does not cover the taps
+    with pytest.raises(GoalForceError):
+        ops.vae_conv3d(x, None, w[:, :192], None, 1, 3, t_off=1, t_out=2)   # frames past the input
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C", [8, 96, 192, 384])
+def test_hip_vae_rmsnorm_all_widths(C):
+    """Every lanes-per-row variant of the RMS_norm kernel against the eager bf16 ops, including a ragged last wave."""
+    from goal_force_amd import ops
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(C)
+    xx = (torch.randn((3, 7, 11, C), generator=g) * 3).to(BF)
+    gam = (1 + 0.1 * torch.randn(C, generator=g)).to(BF)
+    for silu in (True, False):
+        ref = F.normalize(xx, dim=-1) * (C ** 0.5) * gam
+        ref = F.silu(ref) if silu else ref
+        got = ops.vae_rmsnorm_silu(xx.cuda(), gam.cuda(), silu=silu).cpu()
+        bad = ((got.view(torch.int16).int() - ref.view(torch.int16).int()).abs() > 1).float().mean()
+        assert rel_l2(got.float(), ref.float()) < 3e-3 and float(bad) < 5e-3
+
+
+@pytest.mark.gpu
 def test_hip_vae_decode_vs_reference_golden():
     g, sd, z1, z2 = _fixture()
     vae = _gpu_vae(sd)
@@ -120,6 +185,24 @@ def test_hip_vae_decode_vs_reference_golden():
     # streaming property: the first output frame depends only on the first latent frame
     got1 = vae.decode(z1[:, :, :1].cuda(), tiled=False).cpu()
     assert torch.equal(got1[:, :, 0], got[:, :, 0])
+
+
+@pytest.mark.gpu
+def test_hip_vae_frame_grouping_is_bit_identical_to_streaming():
+    """Decoding / encoding the frames after the first in groups == one latent frame (one 4-frame chunk) at a time."""
+    g, sd, z1, z2 = _fixture()
+    vae = _gpu_vae(sd)
+    gen = torch.Generator().manual_seed(3)
+    z = torch.randn((1, 16, 6, 8, 8), generator=gen).to(BF).cuda()
+    video = (torch.rand((3, 21, 64, 64), generator=gen) * 2 - 1).to(BF).cuda()
+    outs, encs = [], []
+    for fpc in (1, 2, 20):
+        vae.frames_per_chunk = fpc
+        outs.append(vae.decode(z, tiled=False))
+        encs.append(vae.encode([video], tiled=False))
+    assert outs[0].shape == (1, 3, 21, 64, 64) and encs[0].shape == (1, 16, 6, 8, 8)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert torch.equal(encs[0], encs[1]) and torch.equal(encs[0], encs[2])
 
 
 @pytest.mark.gpu
