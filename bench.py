@@ -208,7 +208,7 @@ def main():
             "step_mfma_frac": (sum(step_flops) / elapsed / 1e12) / PEAK_BF16_TFLOPS,
             "frames_per_sec_schedule_weighted": (videos * 81.0 / ((21 * sum(hi) / len(hi) + 29 * sum(lo) / len(lo)) / 1e3 + vae_s)
                                                  if hi and lo else None),
-            "roofline": {"bound": "mfma", "kernel": "flash_attn_fwd_kernel2 (self-attention, S=32760, 40 heads, d=128)",
+            "roofline": {"bound": "mfma", "kernel": "flash_attn_fwd_kernel2<true> + transpose_v_kernel (self-attention, S=32760, 40 heads, d=128)",
                          "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "peak_note": "dense bf16 MFMA peak = 256 CU x 4096 FLOP/clk x 2.4 GHz (MI355X_MICROARCH.md); under this "
                                       "load the chip holds ~2.0-2.05 GHz (rocprofv3 GRBM_GUI_ACTIVE), i.e. ~2.1 PFLOP/s",
@@ -216,7 +216,9 @@ def main():
                          # HBM bytes per launch from rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes over
                          # tools/microbench.py attn, profiles/r01/pmc/): (2 x FETCH_SIZE [gfx950 reports half of a 16-B/lane
                          # stream] + WRITE_SIZE) KiB -> bytes.  Not collected live: PMC needs the profiler.
-                         "traffic": (2 * 1753460 + 409524) * 1024, "traffic_source": "profiles/r01/pmc/attn_k2_{FETCH,WRITE}_SIZE_counter_collection.csv",
+                         # The launch = transpose_v_kernel + flash_attn_fwd_kernel2<true> (both inside the timed events).
+                         "traffic": ((2 * 1894109 + 327602) + (2 * 163820 + 327767)) * 1024,
+                         "traffic_source": "profiles/r01/pmc/attn_k2vt_{FETCH,WRITE}_SIZE_counter_collection.csv",
                          "launches": len(self_att), "avg_launch_ms": att_ms if self_att else None,
                          "algorithmic_flops_per_launch": att_flops},
         }
