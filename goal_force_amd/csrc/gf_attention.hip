@@ -413,6 +413,13 @@ __global__ __launch_bounds__(AT_THREADS, 2) void flash_attn_fwd_kernel(const Att
 //     against it, but O (still receiving PV(p-1), which is in the OLD scale) is multiplied at the top of phase p+1.
 //   * K and V tiles are staged separately by LDS-DMA, two buffers each (64 KiB): K(p+2) and V(p) are issued at the top
 //     of phase p and waited for at its closing barrier (K(j) is consumed in phase j-1, V(j) in phase j+1).
+// GF_ATTN_WHATIF (tools/attn_whatif.py): timing-only builds of kernel 2 with parts of the steady phase left out — RESULTS ARE
+// WRONG, never shipped: 1 no fma/exp2/sum/pack, 2 no row max / rescale decision, 4 no fragment LDS reads, 8 no closing wait +
+// barrier, 16 no K/V staging, 32 no deferred O rescale, 128 no V staging, 256 no K staging; 64 = (correct results) the DMA pieces issued at the
+// top of the phase (the first version) instead of inside its slots.
+#ifndef GF_ATTN_WHATIF
+#define GF_ATTN_WHATIF 0
+#endif
 constexpr int AT2_THREADS = 512;
 constexpr int AT2_V_BASE = 2 * KV_TILE_BYTES;
 constexpr int AT2_LDS = 4 * KV_TILE_BYTES;
@@ -517,6 +524,28 @@ __global__ __launch_bounds__(AT2_THREADS, 2) void flash_attn_fwd_kernel2(const A
                 const int lch = (lane & 15) ^ ((dma_r << 2) | (j & 3));
                 dma16(g + rr * stride + head * HD + lch * 8, base + jj * 1024);
             }
+        }
+    };
+
+    // one of the two DMA pieces of stage(which, t, buf)
+    auto stage_piece = [&](int which, int t, int buf, int jj) {
+        GF_LDS char* base = lds + which * AT2_V_BASE + buf * KV_TILE_BYTES + wave * 2048;
+        if constexpr (VT) {
+            if (which) {
+                dma16(p.vt + (vt_off[jj] + (unsigned)t * KVB), base + jj * 1024);
+                return;
+            }
+        }
+        const u16* g = which ? p.v : p.k;
+        if ((t + 1) * KVB <= p.kv_len) {
+            const unsigned tt = (unsigned)t * (which ? vstep : kstep);
+            dma16(g + (dma_off[jj][which] + tt), base + jj * 1024);
+        } else {
+            const long stride = which ? p.v_stride : p.k_stride;
+            const int j = 2 * wave + jj;
+            const long rr = min(t * KVB + 4 * j + dma_r, p.kv_len - 1);
+            const int lch = (lane & 15) ^ ((dma_r << 2) | (j & 3));
+            dma16(g + rr * stride + head * HD + lch * 8, base + jj * 1024);
         }
     };
 
@@ -658,9 +687,16 @@ __global__ __launch_bounds__(AT2_THREADS, 2) void flash_attn_fwd_kernel2(const A
     // slot pins the written order; the empty volatile asms pin each score's VALU work INTO its slot (instruction
     // selection would otherwise hoist all 32 exps to the top of the phase).
     bf16x8 fr[4];
+    if constexpr ((GF_ATTN_WHATIF & 4) != 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fr[i] = qf[i];
+    }
     auto frag_load = [&](auto g_c, auto par_c) {
         constexpr int G = decltype(g_c)::value, PAR = decltype(par_c)::value;
-        if constexpr (G < 16) {
+        if constexpr ((GF_ATTN_WHATIF & 4) != 0) {
+            bf16x8& f = fr[G & 3];
+            asm volatile("" : "+v"(f));
+        } else if constexpr (G < 16) {
             constexpr int kt = G >> 3, sq = (G >> 2) & 1, d = G & 3;
             if constexpr (VT) {
                 fr[G & 3] = *(GF_LDS bf16x8*)(lds + vt_rd[2 * kt + sq] + (1 - PAR) * KV_TILE_BYTES + d * 4096);
@@ -692,11 +728,27 @@ __global__ __launch_bounds__(AT2_THREADS, 2) void flash_attn_fwd_kernel2(const A
             }
         }
     };
+    // The four DMA pieces of a phase are issued inside its slots (V(p) in slots 5 and 9, K(p+2) in 13 and 17) instead of back to
+    // back at its top: +1 % (18 of the phase's 32 slots still lie between the last piece and the closing wait).  Staggering them
+    // over the waves as well (two waves per slot) measured 1.7 % SLOWER.  GF_ATTN_WHATIF & 64 restores the issue at the top.
+    auto dma_slot = [&](auto g_c, auto par_c, int pidx) {
+        constexpr int G = decltype(g_c)::value, PAR = decltype(par_c)::value;
+        if constexpr (!(GF_ATTN_WHATIF & (16 | 64))) {
+            if constexpr (G == 5 && !(GF_ATTN_WHATIF & 128)) stage_piece(1, pidx, PAR, 0);
+            if constexpr (G == 9 && !(GF_ATTN_WHATIF & 128)) stage_piece(1, pidx, PAR, 1);
+            if constexpr (G == 13 && !(GF_ATTN_WHATIF & 256)) { if (pidx + 2 < nt) stage_piece(0, pidx + 2, PAR, 0); }
+            if constexpr (G == 17 && !(GF_ATTN_WHATIF & 256)) { if (pidx + 2 < nt) stage_piece(0, pidx + 2, PAR, 1); }
+        }
+    };
     auto phase = [&](auto par_c, int pidx) {
         constexpr int PAR = decltype(par_c)::value;
-        if (pidx + 2 < nt) stage(0, pidx + 2, PAR);
-        stage(1, pidx, PAR);
-        apply_pending();
+        if constexpr ((GF_ATTN_WHATIF & 64) != 0 && !(GF_ATTN_WHATIF & 16)) {
+            if constexpr (!(GF_ATTN_WHATIF & 256)) {
+                if (pidx + 2 < nt) stage(0, pidx + 2, PAR);
+            }
+            if constexpr (!(GF_ATTN_WHATIF & 128)) stage(1, pidx, PAR);
+        }
+        if constexpr (!(GF_ATTN_WHATIF & 32)) apply_pending();
         frag_load(std::integral_constant<int, 0>{}, par_c);
         frag_load(std::integral_constant<int, 1>{}, par_c);
         frag_load(std::integral_constant<int, 2>{}, par_c);
@@ -705,29 +757,34 @@ __global__ __launch_bounds__(AT2_THREADS, 2) void flash_attn_fwd_kernel2(const A
             constexpr int G = decltype(i_c)::value;
             mfma_op(i_c, par_c);
             frag_load(std::integral_constant<int, G + 3>{}, par_c);
-            if constexpr (G == 1) {
+            dma_slot(i_c, par_c, pidx);
+            if constexpr ((GF_ATTN_WHATIF & 2) != 0) {
+            } else if constexpr (G == 1 || G == 2) {   // two independent v_max3 chains per slot (a wave issues in order)
+                float m0 = mx, m1 = -INFINITY;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sc[PAR][0][e]);
-            } else if constexpr (G == 2) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sc[PAR][1][e]);
-                mo = __shfl_xor(mx, 32);
+                for (int e = 0; e < 16; e += 4) {
+                    m0 = fmaxf(fmaxf(m0, sc[PAR][G - 1][e]), sc[PAR][G - 1][e + 1]);
+                    m1 = fmaxf(fmaxf(m1, sc[PAR][G - 1][e + 2]), sc[PAR][G - 1][e + 3]);
+                }
+                mx = fmaxf(m0, m1);
+                if constexpr (G == 2) mo = __shfl_xor(mx, 32);
             } else if constexpr (G == 3) {
                 mx = fmaxf(mx, mo);
             }
             __builtin_amdgcn_sched_barrier(0);
         });
-        new_max(mx);
+        if constexpr (!(GF_ATTN_WHATIF & 2)) new_max(mx);
         const float mc = m_run * c;
         float rs = 0.f, pe[2];
         static_for<4, 32>([&](auto i_c) {
             constexpr int G = decltype(i_c)::value;
             mfma_op(i_c, par_c);
             frag_load(std::integral_constant<int, G + 3>{}, par_c);
+            dma_slot(i_c, par_c, pidx);
             // scores 0..7 two per slot in slots 4-7, scores 8..31 one per slot in slots 8-31
             constexpr int n_el = (G < 8) ? 2 : 1;
             constexpr int el0 = (G < 8) ? 2 * (G - 4) : G;
-            static_for<0, n_el>([&](auto k_c) {
+            static_for<0, (GF_ATTN_WHATIF & 1) ? 0 : n_el>([&](auto k_c) {
                 constexpr int el = el0 + decltype(k_c)::value, half = el >> 4, e = el & 15;
                 float sv = sc[PAR][half][e];
                 asm volatile("" : "+v"(sv));
@@ -742,8 +799,10 @@ __global__ __launch_bounds__(AT2_THREADS, 2) void flash_attn_fwd_kernel2(const A
             __builtin_amdgcn_sched_barrier(0);
         });
         l_run += rs;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if constexpr (!(GF_ATTN_WHATIF & 8)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
     };
 
     // ---- prologue: K(0), K(1) staged; S(0)
