@@ -71,6 +71,9 @@ def main():
             fl = 2.0 * s * n * k
             med, mn = timeit(lambda: ops.gemm(inp, w, b, out=out), a.iters)
             print(f"gemm bf16 {name}: median {med:.3f} ms ({fl / med / 1e9:.1f} TFLOP/s), min {mn:.3f} ms")
+            if n == F:
+                med, mn = timeit(lambda: ops.gemm(inp, w, b, out=out, epilogue=ops.EPI_BIAS_GELU_TANH), a.iters)
+                print(f"gemm bf16 {name} + GELU(tanh) epilogue: median {med:.3f} ms ({fl / med / 1e9:.1f} TFLOP/s), min {mn:.3f} ms")
             if a.ref:
                 med, mn = timeit(lambda: torch.nn.functional.linear(inp, w, b), a.iters)
                 print(f"   torch F.linear {name}: median {med:.3f} ms ({fl / med / 1e9:.1f} TFLOP/s), min {mn:.3f} ms")
