@@ -211,7 +211,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "flash_attn_fwd_kernel2<true> + transpose_v_kernel (self-attention, S=32760, 40 heads, d=128)",
                          "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "peak_note": "dense bf16 MFMA peak = 256 CU x 4096 FLOP/clk x 2.4 GHz (MI355X_MICROARCH.md); under this "
-                                      "load the chip holds ~2.0-2.05 GHz (rocprofv3 GRBM_GUI_ACTIVE), i.e. ~2.1 PFLOP/s",
+                                      "load the chip holds 1.8-2.05 GHz depending on the box (rocprofv3 GRBM_GUI_ACTIVE), i.e. 1.9-2.1 PFLOP/s",
                          "frac": None if achieved is None else achieved / PEAK_BF16_TFLOPS,
                          # HBM bytes per launch from rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes over
                          # tools/microbench.py attn, profiles/r01/pmc/): (2 x FETCH_SIZE [gfx950 reports half of a 16-B/lane

@@ -639,9 +639,23 @@ constexpr int SL_NST = 4;
 constexpr int SL_STAGE = 2 * 256 * SL_BK * 2;      // 32 KiB: A then W
 constexpr int SL_LDS = SL_NST * SL_STAGE;          // 128 KiB (the epilogue's 256 x 512 B image reuses it)
 
+typedef __attribute__((ext_vector_type(4))) int i32x4;
 __device__ __forceinline__ void sl_dma(const void* base, unsigned off, GF_LDS char* l) {
     unsigned keep;
     const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)l);
+#if GF_SL_BUFFER_DMA   // experiment: the buffer form of the same LDS-DMA (SRD base + VGPR offset), as the vendor GEMMs issue it
+    const unsigned long b = (unsigned long)base;
+    i32x4 srd;
+    srd[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)b);
+    srd[1] = __builtin_amdgcn_readfirstlane((int)((b >> 32) & 0xffff));
+    srd[2] = -1;            // num_records
+    srd[3] = 0x00020000;    // raw buffer, 32-bit data format
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(off), "s"(srd), "s"(dst)
+                 : "memory");
+    return;
+#endif
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(off), "s"(base), "s"(dst)

@@ -136,16 +136,20 @@ class SelfAttention(nn.Module):
         self.q, self.k, self.v, self.o = (nn.Linear(dim, dim) for _ in range(4))
         self.norm_q, self.norm_k = RMSNorm(dim, eps=eps), RMSNorm(dim, eps=eps)
 
-    def attend(self, x2: torch.Tensor, rope: RopeTable, sp=None) -> torch.Tensor:
+    def attend(self, x2: torch.Tensor, rope: RopeTable, sp=None, keep=None) -> torch.Tensor:
         """x2 [S,D] -> attention output BEFORE the o projection, [S,D].  With a sequence_parallel.SequenceParallel
         group `sp`, x2 and rope are this rank's token chunk and the heads are exchanged over xGMI (usp_attn_forward,
-        diffsynth/distributed/xdit_context_parallel.py:109-131)."""
+        diffsynth/distributed/xdit_context_parallel.py:109-131).  `keep` (a dict, training): the attention output and the
+        rows' log-sum-exp are stored under "attn" / "lse" so that the backward does not run the attention again."""
         xin = QuantizedInput(x2) if getattr(self.q, "_gf_w8", None) is not None else x2
         q, k, v = linear(xin, self.q), linear(xin, self.k), linear(xin, self.v)
         ops.rmsnorm_rope(q, self.norm_q.weight, rope.cos, rope.sin, self.head_dim, self.norm_q.eps)
         ops.rmsnorm_rope(k, self.norm_k.weight, rope.cos, rope.sin, self.head_dim, self.norm_k.eps)
         if sp is not None:
             return sp.attention(q, k, v, self.num_heads)
+        if keep is not None:
+            keep["attn"], keep["lse"] = ops.flash_attn_lse(q, k, v, self.num_heads)
+            return keep["attn"]
         return ops.flash_attn(q, k, v, self.num_heads)
 
     def forward(self, x, freqs):
@@ -207,7 +211,7 @@ class DiTBlock(nn.Module):
         self.modulation = nn.Parameter(torch.randn(1, 6, dim) / dim ** 0.5)
         self.gate = GateModule()
 
-    def forward(self, x, context, t_mod, freqs, context_kv=None, out=None, sp=None):
+    def forward(self, x, context, t_mod, freqs, context_kv=None, out=None, sp=None, keep=None):
         if t_mod.dim() == 4:
             raise NotImplementedError("per-token t_mod (seperated_timestep) is outside the Goal-Force path")
         x2 = _tokens2d(x)
@@ -215,7 +219,7 @@ class DiTBlock(nn.Module):
         # rows: shift_msa, 1+scale_msa, gate_msa, shift_mlp, 1+scale_mlp, gate_mlp   (DIT:218-219, 64-65)
         mod = ops.modulation(self.modulation, t_mod.contiguous(), onep_mask=0b010010)
         h = ops.layernorm_modulate(x2, scale1p=mod[1], shift=mod[0], eps=self.eps)              # DIT:225
-        a = self.self_attn.attend(h, rope, sp)
+        a = self.self_attn.attend(h, rope, sp, keep)
         x_new = out if out is not None else torch.empty_like(x2)
         linear(a, self.self_attn.o, epilogue=ops.EPI_BIAS_GATE_RESID, resid=x2, gate=mod[2], out=x_new)   # DIT:226
         ops.layernorm_modulate(x_new, weight=self.norm3.weight, bias=self.norm3.bias, eps=self.eps, out=h)
