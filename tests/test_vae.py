@@ -118,6 +118,8 @@ def test_hip_vae_im2col_and_norm_kernels_exact():
     dict(T=2, H=6, W=5, C=32, N=64, kt=3, ks=1, gather=dict(t_off=1, t_out=1)),    # decoder time_conv, one frame at a time
     dict(T=1, H=12, W=12, C=8, N=96, kt=3, ks=3),                                  # encoder conv1 on RGB padded to 8
     dict(T=1, H=40, W=40, C=384, N=384, kt=3, ks=3, resid=True),                   # widest level: K 10368, 2 N tiles
+    dict(T=2, H=60, W=104, C=96, N=96, kt=3, ks=3),                                # 49 M tiles: the XCD-aware tile map
+    dict(T=2, H=30, W=52, C=192, N=96, kt=1, ks=3, gather=dict(upsample2x=True), resid=True),   # upsample conv, 49 M tiles
 ])
 def test_hip_implicit_conv_bit_identical_to_im2col_gemm(case):
     """gf_conv3d_bf16 (no patch matrix) == gf_vae_im2col + gf_gemm_bf16, bit for bit, in every gather mode."""
