@@ -947,6 +947,7 @@ const u16* conv_zero_page() {
         void* z = nullptr;
         if (hipMalloc(&z, 256) != hipSuccess) return nullptr;
         if (hipMemset(z, 0, 256) != hipSuccess) return nullptr;
+        if (hipStreamSynchronize(nullptr) != hipSuccess) return nullptr;   // once: the first launch may be on a non-blocking stream
         page[dev] = (const u16*)z;
     }
     return page[dev];
