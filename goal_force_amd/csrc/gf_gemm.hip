@@ -298,9 +298,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmArgs p)
 //     barrier late — one partner feeds the matrix pipe while the other feeds LDS.
 //   * epilogue: all waves park their bf16 quadrants in one swizzled 256x256 LDS image, then every wave writes full
 //     512-byte rows (16 B per lane), reading residual / gate / bias in the same coalesced pattern.
-template <int EPI, bool FP8, bool CONV = false>
+// NB = number of 128-column halves of the tile: 2 = the 256 x 256 tile described above; 1 = a 256 x 128 tile (convolutions with
+// Cout <= 128: the decoder's 96-channel level and its RGB head would otherwise multiply 160 / 248 padding columns) — two phases
+// per K-tile, (A0, B0) and (A1, B0), half-tile stream A0 B0 A1 with three stage calls (6 DMA instructions) in flight.
+template <int EPI, bool FP8, bool CONV = false, int NB = 2>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs p) {
     static_assert(!(CONV && FP8), "the implicit-GEMM convolution is bf16 only");
+    static_assert(NB == 2 || (NB == 1 && !FP8), "NB = 1 is built for bf16");
+    constexpr int BNT = NB * 128;   // tile width
     constexpr int ESZ = FP8 ? 1 : 2;
     constexpr int BKE = 128 / ESZ;
     constexpr int HALF_BYTES = 128 * 128;  // 16 KiB
@@ -325,7 +330,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs
     const int first_m = group * GROUP_M;
     const int gsz = min(p.tiles_m - first_m, GROUP_M);
     const int in_group = v - group * per_group;
-    const int m0 = (first_m + in_group % gsz) * BM, n0 = (in_group / gsz) * BN;
+    const int m0 = (first_m + in_group % gsz) * BM, n0 = (in_group / gsz) * BNT;
 
     // ---- DMA sources: wave w fills row-groups 2w, 2w+1 (8 rows x 128 B each) of every half-tile -------------------
     const int srow = lane >> 3;
@@ -434,11 +439,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs
         }
     };
 
-    f32x4 acc[2][2][4][2];  // [a][b][i][j]
+    f32x4 acc[2][NB][4][2];  // [a][b][i][j]
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -472,8 +477,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs
     };
 
     // ---- prologue: half-tiles seq 0..5 = (t0: A0 B0 B1 A1) (t1: A0 B0) ------------------------------------------------
-    const int total = 4 * nk;  // half-tiles in the stream
-    {
+    const int total = (NB == 2 ? 4 : 3) * nk;  // half-tiles in the stream
+    if constexpr (NB == 2) {
         stage(0, 0);
         stage(0, 1);
         stage(0, 2);
@@ -486,13 +491,26 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
+    } else {   // stream A0 B0 A1 per tile: seq 3t, 3t+1, 3t+2
+        stage(0, 0);
+        stage(0, 1);
+        stage(0, 3);
+        if (nk > 1) {
+            stage(1, 0);
+            stage(1, 1);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // seq 0,1 landed
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
     }
     if (wr == 1) __builtin_amdgcn_s_barrier();  // wave row 1 runs half a phase behind wave row 0
 
 #define GF_PHASE_END(SEQ_ISSUED)                                                  \
     GSTAMP(1)                                                                    \
-    if ((SEQ_ISSUED) < total) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   \
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        \
+    if ((SEQ_ISSUED) >= total) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  \
+    else if constexpr (NB == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); \
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                        \
     GSTAMP(2)                                                                    \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                           \
     GSTAMP(3)                                                                    \
@@ -509,6 +527,28 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs
     __builtin_amdgcn_sched_barrier(0);     \
     __builtin_amdgcn_s_barrier();          \
     GSTAMP(6)
+    if constexpr (NB == 1) {
+        for (int c = 0; c < nk; ++c) {
+            GF_LDS char* buf = lds + (c & 1) * STAGE_BYTES;
+            const int g = 3 * c;
+            // ---- phase 0: stream A1(c+1); read A-sub0, B-sub0; half (0,0)
+            if (g + 5 < total) stage(c + 1, 3);
+            read_b(buf, 0);
+            read_a(buf, 0);
+            GF_PHASE_END(g + 5)
+            mma(0, 0);
+            GF_AFTER_MMA
+            // ---- phase 1: stream A0(c+2), B0(c+2); read A-sub1 (B-sub0 still in registers); half (1,0)
+            if (g + 6 < total) {
+                stage(c + 2, 0);
+                stage(c + 2, 1);
+            }
+            read_a(buf, 1);
+            GF_PHASE_END(g + 7)
+            mma(1, 0);
+            GF_AFTER_MMA
+        }
+    } else
     for (int c = 0; c < nk; ++c) {
         GF_LDS char* buf = lds + (c & 1) * STAGE_BYTES;
         const int g = 4 * c;
@@ -552,7 +592,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs
     // ---- epilogue: bf16 quadrants -> swizzled 256 x 256 LDS image (512-byte rows) -> full-row stores ---------------------
     // acc[a][b][i][j][r] = C[m0 + a*128 + wr*64 + i*16 + frow][n0 + b*128 + wc*32 + j*16 + fq*4 + r]
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < NB; ++b)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int ncol = b * 128 + wc * 32 + j * 16 + fq * 4;  // column inside the tile
@@ -587,7 +627,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs
     {
         const int cc = lane & 31;                 // 16-byte chunk of the row
         const int n = n0 + cc * 8;
-        const bool n_ok = n < p.N;
+        const bool n_ok = n < p.N && cc * 8 < BNT;
         u16x8 g8;
         if (EPI == GF_EPI_BIAS_GATE_RESID && n_ok) g8 = *reinterpret_cast<const u16x8*>(p.gate + n);
 #pragma unroll 4
@@ -920,11 +960,11 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
     return GF_OK;
 }
 
-template <int EPI>
+template <int EPI, int NB>
 int launch_conv(const GemmArgs& a, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ph_kernel<EPI, false, true>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ph_kernel<EPI, false, true, NB>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
         if (e != hipSuccess) {
             gf_set_error("gf_conv3d: hipFuncSetAttribute(%d B LDS) failed: %s", GEMM_LDS, hipGetErrorString(e));
@@ -932,7 +972,7 @@ int launch_conv(const GemmArgs& a, hipStream_t stream) {
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_ph_kernel<EPI, false, true>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(GEMM_THREADS),
+    hipLaunchKernelGGL((gemm_ph_kernel<EPI, false, true, NB>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(GEMM_THREADS),
                        GEMM_LDS, stream, a);
     GF_CHECK_LAUNCH("gf_conv3d_bf16");
     return GF_OK;
@@ -1072,8 +1112,15 @@ extern "C" GF_API int gf_conv3d_bf16(const void* src, const void* cache, const v
     a.ldw = ldw;
     a.ldc = ldc;
     a.ldr = ldr;
+    // Cout <= 128 (the 96-channel level, the RGB head): the 256 x 128 tile; GF_CONV_NB=2 forces the 256 x 256 tile (A/B timing)
+    static int force_nb = -1;
+    if (force_nb < 0) {
+        const char* ev = getenv("GF_CONV_NB");
+        force_nb = ev ? atoi(ev) : 0;
+    }
+    const bool narrow = force_nb ? force_nb == 1 : N <= 128;
     a.tiles_m = (int)((M + BM - 1) / BM);
-    a.tiles_n = (int)((N + BN - 1) / BN);
+    a.tiles_n = narrow ? (int)((N + 127) / 128) : (int)((N + BN - 1) / BN);
     a.dbg = nullptr;
     a.cv.src = (const u16*)src;
     a.cv.cache = (const u16*)cache;
@@ -1097,5 +1144,6 @@ extern "C" GF_API int gf_conv3d_bf16(const void* src, const void* cache, const v
     a.cv.inv_c = 1.0f / (float)C;
     a.cv.inv_ks2 = 1.0f / (float)(ks * ks);
     hipStream_t s = (hipStream_t)stream;
-    return epilogue == GF_EPI_BIAS ? launch_conv<GF_EPI_BIAS>(a, s) : launch_conv<GF_EPI_BIAS_RESID>(a, s);
+    if (narrow) return epilogue == GF_EPI_BIAS ? launch_conv<GF_EPI_BIAS, 1>(a, s) : launch_conv<GF_EPI_BIAS_RESID, 1>(a, s);
+    return epilogue == GF_EPI_BIAS ? launch_conv<GF_EPI_BIAS, 2>(a, s) : launch_conv<GF_EPI_BIAS_RESID, 2>(a, s);
 }

@@ -119,6 +119,10 @@ def test_hip_vae_im2col_and_norm_kernels_exact():
     dict(T=1, H=12, W=12, C=8, N=96, kt=3, ks=3),                                  # encoder conv1 on RGB padded to 8
     dict(T=1, H=40, W=40, C=384, N=384, kt=3, ks=3, resid=True),                   # widest level: K 10368, 2 N tiles
     dict(T=2, H=60, W=104, C=96, N=96, kt=3, ks=3),                                # 49 M tiles: the XCD-aware tile map
+    dict(T=3, H=33, W=20, C=96, N=8, kt=3, ks=3),                                  # RGB head (3 -> 8 columns), ragged last M tile
+    dict(T=1, H=16, W=16, C=64, N=128, kt=3, ks=3, resid=True),                    # exactly one 128-column tile, K 1728
+    dict(T=1, H=16, W=16, C=64, N=136, kt=1, ks=3),                                # just past it: the 256-wide tile again
+    dict(T=1, H=16, W=16, C=8, N=16, kt=1, ks=1),                                  # a single K tile (nk = 1)
     dict(T=2, H=30, W=52, C=192, N=96, kt=1, ks=3, gather=dict(upsample2x=True), resid=True),   # upsample conv, 49 M tiles
 ])
 def test_hip_implicit_conv_bit_identical_to_im2col_gemm(case):
