@@ -369,6 +369,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs
             if (kind == 0 || kind == 3) {
                 const ConvGeom& g = p.cv;
                 const int a = kind == 3;
+#if GF_CONV_WHATIF   // timing only (wrong results): the gather without its address arithmetic
+                if (g.mode == 0) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    glds16(g.src + (long)(cyx[a][i] & 0xffff) * g.C + ((cyx[a][i] >> 16) * g.W) * g.C + ((tile * 8) & 63), dst + i * 1024);
+                return;
+                }
+#endif
                 const int ke = tile * 64 + schunk * 8;                       // first of this lane's 8 channels along K
                 const int tap = (int)(((float)ke + 0.5f) * g.inv_c);         // exact: ke < 2^16, C <= 512
                 const int c = ke - tap * g.C;
