@@ -63,6 +63,7 @@ struct ConvGeom {
     const u16* cache;   // [2, H, W, C]: frames -2, -1 (kt == 3)
     const u16* zero;    // >= 16 zero bytes
     int H, W, C, Ho, Wo, kt, ks, mode, t_stride, t_off, taps;
+    int hist_front;     // kt == 3 without `cache`: frames -2, -1 lie directly in front of src (one [2 + T, H, W, C] buffer)
     long frame;         // H*W*C
     float inv_c, inv_ks2;
 };
@@ -301,7 +302,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmArgs p)
 // NB = number of 128-column halves of the tile: 2 = the 256 x 256 tile described above; 1 = a 256 x 128 tile (convolutions with
 // Cout <= 128: the decoder's 96-channel level and its RGB head would otherwise multiply 160 / 248 padding columns) — two phases
 // per K-tile, (A0, B0) and (A1, B0), half-tile stream A0 B0 A1 with three stage calls (6 DMA instructions) in flight.
-template <int EPI, bool FP8, bool CONV = false, int NB = 2>
+// CONV: 0 = dense A operand; 1 = the general gather (all modes, history from `cache`); 2 = stride-1 gather whose source frames
+// are one contiguous run (mode 0 with the causal history in front of src, or no temporal taps): each A row keeps a 64-bit
+// pointer to its pixel in its first source frame plus 4 border flags, and a piece's address is that pointer + one per-tap offset.
+template <int EPI, bool FP8, int CONV = 0, int NB = 2>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs p) {
     static_assert(!(CONV && FP8), "the implicit-GEMM convolution is bf16 only");
     static_assert(NB == 2 || (NB == 1 && !FP8), "NB = 1 is built for bf16");
@@ -348,7 +352,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs
     }
     // CONV: this lane's four A rows as output pixels: (Y << 16 | X) and the first source frame of the causal window
     int cyx[2][2], cf[2][2];
-    if constexpr (CONV) {
+    const u16* rowp[2][2];   // CONV == 2: the row's pixel in its first source frame
+    int rmask[2][2];         // CONV == 2: 1 no row above, 2 none below, 4 no column to the left, 8 none to the right, 16 always
+    if constexpr (CONV != 0) {
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -356,8 +362,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs
                 const int m = min(m0 + a * 128 + (wave * 2 + i) * 8 + srow, p.M - 1);
                 const int X = m % p.cv.Wo, t = m / p.cv.Wo;
                 const int Y = t % p.cv.Ho, j = t / p.cv.Ho;
-                cyx[a][i] = (Y << 16) | X;
-                cf[a][i] = p.cv.t_off + j * p.cv.t_stride - (p.cv.kt - 1);
+                const int f0 = p.cv.t_off + j * p.cv.t_stride - (p.cv.kt - 1);
+                if constexpr (CONV == 2) {
+                    rowp[a][i] = p.cv.src + ((long)f0 * p.cv.frame + ((long)Y * p.cv.W + X) * p.cv.C);
+                    rmask[a][i] = 16 | (Y == 0 ? 1 : 0) | (Y == p.cv.H - 1 ? 2 : 0) | (X == 0 ? 4 : 0) | (X == p.cv.W - 1 ? 8 : 0);
+                } else {
+                    cyx[a][i] = (Y << 16) | X;
+                    cf[a][i] = f0;
+                }
             }
     }
     const int nk = p.K / BKE;
@@ -365,12 +377,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs
     auto region = [](int kind) { return kind == 0 ? 0 : (kind == 3 ? HALF_BYTES : (kind == 1 ? 2 * HALF_BYTES : 3 * HALF_BYTES)); };
     auto stage = [&](int tile, int kind) {  // issue the 2 DMA instructions of half-tile (tile, kind)
         GF_LDS char* dst = lds + (tile & 1) * STAGE_BYTES + region(kind) + wave * 2048;
-        if constexpr (CONV) {
+        if constexpr (CONV != 0) {
             if (kind == 0 || kind == 3) {
                 const ConvGeom& g = p.cv;
                 const int a = kind == 3;
 #if GF_CONV_WHATIF   // timing only (wrong results): the gather without its address arithmetic
-                if (g.mode == 0) {
+                if (CONV == 1 && g.mode == 0) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
                     glds16(g.src + (long)(cyx[a][i] & 0xffff) * g.C + ((cyx[a][i] >> 16) * g.W) * g.C + ((tile * 8) & 63), dst + i * 1024);
@@ -388,6 +400,16 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs
                     dx = rem - 3 * dy;
                 }
                 const int half = g.ks >> 1;
+                if constexpr (CONV == 2) {
+                    // one offset per tap: dt frames, dy - half rows, dx - half columns, c channels; `need` = the border flags
+                    // that make this tap a padding tap (bit 4: a K-padding column past the last tap)
+                    const long toff = (long)dt * g.frame + (long)(((dy - half) * g.W + (dx - half)) * g.C + c);
+                    int need = tap < g.taps ? 0 : 16;
+                    if (g.ks == 3) need |= (dy == 0 ? 1 : 0) | (dy == 2 ? 2 : 0) | (dx == 0 ? 4 : 0) | (dx == 2 ? 8 : 0);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) glds16((need & rmask[a][i]) ? g.zero : rowp[a][i] + toff, dst + i * 1024);
+                    return;
+                }
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int Y = cyx[a][i] >> 16, X = cyx[a][i] & 0xffff;
@@ -404,7 +426,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs
                         sx = g.mode == 1 ? (xx >> 1) : xx;
                     }
                     const int f = cf[a][i] + dt;
-                    const u16* base = f >= 0 ? g.src + (long)f * g.frame : g.cache + (long)(2 + f) * g.frame;
+                    const u16* base = (f >= 0 || g.hist_front) ? g.src + (long)f * g.frame : g.cache + (long)(2 + f) * g.frame;
                     const u16* src = (ok && tap < g.taps) ? base + ((long)sy * g.W + sx) * g.C + c : g.zero;
                     glds16(src, dst + i * 1024);
                 }
@@ -968,11 +990,11 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
     return GF_OK;
 }
 
-template <int EPI, int NB>
+template <int EPI, int NB, int CONV>
 int launch_conv(const GemmArgs& a, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ph_kernel<EPI, false, true, NB>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ph_kernel<EPI, false, CONV, NB>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
         if (e != hipSuccess) {
             gf_set_error("gf_conv3d: hipFuncSetAttribute(%d B LDS) failed: %s", GEMM_LDS, hipGetErrorString(e));
@@ -980,7 +1002,7 @@ int launch_conv(const GemmArgs& a, hipStream_t stream) {
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_ph_kernel<EPI, false, true, NB>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(GEMM_THREADS),
+    hipLaunchKernelGGL((gemm_ph_kernel<EPI, false, CONV, NB>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(GEMM_THREADS),
                        GEMM_LDS, stream, a);
     GF_CHECK_LAUNCH("gf_conv3d_bf16");
     return GF_OK;
@@ -1089,7 +1111,7 @@ extern "C" GF_API int gf_conv3d_bf16(const void* src, const void* cache, const v
     GF_CHECK_ARG((kt == 1 || kt == 3) && (ks == 1 || ks == 3), "gf_conv3d_bf16: kt/ks must be 1 or 3");
     GF_CHECK_ARG(mode >= 0 && mode <= 2 && (mode == 0 || ks == 3), "gf_conv3d_bf16: bad mode");
     GF_CHECK_ARG(mode != 2 || (H % 2 == 0 && W % 2 == 0), "gf_conv3d_bf16: stride-2 mode needs even H, W");
-    GF_CHECK_ARG(kt == 1 || cache, "gf_conv3d_bf16: a temporal kernel needs the 2-frame cache");
+    // kt == 3 with cache == NULL: the two history frames lie directly in front of src (src points 2 frames into one buffer)
     GF_CHECK_ARG(t_stride >= 1 && t_off >= 0 && (T_out == 0 || t_off + (T_out - 1) * t_stride < T_in),
                  "gf_conv3d_bf16: output frames reach past the input");
     const long taps = (long)kt * ks * ks;
@@ -1152,6 +1174,20 @@ extern "C" GF_API int gf_conv3d_bf16(const void* src, const void* cache, const v
     a.cv.inv_c = 1.0f / (float)C;
     a.cv.inv_ks2 = 1.0f / (float)(ks * ks);
     hipStream_t s = (hipStream_t)stream;
-    if (narrow) return epilogue == GF_EPI_BIAS ? launch_conv<GF_EPI_BIAS, 1>(a, s) : launch_conv<GF_EPI_BIAS_RESID, 1>(a, s);
-    return epilogue == GF_EPI_BIAS ? launch_conv<GF_EPI_BIAS, 2>(a, s) : launch_conv<GF_EPI_BIAS_RESID, 2>(a, s);
+    a.cv.hist_front = (kt == 3 && !cache) ? 1 : 0;
+    // contiguous source frames and stride-1 taps: the pointer-per-row gather (GF_CONV_GATHER=1 forces the general one, A/B)
+    static int force_g = -1;
+    if (force_g < 0) {
+        const char* ev = getenv("GF_CONV_GATHER");
+        force_g = ev ? atoi(ev) : 0;
+    }
+    const bool fast = force_g != 1 && mode == 0 && (kt == 1 || !cache);
+#define GF_CONV_CASE(E, NBV, CV) return launch_conv<E, NBV, CV>(a, s)
+    if (fast) {
+        if (narrow) { if (epilogue == GF_EPI_BIAS) GF_CONV_CASE(GF_EPI_BIAS, 1, 2); else GF_CONV_CASE(GF_EPI_BIAS_RESID, 1, 2); }
+        if (epilogue == GF_EPI_BIAS) GF_CONV_CASE(GF_EPI_BIAS, 2, 2); else GF_CONV_CASE(GF_EPI_BIAS_RESID, 2, 2);
+    }
+    if (narrow) { if (epilogue == GF_EPI_BIAS) GF_CONV_CASE(GF_EPI_BIAS, 1, 1); else GF_CONV_CASE(GF_EPI_BIAS_RESID, 1, 1); }
+    if (epilogue == GF_EPI_BIAS) GF_CONV_CASE(GF_EPI_BIAS, 2, 1); else GF_CONV_CASE(GF_EPI_BIAS_RESID, 2, 1);
+#undef GF_CONV_CASE
 }

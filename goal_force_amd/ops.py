@@ -357,14 +357,22 @@ def vae_im2col(src, cache, kt, ks, kpad, upsample2x=False, downsample2=False, t_
 
 
 def vae_conv3d(src, cache, w, bias, kt, ks, upsample2x=False, downsample2=False, t_stride=1, t_off=0, t_out=None,
-               resid=None, out=None):
+               resid=None, out=None, history_in_front=False):
     """Causal conv as one implicit GEMM (gf_conv3d_bf16): src [T,H,W,C] (+cache [2,H,W,C]) x w [N, kpad] -> [T_out*Ho*Wo, N].
-    Same arguments as vae_im2col + gemm(epilogue BIAS / BIAS_RESID); bit-identical to that pair."""
+    Same arguments as vae_im2col + gemm(epilogue BIAS / BIAS_RESID); bit-identical to that pair.
+    history_in_front: src is frames [2:] of one contiguous [2+T,H,W,C] buffer whose first two frames hold the causal history
+    (pass cache=None): the faster pointer-per-row gather."""
     _req(src, "vae_conv3d.src")
     _req(w, "vae_conv3d.w")
     if not src.is_contiguous() or src.dim() != 4:
         raise GoalForceError("vae_conv3d.src must be contiguous [T,H,W,C]")
     T, H, W, C = src.shape
+    if kt == 3:
+        if history_in_front:
+            if cache is not None or src.storage_offset() < 2 * H * W * C:
+                raise GoalForceError("vae_conv3d: history_in_front needs cache=None and src = buffer[2:] of a [2+T,H,W,C] buffer")
+        elif cache is None:
+            raise GoalForceError("vae_conv3d: a temporal kernel needs its 2-frame cache (or history_in_front)")
     if cache is not None:
         _req(cache, "vae_conv3d.cache")
         if tuple(cache.shape) != (2, H, W, C) or not cache.is_contiguous():
@@ -406,13 +414,18 @@ def vae_finish_latent(x, mean, inv_std, C):
     return out
 
 
-def vae_rmsnorm_silu(x, gamma, silu=True):
-    """x [..., C] channels-last -> RMS_norm(+SiLU), same shape."""
+def vae_rmsnorm_silu(x, gamma, silu=True, out=None):
+    """x [..., C] channels-last -> RMS_norm(+SiLU), same shape (into `out` if given: contiguous, same shape)."""
     _req(x, "vae_rmsnorm_silu.x")
     _req(gamma, "vae_rmsnorm_silu.gamma")
     if not x.is_contiguous() or gamma.numel() != x.shape[-1]:
         raise GoalForceError("vae_rmsnorm_silu: x must be contiguous and gamma match the channel dim")
-    out = torch.empty_like(x)
+    if out is None:
+        out = torch.empty_like(x)
+    else:
+        _req(out, "vae_rmsnorm_silu.out")
+        if out.shape != x.shape or not out.is_contiguous():
+            raise GoalForceError("vae_rmsnorm_silu.out must be contiguous with the shape of x")
     C = x.shape[-1]
     _lib.check(_lib.load().gf_vae_rmsnorm_silu(_ptr(x), _ptr(gamma), _ptr(out), x.numel() // C, C, 1 if silu else 0,
                                                _stream(x)), "gf_vae_rmsnorm_silu")

@@ -51,6 +51,14 @@ def _conv(x, cache, c, resid=None, **gather):
     return ops.gemm(cols, c["w"], c["b"], epilogue=ops.EPI_BIAS if resid is None else ops.EPI_BIAS_RESID, resid=resid)
 
 
+def _with_history(shape, like):
+    """A [2+T,H,W,C] buffer and its frames [2:]: a conv input written into the second part has room for its two history frames
+    directly in front of it (gf_conv3d_bf16's pointer-per-row gather)."""
+    T, H, W, C = shape
+    buf = torch.empty((T + CACHE_T, H, W, C), dtype=like.dtype, device=like.device)
+    return buf, buf[CACHE_T:]
+
+
 def _roll_cache(cache, x):
     """The feature cache after a chunk: the last CACHE_T frames of [cache, x] (VAE:283-294) ."""
     if x.shape[0] >= CACHE_T:
@@ -278,14 +286,23 @@ class WanVideoVAE(nn.Module):
         return P
 
     # ---------------------------------------------------------------- building blocks (channels-last [T,H,W,C])
-    def _causal_conv(self, P, name, x, resid=None):
-        """CausalConv3d with its feature cache (VAE:33-52 + the cache handling of VAE:283-294)."""
+    def _causal_conv(self, P, name, x, resid=None, front=None):
+        """CausalConv3d with its feature cache (VAE:33-52 + the cache handling of VAE:283-294).  `front`: the [2+T,H,W,C] buffer
+        whose frames [2:] are x (see _with_history) — the cached history is copied into its first two frames."""
         c = P[name]
         T, H, W, C = x.shape
         r2 = None if resid is None else resid.reshape(T * H * W, -1)
         cache = None
         if c["kt"] == 3:
             cache = self._cache.get(name)
+            if front is not None and IMPLICIT_CONV:
+                if cache is None:
+                    front[:CACHE_T].zero_()
+                    self._cache[name] = _roll_cache(front[:CACHE_T], x)
+                else:
+                    front[:CACHE_T].copy_(cache)
+                    self._cache[name] = _roll_cache(cache, x)
+                return ops.vae_conv3d(x, None, c["w"], c["b"], 3, c["ks"], resid=r2, history_in_front=True).view(T, H, W, -1)
             if cache is None:
                 cache = torch.zeros((CACHE_T, H, W, C), dtype=x.dtype, device=x.device)
             self._cache[name] = _roll_cache(cache, x)
@@ -297,10 +314,12 @@ class WanVideoVAE(nn.Module):
     def _res_block(self, P, name, x, cin, cout):
         """ResidualBlock (VAE:267-301)."""
         h = x if cin == cout else self._causal_conv(P, name + ".shortcut", x)
-        y = ops.vae_rmsnorm_silu(x, P[name + ".residual.0.gamma"], silu=True)
-        y = self._causal_conv(P, name + ".residual.2", y)
-        y = ops.vae_rmsnorm_silu(y, P[name + ".residual.3.gamma"], silu=True)
-        return self._causal_conv(P, name + ".residual.6", y, resid=h)
+        front, y = _with_history(x.shape, x)
+        ops.vae_rmsnorm_silu(x, P[name + ".residual.0.gamma"], silu=True, out=y)
+        y = self._causal_conv(P, name + ".residual.2", y, front=front)
+        front, y2 = _with_history(y.shape, y)
+        ops.vae_rmsnorm_silu(y, P[name + ".residual.3.gamma"], silu=True, out=y2)
+        return self._causal_conv(P, name + ".residual.6", y2, resid=h, front=front)
 
     def _attention(self, P, name, x, C):
         """AttentionBlock (VAE:304-342): single head of width C over the h*w positions of each frame."""
@@ -350,8 +369,9 @@ class WanVideoVAE(nn.Module):
             elif kind == "up":
                 x = self._upsample(P, name, x, step[2], step[3], first)
             elif kind == "head":
-                x = ops.vae_rmsnorm_silu(x, P[name + ".0.gamma"], silu=True)
-                x = self._causal_conv(P, name + ".2", x)
+                front, y = _with_history(x.shape, x)
+                ops.vae_rmsnorm_silu(x, P[name + ".0.gamma"], silu=True, out=y)
+                x = self._causal_conv(P, name + ".2", y, front=front)
         return x
 
     def decode_tile_channels_last(self, z_slice: torch.Tensor) -> torch.Tensor:
@@ -400,8 +420,9 @@ class WanVideoVAE(nn.Module):
             elif kind == "down":
                 x = self._downsample(P, name, x, step[2], step[3])
             elif kind == "head":
-                x = ops.vae_rmsnorm_silu(x, P[name + ".0.gamma"], silu=True)
-                x = self._causal_conv(P, name + ".2", x)
+                front, y = _with_history(x.shape, x)
+                ops.vae_rmsnorm_silu(x, P[name + ".0.gamma"], silu=True, out=y)
+                x = self._causal_conv(P, name + ".2", y, front=front)
         return x
 
     def encode_tile_channels_last(self, video_slice: torch.Tensor) -> torch.Tensor:

@@ -274,7 +274,10 @@ GF_API int gf_vae_im2col(const void* src, const void* cache, void* out, int64_t 
  * and the K padding columns from a zero page).  Replaces CausalConv3d.forward (VAE:33-52) and the convs inside Resample
  * (VAE:82-174) end to end; arguments as gf_vae_im2col (T_in = frames in src) + gf_gemm_bf16 (Wm [N, ldw] with columns
  * ((dt*ks+dy)*ks+dx)*C+c, zero from kt*ks*ks*C up to K; K a multiple of 64; epilogue GF_EPI_BIAS or GF_EPI_BIAS_RESID).
- * out [T_out*Ho*Wo, ldc].  Bit-identical to gf_vae_im2col + gf_gemm_bf16. */
+ * out [T_out*Ho*Wo, ldc].  Bit-identical to gf_vae_im2col + gf_gemm_bf16.
+ * kt == 3 with cache == NULL: the two history frames lie directly IN FRONT of src (src points two frames into one
+ * [2 + T_in, H, W, C] buffer) — with mode 0 this selects the pointer-per-row gather (one 64-bit pointer + 4 border flags per
+ * output pixel, one offset per tap), 20 % faster than the general one. */
 GF_API int gf_conv3d_bf16(const void* src, const void* cache, const void* Wm, int64_t ldw, const void* bias,
                           void* out, int64_t ldc, int64_t T_in, int64_t T_out, int64_t H, int64_t W, int64_t C,
                           int kt, int ks, int mode, int t_stride, int t_off, int64_t N, int64_t K, int epilogue,

@@ -148,6 +148,33 @@ def test_hip_implicit_conv_bit_identical_to_im2col_gemm(case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("T,H,W,C,N,ks", [(3, 9, 11, 96, 96, 3), (5, 18, 20, 96, 8, 3), (2, 6, 5, 32, 64, 1), (4, 13, 7, 192, 192, 3),
+                                          (1, 5, 5, 16, 24, 3)])
+def test_hip_conv_history_in_front_bit_identical(T, H, W, C, N, ks):
+    """The pointer-per-row gather (history frames in front of src, one buffer) == the general gather with a separate cache
+    == gf_vae_im2col + gf_gemm_bf16, bit for bit, with and without a residual."""
+    from goal_force_amd import ops
+    g = torch.Generator().manual_seed(T * 100 + H)
+    k = 3 * ks * ks * C
+    kpad = -(-k // 64) * 64
+    buf = torch.randn((T + 2, H, W, C), generator=g).to(BF).cuda()
+    x, cache = buf[2:], buf[:2].clone()
+    w = torch.zeros((N, kpad), dtype=BF)
+    w[:, :k] = (torch.randn((N, k), generator=g) / k ** 0.5).to(BF)
+    w = w.cuda()
+    b = torch.randn((N,), generator=g).to(BF).cuda()
+    resid = torch.randn((T * H * W, N), generator=g).to(BF).cuda()
+    ref = ops.gemm(ops.vae_im2col(x.contiguous(), cache, 3, ks, kpad), w, b)
+    assert torch.equal(ops.vae_conv3d(x, None, w, b, 3, ks, history_in_front=True), ref)
+    assert torch.equal(ops.vae_conv3d(x.contiguous(), cache, w, b, 3, ks), ref)
+    ref_r = ops.gemm(ops.vae_im2col(x.contiguous(), cache, 3, ks, kpad), w, b, epilogue=ops.EPI_BIAS_RESID, resid=resid)
+    assert torch.equal(ops.vae_conv3d(x, None, w, b, 3, ks, resid=resid, history_in_front=True), ref_r)
+    from goal_force_amd._lib import GoalForceError
+    with pytest.raises(GoalForceError):
+        ops.vae_conv3d(x.clone(), None, w, b, 3, ks, history_in_front=True)        # no room in front of a fresh tensor
+
+
+@pytest.mark.gpu
 def test_hip_implicit_conv_rejects_bad_arguments():
     from goal_force_amd import ops
     from goal_force_amd._lib import GoalForceError
