@@ -296,6 +296,8 @@ class WanVideoVAE(nn.Module):
         if c["kt"] == 3:
             cache = self._cache.get(name)
             if front is not None and IMPLICIT_CONV:
+                if x.data_ptr() != front[CACHE_T:].data_ptr() or front.shape[1:] != x.shape[1:]:
+                    raise GoalForceError("_causal_conv: x must be frames [2:] of `front`")
                 if cache is None:
                     front[:CACHE_T].zero_()
                     self._cache[name] = _roll_cache(front[:CACHE_T], x)
