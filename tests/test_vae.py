@@ -175,6 +175,45 @@ def test_hip_conv_history_in_front_bit_identical(T, H, W, C, N, ks):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(24))
+def test_hip_implicit_conv_random_shapes(seed):
+    """Randomised geometry (frames, image size, channels, output width, kernel, gather mode, temporal stride / offset, history in
+    front or separate, residual): every variant of the implicit GEMM == gf_vae_im2col + gf_gemm_bf16 bit for bit."""
+    import random
+    from goal_force_amd import ops
+    rnd = random.Random(1000 + seed)
+    g = torch.Generator().manual_seed(seed)
+    kt, ks = rnd.choice([(3, 3), (3, 3), (1, 3), (3, 1), (1, 1)])
+    mode = rnd.choice([0, 0, 1, 2]) if ks == 3 and kt == 1 else 0
+    C = rnd.choice([8, 16, 24, 64, 96, 192])
+    N = rnd.choice([8, 24, 96, 128, 136, 192])
+    H, W = rnd.randrange(2, 14) * 2, rnd.randrange(2, 14) * 2
+    T = rnd.randrange(1, 6)
+    t_stride = 2 if (kt == 3 and ks == 1 and T >= 3 and rnd.random() < 0.5) else 1
+    t_off = rnd.randrange(0, 2) if T >= 3 else 0
+    t_out = max(1, (T - t_off + t_stride - 1) // t_stride - rnd.randrange(0, 2))
+    if t_off + (t_out - 1) * t_stride >= T:
+        t_out = (T - t_off + t_stride - 1) // t_stride
+    gather = dict(upsample2x=(mode == 1), downsample2=(mode == 2), t_stride=t_stride, t_off=t_off, t_out=t_out)
+    k = kt * ks * ks * C
+    kpad = -(-k // 64) * 64
+    buf = torch.randn((T + 2, H, W, C), generator=g).to(BF).cuda()
+    x, cache = buf[2:], (buf[:2].clone() if kt == 3 else None)
+    w = torch.zeros((N, kpad), dtype=BF)
+    w[:, :k] = (torch.randn((N, k), generator=g) / k ** 0.5).to(BF)
+    w = w.cuda()
+    b = torch.randn((N,), generator=g).to(BF).cuda()
+    cols = ops.vae_im2col(x.clone(), cache, kt, ks, kpad, **gather)
+    resid = torch.randn((cols.shape[0], N), generator=g).to(BF).cuda() if rnd.random() < 0.5 else None
+    ref = ops.gemm(cols, w, b, epilogue=ops.EPI_BIAS if resid is None else ops.EPI_BIAS_RESID, resid=resid)
+    got = ops.vae_conv3d(x.clone(), cache, w, b, kt, ks, resid=resid, **gather)
+    assert torch.equal(got, ref), (kt, ks, mode, C, N, H, W, T, gather)
+    if kt == 3:
+        got2 = ops.vae_conv3d(x, None, w, b, kt, ks, resid=resid, history_in_front=True, **gather)
+        assert torch.equal(got2, ref), ("history in front", kt, ks, mode, C, N, H, W, T, gather)
+
+
+@pytest.mark.gpu
 def test_hip_implicit_conv_rejects_bad_arguments():
     from goal_force_amd import ops
     from goal_force_amd._lib import GoalForceError
