@@ -207,7 +207,13 @@ __global__ __launch_bounds__(DQ_THREADS, 2) void attn_bwd_dq_kernel(const BwdArg
 }
 
 // ---- dK, dV: wave owns keys k0 + r -------------------------------------------------------------------------------------
-__global__ __launch_bounds__(DKV_THREADS, 1) void attn_bwd_dkv_kernel(const BwdArgs p) {
+// PART 0: dK and dV in one pass (≈320 registers: ONE wave per SIMD).  PART 1: dV only (S, dV: 2 products), PART 2: dK only (S, dP,
+// dK: 3 products) — each fits 256 registers, so two workgroups share a CU (two waves per SIMD) like the dQ kernel; the pair
+// recomputes S once more (5 products instead of 4) and still takes less time than PART 0: a lone wave per SIMD leaves the matrix
+// pipe idle through every one of its own waits.
+template <int PART>
+__global__ __launch_bounds__(DKV_THREADS, PART == 0 ? 1 : 2) void attn_bwd_dkv_kernel(const BwdArgs p) {
+    constexpr bool DO_V = PART != 2, DO_K = PART != 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     GF_LDS char* lds = (GF_LDS char*)smem;
     GF_LDS float* scal = (GF_LDS float*)(lds + 4 * TILE_BYTES);    // [stage][lse 64 | delta 64]
@@ -226,7 +232,7 @@ __global__ __launch_bounds__(DKV_THREADS, 1) void attn_bwd_dkv_kernel(const BwdA
 #pragma unroll
         for (int kd = 0; kd < 8; ++kd) {
             kf[kd] = *reinterpret_cast<const bf16x8*>(kp + 16 * kd);
-            vf[kd] = *reinterpret_cast<const bf16x8*>(vp + 16 * kd);
+            if constexpr (DO_K) vf[kd] = *reinterpret_cast<const bf16x8*>(vp + 16 * kd);
         }
     }
     const float c = p.scale_log2e;
@@ -244,7 +250,7 @@ __global__ __launch_bounds__(DKV_THREADS, 1) void attn_bwd_dkv_kernel(const BwdA
         if (tid < KVB) {   // before the DMA pieces: the wait for these two loads must not cover the tiles in flight
             const long qi = min(t * KVB + tid, p.q_len - 1);
             scal[(t & 1) * 2 * KVB + tid] = p.lse[qi * p.heads + head];
-            scal[(t & 1) * 2 * KVB + KVB + tid] = p.delta[qi * p.heads + head];
+            if constexpr (DO_K) scal[(t & 1) * 2 * KVB + KVB + tid] = p.delta[qi * p.heads + head];
         }
         stage_tile<4>(p.q + head * HD, p.q_stride, t * KVB, p.q_len, b, wave, lane);
         stage_tile<4>(p.dout + head * HD, p.do_stride, t * KVB, p.q_len, b + TILE_BYTES, wave, lane);
@@ -264,12 +270,14 @@ __global__ __launch_bounds__(DKV_THREADS, 1) void attn_bwd_dkv_kernel(const BwdA
         for (int kd = 0; kd < 8; ++kd) {
             const bf16x8 q0f = *(GF_LDS bf16x8*)(qbuf + fo.row[kd]);
             const bf16x8 q1f = *(GF_LDS bf16x8*)(qbuf + fo.row[kd] + 32 * 256);
-            const bf16x8 d0f = *(GF_LDS bf16x8*)(dobuf + fo.row[kd]);
-            const bf16x8 d1f = *(GF_LDS bf16x8*)(dobuf + fo.row[kd] + 32 * 256);
             mfma32(sc[0], q0f, kf[kd]);     // S[query, key]: lane = key, registers = queries
             mfma32(sc[1], q1f, kf[kd]);
-            mfma32(dp[0], d0f, vf[kd]);     // dP[query, key] = dO V^T
-            mfma32(dp[1], d1f, vf[kd]);
+            if constexpr (DO_K) {
+                const bf16x8 d0f = *(GF_LDS bf16x8*)(dobuf + fo.row[kd]);
+                const bf16x8 d1f = *(GF_LDS bf16x8*)(dobuf + fo.row[kd] + 32 * 256);
+                mfma32(dp[0], d0f, vf[kd]);     // dP[query, key] = dO V^T
+                mfma32(dp[1], d1f, vf[kd]);
+            }
         }
         bf16x8 pf[2][2], dsf[2][2];
 #pragma unroll
@@ -278,14 +286,15 @@ __global__ __launch_bounds__(DKV_THREADS, 1) void attn_bwd_dkv_kernel(const BwdA
             for (int g = 0; g < 4; ++g) {
                 const int qi = 32 * half + 8 * g + 4 * h;      // 4 consecutive queries of registers 4g..4g+3
                 const f32x4 l4 = *(GF_LDS f32x4*)(lse_s + qi);
-                const f32x4 d4 = *(GF_LDS f32x4*)(dl_s + qi);
+                f32x4 d4 = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (DO_K) d4 = *(GF_LDS f32x4*)(dl_s + qi);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int e = 4 * g + i;
                     const bool ok = t * KVB + qi + i < p.q_len;
                     const float pr = ok ? __builtin_amdgcn_exp2f(__builtin_fmaf(sc[half][e], c, -l4[i])) : 0.f;
-                    pf[half][e >> 3][e & 7] = (__bf16)pr;
-                    dsf[half][e >> 3][e & 7] = (__bf16)(pr * (dp[half][e] - d4[i]));
+                    if constexpr (DO_V) pf[half][e >> 3][e & 7] = (__bf16)pr;
+                    if constexpr (DO_K) dsf[half][e >> 3][e & 7] = (__bf16)(pr * (dp[half][e] - d4[i]));
                 }
             }
 #pragma unroll
@@ -294,15 +303,15 @@ __global__ __launch_bounds__(DKV_THREADS, 1) void attn_bwd_dkv_kernel(const BwdA
             for (int s = 0; s < 2; ++s)
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
-                    mfma32(dv[d], tr_frag(dobuf, fo, d, kt, s), pf[kt][s]);    // dV^T += dO^T P
-                    mfma32(dk[d], tr_frag(qbuf, fo, d, kt, s), dsf[kt][s]);    // dK^T += Q^T dS
+                    if constexpr (DO_V) mfma32(dv[d], tr_frag(dobuf, fo, d, kt, s), pf[kt][s]);    // dV^T += dO^T P
+                    if constexpr (DO_K) mfma32(dk[d], tr_frag(qbuf, fo, d, kt, s), dsf[kt][s]);    // dK^T += Q^T dS
                 }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
     if (k0 + r < p.kv_len) {
-        store_rows(p.dk + (long)(k0 + r) * p.dk_stride + head * HD, dk, p.scale, h);
-        store_rows(p.dv + (long)(k0 + r) * p.dv_stride + head * HD, dv, 1.0f, h);
+        if constexpr (DO_K) store_rows(p.dk + (long)(k0 + r) * p.dk_stride + head * HD, dk, p.scale, h);
+        if constexpr (DO_V) store_rows(p.dv + (long)(k0 + r) * p.dv_stride + head * HD, dv, 1.0f, h);
     }
 }
 
@@ -331,8 +340,14 @@ extern "C" GF_API int gf_flash_attn_bwd(const void* q, const void* k, const void
     if (!attr_set) {
         hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel),
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<0>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e2 == hipSuccess)
+            e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<1>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e2 == hipSuccess)
+            e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<2>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e1 != hipSuccess || e2 != hipSuccess) {
             gf_set_error("gf_flash_attn_bwd: hipFuncSetAttribute failed");
             return GF_ERR_LAUNCH;
@@ -352,7 +367,18 @@ extern "C" GF_API int gf_flash_attn_bwd(const void* q, const void* k, const void
     hipLaunchKernelGGL(attn_bwd_delta_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, s, a);
     const unsigned nqb = (unsigned)((q_len + DQ_ROWS - 1) / DQ_ROWS), nkb = (unsigned)((kv_len + DKV_ROWS - 1) / DKV_ROWS);
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(nqb * (unsigned)heads), dim3(DQ_THREADS), lds_bytes, s, a);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(nkb * (unsigned)heads), dim3(DKV_THREADS), lds_bytes, s, a);
+    // GF_ATTN_BWD_FUSED_DKV=1: dK and dV in one pass at one wave per SIMD (the first version, A/B)
+    static int fused = -1;
+    if (fused < 0) {
+        const char* ev = getenv("GF_ATTN_BWD_FUSED_DKV");
+        fused = (ev && ev[0] == '1') ? 1 : 0;
+    }
+    if (fused) {
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<0>, dim3(nkb * (unsigned)heads), dim3(DKV_THREADS), lds_bytes, s, a);
+    } else {
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<1>, dim3(nkb * (unsigned)heads), dim3(DKV_THREADS), lds_bytes, s, a);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<2>, dim3(nkb * (unsigned)heads), dim3(DKV_THREADS), lds_bytes, s, a);
+    }
     GF_CHECK_LAUNCH("gf_flash_attn_bwd");
     return GF_OK;
 }
