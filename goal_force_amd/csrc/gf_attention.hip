@@ -858,17 +858,27 @@ __global__ __launch_bounds__(AT2_THREADS, 2) void flash_attn_fwd_kernel2(const A
         const int qrow = q0 + r;
         // P = exp2(c S - lse) is the softmax row: what the backward kernels rebuild the probabilities from
         if (p.lse && h == 0 && qrow < p.q_len) p.lse[(long)qrow * p.heads + head] = m_run * c + __builtin_amdgcn_logf(l_tot);
-        if (qrow < p.q_len) {
-            u16* op = p.o + (long)qrow * p.o_stride + head * HD + 4 * h;
+        // O leaves through LDS: a lane holds 8-byte pieces of ITS row (16 stores at a 10 KB row pitch touch 32 lines each and are
+        // issue-bound); the wave's 32 x 256 B image, 16-byte chunk c of row r at chunk c ^ (r & 15), goes out as 8 stores of
+        // four whole 256-byte rows.  The K/V tiles are dead: every wave is past its last V read at this barrier.
+        __syncthreads();
+        GF_LDS char* ob = lds + wave * 8192;
 #pragma unroll
-            for (int d = 0; d < 4; ++d)
+        for (int d = 0; d < 4; ++d)
 #pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    u32x2 pk;
-                    pk[0] = pack2bf(oacc[d][4 * rg + 0] * inv, oacc[d][4 * rg + 1] * inv);
-                    pk[1] = pack2bf(oacc[d][4 * rg + 2] * inv, oacc[d][4 * rg + 3] * inv);
-                    *reinterpret_cast<u32x2*>(op + 32 * d + 8 * rg) = pk;
-                }
+            for (int rg = 0; rg < 4; ++rg) {
+                u32x2 pk;
+                pk[0] = pack2bf(oacc[d][4 * rg + 0] * inv, oacc[d][4 * rg + 1] * inv);
+                pk[1] = pack2bf(oacc[d][4 * rg + 2] * inv, oacc[d][4 * rg + 3] * inv);
+                *(GF_LDS u32x2*)(ob + r * 256 + (((4 * d + rg) ^ (r & 15)) << 4) + 8 * h) = pk;
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-local image: LDS is in order, no barrier needed
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = 4 * it + (lane >> 4), ch = lane & 15;
+            const u16x8 v8 = *(GF_LDS u16x8*)(ob + row * 256 + ((ch ^ (row & 15)) << 4));
+            if (q0 + row < p.q_len)
+                *reinterpret_cast<u16x8*>(p.o + (long)(q0 + row) * p.o_stride + head * HD + 8 * ch) = v8;
         }
     }
 }
