@@ -208,9 +208,18 @@ def flash_attn_lse(q, k, v, num_heads, scale=None):
         scale = 1.0 / math.sqrt(head_dim)
     out = torch.empty((sq, hd_all), dtype=_BF16, device=q.device)
     lse = torch.empty((sq, num_heads), dtype=torch.float32, device=q.device)
-    _lib.check(_lib.load().gf_flash_attn_fwd_lse(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), sq, skv, num_heads, head_dim,
-                                                 q.stride(0), k.stride(0), v.stride(0), out.stride(0), float(scale),
-                                                 _stream(q)), "gf_flash_attn_fwd_lse")
+    lib = _lib.load()
+    kv_pad = -(-skv // 64) * 64
+    if skv >= VT_MIN_KV and head_dim == 128 and num_heads * 128 * kv_pad < 2 ** 31:   # as flash_attn: pre-transposed V, same bits
+        vt = _vt_workspace(num_heads * 128 * kv_pad, q.device)
+        _lib.check(lib.gf_transpose_v(_ptr(v), v.stride(0), _ptr(vt), skv, kv_pad, num_heads, _stream(q)), "gf_transpose_v")
+        _lib.check(lib.gf_flash_attn_fwd_vt(_ptr(q), _ptr(k), _ptr(vt), _ptr(out), _ptr(lse), sq, skv, kv_pad, num_heads, head_dim,
+                                            q.stride(0), k.stride(0), out.stride(0), float(scale), _stream(q)),
+                   "gf_flash_attn_fwd_vt")
+        return out, lse
+    _lib.check(lib.gf_flash_attn_fwd_lse(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), sq, skv, num_heads, head_dim,
+                                         q.stride(0), k.stride(0), v.stride(0), out.stride(0), float(scale),
+                                         _stream(q)), "gf_flash_attn_fwd_lse")
     return out, lse
 
 

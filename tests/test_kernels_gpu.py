@@ -224,6 +224,20 @@ def test_flash_attn(ops, sq, skv, heads):
     assert e2 < 8e-3, f"vs bf16 SDPA rel_l2={e2:.3e}"
 
 
+def test_flash_attn_lse_same_on_both_v_paths(ops, monkeypatch):
+    """flash_attn_lse (training forward) through the pre-transposed-V kernel == through the plain kernel: output and log-sum-exp."""
+    g = torch.Generator().manual_seed(77)
+    sq, skv, heads = 300, 2100, 3
+    q, k, v = (dev(torch.randn((n, heads * 128), generator=g).to(BF)) for n in (sq, skv, skv))
+    o1, l1 = ops.flash_attn_lse(q, k, v, heads)                 # skv >= VT_MIN_KV: V^T path
+    monkeypatch.setattr(ops, "VT_MIN_KV", 1 << 30)
+    o2, l2 = ops.flash_attn_lse(q, k, v, heads)                 # plain path
+    assert torch.equal(o1, o2) and torch.equal(l1, l2)
+    ref = torch.logsumexp((q.float().view(sq, heads, 128).transpose(0, 1) @ k.float().view(skv, heads, 128).permute(1, 2, 0))
+                          * (128 ** -0.5), dim=-1).t() * 1.4426950408889634
+    assert float((l1 - ref).abs().max()) < 2e-2
+
+
 def test_flash_attn_forced_rescale_branch(ops):
     """One key row spiked against one query row so the running max jumps far past the lazy-rescale
     threshold in the middle of the KV sweep (guide rule: a rare data-dependent branch needs its own
