@@ -72,6 +72,11 @@ def main():
             fl = 2.0 * s * n * k
             med, mn = timeit(lambda: ops.gemm(inp, w, b, out=out), a.iters)
             print(f"gemm bf16 {name}: median {med:.3f} ms ({fl / med / 1e9:.1f} TFLOP/s), min {mn:.3f} ms")
+            if n == D:
+                res = torch.randn((s, n), device="cuda").to(BF)
+                gate = torch.randn((n,), device="cuda").to(BF)
+                med, mn = timeit(lambda: ops.gemm(inp, w, b, out=out, epilogue=ops.EPI_BIAS_GATE_RESID, resid=res, gate=gate), a.iters)
+                print(f"gemm bf16 {name} + gate*y+resid epilogue: median {med:.3f} ms ({fl / med / 1e9:.1f} TFLOP/s), min {mn:.3f} ms")
             if n == F:
                 med, mn = timeit(lambda: ops.gemm(inp, w, b, out=out, epilogue=ops.EPI_BIAS_GELU_TANH), a.iters)
                 print(f"gemm bf16 {name} + GELU(tanh) epilogue: median {med:.3f} ms ({fl / med / 1e9:.1f} TFLOP/s), min {mn:.3f} ms")
