@@ -123,7 +123,15 @@ class WanVideoPipeline:
         pipe = WanVideoPipeline(device=device, controlnet=controlnet is not None,
                                 controlnet_num_layers=0 if controlnet is None else controlnet.num_layers)
         pipe.dit, pipe.dit2, pipe.controlnet, pipe.controlnet2, pipe.vae = dit, dit2, controlnet, controlnet2, vae
+        pipe._after_models_attached()
         return pipe
+
+    def _after_models_attached(self):
+        """GF:580-582 size division factors follow the VAE; GF:585-586 the prompter learns its text encoder."""
+        if self.vae is not None:
+            self.height_division_factor = self.width_division_factor = self.vae.upsampling_factor * 2
+        if self.text_encoder is not None:
+            self.prompter.fetch_models(self.text_encoder)
 
     def init_controlnets(self):
         d = self.dit
@@ -288,6 +296,11 @@ class WanVideoPipeline:
             context_nega = self.prompter.encode_prompt(negative_prompt, positive=False, device=self.device)
         if y is None and input_image is not None:
             y = self.embed_image(input_image, num_frames, height, width, tiled, tile_size, tile_stride)
+        if y is None and self.dit is not None and self.dit.require_vae_embedding and self.dit.in_dim > noise.shape[1]:
+            # without an image GF:896 returns {} and the reference's patch embedding then fails on the channel count;
+            # the GEMM here K-pads its operand, so the missing channels must be refused, not read as zeros
+            raise GoalForceError(f"this expert's patch embedding takes {self.dit.in_dim} channels: pass input_image "
+                                 "(with pipe.vae attached) or a pre-computed y")
         if controlnet and control_signal_video_latents is None:
             if control_signal_video is None:
                 raise GoalForceError("controlnet=True needs control_signal_video or control_signal_video_latents")
@@ -315,18 +328,19 @@ class WanVideoPipeline:
         return t.permute(2, 0, 1).unsqueeze(0)
 
     def embed_image(self, input_image, num_frames, height, width, tiled, tile_size, tile_stride):
-        """WanVideoUnit_ImageEmbedderVAE (GF:887-917): y = cat(mask[4,f,h,w], vae.encode([image, zeros x (F-1)]))."""
+        """WanVideoUnit_ImageEmbedderVAE, `end_image is None` branch (GF:887-917): y = [mask(4) ; vae.encode(video)(16)]
+        where video = the image followed by num_frames-1 zero frames.  The reference builds the mask by repeating pixel
+        frame 0 four times and folding every 4 pixel frames into the 4 channels of a latent frame (GF:899-909); with only
+        frame 0 set that is: all 4 channels one on latent frame 0, zero elsewhere (pinned by tests/golden/g10)."""
         if self.vae is None:
             raise GoalForceError("embed_image needs pipe.vae")
-        image = self.preprocess_image(input_image.resize((width, height)))
-        msk = torch.ones(1, num_frames, height // 8, width // 8, device=self.device)
-        msk[:, 1:] = 0
-        vae_input = torch.concat([image.transpose(0, 1),
-                                  torch.zeros(3, num_frames - 1, height, width, device=self.device, dtype=self.torch_dtype)], dim=1)
-        msk = torch.concat([torch.repeat_interleave(msk[:, 0:1], repeats=4, dim=1), msk[:, 1:]], dim=1)
-        msk = msk.view(1, msk.shape[1] // 4, 4, height // 8, width // 8).transpose(1, 2)[0]
-        y = self.vae.encode([vae_input], device=self.device, tiled=tiled, tile_size=tile_size, tile_stride=tile_stride)[0]
-        return torch.concat([msk.to(self.torch_dtype), y.to(self.torch_dtype)]).unsqueeze(0)
+        video = torch.zeros((3, num_frames, height, width), device=self.device, dtype=self.torch_dtype)
+        video[:, 0] = self.preprocess_image(input_image.resize((width, height)))[0]
+        lat = self.vae.encode([video], device=self.device, tiled=tiled, tile_size=tile_size, tile_stride=tile_stride)[0]
+        y = torch.zeros((1, 4 + lat.shape[0], *lat.shape[1:]), device=self.device, dtype=self.torch_dtype)
+        y[0, :4, 0] = 1
+        y[0, 4:] = lat
+        return y
 
     def embed_control_video(self, control_signal_video, tiled, tile_size, tile_stride):
         """WanVideoUnit_ControlVideoEmbedder (GF:791-805): 'f h w c -> 1 c f h w' then vae.encode (un-rescaled [0,1])."""

@@ -198,3 +198,22 @@ def to_u16(t: torch.Tensor) -> np.ndarray:
 
 def from_u16(a: np.ndarray) -> torch.Tensor:
     return torch.from_numpy(a.view(np.int16).copy()).view(torch.bfloat16)
+
+
+PRELOOP_SHAPES = ((480, 832, 81), (470, 830, 80), (64, 96, 9), (17, 33, 6))
+
+
+def preloop_inputs(seed=91):
+    """Inputs of the pre-loop units (g10): a 50x70 RGB PIL image (so the unit's resize to 96x64 does work) and a
+    [9,64,96,3] control video in [0,1] with two gaussian blobs (the value range the force maps have, DS:775-889)."""
+    from PIL import Image
+    g = torch.Generator().manual_seed(seed)
+    img = (torch.rand((50, 70, 3), generator=g) * 255).to(torch.uint8).numpy()
+    yy, xx = torch.meshgrid(torch.arange(64.0), torch.arange(96.0), indexing="ij")
+    frames = []
+    for f in range(9):
+        a = torch.exp(-((xx - 20 - 4 * f) ** 2 + (yy - 30) ** 2) / (2 * 6.0 ** 2))
+        b = torch.exp(-((xx - 70) ** 2 + (yy - 12 - 3 * f) ** 2) / (2 * 4.0 ** 2))
+        frames.append(torch.stack([a, b, 0.5 * (a + b)], dim=-1))
+    control = torch.stack(frames).clamp(0, 1).to(torch.bfloat16)
+    return Image.fromarray(img), control
