@@ -28,6 +28,12 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# HBM bytes per self-attention launch (transpose_v_kernel + flash_attn_fwd_kernel2<true>) from rocprofv3 --pmc, separate
+# FETCH_SIZE / WRITE_SIZE passes over tools/microbench.py attn: (2 x FETCH_SIZE [gfx950 reports half of a 16-B/lane stream]
+# + WRITE_SIZE) KiB -> bytes.  PMC needs the profiler, so this is a STATIC figure from the named file, not measured by the
+# run that prints it ("traffic_static": true in the JSON line).
+ATTN_TRAFFIC_BYTES = ((2 * 1894109 + 327602) + (2 * 163820 + 327767)) * 1024
+ATTN_TRAFFIC_SOURCE = "profiles/r01/pmc/attn_k2vt_{FETCH,WRITE}_SIZE_counter_collection.csv"
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md (Chip-level parameters)
 S_TOK, DIM, HEADS, FFN, LTXT = 32760, 5120, 40, 13824, 512
 
@@ -43,9 +49,21 @@ def forward_flops(with_controlnet):
     return fl
 
 
-def cpu_baseline(torch):
+def cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(torch, runs=3):
     """Reference-equivalent CPU path (the oracle's torch-CPU restatement of DiTBlock, pinned to the
-    reference by tests/test_oracle_goldens.py) on BASELINE config 1: one A14B block, S=14040, bf16."""
+    reference by tests/test_oracle_goldens.py) on BASELINE config 1: one A14B block, S=14040, bf16, every host core.
+    SURVEY §8(d): 1 untimed warm-up, then the median of 3 timed runs; CPU model and core count reported."""
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import gen_inputs as gi
     from oracle import wan_oracle as wo
@@ -55,15 +73,30 @@ def cpu_baseline(torch):
     x, ctx, t_mod = gi.block_inputs(cfg["dim"], s, 512, seed=32)
     freqs = wo.rope_freqs_3d(128, 9, 30, 52)
     cores = torch.get_num_threads()
-    t0 = time.time()
-    wo.dit_block(x, ctx, t_mod, freqs, sd, "", cfg["num_heads"], cfg["eps"])
-    dt = time.time() - t0
+    times = []
+    for i in range(runs + 1):
+        t0 = time.time()
+        wo.dit_block(x, ctx, t_mod, freqs, sd, "", cfg["num_heads"], cfg["eps"])
+        if i:                      # run 0 is the warm-up (thread pool, allocator, page faults)
+            times.append(time.time() - t0)
+    dt = sorted(times)[len(times) // 2]
     tflops = block_flops(s) / dt / 1e12
     loop_flops = 21 * 2 * forward_flops(True) + 29 * 2 * forward_flops(True)  # reference runs ControlNet2 too
     return {"value": 81.0 / (loop_flops / (tflops * 1e12)), "unit": "frames/s (derived: 50-step loop FLOPs / measured CPU FLOP/s)",
-            "cores": cores, "kind": "port",
-            "sample": f"one A14B DiTBlock fwd, S=14040 (BASELINE config 1), bf16, torch CPU eager: {dt:.1f} s = {tflops:.2f} TFLOP/s",
+            "cores": cores, "cpu_model": cpu_model_name(), "kind": "port",
+            "sample": f"one A14B DiTBlock fwd, S=14040 (BASELINE config 1), bf16, torch CPU eager, 1 warm-up + median of "
+                      f"{runs}: {dt:.2f} s = {tflops:.2f} TFLOP/s (runs: {', '.join(f'{t:.2f}' for t in times)} s)",
             "block_seconds": dt, "tflops": tflops}
+
+
+def tensor_digest(torch, t):
+    """sha256 of the raw bytes + a few statistics of a device tensor (self-check of the timed run's outputs)."""
+    import hashlib
+    c = t.detach().contiguous().cpu()
+    raw = c.view(torch.uint8) if c.dtype == torch.uint8 else c.view(torch.int16) if c.element_size() == 2 else c
+    f = c.float()
+    return {"sha256": hashlib.sha256(raw.numpy().tobytes()).hexdigest(), "mean": float(f.mean()), "std": float(f.std()),
+            "absmax": float(f.abs().max())}
 
 
 def main():
@@ -144,37 +177,60 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ops.PROFILE_ATTN = []
+    ops.PROFILE_ATTN, ops.PROFILE_GEMM = [], []
     t0 = time.perf_counter()
-    run(step_ids, record=True)
+    final = run(step_ids, record=True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     prof, ops.PROFILE_ATTN = ops.PROFILE_ATTN, None
-    # VAE tiled decode of one video (GF:733; tile (30,52)/(15,26)), timed after the K steps: 1 warm-up + 1 timed
+    gprof, ops.PROFILE_GEMM = ops.PROFILE_GEMM, None
+    # ---- self-check of what the timed steps produced: a forward that overflowed would time the same
+    if not bool(torch.isfinite(final.float()).all()):
+        raise SystemExit(f"rank {rank}: non-finite latents after the timed steps")
+    lat_digest = tensor_digest(torch, final)
+    if not (1e-3 < lat_digest["std"] < 1e3):
+        raise SystemExit(f"rank {rank}: degenerate latents after the timed steps: {lat_digest}")
+    # VAE tiled decode of THIS run's latents (GF:733; tile (30,52)/(15,26)), timed after the K steps: 1 warm-up + 1 timed
     # N > 1: the 9 tiles are split over the two ranks of the CFG pair (both hold the final latents) and exchanged
-    zlat = pipe.generate_noise((1, 16, 21, 60, 104), seed=11)
     tgroup = None if cfgp is None else cfgp.pair_group
-    vae.decode(zlat, tiled=True, tile_size=(30, 52), tile_stride=(15, 26), tile_group=tgroup)
+    vae.decode(final, tiled=True, tile_size=(30, 52), tile_stride=(15, 26), tile_group=tgroup)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     tv = time.perf_counter()
-    frames = vae.decode(zlat, tiled=True, tile_size=(30, 52), tile_stride=(15, 26), tile_group=tgroup)
+    frames = vae.decode(final, tiled=True, tile_size=(30, 52), tile_stride=(15, 26), tile_group=tgroup)
     torch.cuda.synchronize()
     vae_s = time.perf_counter() - tv
     assert tuple(frames.shape) == (1, 3, 81, 480, 832)
+    if not bool(torch.isfinite(frames.float()).all()):
+        raise SystemExit(f"rank {rank}: non-finite decoded frames")
+    u8 = pipe.frames_uint8(frames)                      # [81,480,832,3] uint8, 97 MB (what the reference saves, GF:735)
+    frames_digest = tensor_digest(torch, u8)
+    # end-of-run all-gather of every sample's frames over the world group: 1 warm-up + 1 timed
+    gather_s, n_gathered = 0.0, 1
+    if cfgp is not None:
+        cfgp.gather_frames(u8, tuple(u8.shape), torch.uint8, dev)
+        torch.cuda.synchronize()
+        dist.barrier()
+        tg = time.perf_counter()
+        allf = cfgp.gather_frames(u8, tuple(u8.shape), torch.uint8, dev)
+        torch.cuda.synchronize()
+        gather_s = time.perf_counter() - tg
+        n_gathered = len(allf)
+        if not torch.equal(allf[cfgp.sample], u8):
+            raise SystemExit(f"rank {rank}: the gathered frames of sample {cfgp.sample} differ from the local decode")
     if world > 1:
-        t = torch.tensor([elapsed, vae_s], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed, vae_s, gather_s], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, vae_s = float(t[0].item()), float(t[1].item())
+        elapsed, vae_s, gather_s = (float(v) for v in t.tolist())
 
     if rank == 0:
         sec_per_step = elapsed / k
         videos = 1 if world == 1 else world // (2 * args.sp)
         loop_s = n_sched * sec_per_step
-        value = videos * 81.0 / (loop_s + vae_s)
+        value = videos * 81.0 / (loop_s + vae_s + gather_s)
         hi = [ms for ms, low in pipe.last_step_ms if not low]
         lo = [ms for ms, low in pipe.last_step_ms if low]
         # dominant kernel: self-attention flash-attention launches (q_len == kv_len == S)
@@ -202,6 +258,15 @@ def main():
                                      "timed steps and included in value: frames/s = videos*81 / (50*s_per_step + vae_s)"
                                      + ("" if world == 1 else "; tiles split over the two ranks of each CFG pair")},
             "vae_decode_s": vae_s, "denoise_loop_s_50_steps": loop_s,
+            "frame_allgather_s": gather_s, "samples_gathered": n_gathered,
+            "distributed": {"world": world, "backend": dist.get_backend() if world > 1 else None,
+                            "rccl_ranks": world if (world > 1 and dist.get_backend() == "nccl") else 0,
+                            "collectives": None if world == 1 else "per step: all-gather of the 4.19 MB noise prediction inside each "
+                                           "CFG pair; VAE tiles broadcast inside the pair; end of run: world all-gather of the "
+                                           "uint8 frames (97 MB per sample), timed as frame_allgather_s and included in value"},
+            "self_check": {"latents_finite": True, "frames_finite": True, "latents": lat_digest, "frames_uint8": frames_digest,
+                           "note": "latents = output of the K timed steps of rank 0's sample (finite, std in (1e-3,1e3) or the run "
+                                   "aborts); frames = tiled VAE decode of those latents -> uint8 as the reference saves them"},
             "frames_per_sec_denoise_only": videos * 81.0 / loop_s,
             "denoise_step_ms_high_noise": sum(hi) / len(hi) if hi else None,
             "denoise_step_ms_low_noise": sum(lo) / len(lo) if lo else None,
@@ -217,11 +282,25 @@ def main():
                          # tools/microbench.py attn, profiles/r01/pmc/): (2 x FETCH_SIZE [gfx950 reports half of a 16-B/lane
                          # stream] + WRITE_SIZE) KiB -> bytes.  Not collected live: PMC needs the profiler.
                          # The launch = transpose_v_kernel + flash_attn_fwd_kernel2<true> (both inside the timed events).
-                         "traffic": ((2 * 1894109 + 327602) + (2 * 163820 + 327767)) * 1024,
-                         "traffic_source": "profiles/r01/pmc/attn_k2vt_{FETCH,WRITE}_SIZE_counter_collection.csv",
+                         "traffic": ATTN_TRAFFIC_BYTES, "traffic_static": True,
+                         "traffic_source": ATTN_TRAFFIC_SOURCE,
                          "launches": len(self_att), "avg_launch_ms": att_ms if self_att else None,
                          "algorithmic_flops_per_launch": att_flops},
         }
+        # second entry: the FFN GEMMs (D->F with the GELU epilogue, F->D with gate*+residual) — with the four D->D
+        # projections the GEMMs are the other ~45 % of a step
+        def gemm_entry(n, kk, name):
+            ms = [a.elapsed_time(b) for a, b, M, N, K, _ in gprof if (M, N, K) == (S_TOK // args.sp, n, kk)]
+            if not ms:
+                return None
+            avg = sum(ms) / len(ms)
+            fl = 2.0 * (S_TOK // args.sp) * n * kk
+            return {"bound": "mfma", "kernel": name, "achieved": fl / (avg * 1e-3) / 1e12, "peak": PEAK_BF16_TFLOPS,
+                    "unit": "TFLOP/s", "frac": fl / (avg * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, "traffic": None,
+                    "launches": len(ms), "avg_launch_ms": avg, "algorithmic_flops_per_launch": fl}
+        out["roofline_gemm"] = [e for e in (gemm_entry(FFN, DIM, "gemm_ph_kernel<GELU> FFN1 [S,5120]x[13824,5120]^T"),
+                                            gemm_entry(DIM, FFN, "gemm_ph_kernel<gate*+resid> FFN2 [S,13824]x[5120,13824]^T"),
+                                            gemm_entry(DIM, DIM, "gemm_ph_kernel D->D projections (q,k,v,o, zero-conv)")) if e]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(torch)
         print(json.dumps(out))

@@ -27,9 +27,16 @@ _BF16 = torch.bfloat16
 # flash_attn() brackets every launch with events recorded on the launch stream and appends
 # (start, end, q_len, kv_len, heads).  None (default) = no events, no overhead.
 PROFILE_ATTN = None
+# Same for the GEMM (bench.py's second roofline entry): a list collects (start, end, M, N, K, epilogue) per launch.
+PROFILE_GEMM = None
 
 
 def _stream(t: torch.Tensor):
+    """The HIP stream the launch goes to: torch's current stream of the tensor's device.  The C ABI launches on the
+    CURRENT HIP device, so a tensor of another device is refused instead of being launched on the wrong GPU."""
+    if t.device.index != torch.cuda.current_device():
+        raise GoalForceError(f"tensor lives on cuda:{t.device.index} but the current device is cuda:"
+                             f"{torch.cuda.current_device()}: call torch.cuda.set_device (one process per GPU)")
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
@@ -135,8 +142,15 @@ def gemm(a, w, bias=None, epilogue=EPI_BIAS, resid=None, gate=None, out=None):
         _req(bias, "gemm.bias")
         if bias.numel() != N or not bias.is_contiguous():
             raise GoalForceError(f"gemm.bias: expected contiguous [{N}]")
+    prof = PROFILE_GEMM
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.check(_lib.load().gf_gemm_bf16(_ptr(av), lda, _ptr(w), w.stride(0), _ptr(bias), _ptr(ov), ldc, M, N, K,
                                         int(epilogue), _ptr(resid), ldr, _ptr(gate), _stream(a)), "gf_gemm_bf16")
+    if prof is not None:
+        e1.record()
+        prof.append((e0, e1, M, N, K, int(epilogue)))
     return out
 
 
@@ -145,9 +159,9 @@ _VT_WS = {}
 
 
 def _vt_workspace(numel, device):
-    """One reusable V^T buffer per device (stream-ordered reuse: every attention launch that reads it is enqueued before the
-    next transpose that overwrites it)."""
-    key = (device.type, device.index)
+    """One reusable V^T buffer per (device, stream): on one stream the reuse is ordered (every attention launch that reads
+    it is enqueued before the next transpose that overwrites it); launches on another stream get their own buffer."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     ws = _VT_WS.get(key)
     if ws is None or ws.numel() < numel:
         ws = _VT_WS[key] = torch.empty((numel,), dtype=_BF16, device=device)

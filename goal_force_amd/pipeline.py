@@ -187,12 +187,17 @@ class WanVideoPipeline:
         noise = torch.randn(shape, generator=generator, device=rand_device, dtype=rand_torch_dtype)
         return noise.to(dtype=torch_dtype or self.torch_dtype, device=device or self.device)
 
+    def frames_uint8(self, vae_output, min_value=-1, max_value=1):
+        """[1,3,T,H,W] in [-1,1] -> [T,H,W,3] uint8 on the same device.  UTIL:76-91 computes `(x - min) * (255 / (max -
+        min))`, the clip and the truncating uint8 cast in the VAE output's own dtype (bf16 here, so 200.7 becomes 201
+        before the cast): same arithmetic, same bytes (tests/golden/g10 `frames_u8`)."""
+        v = vae_output.mean(dim=0).permute(1, 2, 3, 0)
+        return ((v - min_value) * (255 / (max_value - min_value))).clip(0, 255).to(torch.uint8)
+
     def vae_output_to_video(self, vae_output, min_value=-1, max_value=1):
-        """UTIL:76-91 — [1,3,T,H,W] in [-1,1] -> list of PIL frames."""
+        """UTIL:85-91 — list of PIL frames."""
         from PIL import Image
-        v = vae_output.float().mean(dim=0).permute(1, 2, 3, 0)  # T H W C
-        v = ((v - min_value) * (255 / (max_value - min_value))).clip(0, 255).to(device="cpu", dtype=torch.uint8)
-        return [Image.fromarray(f.numpy()) for f in v]
+        return [Image.fromarray(f.numpy()) for f in self.frames_uint8(vae_output, min_value, max_value).cpu()]
 
     # ------------------------------------------------------------------ the hot loop
     @torch.no_grad()
@@ -272,7 +277,7 @@ class WanVideoPipeline:
                  control_signal_video=None,
                  # pre-computed conditioning (outputs of the pre-loop units GF:791-917 / GF:808)
                  context_posi=None, context_nega=None, y=None, control_signal_video_latents=None,
-                 output_type="pil", cfg_parallel=None, sequence_parallel=None):
+                 output_type="pil", cfg_parallel=None, sequence_parallel=None, gather_frames=False):
         for name, val in (("end_image", end_image), ("input_video", input_video), ("input_audio", input_audio),
                           ("audio_embeds", audio_embeds), ("s2v_pose_video", s2v_pose_video),
                           ("motion_video", motion_video), ("control_video", control_video),
@@ -318,6 +323,13 @@ class WanVideoPipeline:
         # multi-GPU (distributed.CfgPairParallel): both ranks of the CFG pair hold these latents -> they share the tiles
         video = self.vae.decode(latents, device=self.device, tiled=tiled, tile_size=tile_size, tile_stride=tile_stride,
                                 tile_group=None if cfg_parallel is None else cfg_parallel.pair_group)
+        if gather_frames:
+            # end-of-run all-gather of every sample's decoded frames over the world group (RCCL / xGMI),
+            # 81x480x832x3 uint8 = 97 MB per sample -> list (one [T,H,W,3] uint8 tensor per sample) on every rank
+            if cfg_parallel is None:
+                return [self.frames_uint8(video)]
+            u8 = self.frames_uint8(video)
+            return cfg_parallel.gather_frames(u8, tuple(u8.shape), torch.uint8, u8.device)
         return video if output_type == "pt" else self.vae_output_to_video(video)
 
     # ---------------------------------------------------------------- pre-loop units that use the VAE encoder

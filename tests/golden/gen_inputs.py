@@ -217,3 +217,26 @@ def preloop_inputs(seed=91):
         frames.append(torch.stack([a, b, 0.5 * (a + b)], dim=-1))
     control = torch.stack(frames).clamp(0, 1).to(torch.bfloat16)
     return Image.fromarray(img), control
+
+
+def preloop_decoded_video(seed=92):
+    """A [1,3,2,8,8] 'decoded video' slightly outside [-1,1] (the clip must act) for the frames-to-uint8 conversion."""
+    return (torch.rand((1, 3, 2, 8, 8), generator=torch.Generator().manual_seed(seed)) * 2.4 - 1.2).to(torch.bfloat16)
+
+
+FP8_CASES = ((72, 256, 256), (300, 528, 384), (515, 1024, 2048))
+
+
+def fp8_case(M, N, K):
+    """Seeded x [M,K], w [N,K], b [N] (bf16) for the fp8_linear contract (VRAM:115-151): activations of std 3 with one
+    entry of 1500 (its row then has scale_a = 1500/448 > 1), one row of exact zeros and one row whose maximum is
+    exactly 448 (the clamp's boundary)."""
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    x = (torch.randn((M, K), generator=g) * 3).to(torch.bfloat16)
+    x[M // 2, 5] = 1500.0
+    x[1] = 0
+    x[2] = x[2].clamp(-400, 400)
+    x[2, 7] = 448.0
+    w = (torch.randn((N, K), generator=g) / math.sqrt(K)).to(torch.bfloat16)
+    b = (0.1 * torch.randn(N, generator=g)).to(torch.bfloat16)
+    return x, w, b

@@ -194,3 +194,108 @@ def test_cfg_scale_one_is_single_forward():
     pipe.denoise(inp["latents"], inp["ctx_posi"], None, inp["y"], inp["control"], num_inference_steps=2,
                  cfg_scale=1.0, controlnet=True)
     assert len(calls) == 2
+
+
+def _block_rows_fp32(x, ctx, t_mod, freqs, sd, rows, nh, eps):
+    """The block's output on the token rows `rows` only, fp32 math on the (bf16-valued) inputs, built from the oracle's
+    pinned primitives (wan_oracle layer_norm / modulate / rms_norm / rope_apply / attention_fp64, DIT:214-230) on the GPU
+    through plain torch.  Keys and values need every token, everything after the attention only the sampled rows."""
+    lin = lambda t, n: torch.nn.functional.linear(t, sd[n + ".weight"], sd[n + ".bias"])
+    mod = sd["modulation"] + t_mod
+    sh_a, sc_a, g_a, sh_m, sc_m, g_m = mod.chunk(6, dim=1)
+    h = wo.modulate(wo.layer_norm(x, eps=eps), sh_a, sc_a)                         # all tokens
+    k = wo.rope_apply(wo.rms_norm(lin(h, "self_attn.k"), sd["self_attn.norm_k.weight"], eps), freqs, nh)
+    v = lin(h, "self_attn.v")
+    q = wo.rope_apply(wo.rms_norm(lin(h[:, rows], "self_attn.q"), sd["self_attn.norm_q.weight"], eps), freqs[rows], nh)
+    xr = x[:, rows] + g_a * lin(wo.attention_fp64(q, k, v, nh).float(), "self_attn.o")
+    del h, k, v
+    h = wo.layer_norm(xr, sd["norm3.weight"], sd["norm3.bias"], eps)
+    xr = xr + wo.cross_attention(h, ctx, sd, "cross_attn.", nh, eps)
+    h = wo.modulate(wo.layer_norm(xr, eps=eps), sh_m, sc_m)
+    h = lin(torch.nn.functional.gelu(lin(h, "ffn.0"), approximate="tanh"), "ffn.2")
+    return xr + g_m * h
+
+
+def test_a14b_block_full_size_sampled_rows_vs_fp32_chain():
+    """BASELINE config 2's token count: one A14B block at S = 21x30x52 = 32760 (the size every forward of the 50-step
+    run executes 50x).  192 sampled token rows (first/last tiles of the attention grid included) against the fp32 chain;
+    bar = the per-block bar of SURVEY §8(d): rel-L2 <= 5e-3; every row norm of the output must be finite."""
+    cfg = gi.A14B
+    grid = (21, 30, 52)
+    S = 21 * 30 * 52
+    sd = gi.block_sd(torch.Generator().manual_seed(31), cfg["dim"], cfg["ffn_dim"], "", BF)
+    x, ctx, t_mod = gi.block_inputs(cfg["dim"], S, 512, seed=33)
+    got = _block(cfg, sd)(x.cuda(), ctx.cuda(), t_mod.cuda(), _rope(cfg, grid))
+    assert bool(torch.isfinite(got.float().norm(dim=-1)).all())
+    g = torch.Generator().manual_seed(5)
+    rows = torch.cat([torch.arange(0, 32), torch.arange(S - 32, S), torch.randperm(S, generator=g)[:128]]).cuda()
+    sd32 = {k: v.float().cuda() for k, v in sd.items()}
+    freqs = wo.rope_freqs_3d(128, *grid).cuda()
+    ref = _block_rows_fp32(x.float().cuda(), ctx.float().cuda(), t_mod.float().cuda(), freqs, sd32, rows,
+                           cfg["num_heads"], cfg["eps"])
+    e = rel_l2(got[:, rows].float(), ref)
+    worst = float(((got[0, rows].float() - ref[0]).norm(dim=-1) / ref[0].norm(dim=-1)).max())
+    assert e < 5e-3 and worst < 1e-2, f"S=32760 block vs fp32 chain: rel-L2 {e:.3e}, worst row {worst:.3e}"
+
+
+def test_block_rows_chain_equals_full_oracle_block_at_small_size():
+    """The sampled-rows chain above is the oracle's dit_block restricted to rows (checked where the full block fits)."""
+    cfg = gi.MID
+    grid = (2, 6, 8)
+    sd = {k: v.float() for k, v in gi.block_sd(torch.Generator().manual_seed(21), cfg["dim"], cfg["ffn_dim"], "", BF).items()}
+    x, ctx, t_mod = (t.float() for t in gi.block_inputs(cfg["dim"], 96, 64, seed=22))
+    freqs = wo.rope_freqs_3d(128, *grid)
+    rows = torch.tensor([0, 5, 17, 95])
+    full = wo.dit_block(x, ctx, t_mod, freqs, sd, "", cfg["num_heads"], cfg["eps"])
+    part = _block_rows_fp32(x, ctx, t_mod, freqs, sd, rows, cfg["num_heads"], cfg["eps"])
+    assert rel_l2(part, full[:, rows]) < 1e-5
+
+
+def test_fp8_model_fn_and_loop_vs_fp8_oracle():
+    """BASELINE config 5 above block level: tiny model_fn with ControlNet and the 3-step CFG loop with the expert
+    switch, every Linear inside the DiT / ControlNet blocks on the fp8_linear contract (VRAM:115-151) — HIP against the
+    oracle's model_fn with the restated fp8_linear swapped in for exactly those Linears."""
+    import torch.nn.functional as F
+    from oracle import fp8_oracle as fo
+    from goal_force_amd.dit import enable_fp8
+    from goal_force_amd.model_fn import model_fn_wan_video
+    from goal_force_amd.pipeline import WanVideoPipeline
+    cfg = gi.TINY
+    inp = gi.tiny_inputs()
+    dev = {k: v.cuda() for k, v in inp.items()}
+    sds = [(gi.dit_sd(cfg, seed=41), gi.controlnet_sd(cfg, 1, seed=42)),
+           (gi.dit_sd(cfg, seed=43), gi.controlnet_sd(cfg, 1, seed=42, zero_convs_zero=True))]
+    block_w = {id(t) for dsd, csd in sds for sd_ in (dsd, csd) for k, t in sd_.items()
+               if ("blocks." in k) and k.endswith(".weight") and t.dim() == 2}
+
+    def lin(x, w, b=None):
+        return fo.fp8_linear(x, w, b) if id(w) in block_w else F.linear(x, w, b)
+
+    ts = torch.tensor([995.9], dtype=BF)
+    old = wo.LINEAR
+    try:
+        exact = wo.model_fn(sds[0][0], cfg, inp["latents"], ts, inp["ctx_posi"], inp["y"], sds[0][1], inp["control"], 1)
+        wo.LINEAR = lin
+        ref = wo.model_fn(sds[0][0], cfg, inp["latents"], ts, inp["ctx_posi"], inp["y"], sds[0][1], inp["control"], 1)
+        ref_loop = wo.denoise_loop([(sds[0][0], cfg, sds[0][1], 1), (sds[1][0], cfg, sds[1][1], 1)], inp["latents"],
+                                   inp["ctx_posi"], inp["ctx_nega"], inp["y"], inp["control"], 3)
+    finally:
+        wo.LINEAR = old
+    dit1, cn1 = _tiny_pipeline(False)
+    dit2, cn2 = _tiny_pipeline(True, dit_seed=43)
+    for m in (dit1, cn1, dit2, cn2):
+        enable_fp8(m)
+    got = model_fn_wan_video(dit1, latents=dev["latents"], timestep=ts.cuda(), context=dev["ctx_posi"], y=dev["y"],
+                             controlnet=cn1, control_signal_video_latents=dev["control"]).cpu()
+    e, e_q = rel_l2(got.float(), ref.float()), rel_l2(ref.float(), exact.float())
+    assert e_q > 5e-3, "the fp8 contract must actually be in force in the oracle run"
+    assert e < 0.5 * e_q, f"fp8 model_fn: HIP vs fp8 oracle {e:.3e} (fp8 contract vs bf16 graph {e_q:.3e})"
+    pipe = WanVideoPipeline.from_modules(dit1, dit2, cn1, cn2)
+    lat = pipe.denoise(dev["latents"], dev["ctx_posi"], dev["ctx_nega"], dev["y"], dev["control"],
+                       num_inference_steps=3, cfg_scale=5.0, controlnet=True).cpu()
+    g = _load("g5_model_fn.npz")
+    f32 = torch.from_numpy(g["loop3_f32"])
+    e_loop, e_ref = rel_l2(lat.float(), ref_loop.float()), rel_l2(ref_loop.float(), f32)
+    # CFG x5 over 3 steps amplifies every rounding difference (the bf16 reference itself is 0.153 from fp32 math here):
+    # the two fp8 runs must be closer to each other than the fp8 oracle run is to exact math
+    assert e_loop < e_ref, f"fp8 3-step loop: HIP vs fp8 oracle {e_loop:.3e} (fp8 oracle vs fp32 math {e_ref:.3e})"

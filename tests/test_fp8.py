@@ -1,6 +1,13 @@
-"""fp8 Linear (BASELINE config 5 semantics, VRAM:115-151): oracle known-answer vectors on CPU; HIP quantiser
-bit-exact with the oracle and the scaled-MFMA GEMM within bf16 rounding of it on the GPU."""
+"""fp8 Linear (BASELINE config 5 semantics, VRAM:115-151).
+CPU: oracle known-answer vectors, and the oracle against tests/golden/g11_fp8_scaled_mm.npz — outputs of
+`torch._scaled_mm` run on an MI355X through the reference's call sequence (tests/golden/make_fp8_golden_gpu.py).
+GPU: the HIP quantiser bit-exact with that sequence run live (`torch._scaled_mm` itself, same box) and with the oracle;
+the scaled-MFMA GEMM within 1 bf16 ulp of `torch._scaled_mm` (accumulation order is the only freedom: every e4m3 x e4m3
+product is exact in fp32)."""
 import math
+import os
+
+import numpy as np
 
 import pytest
 import torch
@@ -29,6 +36,51 @@ def test_oracle_known_answers():
     # row 0 col 0: (448 - 224 + 1.5 + 0.25) * 2 + 0 = 451.5 -> bf16 452;  col 1: (224 - 3 + 2) * 2 + 1 = 447 -> bf16 448
     assert out[0, 0].item() == 452.0 and out[0, 1].item() == 448.0
     assert out[1, 0].item() == 4.0 and out[1, 1].item() == 0.5 + 6 + 32 + 1
+
+
+def _ulp_stats(got, ref):
+    """fraction of bf16 outputs more than 1 ulp apart, and the rel-L2 distance."""
+    d = (got.view(torch.int16).int() - ref.view(torch.int16).int()).abs()
+    return float((d > 1).float().mean()), rel_l2(got.float(), ref.float())
+
+
+def test_oracle_vs_scaled_mm_fixture():
+    """The oracle's pin: torch._scaled_mm outputs recorded on the GPU (the reference's fp8_linear is that torch call)."""
+    import gen_inputs as gi
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "g11_fp8_scaled_mm.npz"))
+    for i, (M, N, K) in enumerate(gi.FP8_CASES):
+        x, w, b = gi.fp8_case(M, N, K)
+        assert gi.same_checksum(gi.checksum([x, w, b]), g[f"ck{i}"])
+        x8, s = fo.quantize_activation(x)
+        assert np.array_equal(x8.view(torch.uint8).numpy(), g[f"x8_{i}"]), "quantised activations: bit-exact"
+        assert np.array_equal(s.numpy(), g[f"s{i}"])
+        if g[f"w8_{i}"].size:
+            assert np.array_equal(w.to(fo.FP8).view(torch.uint8).numpy(), g[f"w8_{i}"])
+        bad, e = _ulp_stats(fo.fp8_linear(x, w, b), gi.from_u16(g[f"y{i}"]))
+        assert bad < 1e-3 and e < 1e-3, f"case {i}: >1ulp frac {bad:.2e}, rel-L2 {e:.3e}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(72, 256, 256), (300, 528, 384), (1000, 5120, 5120), (257, 13824, 1024)])
+def test_hip_fp8_vs_torch_scaled_mm(M, N, K):
+    """The reference's fp8_linear run live: torch._scaled_mm on this GPU through the call sequence of VRAM:115-151."""
+    import sys
+    from conftest import GOLDEN
+    sys.path.insert(0, GOLDEN)
+    from make_fp8_golden_gpu import scaled_mm_linear
+    import gen_inputs as gi
+    from goal_force_amd import ops
+    x, w, b = gi.fp8_case(M, N, K)
+    ref, r8, rs, rw8 = scaled_mm_linear(x.cuda(), w.cuda(), b.cuda())
+    x8, s = ops.quant_fp8_rowscale(x.cuda())
+    assert torch.equal(x8.view(torch.uint8), r8.view(torch.uint8)), "quantised activations must be bit-exact"
+    assert torch.equal(s, rs.flatten())
+    w8 = ops.cast_fp8(w.cuda())
+    assert torch.equal(w8.view(torch.uint8), rw8.view(torch.uint8))
+    got = ops.gemm_fp8(x8, s, w8, b.cuda())
+    bad, e = _ulp_stats(got.cpu(), ref.cpu())
+    assert bad < 1e-3 and e < 1e-3, f"vs torch._scaled_mm: >1ulp frac {bad:.2e}, rel-L2 {e:.3e}"
 
 
 @pytest.mark.gpu

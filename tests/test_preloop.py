@@ -122,3 +122,16 @@ def test_call_requires_image_conditioning_when_the_dit_needs_it():
     with pytest.raises(GoalForceError, match="input_image"):
         pipe(context_posi=inp["ctx_posi"], context_nega=inp["ctx_nega"], height=64, width=96, num_frames=9,
              num_inference_steps=1, output_type="latent")
+
+
+def test_frames_to_uint8_matches_reference_bytes():
+    """Post-loop host step (GF:735 -> UTIL:76-91) on CPU tensors: the bf16 arithmetic rounds before the uint8 cast."""
+    from goal_force_amd.pipeline import WanVideoPipeline
+    g = np.load(os.path.join(GOLDEN, "g10_preloop.npz"))
+    pipe = WanVideoPipeline(device="cpu")
+    vid = gi.preloop_decoded_video()
+    assert np.array_equal(pipe.frames_uint8(vid).numpy(), g["frames_u8_bf16"])
+    assert np.array_equal(pipe.frames_uint8(vid.float()).numpy(), g["frames_u8_f32"])
+    assert not np.array_equal(g["frames_u8_bf16"], g["frames_u8_f32"])      # the dtype of the arithmetic matters
+    ims = pipe.vae_output_to_video(vid)
+    assert len(ims) == 2 and ims[0].size == (8, 8) and np.array_equal(np.array(ims[1]), g["frames_u8_bf16"][1])
