@@ -13,7 +13,7 @@ import torch.nn as nn
 
 from . import ops
 from ._lib import GoalForceError
-from .dit import DiTBlock, WanModel
+from .dit import DiTBlock, WanModel, param_key
 
 
 def zero_module(module):
@@ -41,22 +41,18 @@ class ControlNet_PatchEmbedding(nn.Module):
     def __init__(self, in_channels=16, dim=5120, patch_size=(1, 2, 2)):
         super().__init__()
         self.patch_embedding = nn.Conv3d(in_channels, dim, kernel_size=patch_size, stride=patch_size)
-        self._patch_w = None
+        self._patch_w, self._patch_w_key = None, None
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if x.dim() == 4:
             x = x.unsqueeze(0)
         if x.dim() != 5 or x.shape[0] != 1:
             raise GoalForceError("ControlNet_PatchEmbedding takes [1,16,f,H,W]")
-        if self._patch_w is None or self._patch_w.device != x.device:
-            self._patch_w = WanModel.padded_patch_weight(self.patch_embedding)
+        if self._patch_w is None or self._patch_w_key != param_key(self.patch_embedding.weight):
+            self._patch_w = WanModel.padded_patch_weight(self.patch_embedding)      # rebuilt after every weight update
+            self._patch_w_key = param_key(self.patch_embedding.weight)
         cols = ops.patchify_im2col(x[0].contiguous(), None, kpad=self._patch_w.shape[1])
         return ops.gemm(cols, self._patch_w, self.patch_embedding.bias).unsqueeze(0)
-
-    def _load_from_state_dict(self, *args, **kwargs):
-        self._patch_w = None
-        return super()._load_from_state_dict(*args, **kwargs)
-
 
 class ControlNet(nn.Module):
     """GF:97-117 — all trainable ControlNet parameters."""
@@ -70,7 +66,7 @@ class ControlNet(nn.Module):
         self.controlnet_dit = ControlNet_DiT(num_layers, dim, num_heads, ffn_dim, eps)
         self.controlnet_zero_convs_after = nn.ModuleList(
             [zero_module(nn.Conv1d(dim, dim, kernel_size=1, dtype=torch_dtype)) for _ in range(num_layers)])
-        self._is_zero = None
+        self._is_zero, self._is_zero_key = None, None
 
     def zero_conv_weight(self, i):
         w = self.controlnet_zero_convs_after[i].weight
@@ -79,7 +75,9 @@ class ControlNet(nn.Module):
     def all_zero(self) -> bool:
         """True when every zero-conv is exactly zero (the never-trained low-noise ControlNet2, GF:565,
         INF:108-109): its contribution is x + 0 == x bitwise, so model_fn may skip the ControlNet."""
-        if self._is_zero is None:
+        key = param_key(*(t for c in self.controlnet_zero_convs_after for t in (c.weight, c.bias)))
+        if self._is_zero is None or self._is_zero_key != key:        # re-examined after any update of a zero-conv
+            self._is_zero_key = key
             z = True
             for c in self.controlnet_zero_convs_after:
                 if bool(c.weight.detach().ne(0).any()) or bool(c.bias.detach().ne(0).any()):
@@ -88,10 +86,8 @@ class ControlNet(nn.Module):
             self._is_zero = z
         return self._is_zero
 
-    def _load_from_state_dict(self, *args, **kwargs):
+    def invalidate(self):
+        """Drop everything derived from the parameters (not needed after optimiser steps or load_state_dict — the caches
+        compare parameter versions — but harmless, and the explicit hook for code that writes weights behind torch's back)."""
         self._is_zero = None
-        return super()._load_from_state_dict(*args, **kwargs)
-
-    def load_state_dict(self, *args, **kwargs):
-        self._is_zero = None
-        return super().load_state_dict(*args, **kwargs)
+        self.controlnet_patch_embedding._patch_w = None

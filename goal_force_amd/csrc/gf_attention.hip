@@ -940,22 +940,24 @@ static int flash_attn_fwd_impl(const void* q, const void* k, const void* v, void
     GF_CHECK_ARG((kv_len + 64) * k_stride < (1LL << 31) && (kv_len + 64) * v_stride < (1LL << 31),
                  "gf_flash_attn_fwd: kv_len*stride must stay below 2^31 elements");
     if (q_len == 0) return GF_OK;
-    static bool attr_set = false;
-    static bool use_k2 = true;
-    if (!attr_set) {
-        const char* ev = getenv("GF_ATTN_KERNEL");   // tuning switch: 1 = the phase-serial kernel, 2 = the slot-pipelined kernel
-        use_k2 = !(ev && ev[0] == '1');
-        hipError_t e = hipFuncSetAttribute(use_k2 ? reinterpret_cast<const void*>(flash_attn_fwd_kernel2<false>)
+    // tuning switch: GF_ATTN_KERNEL=1 = the phase-serial kernel, otherwise the slot-pipelined kernel 2
+    static const bool use_k2 = [] {
+        const char* ev = getenv("GF_ATTN_KERNEL");
+        return !(ev && ev[0] == '1');
+    }();
+    static GfDeviceOnce once;
+    hipError_t e = gf_once_per_device(once, [] {
+        hipError_t r = hipFuncSetAttribute(use_k2 ? reinterpret_cast<const void*>(flash_attn_fwd_kernel2<false>)
                                                   : reinterpret_cast<const void*>(flash_attn_fwd_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, use_k2 ? AT2_LDS : AT_LDS);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_fwd_kernel2<true>),
+        if (r == hipSuccess)
+            r = hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_fwd_kernel2<true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, AT2_LDS);
-        if (e != hipSuccess) {
-            gf_set_error("gf_flash_attn_fwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-            return GF_ERR_LAUNCH;
-        }
-        attr_set = true;
+        return r;
+    });
+    if (e != hipSuccess) {
+        gf_set_error("gf_flash_attn_fwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+        return GF_ERR_LAUNCH;
     }
     AttnArgs a;
     a.q = (const u16*)q;

@@ -335,24 +335,20 @@ extern "C" GF_API int gf_flash_attn_bwd(const void* q, const void* k, const void
     GF_CHECK_ARG(gf_aligned16(q) && gf_aligned16(k) && gf_aligned16(v) && gf_aligned16(o) && gf_aligned16(dout) &&
                      gf_aligned16(dq) && gf_aligned16(dk) && gf_aligned16(dv),
                  "gf_flash_attn_bwd: 16-byte alignment required");
-    static bool attr_set = false;
     const int lds_bytes = BWD_LDS;
-    if (!attr_set) {
-        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<0>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        if (e2 == hipSuccess)
-            e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<1>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        if (e2 == hipSuccess)
-            e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<2>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        if (e1 != hipSuccess || e2 != hipSuccess) {
-            gf_set_error("gf_flash_attn_bwd: hipFuncSetAttribute failed");
-            return GF_ERR_LAUNCH;
+    static GfDeviceOnce once;
+    hipError_t e = gf_once_per_device(once, [] {
+        const void* fns[4] = {reinterpret_cast<const void*>(attn_bwd_dq_kernel), reinterpret_cast<const void*>(attn_bwd_dkv_kernel<0>),
+                              reinterpret_cast<const void*>(attn_bwd_dkv_kernel<1>), reinterpret_cast<const void*>(attn_bwd_dkv_kernel<2>)};
+        for (const void* fn : fns) {
+            hipError_t r = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
+            if (r != hipSuccess) return r;
         }
-        attr_set = true;
+        return hipSuccess;
+    });
+    if (e != hipSuccess) {
+        gf_set_error("gf_flash_attn_bwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+        return GF_ERR_LAUNCH;
     }
     BwdArgs a;
     a.q = (const u16*)q; a.k = (const u16*)k; a.v = (const u16*)v; a.o = (const u16*)o; a.dout = (const u16*)dout;

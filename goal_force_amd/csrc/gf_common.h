@@ -77,3 +77,27 @@ void gf_set_error(const char* fmt, ...);
         }                                                                            \
     } while (0)
 static inline bool gf_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+// One-time, per-DEVICE, thread-safe launcher setup (hipFuncSetAttribute is a property of the function on the current
+// device: a process that drives a second GPU must set it there too).  `f()` runs at most once per device and returns
+// a hipError_t; a failure is not latched (the next call retries).
+#include <atomic>
+#include <mutex>
+struct GfDeviceOnce {
+    std::atomic<uint64_t> done{0};
+    std::mutex mu;
+};
+template <class F>
+static inline hipError_t gf_once_per_device(GfDeviceOnce& st, F&& f) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    const uint64_t bit = 1ull << dev;
+    if (st.done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    std::lock_guard<std::mutex> lock(st.mu);
+    if (st.done.load(std::memory_order_relaxed) & bit) return hipSuccess;
+    e = f();
+    if (e == hipSuccess) st.done.fetch_or(bit, std::memory_order_release);
+    return e;
+}

@@ -936,15 +936,14 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gemm_sl_kernel(const GemmArgs
 
 template <int EPI, int NW>
 int launch_gemm_sl(const GemmArgs& a, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sl_kernel<EPI, NW>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, SL_LDS);
-        if (e != hipSuccess) {
-            gf_set_error("gf_gemm: hipFuncSetAttribute(%d B LDS) failed: %s", SL_LDS, hipGetErrorString(e));
-            return GF_ERR_LAUNCH;
-        }
-        attr_set = true;
+    static GfDeviceOnce once;
+    hipError_t e = gf_once_per_device(once, [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sl_kernel<EPI, NW>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, SL_LDS);
+    });
+    if (e != hipSuccess) {
+        gf_set_error("gf_gemm: hipFuncSetAttribute(%d B LDS) failed: %s", SL_LDS, hipGetErrorString(e));
+        return GF_ERR_LAUNCH;
     }
     hipLaunchKernelGGL((gemm_sl_kernel<EPI, NW>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(64 * NW), SL_LDS, stream, a);
     GF_CHECK_LAUNCH("gf_gemm_bf16");
@@ -964,21 +963,21 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
         if (use_sl && (long)a.M * a.lda < (1L << 31) && (long)a.N * a.ldw < (1L << 31))
             return use_sl == 8 ? launch_gemm_sl<EPI, 8>(a, stream) : launch_gemm_sl<EPI, 4>(a, stream);
     }
-    static bool attr_set = false;  // per-instantiation; benign race (idempotent call)
-    static bool use_v1 = false;
-    if (!attr_set) {
-        // bf16 ships the phased kernel (+5..11 % at the DiT shapes); fp8 ships the one-barrier-per-K-tile kernel (at 254
-        // VGPRs the phased fp8 variant measured 10-15 % slower).  GF_GEMM_V1=0/1 overrides for A/B tuning.
+    // bf16 ships the phased kernel (+5..11 % at the DiT shapes); fp8 ships the one-barrier-per-K-tile kernel (at 254
+    // VGPRs the phased fp8 variant measured 10-15 % slower).  GF_GEMM_V1=0/1 overrides for A/B tuning.
+    static const bool use_v1 = [] {
         const char* ev = getenv("GF_GEMM_V1");
-        use_v1 = ev ? (ev[0] == '1') : FP8;
+        return ev ? (ev[0] == '1') : FP8;
+    }();
+    static GfDeviceOnce once;   // per instantiation
+    hipError_t e = gf_once_per_device(once, [] {
         const void* fn = use_v1 ? reinterpret_cast<const void*>(gemm_kernel<EPI, FP8>)
                                 : reinterpret_cast<const void*>(gemm_ph_kernel<EPI, FP8>);
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-        if (e != hipSuccess) {
-            gf_set_error("gf_gemm: hipFuncSetAttribute(%d B LDS) failed: %s", GEMM_LDS, hipGetErrorString(e));
-            return GF_ERR_LAUNCH;
-        }
-        attr_set = true;
+        return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+    });
+    if (e != hipSuccess) {
+        gf_set_error("gf_gemm: hipFuncSetAttribute(%d B LDS) failed: %s", GEMM_LDS, hipGetErrorString(e));
+        return GF_ERR_LAUNCH;
     }
     if (use_v1)
         hipLaunchKernelGGL((gemm_kernel<EPI, FP8>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(GEMM_THREADS), GEMM_LDS,
@@ -992,15 +991,14 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
 
 template <int EPI, int NB, int CONV>
 int launch_conv(const GemmArgs& a, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ph_kernel<EPI, false, CONV, NB>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-        if (e != hipSuccess) {
-            gf_set_error("gf_conv3d: hipFuncSetAttribute(%d B LDS) failed: %s", GEMM_LDS, hipGetErrorString(e));
-            return GF_ERR_LAUNCH;
-        }
-        attr_set = true;
+    static GfDeviceOnce once;
+    hipError_t e = gf_once_per_device(once, [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ph_kernel<EPI, false, CONV, NB>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+    });
+    if (e != hipSuccess) {
+        gf_set_error("gf_conv3d: hipFuncSetAttribute(%d B LDS) failed: %s", GEMM_LDS, hipGetErrorString(e));
+        return GF_ERR_LAUNCH;
     }
     hipLaunchKernelGGL((gemm_ph_kernel<EPI, false, CONV, NB>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(GEMM_THREADS),
                        GEMM_LDS, stream, a);
@@ -1008,19 +1006,23 @@ int launch_conv(const GemmArgs& a, hipStream_t stream) {
     return GF_OK;
 }
 
-// 256 zero bytes per device: where the convolution's padding taps and K-padding columns are fetched from
+// 256 zero bytes per device: where the convolution's padding taps and K-padding columns are fetched from.  A __device__
+// array of the code object (zero-initialised when the module is loaded on a device): looking up its address neither
+// allocates nor synchronises, so gf_conv3d_bf16 keeps the header's contract and works under stream capture.
+__device__ const u16 gf_conv_zero_page[128] = {};
+
 const u16* conv_zero_page() {
+    static GfDeviceOnce once;
     static const u16* page[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    if (!page[dev]) {
+    hipError_t e = gf_once_per_device(once, [dev] {
         void* z = nullptr;
-        if (hipMalloc(&z, 256) != hipSuccess) return nullptr;
-        if (hipMemset(z, 0, 256) != hipSuccess) return nullptr;
-        if (hipStreamSynchronize(nullptr) != hipSuccess) return nullptr;   // once: the first launch may be on a non-blocking stream
-        page[dev] = (const u16*)z;
-    }
-    return page[dev];
+        hipError_t r = hipGetSymbolAddress(&z, HIP_SYMBOL(gf_conv_zero_page));
+        if (r == hipSuccess) page[dev] = (const u16*)z;
+        return r;
+    });
+    return e == hipSuccess ? page[dev] : nullptr;
 }
 
 }  // namespace

@@ -73,6 +73,13 @@ def sinusoidal_embedding_1d(dim, position):
     return x.to(position.dtype).to(position.device)
 
 
+def param_key(*tensors):
+    """Identity + modification state of parameters a derived copy was built from: (storage address, autograd version) per
+    tensor.  Optimiser steps (ops.adamw_step bumps the version), load_state_dict, .to() and in-place edits all change it,
+    so a cache that compares keys can never serve weights captured before an update."""
+    return tuple((t.data_ptr(), t._version) for t in tensors)
+
+
 class QuantizedInput:
     """Row-quantised activation (e4m3 bytes + per-row scale) shared by the GEMMs that read the same input."""
 
@@ -87,6 +94,9 @@ def linear(x2, lin: nn.Linear, epilogue=ops.EPI_BIAS, resid=None, gate=None, out
     w8 = getattr(lin, "_gf_w8", None)
     if w8 is None:
         return ops.gemm(x2, lin.weight, lin.bias, epilogue=epilogue, resid=resid, gate=gate, out=out)
+    if lin._gf_w8_key != param_key(lin.weight):          # the bf16 master changed since the cast: refresh the copy
+        w8 = lin._gf_w8 = ops.cast_fp8(lin.weight.detach().contiguous())
+        lin._gf_w8_key = param_key(lin.weight)
     q = x2 if isinstance(x2, QuantizedInput) else QuantizedInput(x2)
     return ops.gemm_fp8(q.x8, q.scale, w8, lin.bias, epilogue=epilogue, resid=resid, gate=gate, out=out)
 
@@ -100,6 +110,7 @@ def enable_fp8(module: nn.Module, enabled=True):
             for lin in blk.modules():
                 if isinstance(lin, nn.Linear):
                     lin._gf_w8 = ops.cast_fp8(lin.weight.detach().contiguous()) if enabled else None
+                    lin._gf_w8_key = param_key(lin.weight) if enabled else None
     return module
 
 
@@ -286,7 +297,7 @@ class WanModel(nn.Module):
         self.freqs = precompute_freqs_cis_3d(dim // num_heads)  # plain CPU tuple, like DIT:328
         self.control_adapter = None
         self._rope_cache = {}
-        self._patch_w = None  # K-padded [dim, kpad] copy of patch_embedding.weight for the GEMM
+        self._patch_w, self._patch_w_key = None, None  # K-padded [dim, kpad] copy of patch_embedding.weight for the GEMM
 
     # ---- pieces used by model_fn ---------------------------------------------------------------
     def rope_table(self, f, h, w, device) -> RopeTable:
@@ -334,8 +345,9 @@ class WanModel(nn.Module):
             raise NotImplementedError("camera control adapter is outside the Goal-Force path")
         if x.shape[0] != 1:
             raise GoalForceError("patchify takes batch 1")
-        if self._patch_w is None or self._patch_w.device != x.device:
+        if self._patch_w is None or self._patch_w_key != param_key(self.patch_embedding.weight):
             self._patch_w = self.padded_patch_weight(self.patch_embedding)
+            self._patch_w_key = param_key(self.patch_embedding.weight)
         s0 = x[0].contiguous()
         s1 = None if extra is None else extra[0].contiguous()
         f, hh, ww = s0.shape[1], s0.shape[2] // 2, s0.shape[3] // 2

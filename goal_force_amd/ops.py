@@ -653,6 +653,9 @@ def adamw_step(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), e
                                          _ptr(_f32(exp_avg_sq, "exp_avg_sq")), param.numel(), float(lr), float(betas[0]),
                                          float(betas[1]), float(eps), float(weight_decay), int(step), float(grad_scale),
                                          _stream(param)), "gf_adamw_step")
+    # the kernel wrote through the raw pointer: tell torch, so that everything derived from the old values (K-padded
+    # patch weights, fp8 copies, the all-zero flag of a ControlNet — dit.param_key) is rebuilt on its next use
+    torch.autograd.graph.increment_version(param)
 
 
 def f32_to_bf16(acc):

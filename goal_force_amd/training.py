@@ -216,6 +216,9 @@ class DiTBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, block, rope, x2, ctx2, t_mod, *params):
         ctx.block, ctx.rope = block, rope
+        if any(getattr(m, "_gf_w8", None) is not None for m in block.modules()):
+            # the backward recomputes the block on the bf16 kernels: an fp8 forward would not be the function differentiated
+            raise GoalForceError("training through an enable_fp8 block is refused: call enable_fp8(module, False) first")
         ctx.param_needs = [p.requires_grad for p in params]
         keep = {} if KEEP_ATTENTION else None
         with torch.no_grad():
@@ -422,7 +425,7 @@ class AdamW:
             if st is None:
                 st = self.state[p] = (torch.zeros(p.shape, dtype=torch.float32, device=p.device),
                                       torch.zeros(p.shape, dtype=torch.float32, device=p.device))
-            ops.adamw_step(p.data, p.grad.contiguous(), st[0], st[1], self.step_count, self.lr, self.betas, self.eps,
+            ops.adamw_step(p.detach(), p.grad.contiguous(), st[0], st[1], self.step_count, self.lr, self.betas, self.eps,
                            self.weight_decay, grad_scale=scale)
 
 
