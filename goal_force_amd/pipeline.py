@@ -21,38 +21,11 @@ import torch
 
 from . import ops
 from ._lib import GoalForceError
+from .checkpoints import ModelConfig, load_model, load_state_dict  # noqa: F401  (re-exported under the reference's names)
 from .controlnet import ControlNet
 from .dit import A14B_CONFIG, WanModel
 from .model_fn import ContextCache, model_fn_wan_video
 from .scheduler import FlowMatchScheduler
-
-
-class ModelConfig:
-    """Host-side record of where a checkpoint lives (diffsynth/utils ModelConfig, UTIL:137-...).
-    Downloading is out of scope (no network): `path` must point at local .safetensors file(s)."""
-
-    def __init__(self, path=None, model_id=None, origin_file_pattern=None, offload_device=None, offload_dtype=None,
-                 **kwargs):
-        self.path, self.model_id, self.origin_file_pattern = path, model_id, origin_file_pattern
-        self.offload_device, self.offload_dtype = offload_device, offload_dtype
-
-
-def load_state_dict(path, torch_dtype=None, device="cpu"):
-    """safetensors / torch checkpoint reader (diffsynth/models/utils.py load_state_dict)."""
-    paths = path if isinstance(path, (list, tuple)) else [path]
-    sd = {}
-    for p in paths:
-        if str(p).endswith(".safetensors"):
-            from safetensors import safe_open
-            with safe_open(p, framework="pt", device=str(device)) as f:
-                for k in f.keys():
-                    t = f.get_tensor(k)
-                    sd[k] = t.to(torch_dtype) if torch_dtype is not None else t
-        else:
-            part = torch.load(p, map_location=device, weights_only=True)
-            for k, t in part.items():
-                sd[k] = t.to(torch_dtype) if (torch_dtype is not None and torch.is_tensor(t)) else t
-    return sd
 
 
 class WanVideoPipeline:
@@ -85,28 +58,32 @@ class WanVideoPipeline:
 
     # ------------------------------------------------------------------ construction
     @staticmethod
-    def from_pretrained(torch_dtype=torch.bfloat16, device="cuda", model_configs=(), tokenizer_config=None,
-                        audio_processor_config=None, redirect_common_files=True, use_usp=False, controlnet=False,
-                        controlnet_num_layers=0, controlnet_stride=None, apply_strided_controlnet=False):
-        """GF:483-595.  Loads local Wan2.2-I2V-A14B expert checkpoints (high-noise first, then low-noise);
-        ControlNet blocks are initialised as copies of DiT blocks 0..N-1 of the matching expert and
-        controlnet2 is a copy made before any ControlNet weights are loaded (GF:559-568)."""
+    def from_pretrained(torch_dtype=torch.bfloat16, device="cuda", model_configs=(),
+                        tokenizer_config=None, audio_processor_config=None, redirect_common_files=True, use_usp=False,
+                        controlnet=False, controlnet_num_layers=0, controlnet_stride=None, apply_strided_controlnet=False):
+        """GF:483-595 for local files (no network): every ModelConfig is loaded and recognised by its keys
+        (checkpoints.load_model) — Wan DiT experts in the order given (high-noise first, then low-noise: GF:529-533), the umT5
+        text encoder, the Wan VAE; `tokenizer_config.path` is handed to the prompter (GF:584-586); ControlNet blocks
+        are initialised as copies of DiT blocks 0..N-1 of the matching expert, controlnet2 is a copy made before any
+        ControlNet weights are loaded (GF:559-568).  The reference's call INF:81-106 runs as written.
+        `redirect_common_files` only renames download sources in the reference (GF:498-510): nothing to do for local paths."""
         if apply_strided_controlnet:
             raise NotImplementedError("strided ControlNet is not part of the Goal-Force sampling path")
+        if audio_processor_config is not None:
+            raise NotImplementedError("audio processor (S2V) is a pipeline branch Goal Force never takes")
         pipe = WanVideoPipeline(device=device, torch_dtype=torch_dtype, controlnet=controlnet,
                                 controlnet_num_layers=controlnet_num_layers, controlnet_stride=controlnet_stride)
         dits = []
         for mc in model_configs:
-            if mc.path is None:
-                raise GoalForceError("ModelConfig.path must name local checkpoint files (no network here)")
-            sd = load_state_dict(mc.path, torch_dtype=torch_dtype)
-            if "blocks.0.self_attn.q.weight" in sd and "patch_embedding.weight" in sd:
-                m = WanModel(**A14B_CONFIG)
-                m.load_state_dict(sd, strict=True)
-                dits.append(m.to(dtype=torch_dtype, device=device))
-            else:
-                raise NotImplementedError(f"checkpoint {mc.path}: only Wan DiT experts are loaded here; text encoder "
-                                          "and VAE-encoder weights belong to the 'next' rows (SURVEY §8f)")
+            kind, module = load_model(mc, torch_dtype=mc.offload_dtype or torch_dtype, device=device)
+            if kind == "wan_video_dit":
+                dits.append(module)
+            elif kind == "wan_video_text_encoder":
+                pipe.text_encoder = module
+            elif kind == "wan_video_vae":
+                pipe.vae = module
+        if len(dits) > 2:
+            raise GoalForceError(f"{len(dits)} DiT checkpoints given: the pipeline holds a high-noise and a low-noise expert")
         # GF:516/594 `use_usp`: head-parallel attention over the whole process group (sequence_parallel.py); the
         # pipeline's __call__ / denoise then pass use_unified_sequence_parallel to model_fn (GF:1107-1109)
         pipe.use_unified_sequence_parallel = bool(use_usp)
@@ -114,7 +91,13 @@ class WanVideoPipeline:
             pipe.dit = dits[0]
             pipe.dit2 = dits[1] if len(dits) > 1 else None
         if controlnet:
+            if pipe.dit is None:
+                raise GoalForceError("controlnet=True needs a DiT expert among model_configs (its blocks seed the ControlNet)")
             pipe.init_controlnets()
+        pipe._after_models_attached()
+        if tokenizer_config is not None:
+            tokenizer_config.download_if_necessary(use_usp=use_usp)
+            pipe.prompter.fetch_tokenizer(tokenizer_config.path)                     # GF:586
         return pipe
 
     @staticmethod

@@ -42,12 +42,18 @@ def main():
     from goal_force_amd.dit import A14B_CONFIG
     from goal_force_amd.distributed import split_list_across_devices_contiguous
     from goal_force_amd.force_map import ControlSignalDataset_Balls
-    from goal_force_amd.pipeline import (ModelConfig, WanVideoPipeline, build_random_controlnet, build_random_expert,
-                                         load_state_dict)
+    from goal_force_amd.pipeline import ModelConfig, WanVideoPipeline, build_random_controlnet, build_random_expert
     from goal_force_amd.vae import WanVideoVAE
 
     torch.set_grad_enabled(False)
-    dev = torch.device("cuda", 0)
+    # INF:62-67: with HIP_/CUDA_VISIBLE_DEVICES set the isolated GPU appears as cuda:0, otherwise this process takes
+    # cuda:{device_id}.  The C-ABI launches go to the CURRENT HIP device, so it is selected before anything is built.
+    isolated = any(v in os.environ for v in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"))
+    dev = torch.device("cuda", 0 if isolated else a.device_id)
+    if dev.index >= torch.cuda.device_count():
+        raise SystemExit(f"--device_id {a.device_id}: only {torch.cuda.device_count()} GPU(s) visible")
+    torch.cuda.set_device(dev)
+    print(f"[Device {a.device_id}] world size {a.world_size}, device {dev}, seed {a.seed}")
     if a.synthetic:
         cfg = dict(A14B_CONFIG, num_layers=a.layers)
         n_cn = min(CONTROLNET_NUM_LAYERS, a.layers)
@@ -56,18 +62,14 @@ def main():
                                              build_random_controlnet(n_cn, cfg, 400, dev, zero_convs_zero=True),
                                              vae=WanVideoVAE().to(torch.bfloat16).to(dev), device=dev)
     else:
-        pipe = WanVideoPipeline.from_pretrained(torch_dtype=torch.bfloat16, device=dev,
-                                                model_configs=[ModelConfig(path=a.dit_high), ModelConfig(path=a.dit_low)],
-                                                controlnet=True, controlnet_num_layers=CONTROLNET_NUM_LAYERS)
+        # the reference's call (INF:81-106): both experts as shard lists, the umT5 encoder and the VAE .pth, the tokenizer
+        pipe = WanVideoPipeline.from_pretrained(
+            torch_dtype=torch.bfloat16, device=dev,
+            tokenizer_config=ModelConfig(model_id="Wan-AI/Wan2.1-T2V-1.3B", origin_file_pattern="google/*", path=a.tokenizer),
+            model_configs=[ModelConfig(path=a.dit_high), ModelConfig(path=a.dit_low), ModelConfig(path=a.text_encoder),
+                           ModelConfig(path=a.vae)],
+            controlnet=True, controlnet_num_layers=CONTROLNET_NUM_LAYERS)
         pipe.load_controlnet_weights(pipe.controlnet, a.controlnet_checkpoint, torch_dtype=torch.bfloat16)   # INF:108
-        pipe.vae = WanVideoVAE()
-        pipe.vae.load_state_dict(load_state_dict(a.vae), strict=True)
-        pipe.vae = pipe.vae.to(torch.bfloat16).to(dev)
-        from goal_force_amd.text_encoder import WanTextEncoder
-        pipe.text_encoder = WanTextEncoder()
-        pipe.text_encoder.load_state_dict(load_state_dict(a.text_encoder, torch_dtype=torch.bfloat16), strict=True)
-        pipe.text_encoder = pipe.text_encoder.to(torch.bfloat16).to(dev)
-        pipe.prompter.fetch_tokenizer(a.tokenizer)
     pipe.enable_vram_management()   # INF:111 (accepted no-op: everything is resident)
 
     os.makedirs(a.output_dir, exist_ok=True)

@@ -328,3 +328,66 @@ def test_training_steps_reduce_the_loss():
     assert abs(opt.grad_norm() - want) < 1e-4 * want
     sd = tr.controlnet_state_dict(cn)
     assert all(k.startswith("pipe.controlnet.") for k in sd) and len(sd) == len(cn.state_dict())
+
+
+def test_derived_weight_caches_follow_optimizer_steps():
+    """train -> validate -> train -> validate in one process: the K-padded patch-embedding copy, the
+    all-zero flag of the ControlNet and fp8 weight copies must be rebuilt after AdamW steps, so model_fn on the trained
+    module equals model_fn on a freshly constructed module holding the same weights, bit for bit."""
+    import gen_inputs as gi
+    from goal_force_amd import training as tr
+    from goal_force_amd._lib import GoalForceError
+    from goal_force_amd.controlnet import ControlNet
+    from goal_force_amd.dit import enable_fp8
+    from goal_force_amd.model_fn import model_fn_wan_video
+    cfg = gi.TINY
+    dit, cn = _tiny_train_models()
+    with torch.no_grad():
+        for c in cn.controlnet_zero_convs_after:          # a never-trained ControlNet: zero-convs exactly zero
+            c.weight.zero_()
+            c.bias.zero_()
+    pipe = _tiny_train_pipe(dit, cn)
+    inp = {k: v.cuda() for k, v in gi.train_inputs().items()}
+    ts = torch.tensor([500.0], dtype=BF).cuda()
+
+    def validate(module):
+        with torch.no_grad():
+            return model_fn_wan_video(dit, latents=inp["noise"], timestep=ts, context=inp["context"], y=inp["y"],
+                                      controlnet=module, control_signal_video_latents=inp["control"])
+
+    before = validate(cn)                                 # fills the caches with the pre-training weights
+    assert cn.all_zero()
+    opt = tr.AdamW(cn.parameters(), lr=1e-3, weight_decay=0.0)
+    for _ in range(2):
+        opt.zero_grad()
+        with torch.enable_grad():
+            loss = tr.training_loss(pipe, input_latents=inp["input_latents"], noise=inp["noise"], context=inp["context"],
+                                    y=inp["y"], control_signal_video_latents=inp["control"], timestep_id=gi.TRAIN_TIMESTEP_ID)
+            loss.backward()
+        opt.step()
+    assert not cn.all_zero(), "the zero-convs were trained: the ControlNet may no longer be skipped"
+    after = validate(cn)
+    fresh = ControlNet(cn.num_layers, dim=cfg["dim"], num_heads=cfg["num_heads"], ffn_dim=cfg["ffn_dim"])
+    fresh.load_state_dict({k: v.detach().cpu() for k, v in cn.state_dict().items()}, strict=True)
+    fresh = fresh.to(BF).cuda()
+    assert torch.equal(after, validate(fresh)) and not torch.equal(after, before)
+    # fp8 copies: refreshed after an update as well, and training through an fp8 block is refused
+    enable_fp8(cn)
+    a8 = validate(cn)
+    opt.zero_grad()
+    with pytest.raises(GoalForceError, match="enable_fp8"):
+        with torch.enable_grad():
+            tr.training_loss(pipe, input_latents=inp["input_latents"], noise=inp["noise"], context=inp["context"],
+                             y=inp["y"], control_signal_video_latents=inp["control"], timestep_id=gi.TRAIN_TIMESTEP_ID)
+    with torch.no_grad():
+        for p_ in cn.controlnet_dit.parameters():
+            if p_.dim() == 2:
+                p_.mul_(0.5)                               # an in-place update torch sees (version bump)
+    b8 = validate(cn)
+    enable_fp8(fresh)
+    with torch.no_grad():
+        for p_ in fresh.controlnet_dit.parameters():
+            if p_.dim() == 2:
+                p_.mul_(0.5)
+    enable_fp8(fresh)                                      # fresh copies cast from the updated masters
+    assert torch.equal(b8, validate(fresh)) and not torch.equal(a8, b8)
