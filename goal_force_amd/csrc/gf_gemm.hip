@@ -81,6 +81,8 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     unsigned long long* dbg;
     ConvGeom cv;
+    int whatif;   // -DGF_A4_WHATIF diagnostic builds only (tools/gemm_a4_whatif.py)
+    int stagger;  // gemm_a4_kernel: rotate the K loop per column tile (GF_A4_STAGGER=0 turns it off for A/B runs)
 };
 
 __device__ __forceinline__ void glds16(const void* g, GF_LDS char* l) {
@@ -684,6 +686,188 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs
 }
 
 // ================================================================================================================
+// gemm_a4_kernel — the bf16 GEMM of the large DiT shapes (M >= 512): ONE wave per SIMD.
+//   * 256 threads = 4 waves (wm, wn) in 2 x 2 on a 256 x 256 x 64 tile, 128 x 128 of C per wave = 8 x 8 tiles of
+//     v_mfma_f32_16x16x32_bf16; the 256 fp32 accumulators live in AGPRs a[0:255], 128 fragment registers in v[128:255].
+//     Per K tile a wave issues 128 MFMAs, 32 ds_read_b128 and 16 LDS-DMA pieces (the 8-wave phased kernel: 2 x 64 MFMAs,
+//     2 x 24 reads, 2 x 8 pieces per SIMD) and crosses 3 barriers instead of 8.
+//   * staging by `buffer_load_dwordx4 ... offen lds`: descriptor + SGPR row-group offset + one per-lane voffset that
+//     advances by 128 B per K tile — no vector address arithmetic and no M0 save/restore per piece (the phased kernel
+//     spends ~100 issue cycles per piece on global_load_lds with 64-bit per-lane addresses, profiles/r01/gemm_stamps.txt);
+//     rows past M / N and tiles past K are cut off by the descriptor's num_records (reads return 0): no clamping.
+//   * the K loop is ONE asm statement with hand-allocated registers and a fixed slot for every read, piece, counted wait
+//     and barrier (tools/gen_gemm_a4.py -> gf_gemm_a4_loop.inc; hipcc spills at this pressure and re-orders the slots).
+//     Register double buffering by k-sub-step: while the 64 MFMAs of sub-step 0 run, the fragments of sub-step 1 are
+//     read; while those run, the sub-step-0 fragments of the NEXT tile (other LDS stage) are read; tile t+2 streams into
+//     the stage tile t has just been read out of.
+//   * same XOR-swizzled 128-byte-row LDS image, swapped operands and fused epilogues (bias / GELU-tanh / SiLU /
+//     gate*+residual / +residual / *multiply, the reference's bf16 rounding sequence) as the other kernels; the epilogue
+//     transposes each wave's 128 x 128 through a private 32 KiB LDS image and stores whole 256-byte row segments.
+#include "gf_gemm_a4_loop.inc"
+constexpr int A4_THREADS = 256;
+
+template <int I>
+__device__ __forceinline__ float a4_acc() {
+    float x;
+    asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(x) : "n"(I));
+    return x;
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void a4_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        a4_static_for<I + 1, N>(f);
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(A4_THREADS, 1) void gemm_a4_kernel(const GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    GF_LDS char* lds = (GF_LDS char*)smem;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    int v;
+    {
+        const int pid = blockIdx.x;
+        const int xcd = pid & 7, local = pid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    }
+    const int per_group = GROUP_M * p.tiles_n;
+    const int group = v / per_group;
+    const int first_m = group * GROUP_M;
+    const int gsz = min(p.tiles_m - first_m, GROUP_M);
+    const int in_group = v - group * per_group;
+    const int m0 = (first_m + in_group % gsz) * BM, n0 = (in_group / gsz) * BN;
+
+    // ---- staging: wave w fills rows [64w, 64w+64) of both operand tiles, 8 pieces of 8 rows x 128 B each; lane l of a piece
+    // fills LDS chunk (l & 7) of row (l >> 3) and must fetch logical chunk (l & 7) ^ (row & 7) of that row
+    const int srow = lane >> 3;
+    unsigned voffA = (unsigned)srow * (unsigned)p.lda * 2u + (unsigned)(((lane & 7) ^ srow) << 4);
+    unsigned voffB = (unsigned)srow * (unsigned)p.ldw * 2u + (unsigned)(((lane & 7) ^ srow) << 4);
+#ifdef GF_A4_WHATIF
+    if (p.whatif == 16) {   // timing only: un-permuted source chunks (what a padded, un-swizzled LDS image would fetch)
+        voffA = (unsigned)srow * (unsigned)p.lda * 2u + (unsigned)((lane & 7) << 4);
+        voffB = (unsigned)srow * (unsigned)p.ldw * 2u + (unsigned)((lane & 7) << 4);
+    }
+#endif
+    // L2 warm-up loads (one line per lane): lane l = row l of this wave's 64 staging rows
+    unsigned pfA = (unsigned)lane * (unsigned)p.lda * 2u, pfB = (unsigned)lane * (unsigned)p.ldw * 2u;
+    const unsigned long baseA = (unsigned long)(p.A + (long)m0 * p.lda), baseB = (unsigned long)(p.W + (long)n0 * p.ldw);
+    const unsigned aLo = (unsigned)baseA, aHi = (unsigned)(baseA >> 32) & 0xffffu;
+    const unsigned bLo = (unsigned)baseB, bHi = (unsigned)(baseB >> 32) & 0xffffu;
+    const unsigned nrA = (unsigned)(((long)(min(p.M - m0, BM) - 1) * p.lda + p.K) * 2);   // valid bytes from the tile's first row
+    const unsigned nrB = (unsigned)(((long)(min(p.N - n0, BN) - 1) * p.ldw + p.K) * 2);
+    const unsigned stA = 8u * (unsigned)p.lda * 2u, stB = 8u * (unsigned)p.ldw * 2u;
+    const unsigned soA = (unsigned)wave * 8u * stA, soB = (unsigned)wave * 8u * stB;
+    const unsigned ldsW = (unsigned)(unsigned long)lds + (unsigned)wave * 8192u;
+    const unsigned nk = (unsigned)(p.K / BK);
+    // Staggered K start: the workgroups of column tile j begin their K loop at K tile (2 j) mod nk and wrap around, so
+    // that the ~32 column tiles in flight at any time fetch from different 256-byte blocks of their rows.  All rows of the
+    // operands have the same pitch, so without this every workgroup of the chip walks the SAME few memory channels at the
+    // same time (pitch 10 KiB: 16 of 128 channel slots).  The sum over k is only rotated; it depends on the column tile
+    // alone, so an output element's bits do not depend on how the rows are cut into tiles or sharded over GPUs.
+    const unsigned k0 = p.stagger ? (unsigned)((2 * (n0 / BN)) % (int)nk) : 0u;
+    const unsigned kb = (unsigned)p.K * 2u;
+
+    // ---- fragment read addresses: (row, chunk) at row * 128 + ((chunk ^ (row & 7)) << 4); sub-step ks reads chunk 4 ks + fq
+    const int frow = lane & 15, fq = lane >> 4, sw = frow & 7;
+    const unsigned lbase = (unsigned)(unsigned long)lds;
+    unsigned rdA0 = lbase + (unsigned)((wm * 128 + frow) * 128 + (((0 + fq) ^ sw) << 4));
+    unsigned rdA1 = lbase + (unsigned)((wm * 128 + frow) * 128 + (((4 + fq) ^ sw) << 4));
+    unsigned rdB0 = lbase + (unsigned)(TILE_BYTES + (wn * 128 + frow) * 128 + (((0 + fq) ^ sw) << 4));
+    unsigned rdB1 = lbase + (unsigned)(TILE_BYTES + (wn * 128 + frow) * 128 + (((4 + fq) ^ sw) << 4));
+
+#ifdef GF_A4_WHATIF   // timing-only variants of the loop (wrong results), selected per launch
+    if (p.whatif == 1) GF_A4_LOOP_ASM_W1(voffA, voffB, pfA, pfB, rdA0, rdA1, rdB0, rdB1, aLo, aHi, nrA, bLo, bHi, nrB, soA, stA, soB, stB, ldsW, nk, k0, kb);
+    else if (p.whatif == 2) GF_A4_LOOP_ASM_W2(voffA, voffB, pfA, pfB, rdA0, rdA1, rdB0, rdB1, aLo, aHi, nrA, bLo, bHi, nrB, soA, stA, soB, stB, ldsW, nk, k0, kb);
+    else if (p.whatif == 4) GF_A4_LOOP_ASM_W4(voffA, voffB, pfA, pfB, rdA0, rdA1, rdB0, rdB1, aLo, aHi, nrA, bLo, bHi, nrB, soA, stA, soB, stB, ldsW, nk, k0, kb);
+    else if (p.whatif == 5) GF_A4_LOOP_ASM_W5(voffA, voffB, pfA, pfB, rdA0, rdA1, rdB0, rdB1, aLo, aHi, nrA, bLo, bHi, nrB, soA, stA, soB, stB, ldsW, nk, k0, kb);
+    else
+#endif
+    GF_A4_LOOP_ASM(voffA, voffB, pfA, pfB, rdA0, rdA1, rdB0, rdB1, aLo, aHi, nrA, bLo, bHi, nrB, soA, stA, soB, stB, ldsW, nk, k0, kb);
+
+    // ---- epilogue: a[(i*8+j)*4 + r] = C[m0 + wm*128 + 16 i + frow][n0 + wn*128 + 16 j + 4 fq + r]  (the asm ended on a barrier:
+    // every wave is past its LDS reads and every LDS-DMA has landed)
+    GF_LDS char* ep = lds + wave * 32768;   // private 128 rows x 256 B; 8-byte slot s of row r at slot s ^ ((r & 15) << 1)
+    a4_static_for<0, 8>([&](auto j_c) {
+        constexpr int j = decltype(j_c)::value;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        const int n = n0 + wn * 128 + j * 16 + fq * 4;
+        if (p.bias && n < p.N) {   // N % 8 == 0: n .. n+3 are all valid
+            const u16x4 b4 = *reinterpret_cast<const u16x4*>(p.bias + n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bv[r] = bf2f(b4[r]);
+        }
+        a4_static_for<0, 8>([&](auto i_c) {
+            constexpr int i = decltype(i_c)::value;
+            constexpr int A0 = (i * 8 + j) * 4;
+            float y[4] = {a4_acc<A0>(), a4_acc<A0 + 1>(), a4_acc<A0 + 2>(), a4_acc<A0 + 3>()};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                y[r] = rbf(y[r] + bv[r]);  // the Linear's own bf16 output
+                if (EPI == GF_EPI_BIAS_GELU_TANH) y[r] = gelu_tanh_f(y[r]);
+                if (EPI == GF_EPI_BIAS_SILU) y[r] = y[r] / (1.0f + expf(-y[r]));
+            }
+            u32x2 pk;
+            pk[0] = pack2bf(y[0], y[1]);
+            pk[1] = pack2bf(y[2], y[3]);
+            const int row = i * 16 + frow;
+            const int slot = (j * 4 + fq) ^ ((row & 15) << 1);
+            *(GF_LDS u32x2*)(ep + row * 256 + slot * 8) = pk;
+        });
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private image: LDS is in order, no barrier needed
+    {
+        const int cc = lane & 15;                 // 16-byte chunk of the 256-byte row segment
+        const int n = n0 + wn * 128 + cc * 8;
+        const bool n_ok = n < p.N;
+        u16x8 g8;
+        if (EPI == GF_EPI_BIAS_GATE_RESID && n_ok) g8 = *reinterpret_cast<const u16x8*>(p.gate + n);
+#pragma unroll 4
+        for (int it = 0; it < 32; ++it) {
+            const int row = it * 4 + (lane >> 4);
+            const int m = m0 + wm * 128 + row;
+            const u16x8 yv = *(GF_LDS u16x8*)(ep + row * 256 + ((cc ^ (row & 15)) << 4));
+            if (m < p.M && n_ok) {
+                u16x8 o = yv;
+                if (EPI == GF_EPI_BIAS_GATE_RESID || EPI == GF_EPI_BIAS_RESID || EPI == GF_EPI_BIAS_MUL) {
+                    const u16x8 r8 = *reinterpret_cast<const u16x8*>(p.R + (long)m * p.ldr + n);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float t = bf2f(yv[e]);
+                        if (EPI == GF_EPI_BIAS_GATE_RESID) t = rbf(bf2f(g8[e]) * t);  // gate * residual
+                        o[e] = (EPI == GF_EPI_BIAS_MUL) ? f2bf(t * bf2f(r8[e]))       // fc1(x) * gelu(gate(x))
+                                                        : f2bf(bf2f(r8[e]) + t);      // x + ...
+                    }
+                }
+                *reinterpret_cast<u16x8*>(p.C + (long)m * p.ldc + n) = o;
+            }
+        }
+    }
+}
+
+template <int EPI>
+int launch_gemm_a4(const GemmArgs& a, hipStream_t stream) {
+    static GfDeviceOnce once;
+    hipError_t e = gf_once_per_device(once, [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_a4_kernel<EPI>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+    });
+    if (e != hipSuccess) {
+        gf_set_error("gf_gemm: hipFuncSetAttribute(%d B LDS) failed: %s", GEMM_LDS, hipGetErrorString(e));
+        return GF_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL((gemm_a4_kernel<EPI>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(A4_THREADS), GEMM_LDS, stream, a);
+    GF_CHECK_LAUNCH("gf_gemm_bf16");
+    return GF_OK;
+}
+
+// ================================================================================================================
 // EXPERIMENTAL, NOT THE SHIPPED PATH (GF_GEMM_KERNEL=sl / sl8 select it; parity-tested): measured 1.07 / 1.22 / 1.20 PFLOP/s
 // (sl8, the two-waves-per-SIMD form: 1.07 / 1.18 / 1.17) against the phased kernel's 1.18 / 1.34 / 1.35.  What-if builds: without its DMA instructions the same loop runs at
 // 1.85 PFLOP/s, without its barrier and waits still at 1.22 — with ONE wave per SIMD the LDS-DMA issue back-pressure
@@ -962,6 +1146,13 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
         }
         if (use_sl && (long)a.M * a.lda < (1L << 31) && (long)a.N * a.ldw < (1L << 31))
             return use_sl == 8 ? launch_gemm_sl<EPI, 8>(a, stream) : launch_gemm_sl<EPI, 4>(a, stream);
+        // the 4-wave kernel for the large shapes (every Linear of a DiT block at S >= 512): GF_GEMM_KERNEL=ph selects the
+        // 8-wave phased kernel instead (A/B runs).  Its 32-bit staging offsets cover 256 rows of either operand.
+        const char* ek4 = getenv("GF_GEMM_KERNEL");   // read per call: A/B runs toggle it inside one process
+        const bool use_a4 = !(ek4 && ek4[0] == 'p');
+        if (use_a4 && a.M >= 512 && a.K % 64 == 0 && 256L * a.lda * 2 + a.K * 2L < (1L << 31) &&
+            256L * a.ldw * 2 + a.K * 2L < (1L << 31))
+            return launch_gemm_a4<EPI>(a, stream);
     }
     // bf16 ships the phased kernel (+5..11 % at the DiT shapes); fp8 ships the one-barrier-per-K-tile kernel (at 254
     // VGPRs the phased fp8 variant measured 10-15 % slower).  GF_GEMM_V1=0/1 overrides for A/B tuning.
@@ -1070,6 +1261,14 @@ static int gemm_dispatch(bool fp8, const void* A, int64_t lda, const void* W, in
 #else
     a.dbg = nullptr;
 #endif
+    a.whatif = 0;
+    {
+        const char* es = getenv("GF_A4_STAGGER");
+        a.stagger = !(es && es[0] == '0');
+    }
+#ifdef GF_A4_WHATIF
+    if (const char* ew = getenv("GF_A4_WHATIF")) a.whatif = atoi(ew);
+#endif
     hipStream_t s = (hipStream_t)stream;
 #define GF_GEMM_CASE(E) case E: return fp8 ? launch_gemm<E, true>(a, s) : launch_gemm<E, false>(a, s);
     switch (epilogue) {
@@ -1154,6 +1353,8 @@ extern "C" GF_API int gf_conv3d_bf16(const void* src, const void* cache, const v
     a.tiles_m = (int)((M + BM - 1) / BM);
     a.tiles_n = narrow ? (int)((N + 127) / 128) : (int)((N + BN - 1) / BN);
     a.dbg = nullptr;
+    a.whatif = 0;
+    a.stagger = 0;
     a.cv.src = (const u16*)src;
     a.cv.cache = (const u16*)cache;
     a.cv.zero = conv_zero_page();

@@ -401,3 +401,49 @@ print("ok")
     env = dict(os.environ, GF_ATTN_KERNEL="1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+A4_SHAPES = [(512, 256, 64), (513, 520, 192), (1000, 768, 1024), (777, 5120, 5120), (2048, 13824, 512), (4096, 264, 13824)]
+
+
+@pytest.mark.parametrize("M,N,K", A4_SHAPES)
+def test_gemm_a4_vs_phased_kernel(ops, M, N, K):
+    """The 4-wave kernel (M >= 512; one wave per SIMD, asm K loop, buffer LDS-DMA with num_records cut-off instead of row
+    clamping) against the 8-wave phased kernel on ragged M / N tiles, single-K-tile problems and every fused epilogue.
+    With the staggered K start off (GF_A4_STAGGER=0) both accumulate every C element over k in the same order with the
+    same MFMA: BIT-IDENTICAL.  With it on (shipped) the sum over k is rotated per column tile: equal to fp32 rounding
+    (<= 1 bf16 ulp on all but a sliver of the outputs), and a row's bits do not depend on which M tile it falls in."""
+    g = torch.Generator().manual_seed(M + 3 * N + K)
+    a = dev(torch.randn((M, K), generator=g).to(BF))
+    w = dev((torch.randn((N, K), generator=g) / math.sqrt(K)).to(BF))
+    bias = dev((0.1 * torch.randn(N, generator=g)).to(BF))
+    resid = dev(torch.randn((M, N), generator=g).to(BF))
+    gate = dev(torch.randn(N, generator=g).to(BF))
+    cases = [dict(), dict(epilogue=ops.EPI_BIAS_GELU_TANH), dict(epilogue=ops.EPI_BIAS_SILU),
+             dict(epilogue=ops.EPI_BIAS_RESID, resid=resid), dict(epilogue=ops.EPI_BIAS_GATE_RESID, resid=resid, gate=gate),
+             dict(epilogue=ops.EPI_BIAS_MUL, resid=resid)]
+    try:
+        for kw in cases:
+            os.environ["GF_GEMM_KERNEL"] = "ph"
+            want = ops.gemm(a, w, bias, **kw)
+            os.environ["GF_GEMM_KERNEL"] = "a4"
+            os.environ["GF_A4_STAGGER"] = "0"
+            got = ops.gemm(a, w, bias, **kw)
+            assert torch.equal(got, want), f"{kw.get('epilogue')}: {int((got != want).sum())} elements differ"
+            os.environ.pop("GF_A4_STAGGER")
+            rot = ops.gemm(a, w, bias, **kw)
+            assert ulp_mismatch_frac(rot, want, ulps=1) < 2e-3 and rel_l2(rot.float(), want.float()) < 1e-3
+        os.environ["GF_GEMM_KERNEL"] = "a4"
+        assert torch.equal(ops.gemm(a, w, None), ops.gemm(a, w, torch.zeros_like(bias)))
+        # rows keep their bits when the M tiling changes (what the sharded forwards rely on)
+        full = ops.gemm(a, w, bias)
+        assert torch.equal(ops.gemm(a[M - 512:], w, bias), full[M - 512:])
+        # strided A (a column slice of a wider activation) and a strided output
+        wide = dev(torch.randn((M, K + 64), generator=g).to(BF))
+        big = torch.zeros((M, N + 16), dtype=BF, device="cuda")
+        ops.gemm(wide[:, 64:], w, bias, out=big[:, 8:8 + N])
+        assert torch.equal(big[:, 8:8 + N], ops.gemm(wide[:, 64:].contiguous(), w, bias))
+        assert float(big[:, :8].abs().sum()) == 0 and float(big[:, 8 + N:].abs().sum()) == 0
+    finally:
+        os.environ.pop("GF_GEMM_KERNEL", None)
+        os.environ.pop("GF_A4_STAGGER", None)

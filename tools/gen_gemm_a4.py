@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""Generates goal_force_amd/csrc/gf_gemm_a4_loop.inc: the K loop of the 4-wave bf16 GEMM (gemm_a4_kernel, gf_gemm.hip)
+as ONE inline-asm statement with hand-allocated registers.
+
+    python tools/gen_gemm_a4.py            # rewrites the .inc (committed; the build does not run this)
+
+Why asm: the loop keeps 256 fp32 accumulators in a[0:255] and 128 fragment registers in v[128:255] live; hipcc spills
+at that pressure (gemm_sl_kernel), and the schedule below needs every LDS read, LDS-DMA piece, counted wait
+and barrier at a fixed MFMA slot.
+
+Per workgroup: 256 threads = 4 waves (wm, wn) in 2 x 2, C tile 256 x 256, K step 64; wave = 128 x 128 of C = 8 x 8 MFMA tiles
+of v_mfma_f32_16x16x32_bf16 (operands swapped: D = W_frag x A_frag, a lane holds 4 consecutive n of one m).
+LDS: 2 stages x (A tile 256 rows x 128 B | B tile 256 rows x 128 B) = 128 KiB, 16-byte chunk c of row r at chunk c ^ (r & 7).
+Staging: buffer_load_dwordx4 ... offen lds (1 KiB = 8 rows per wave instruction), descriptor in s[60:63] / s[64:67], the
+piece's row group as an SGPR soffset, the K position in the per-lane voffset: no vector address arithmetic per piece.
+
+Pipeline (tile t multiplies from registers while tile t+1 sits in LDS stage (t+1)&1 and tile t+2 is in flight):
+  iteration t, first half  (64 MFMAs on the k-sub-step-0 fragments): read the k-sub-step-1 fragments of tile t (8 A reads,
+      lgkmcnt(0), barrier B1 -> stage t&1's A region is dead -> 8 DMA pieces of A(t+2) into it; 8 B reads, lgkmcnt(0), barrier
+      B2 -> 8 DMA pieces of B(t+2));
+  second half (64 MFMAs on the k-sub-step-1 fragments): s_waitcnt vmcnt(16) (everything older than this iteration's 16
+      pieces = tile t+1) + barrier B3 -> read the k-sub-step-0 fragments of tile t+1 from the other stage; lgkmcnt(0).
+Tiles past K are staged with num_records = 0 (reads return 0, no memory traffic), so the loop needs no peeled tail.
+"""
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "goal_force_amd", "csrc", "gf_gemm_a4_loop.inc")
+
+# ---- register plan -------------------------------------------------------------------------------------------------
+A_K0, B_K0, A_K1, B_K1 = 128, 160, 192, 224          # fragment i of a set: v[base + 4 i : base + 4 i + 3]
+SRD_A, SRD_B = 60, 64                                 # s[60:63], s[64:67]
+SOFF_A, SOFF_B = 36, 44                               # s[36:43], s[44:51]: row-group offsets of this wave's 8 pieces
+S_M0SAVE, S_CNT, S_WR, S_NRA, S_NRB = 52, 53, 54, 56, 57
+S_POS, S_STEP, S_NK, S_WRAP = 58, 59, 68, 69          # staged K tile position (wraps at nk), voffset step of the next advance
+STAGE = 65536
+B_TILE = 32768
+CLOBBER_S = list(range(36, 60)) + list(range(60, 70))
+
+
+def advance_k():
+    """Scalar half of moving the staging position one K tile on: 128 bytes, or back to the row start at the wrap."""
+    return [f"s_add_u32 s{S_POS}, s{S_POS}, 1", f"s_cmp_eq_u32 s{S_POS}, s{S_NK}",
+            f"s_cselect_b32 s{S_STEP}, s{S_WRAP}, 128", f"s_cselect_b32 s{S_POS}, 0, s{S_POS}"]
+
+
+ADVANCE_V = [f"v_add_u32 %[voffA], s{S_STEP}, %[voffA]", f"v_add_u32 %[voffB], s{S_STEP}, %[voffB]",
+             f"v_add_u32 %[pfA], s{S_STEP}, %[pfA]", f"v_add_u32 %[pfB], s{S_STEP}, %[pfB]"]
+WARM = False          # L2 warm-up loads: measured 1.43 -> 1.08 PFLOP/s (one 128-byte line per LANE costs the texture addresser 64
+                      # line look-ups per instruction); kept for the record, not generated
+WAIT_SLOT = 88
+PF_TILES = 6          # L2 warm-up distance beyond the staged tile (K tiles); the instruction offset field holds <= 31
+V_DUMMY = 126         # v[126:127]: destinations of the warm-up loads (never read)
+
+
+def warm(which):
+    """One 4-byte load per lane = one 128-byte line per row of this wave's 64 staging rows, PF_TILES K tiles ahead of the
+    staging position: pulls the lines the LDS-DMA will ask for from HBM / MALL into this XCD's L2 early, so that the DMA's
+    latency is an L2 hit (the two LDS stages give the DMA itself only ~1.3 iterations of lead)."""
+    srd, soff, voff = (SRD_A, SOFF_A, "%[pfA]") if which == 0 else (SRD_B, SOFF_B, "%[pfB]")
+    return f"buffer_load_dword v{V_DUMMY + which}, {voff}, s[{srd}:{srd + 3}], s{soff} offen offset:{PF_TILES * 128}"
+
+
+def v4(base, i):
+    return f"v[{base + 4 * i}:{base + 4 * i + 3}]"
+
+
+def acc(i, j):
+    b = (i * 8 + j) * 4
+    return f"a[{b}:{b + 3}]"
+
+
+def mfma(half, g):
+    i, j = g >> 3, g & 7
+    a, b = (A_K0, B_K0) if half == 0 else (A_K1, B_K1)
+    return f"v_mfma_f32_16x16x32_bf16 {acc(i, j)}, {v4(b, j)}, {v4(a, i)}, {acc(i, j)}"
+
+
+def dma(which, p, back_to_back=False):
+    """One 1-KiB piece + the M0 step to the next piece's LDS address (an M0 write needs one wait state before the next LDS-DMA:
+    in the loop the next piece is several MFMAs away, in the prologue an s_nop pads it)."""
+    srd, soff, voff = (SRD_A, SOFF_A, "%[voffA]") if which == 0 else (SRD_B, SOFF_B, "%[voffB]")
+    return [f"buffer_load_dwordx4 {voff}, s[{srd}:{srd + 3}], s{soff + p} offen lds", "s_add_u32 m0, m0, 0x400"] + \
+        (["s_nop 0"] if back_to_back else [])
+
+
+def dma_tile():
+    """16 pieces of one tile back to back (prologue)."""
+    out = [f"s_mov_b32 m0, s{S_WR}", "s_nop 0"]
+    for p in range(8):
+        out += dma(0, p, True)
+    out += [f"s_add_u32 m0, s{S_WR}, {B_TILE}", "s_nop 0"]
+    for p in range(8):
+        out += dma(1, p, True)
+    out += advance_k() + ADVANCE_V
+    return out
+
+
+def rd(dst_base, i, addr, extra=0):
+    off = i * 2048 + extra
+    return f"ds_read_b128 {v4(dst_base, i)}, {addr}" + (f" offset:{off}" if off else "")
+
+
+def gen(whatif=0):
+    """whatif (timing-only builds, wrong results): 1 = no barriers / counted waits in the loop, 2 = the K position never advances
+    (every tile re-reads the first one: all staging hits L2), 4 = no staging instructions in the loop."""
+    L = []
+    # ---- prologue ------------------------------------------------------------------------------------------------------
+    L += [f"s_mov_b32 s{S_M0SAVE}, m0"]
+    L += [f"s_mov_b32 s{SRD_A}, %[aLo]", f"s_mov_b32 s{SRD_A + 1}, %[aHi]", f"s_mov_b32 s{SRD_A + 2}, %[nrA]",
+          f"s_mov_b32 s{SRD_A + 3}, 0x00020000",
+          f"s_mov_b32 s{SRD_B}, %[bLo]", f"s_mov_b32 s{SRD_B + 1}, %[bHi]", f"s_mov_b32 s{SRD_B + 2}, %[nrB]",
+          f"s_mov_b32 s{SRD_B + 3}, 0x00020000",
+          f"s_mov_b32 s{S_NRA}, %[nrA]", f"s_mov_b32 s{S_NRB}, %[nrB]", f"s_mov_b32 s{S_CNT}, %[nk]",
+          f"s_mov_b32 s{S_WR}, %[ldsW]",
+          # staggered start: this tile's K loop begins at K tile k0 and wraps (the sum over k is rotated, not changed)
+          f"s_mov_b32 s{S_NK}, %[nk]", f"s_mov_b32 s{S_POS}, %[k0]", f"s_sub_u32 s{S_WRAP}, 128, %[kb]",
+          f"s_lshl_b32 s{S_STEP}, %[k0], 7", "s_nop 0",
+          f"v_add_u32 %[voffA], s{S_STEP}, %[voffA]", f"v_add_u32 %[voffB], s{S_STEP}, %[voffB]",
+          f"v_add_u32 %[pfA], s{S_STEP}, %[pfA]", f"v_add_u32 %[pfB], s{S_STEP}, %[pfB]"]
+    L += [f"s_mov_b32 s{SOFF_A}, %[soA]", f"s_mov_b32 s{SOFF_B}, %[soB]"]
+    for p in range(1, 8):
+        L += [f"s_add_u32 s{SOFF_A + p}, s{SOFF_A + p - 1}, %[stA]", f"s_add_u32 s{SOFF_B + p}, s{SOFF_B + p - 1}, %[stB]"]
+    L += dma_tile()                                                   # tile 0 -> stage 0
+    L += [f"s_xor_b32 s{S_WR}, s{S_WR}, {STAGE}",
+          f"s_cmp_gt_u32 s{S_CNT}, 1", f"s_cselect_b32 s{SRD_A + 2}, s{S_NRA}, 0", f"s_cselect_b32 s{SRD_B + 2}, s{S_NRB}, 0",
+          "s_nop 1"]
+    L += dma_tile()                                                   # tile 1 -> stage 1 (zeros past K)
+    L += [f"s_xor_b32 s{S_WR}, s{S_WR}, {STAGE}"]
+    for r in range(256):                                              # zeroed under the latency of the first two tiles
+        L.append(f"v_accvgpr_write_b32 a{r}, 0")
+    L += ["s_waitcnt vmcnt(16)", "s_barrier"]
+    for i in range(8):
+        L.append(rd(A_K0, i, "%[rdA0]"))
+    for j in range(8):
+        L.append(rd(B_K0, j, "%[rdB0]"))
+    L += ["s_waitcnt lgkmcnt(0)"]
+
+    # ---- the loop ------------------------------------------------------------------------------------------------------
+    ev = {}                      # MFMA slot (0..127) -> instructions issued right after it
+
+    def at(slot, *ins):
+        ev.setdefault(slot, []).extend(ins)
+
+    # tile t+2 exists iff remaining > 2
+    at(0, f"s_cmp_gt_u32 s{S_CNT}, 2", f"s_cselect_b32 s{SRD_A + 2}, s{S_NRA}, 0")
+    at(1, f"s_cselect_b32 s{SRD_B + 2}, s{S_NRB}, 0")
+    for i in range(8):
+        at(2 * i, rd(A_K1, i, "%[rdA1]"))
+    if WARM and not (whatif & 8):
+        at(3, warm(0))
+        at(5, warm(1))
+    at(17, f"s_mov_b32 m0, s{S_WR}")
+    at(18, "s_waitcnt lgkmcnt(0)")
+    at(19, "s_barrier")
+    for p in range(8):
+        at(20 + 3 * p, *dma(0, p))
+        at(21 + 3 * p, rd(B_K1, p, "%[rdB1]"))
+    at(45, f"s_add_u32 m0, s{S_WR}, {B_TILE}")
+    at(46, "s_waitcnt lgkmcnt(0)")
+    at(47, "s_barrier")
+    for p in range(8):
+        at(48 + 3 * p, *dma(1, p))
+    at(70, "v_xor_b32 %[rdA0], 0x10000, %[rdA0]", "v_xor_b32 %[rdA1], 0x10000, %[rdA1]")
+    at(71, "v_xor_b32 %[rdB0], 0x10000, %[rdB0]", "v_xor_b32 %[rdB1], 0x10000, %[rdB1]")
+    at(72, f"s_xor_b32 s{S_WR}, s{S_WR}, {STAGE}")
+    # the wait for tile t+1 sits as late as the 16 fragment reads behind it allow: every slot it moves back is lead time for
+    # the LDS-DMA (two LDS stages leave it ~1.3 iterations between issue and this wait)
+    at(WAIT_SLOT, "s_waitcnt vmcnt(18)" if (WARM and not (whatif & 8)) else "s_waitcnt vmcnt(16)")
+    at(WAIT_SLOT + 1, "s_barrier")
+    for i in range(8):
+        at(WAIT_SLOT + 2 + 2 * i, rd(A_K0, i, "%[rdA0]"))
+    for j in range(8):
+        at(WAIT_SLOT + 18 + 2 * j, rd(B_K0, j, "%[rdB0]"))
+    at(76, *advance_k()[:2])
+    at(77, *advance_k()[2:])
+    at(80, *ADVANCE_V)
+    at(124, f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
+    at(125, f"s_cmp_eq_u32 s{S_CNT}, 0")
+    at(126, "s_waitcnt lgkmcnt(0)")
+    L.append("1:")
+    for s in range(128):
+        L.append(mfma(s >> 6, s & 63))
+        for ins in ev.get(s, []):
+            if (whatif & 1) and (ins == "s_barrier" or ins.startswith("s_waitcnt vmcnt")):
+                continue
+            if (whatif & 2) and ins.startswith("v_add_u32 %[voff"):
+                continue
+            if (whatif & 4) and ins.startswith("buffer_load_dwordx4"):
+                continue
+            L.append(ins)
+    L += ["s_cbranch_scc0 1b"]
+    # ---- drain: the last two iterations staged zero tiles; they must have landed (and every wave must be past its reads)
+    # before the epilogue reuses LDS.  MFMA results need 4 passes + margin before v_accvgpr_read.
+    L += ["s_waitcnt vmcnt(0)", "s_nop 7", "s_nop 7", f"s_mov_b32 m0, s{S_M0SAVE}", "s_barrier"]
+    return L
+
+
+def emit(name, lines):
+    n_mfma = sum(1 for l in lines if l.startswith("v_mfma"))
+    assert n_mfma == 128, n_mfma
+    body = "\n".join(f'    "{l}\\n\\t"' for l in lines)
+    vclob = ", ".join(f'"v{r}"' for r in range(V_DUMMY, 256))
+    aclob = ", ".join(f'"a{r}"' for r in range(256))
+    sclob = ", ".join(f'"s{r}"' for r in CLOBBER_S)
+    text = f"""// GENERATED by tools/gen_gemm_a4.py — do not edit.  The K loop of gemm_a4_kernel as one asm statement.
+// operands: voffA/voffB (per-lane source byte offsets, advanced by 128 per K tile), pfA/pfB (row-per-lane offsets of the L2
+// warm-up loads, advanced alike), rdA0/rdA1/rdB0/rdB1 (LDS fragment read
+// addresses of k-sub-steps 0/1, stage toggled by XOR 0x10000), aLo/aHi/nrA, bLo/bHi/nrB (tile row base + valid bytes),
+// soA/stA, soB/stB (this wave's first row-group offset and the 8-row stride, bytes), ldsW (this wave's LDS write base in
+// stage 0), nk (K tiles >= 1), k0 (first K tile of this workgroup's rotated K loop, < nk), kb (K in bytes).  Accumulators are left in a[0:255]: a[(i*8+j)*4 + r] = C[16 i + lane%16][16 j + 4 (lane/16) + r].
+#define {name}(voffA, voffB, pfA, pfB, rdA0, rdA1, rdB0, rdB1, aLo, aHi, nrA, bLo, bHi, nrB, soA, stA, soB, stB, ldsW, nk, k0, kb) \\
+    asm volatile( \\
+{body.replace(chr(10), " " + chr(92) + chr(10))} \\
+        : [voffA] "+v"(voffA), [voffB] "+v"(voffB), [pfA] "+v"(pfA), [pfB] "+v"(pfB), [rdA0] "+v"(rdA0), [rdA1] "+v"(rdA1), [rdB0] "+v"(rdB0), [rdB1] "+v"(rdB1) \\
+        : [aLo] "s"(aLo), [aHi] "s"(aHi), [nrA] "s"(nrA), [bLo] "s"(bLo), [bHi] "s"(bHi), [nrB] "s"(nrB), [soA] "s"(soA), \\
+          [stA] "s"(stA), [soB] "s"(soB), [stB] "s"(stB), [ldsW] "s"(ldsW), [nk] "s"(nk), [k0] "s"(k0), [kb] "s"(kb) \\
+        : "memory", "scc", "vcc", {sclob}, \\
+          {vclob}, \\
+          {aclob})
+"""
+    return text
+
+
+def main():
+    text = emit("GF_A4_LOOP_ASM", gen())
+    # timing-only variants behind -DGF_A4_WHATIF (tools/gemm_a4_whatif.py); never in the shipped library
+    text += "#ifdef GF_A4_WHATIF\n" + "".join(emit(f"GF_A4_LOOP_ASM_W{w}", gen(w)) for w in (1, 2, 4, 5)) + "#endif\n"
+    with open(OUT, "w") as f:
+        f.write(text)
+    print(f"wrote {OUT}")
+
+
+if __name__ == "__main__":
+    main()

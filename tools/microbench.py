@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--fp8", action="store_true")
     ap.add_argument("--s", type=int, default=S)
+    ap.add_argument("--ab", action="store_true", help="gemm: interleaved A/B of GF_GEMM_KERNEL=a4 (4 waves, shipped) and ph (8 waves)")
     ap.add_argument("--ref", action="store_true", help="also time torch F.linear (hipBLASLt) on the same shapes: a yardstick, not a product path")
     a = ap.parse_args()
     torch.manual_seed(0)
@@ -72,6 +73,15 @@ def main():
             fl = 2.0 * s * n * k
             med, mn = timeit(lambda: ops.gemm(inp, w, b, out=out), a.iters)
             print(f"gemm bf16 {name}: median {med:.3f} ms ({fl / med / 1e9:.1f} TFLOP/s), min {mn:.3f} ms")
+            if a.ab:       # interleaved rounds of the 4-wave kernel and the 8-wave phased kernel in this process
+                rounds = {"a4": [], "ph": []}
+                for _ in range(3):
+                    for kern in ("a4", "ph"):
+                        os.environ["GF_GEMM_KERNEL"] = kern
+                        rounds[kern].append(timeit(lambda: ops.gemm(inp, w, b, out=out), a.iters)[0])
+                os.environ.pop("GF_GEMM_KERNEL")
+                for kern, ts in rounds.items():
+                    print(f"   A/B {kern} {name}: medians {', '.join(f'{t:.3f}' for t in ts)} ms -> {fl / min(ts) / 1e9:.1f} TFLOP/s best")
             if n == D:
                 res = torch.randn((s, n), device="cuda").to(BF)
                 gate = torch.randn((n,), device="cuda").to(BF)
