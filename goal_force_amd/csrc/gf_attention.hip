@@ -29,6 +29,9 @@
 #ifndef GF_ATTN_SCHED
 #define GF_ATTN_SCHED 1
 #endif
+#ifndef GF_ATTN_BUFFER_DMA
+#define GF_ATTN_BUFFER_DMA 1   // 1: K/V staging by buffer_load ... lds with scalar tile offsets; 0: global_load_lds (A/B builds)
+#endif
 #ifndef GF_ATTN_LATE_PRIO
 #define GF_ATTN_LATE_PRIO 1
 #endif
@@ -489,6 +492,29 @@ __global__ __launch_bounds__(AT2_THREADS, 2) void flash_attn_fwd_kernel2(const A
                      : "v"(g), "s"(dst)
                      : "memory");
     };
+    // The steady-state pieces go through the BUFFER form of the same LDS-DMA: descriptor (wave-uniform base of K, V or V^T) +
+    // this lane's constant 32-bit byte offset + the tile's byte offset as an SGPR soffset.  No vector address arithmetic per
+    // piece (the global form adds a 64-bit per-lane pointer: two VALU instructions in an issue-bound loop) and one SALU
+    // instruction less.  kv_len * stride * 2 < 2^32 is checked on the host, so voffset + soffset never wraps.
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4s;
+    auto make_srd = [](const void* base) {
+        const unsigned long b = (unsigned long)base;
+        u32x4s r;
+        r[0] = (unsigned)b;
+        r[1] = (unsigned)(b >> 32) & 0xffffu;
+        r[2] = 0xffffffffu;     // num_records: the host checks the extents; ragged tiles take the clamped global form
+        r[3] = 0x00020000u;
+        return r;
+    };
+    const u32x4s srd_k = make_srd(p.k), srd_v = make_srd(VT ? (const void*)p.vt : (const void*)p.v);
+    auto dma16b = [&](const u32x4s& srd, unsigned voff_bytes, unsigned soff_bytes, GF_LDS char* l) {
+        unsigned keep;
+        const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)l);
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(voff_bytes), "s"(srd), "s"(dst), "s"(soff_bytes)
+                     : "memory");
+    };
     // which = 0: K tile t -> K buffer buf;  which = 1: V tile t -> V buffer buf
     // VT: the V tile image is 128 d-rows x 128 B (64 keys), chunk ^ ((row >> 1) & 7); wave w stages rows 16w..16w+15 as two
     // pieces of 8 rows (lane L: row L>>3, physical chunk L&7)
@@ -506,7 +532,10 @@ __global__ __launch_bounds__(AT2_THREADS, 2) void flash_attn_fwd_kernel2(const A
         if constexpr (VT) {
             if (which) {
 #pragma unroll
-                for (int jj = 0; jj < 2; ++jj) dma16(p.vt + (vt_off[jj] + (unsigned)t * KVB), base + jj * 1024);
+                for (int jj = 0; jj < 2; ++jj) {
+                    if constexpr (GF_ATTN_BUFFER_DMA) dma16b(srd_v, vt_off[jj] * 2u, (unsigned)t * (KVB * 2u), base + jj * 1024);
+                    else dma16(p.vt + (vt_off[jj] + (unsigned)t * KVB), base + jj * 1024);
+                }
                 return;
             }
         }
@@ -514,7 +543,10 @@ __global__ __launch_bounds__(AT2_THREADS, 2) void flash_attn_fwd_kernel2(const A
         if ((t + 1) * KVB <= p.kv_len) {
             const unsigned tt = (unsigned)t * (which ? vstep : kstep);
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) dma16(g + (dma_off[jj][which] + tt), base + jj * 1024);
+            for (int jj = 0; jj < 2; ++jj) {
+                if constexpr (GF_ATTN_BUFFER_DMA) dma16b(which ? srd_v : srd_k, dma_off[jj][which] * 2u, tt * 2u, base + jj * 1024);
+                else dma16(g + (dma_off[jj][which] + tt), base + jj * 1024);
+            }
         } else {   // ragged last tile: clamp the row (masked later), 64-bit addressing
             const long stride = which ? p.v_stride : p.k_stride;
 #pragma unroll
@@ -532,14 +564,16 @@ __global__ __launch_bounds__(AT2_THREADS, 2) void flash_attn_fwd_kernel2(const A
         GF_LDS char* base = lds + which * AT2_V_BASE + buf * KV_TILE_BYTES + wave * 2048;
         if constexpr (VT) {
             if (which) {
-                dma16(p.vt + (vt_off[jj] + (unsigned)t * KVB), base + jj * 1024);
+                if constexpr (GF_ATTN_BUFFER_DMA) dma16b(srd_v, vt_off[jj] * 2u, (unsigned)t * (KVB * 2u), base + jj * 1024);
+                else dma16(p.vt + (vt_off[jj] + (unsigned)t * KVB), base + jj * 1024);
                 return;
             }
         }
         const u16* g = which ? p.v : p.k;
         if ((t + 1) * KVB <= p.kv_len) {
             const unsigned tt = (unsigned)t * (which ? vstep : kstep);
-            dma16(g + (dma_off[jj][which] + tt), base + jj * 1024);
+            if constexpr (GF_ATTN_BUFFER_DMA) dma16b(which ? srd_v : srd_k, dma_off[jj][which] * 2u, tt * 2u, base + jj * 1024);
+            else dma16(g + (dma_off[jj][which] + tt), base + jj * 1024);
         } else {
             const long stride = which ? p.v_stride : p.k_stride;
             const int j = 2 * wave + jj;

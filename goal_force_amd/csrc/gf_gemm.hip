@@ -1200,7 +1200,11 @@ int launch_conv(const GemmArgs& a, hipStream_t stream) {
 // 256 zero bytes per device: where the convolution's padding taps and K-padding columns are fetched from.  A __device__
 // array of the code object (zero-initialised when the module is loaded on a device): looking up its address neither
 // allocates nor synchronises, so gf_conv3d_bf16 keeps the header's contract and works under stream capture.
-__device__ const u16 gf_conv_zero_page[128] = {};
+}  // namespace
+// external linkage + default visibility: hipGetSymbolAddress looks the variable up by name in the code object (a variable of
+// the anonymous namespace is a local symbol there: "Cannot create GlobalVar Obj")
+__device__ __attribute__((used, visibility("default"))) u16 gf_conv_zero_page[128] = {};   // not `const`: that would be internal linkage
+namespace {
 
 const u16* conv_zero_page() {
     static GfDeviceOnce once;

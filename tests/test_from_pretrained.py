@@ -15,7 +15,7 @@ from conftest import GOLDEN
 
 BF = torch.bfloat16
 torch.set_grad_enabled(False)
-T5_TINY = dict(vocab=64, dim=256, dim_attn=256, dim_ffn=512, num_heads=4, num_layers=2, num_buckets=32)
+T5_TINY = dict(vocab=64, dim=64, dim_attn=256, dim_ffn=128, num_heads=4, num_layers=2, num_buckets=32)   # dim = TINY text_dim
 
 
 def _write_tokenizer(path):
@@ -151,7 +151,7 @@ def test_pipeline_from_checkpoints_end_to_end_tiny(tmp_path):
     assert tuple(lat.shape) == (1, 16, 3, 8, 12) and bool(torch.isfinite(lat.float()).all())
     ctx_p = pipe.prompter.encode_prompt("the pendulum swings", device="cuda")
     ctx_n = pipe.prompter.encode_prompt("a red block", positive=False, device="cuda")
-    assert tuple(ctx_p.shape) == (1, 512, 256) and float(ctx_p[:, 3:].abs().max()) == 0      # zeroed past the prompt
+    assert tuple(ctx_p.shape) == (1, 512, 64) and float(ctx_p[:, 3:].abs().max()) == 0      # zeroed past the prompt
     y = pipe.embed_image(image, 9, 64, 96, False, (30, 52), (15, 26))
     cl = pipe.embed_control_video(control, False, (30, 52), (15, 26))
     lat2 = pipe(context_posi=ctx_p, context_nega=ctx_n, y=y, control_signal_video_latents=cl, num_frames=9, height=64,

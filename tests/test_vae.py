@@ -65,6 +65,14 @@ def test_oracle_encode_matches_reference():
     assert rel_l2(vo.encode(v1.float(), sd32), torch.from_numpy(g["encode_f32"])) < 1e-5
 
 
+@pytest.fixture(autouse=True)
+def _unrotated_yardstick_gemm(monkeypatch):
+    """The convolution is compared BIT FOR BIT with `gf_vae_im2col + gf_gemm_bf16`: pin that yardstick GEMM to the K order
+    the implicit-GEMM convolution uses (k tiles 0, 1, 2, ...).  The 4-wave GEMM kernel that large dense shapes go through by
+    default starts each column tile's K loop at a staggered tile (same sum, rotated order: test_kernels_gpu.py)."""
+    monkeypatch.setenv("GF_A4_STAGGER", "0")
+
+
 def _gpu_vae(sd):
     from goal_force_amd.vae import WanVideoVAE
     v = WanVideoVAE()
