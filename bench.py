@@ -29,11 +29,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # HBM bytes per self-attention launch (transpose_v_kernel + flash_attn_fwd_kernel2<true>) from rocprofv3 --pmc, separate
-# FETCH_SIZE / WRITE_SIZE passes over tools/microbench.py attn: (2 x FETCH_SIZE [gfx950 reports half of a 16-B/lane stream]
-# + WRITE_SIZE) KiB -> bytes.  PMC needs the profiler, so this is a STATIC figure from the named file, not measured by the
-# run that prints it ("traffic_static": true in the JSON line).
-ATTN_TRAFFIC_BYTES = ((2 * 1894109 + 327602) + (2 * 163820 + 327767)) * 1024
-ATTN_TRAFFIC_SOURCE = "profiles/r01/pmc/attn_k2vt_{FETCH,WRITE}_SIZE_counter_collection.csv"
+# FETCH_SIZE / WRITE_SIZE passes over tools/microbench.py attn (tools/profile_r02.sh): (2 x FETCH_SIZE [gfx950 reports half of a
+# 16-B/lane stream] + WRITE_SIZE) KiB -> bytes, this round's build.  PMC needs the profiler, so this is a STATIC figure from
+# the named files, not measured by the run that prints it ("traffic_static": true in the JSON line).
+ATTN_TRAFFIC_BYTES = ((2 * 1474550 + 327600) + (2 * 163819 + 327776)) * 1024
+ATTN_TRAFFIC_SOURCE = "profiles/r02/pmc/attn_FETCH_SIZE.md + attn_WRITE_SIZE.md"
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md (Chip-level parameters)
 S_TOK, DIM, HEADS, FFN, LTXT = 32760, 5120, 40, 13824, 512
 
@@ -276,7 +276,8 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "flash_attn_fwd_kernel2<true> + transpose_v_kernel (self-attention, S=32760, 40 heads, d=128)",
                          "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "peak_note": "dense bf16 MFMA peak = 256 CU x 4096 FLOP/clk x 2.4 GHz (MI355X_MICROARCH.md); under this "
-                                      "load the chip holds 1.8-2.05 GHz depending on the box (rocprofv3 GRBM_GUI_ACTIVE), i.e. 1.9-2.1 PFLOP/s",
+                                      "load the chip holds 1.74-2.05 GHz depending on the box and build (rocprofv3 GRBM_GUI_ACTIVE: 1.74 GHz "
+                                      "at 65.8 % MFMA-busy in profiles/r02/pmc/attn_SQ.md), i.e. 1.8-2.1 PFLOP/s",
                          "frac": None if achieved is None else achieved / PEAK_BF16_TFLOPS,
                          # HBM bytes per launch from rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes over
                          # tools/microbench.py attn, profiles/r01/pmc/): (2 x FETCH_SIZE [gfx950 reports half of a 16-B/lane
@@ -298,9 +299,9 @@ def main():
             return {"bound": "mfma", "kernel": name, "achieved": fl / (avg * 1e-3) / 1e12, "peak": PEAK_BF16_TFLOPS,
                     "unit": "TFLOP/s", "frac": fl / (avg * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, "traffic": None,
                     "launches": len(ms), "avg_launch_ms": avg, "algorithmic_flops_per_launch": fl}
-        out["roofline_gemm"] = [e for e in (gemm_entry(FFN, DIM, "gemm_ph_kernel<GELU> FFN1 [S,5120]x[13824,5120]^T"),
-                                            gemm_entry(DIM, FFN, "gemm_ph_kernel<gate*+resid> FFN2 [S,13824]x[5120,13824]^T"),
-                                            gemm_entry(DIM, DIM, "gemm_ph_kernel D->D projections (q,k,v,o, zero-conv)")) if e]
+        out["roofline_gemm"] = [e for e in (gemm_entry(FFN, DIM, "gemm_a4_kernel<GELU> FFN1 [S,5120]x[13824,5120]^T"),
+                                            gemm_entry(DIM, FFN, "gemm_a4_kernel<gate*+resid> FFN2 [S,13824]x[5120,13824]^T"),
+                                            gemm_entry(DIM, DIM, "gemm_a4_kernel D->D projections (q,k,v,o, zero-conv)")) if e]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(torch)
         print(json.dumps(out))

@@ -91,6 +91,18 @@ __device__ __forceinline__ void glds16(const void* g, GF_LDS char* l) {
 
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 
+// The Linear's own output is rounded to bf16 before anything else happens to it.  Where the epilogue applies a function to it
+// (GELU, SiLU) that rounding is explicit (rbf); otherwise the pack below IS that rounding — rounding twice to the same grid
+// changes nothing, and leaving the first one out saves ~10 VALU instructions per 4 outputs (half of the epilogue's VALU work).
+template <int EPI>
+__device__ __forceinline__ float gf_epi_act(float lin) {
+    if constexpr (EPI == GF_EPI_BIAS_GELU_TANH) return gelu_tanh_f(rbf(lin));
+    else if constexpr (EPI == GF_EPI_BIAS_SILU) {
+        const float y = rbf(lin);
+        return y / (1.0f + expf(-y));
+    } else return lin;
+}
+
 // FP8 = false: A/W are bf16, K-step 64 elements.  FP8 = true: A/W are OCP e4m3 bytes, K-step 128 elements — the
 // LDS image is the same 128-byte rows, each lane's fragment is 32 consecutive k (two 16-byte chunks) and the
 // product runs on v_mfma_scale_f32_16x16x128_f8f6f4 with unit (E8M0 = 127) block scales: 2x the bf16 MFMA rate.
@@ -237,9 +249,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmArgs p)
                 if constexpr (FP8) rs = p.row_scale[min(m0 + wm * 128 + i * 16 + frow, p.M - 1)];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    y[r] = rbf(acc[i][j][r] * rs + bv[r]);  // the Linear's own bf16 output (x scale_a for fp8)
-                    if (EPI == GF_EPI_BIAS_GELU_TANH) y[r] = gelu_tanh_f(y[r]);
-                    if (EPI == GF_EPI_BIAS_SILU) y[r] = y[r] / (1.0f + expf(-y[r]));
+                    y[r] = gf_epi_act<EPI>(acc[i][j][r] * rs + bv[r]);  // (x scale_a for fp8)
                 }
                 u32x2 pk;
                 pk[0] = pack2bf(y[0], y[1]);
@@ -644,9 +654,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs
                     float y[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        y[r] = rbf(acc[a][b][i][j][r] * rs + bv[r]);  // the Linear's own bf16 output
-                        if (EPI == GF_EPI_BIAS_GELU_TANH) y[r] = gelu_tanh_f(y[r]);
-                        if (EPI == GF_EPI_BIAS_SILU) y[r] = y[r] / (1.0f + expf(-y[r]));
+                        y[r] = gf_epi_act<EPI>(acc[a][b][i][j][r] * rs + bv[r]);
                     }
                     u32x2 pk;
                     pk[0] = pack2bf(y[0], y[1]);
@@ -705,6 +713,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs
 //     transposes each wave's 128 x 128 through a private 32 KiB LDS image and stores whole 256-byte row segments.
 #include "gf_gemm_a4_loop.inc"
 constexpr int A4_THREADS = 256;
+#ifndef GF_A4_NT
+#define GF_A4_NT 1   // the epilogue streams: C stores and residual loads carry the non-temporal hint (D->D +2.6 %, D->F +1.2 %, F->D -0.5 %; 0 for A/B builds)
+#endif
 
 template <int I>
 __device__ __forceinline__ float a4_acc() {
@@ -791,6 +802,9 @@ __global__ __launch_bounds__(A4_THREADS, 1) void gemm_a4_kernel(const GemmArgs p
 #endif
     GF_A4_LOOP_ASM(voffA, voffB, pfA, pfB, rdA0, rdA1, rdB0, rdB1, aLo, aHi, nrA, bLo, bHi, nrB, soA, stA, soB, stB, ldsW, nk, k0, kb);
 
+#ifdef GF_A4_WHATIF
+    if (p.whatif == 32) return;   // timing only: no epilogue at all
+#endif
     // ---- epilogue: a[(i*8+j)*4 + r] = C[m0 + wm*128 + 16 i + frow][n0 + wn*128 + 16 j + 4 fq + r]  (the asm ended on a barrier:
     // every wave is past its LDS reads and every LDS-DMA has landed)
     GF_LDS char* ep = lds + wave * 32768;   // private 128 rows x 256 B; 8-byte slot s of row r at slot s ^ ((r & 15) << 1)
@@ -809,9 +823,7 @@ __global__ __launch_bounds__(A4_THREADS, 1) void gemm_a4_kernel(const GemmArgs p
             float y[4] = {a4_acc<A0>(), a4_acc<A0 + 1>(), a4_acc<A0 + 2>(), a4_acc<A0 + 3>()};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                y[r] = rbf(y[r] + bv[r]);  // the Linear's own bf16 output
-                if (EPI == GF_EPI_BIAS_GELU_TANH) y[r] = gelu_tanh_f(y[r]);
-                if (EPI == GF_EPI_BIAS_SILU) y[r] = y[r] / (1.0f + expf(-y[r]));
+                y[r] = gf_epi_act<EPI>(y[r] + bv[r]);
             }
             u32x2 pk;
             pk[0] = pack2bf(y[0], y[1]);
@@ -836,7 +848,11 @@ __global__ __launch_bounds__(A4_THREADS, 1) void gemm_a4_kernel(const GemmArgs p
             if (m < p.M && n_ok) {
                 u16x8 o = yv;
                 if (EPI == GF_EPI_BIAS_GATE_RESID || EPI == GF_EPI_BIAS_RESID || EPI == GF_EPI_BIAS_MUL) {
+#if GF_A4_NT
+                    const u16x8 r8 = __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(p.R + (long)m * p.ldr + n));
+#else
                     const u16x8 r8 = *reinterpret_cast<const u16x8*>(p.R + (long)m * p.ldr + n);
+#endif
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         float t = bf2f(yv[e]);
@@ -845,7 +861,11 @@ __global__ __launch_bounds__(A4_THREADS, 1) void gemm_a4_kernel(const GemmArgs p
                                                         : f2bf(bf2f(r8[e]) + t);      // x + ...
                     }
                 }
+#if GF_A4_NT
+                __builtin_nontemporal_store(o, reinterpret_cast<u16x8*>(p.C + (long)m * p.ldc + n));
+#else
                 *reinterpret_cast<u16x8*>(p.C + (long)m * p.ldc + n) = o;
+#endif
             }
         }
     }

@@ -21,6 +21,13 @@ Pipeline (tile t multiplies from registers while tile t+1 sits in LDS stage (t+1
   second half (64 MFMAs on the k-sub-step-1 fragments): s_waitcnt vmcnt(16) (everything older than this iteration's 16
       pieces = tile t+1) + barrier B3 -> read the k-sub-step-0 fragments of tile t+1 from the other stage; lgkmcnt(0).
 Tiles past K are staged with num_records = 0 (reads return 0, no memory traffic), so the loop needs no peeled tail.
+
+Measured and NOT kept (same box, one process, tools/gemm_ab.py; profiles/r02/gemm_a4_experiments.md):
+  * rings of 3 A stages + 2 B stages in all 160 KiB of LDS (A tile t+3 / B tile t+2 in flight, loop unrolled 6 x): F->D +2.3 %,
+    but D->D -4 % and D->F -5.5 %;
+  * L2 warm-up loads, one 128-byte line per LANE six K tiles ahead: 1.43 -> 1.08 PFLOP/s (64 line look-ups per instruction
+    in the texture addresser);
+  * un-permuted source chunks (what a padded instead of XOR-swizzled LDS image would fetch): no difference.
 """
 import os
 
