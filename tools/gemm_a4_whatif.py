@@ -10,7 +10,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "build", "whatif", "libgf_a4w.so")
 NAMES = {0: "shipped loop", 1: "no barriers / vmcnt waits", 2: "K position frozen (all staging hits L2)", 4: "no staging instructions",
-         5: "no staging, no barriers", 16: "source chunks not permuted (linear 128-byte rows per 8 lanes)", 32: "no epilogue"}
+         5: "no staging, no barriers", 16: "source chunks not permuted (linear 128-byte rows per 8 lanes)", 32: "no epilogue", 64: "no vmcnt wait (barriers kept)", 128: "no barriers (vmcnt wait kept)"}
 
 
 def build():

@@ -27,7 +27,10 @@ Measured and NOT kept (same box, one process, tools/gemm_ab.py; profiles/r02/gem
     but D->D -4 % and D->F -5.5 %;
   * L2 warm-up loads, one 128-byte line per LANE six K tiles ahead: 1.43 -> 1.08 PFLOP/s (64 line look-ups per instruction
     in the texture addresser);
-  * un-permuted source chunks (what a padded instead of XOR-swizzled LDS image would fetch): no difference.
+  * un-permuted source chunks (what a padded instead of XOR-swizzled LDS image would fetch): no difference;
+  * two barriers per iteration instead of three (all 16 k-sub-step-1 reads, one barrier, then the 16 pieces two MFMAs apart):
+    4 % slower on all three shapes — although a timing-only build WITHOUT barriers is 2.4 / 3.7 / 11 % faster (D->F / D->D /
+    F->D) while one without the counted vmcnt wait gains nothing: the loss is waves waiting for each other, not for memory.
 """
 import os
 
@@ -56,6 +59,7 @@ ADVANCE_V = [f"v_add_u32 %[voffA], s{S_STEP}, %[voffA]", f"v_add_u32 %[voffB], s
 WARM = False          # L2 warm-up loads: measured 1.43 -> 1.08 PFLOP/s (one 128-byte line per LANE costs the texture addresser 64
                       # line look-ups per instruction); kept for the record, not generated
 WAIT_SLOT = 88
+MERGE_B12 = False     # True: one barrier (instead of two) between the k-sub-step-1 reads and the staging of tile t+2 — measured 4 % SLOWER
 PF_TILES = 6          # L2 warm-up distance beyond the staged tile (K tiles); the instruction offset field holds <= 31
 V_DUMMY = 126         # v[126:127]: destinations of the warm-up loads (never read)
 
@@ -152,22 +156,34 @@ def gen(whatif=0):
     # tile t+2 exists iff remaining > 2
     at(0, f"s_cmp_gt_u32 s{S_CNT}, 2", f"s_cselect_b32 s{SRD_A + 2}, s{S_NRA}, 0")
     at(1, f"s_cselect_b32 s{SRD_B + 2}, s{S_NRB}, 0")
-    for i in range(8):
-        at(2 * i, rd(A_K1, i, "%[rdA1]"))
-    if WARM and not (whatif & 8):
-        at(3, warm(0))
-        at(5, warm(1))
-    at(17, f"s_mov_b32 m0, s{S_WR}")
-    at(18, "s_waitcnt lgkmcnt(0)")
-    at(19, "s_barrier")
-    for p in range(8):
-        at(20 + 3 * p, *dma(0, p))
-        at(21 + 3 * p, rd(B_K1, p, "%[rdB1]"))
-    at(45, f"s_add_u32 m0, s{S_WR}, {B_TILE}")
-    at(46, "s_waitcnt lgkmcnt(0)")
-    at(47, "s_barrier")
-    for p in range(8):
-        at(48 + 3 * p, *dma(1, p))
+    if MERGE_B12:
+        # ONE barrier for both operands: all 16 k-sub-step-1 reads first, then the 16 pieces of tile t+2.  (Three barriers per
+        # iteration cost the F->D shape 11 % in waves waiting for each other: tools/gemm_a4_whatif.py, whatif 128.)
+        for i in range(8):
+            at(2 * i, rd(A_K1, i, "%[rdA1]"))
+            at(16 + 2 * i, rd(B_K1, i, "%[rdB1]"))
+        at(33, f"s_mov_b32 m0, s{S_WR}")
+        at(34, "s_waitcnt lgkmcnt(0)")
+        at(35, "s_barrier")
+        for p in range(8):
+            at(36 + 2 * p, *dma(0, p))
+        at(52, f"s_add_u32 m0, s{S_WR}, {B_TILE}")
+        for p in range(8):
+            at(54 + 2 * p, *dma(1, p))
+    else:
+        for i in range(8):
+            at(2 * i, rd(A_K1, i, "%[rdA1]"))
+        at(17, f"s_mov_b32 m0, s{S_WR}")
+        at(18, "s_waitcnt lgkmcnt(0)")
+        at(19, "s_barrier")
+        for p in range(8):
+            at(20 + 3 * p, *dma(0, p))
+            at(21 + 3 * p, rd(B_K1, p, "%[rdB1]"))
+        at(45, f"s_add_u32 m0, s{S_WR}, {B_TILE}")
+        at(46, "s_waitcnt lgkmcnt(0)")
+        at(47, "s_barrier")
+        for p in range(8):
+            at(48 + 3 * p, *dma(1, p))
     at(70, "v_xor_b32 %[rdA0], 0x10000, %[rdA0]", "v_xor_b32 %[rdA1], 0x10000, %[rdA1]")
     at(71, "v_xor_b32 %[rdB0], 0x10000, %[rdB0]", "v_xor_b32 %[rdB1], 0x10000, %[rdB1]")
     at(72, f"s_xor_b32 s{S_WR}, s{S_WR}, {STAGE}")
@@ -190,6 +206,10 @@ def gen(whatif=0):
         L.append(mfma(s >> 6, s & 63))
         for ins in ev.get(s, []):
             if (whatif & 1) and (ins == "s_barrier" or ins.startswith("s_waitcnt vmcnt")):
+                continue
+            if (whatif & 64) and ins.startswith("s_waitcnt vmcnt"):
+                continue
+            if (whatif & 128) and ins == "s_barrier":
                 continue
             if (whatif & 2) and ins.startswith("v_add_u32 %[voff"):
                 continue
@@ -232,7 +252,7 @@ def emit(name, lines):
 def main():
     text = emit("GF_A4_LOOP_ASM", gen())
     # timing-only variants behind -DGF_A4_WHATIF (tools/gemm_a4_whatif.py); never in the shipped library
-    text += "#ifdef GF_A4_WHATIF\n" + "".join(emit(f"GF_A4_LOOP_ASM_W{w}", gen(w)) for w in (1, 2, 4, 5)) + "#endif\n"
+    text += "#ifdef GF_A4_WHATIF\n" + "".join(emit(f"GF_A4_LOOP_ASM_W{w}", gen(w)) for w in (1, 2, 4, 5, 64, 128)) + "#endif\n"
     with open(OUT, "w") as f:
         f.write(text)
     print(f"wrote {OUT}")
