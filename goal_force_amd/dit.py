@@ -64,13 +64,20 @@ def _as_rope(freqs, device) -> RopeTable:
     raise GoalForceError("freqs must be a RopeTable or the reference's complex [S,1,d/2] tensor")
 
 
+_SINUSOID_FREQS = {}
+
+
 def sinusoidal_embedding_1d(dim, position):
-    """DIT:68-72 (host side: 1 timestep -> `dim` numbers, fp64 math)."""
-    pos = position.detach().to("cpu")
-    sinusoid = torch.outer(pos.type(torch.float64),
-                           torch.pow(10000, -torch.arange(dim // 2, dtype=torch.float64).div(dim // 2)))
-    x = torch.cat([torch.cos(sinusoid), torch.sin(sinusoid)], dim=1)
-    return x.to(position.dtype).to(position.device)
+    """DIT:68-72: cat(cos, sin)(t * 10000^(-i/(dim/2))) in fp64, cast to position.dtype.  The frequency table is built once
+    on the host (the reference's fp64 `pow`) and kept on the timestep's device; the product, cos and sin run there in
+    fp64 too, so a forward no longer pulls the timestep to the host (a hidden D2H sync, 100 x per video)."""
+    key = (dim, position.device)
+    inv = _SINUSOID_FREQS.get(key)
+    if inv is None:
+        inv = torch.pow(10000, -torch.arange(dim // 2, dtype=torch.float64).div(dim // 2)).to(position.device)
+        _SINUSOID_FREQS[key] = inv
+    sinusoid = torch.outer(position.detach().type(torch.float64), inv)
+    return torch.cat([torch.cos(sinusoid), torch.sin(sinusoid)], dim=1).to(position.dtype)
 
 
 def param_key(*tensors):

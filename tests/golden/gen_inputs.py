@@ -224,6 +224,17 @@ def preloop_decoded_video(seed=92):
     return (torch.rand((1, 3, 2, 8, 8), generator=torch.Generator().manual_seed(seed)) * 2.4 - 1.2).to(torch.bfloat16)
 
 
+def vae_tile_inputs(seed=93):
+    """One production-size VAE tile: latent [1,16,3,30,52] (normalised-latent scale) and a video [1,3,9,240,416] in [-1,1]
+    (smooth low-frequency content + noise, so the encoder sees image-like statistics)."""
+    g = torch.Generator().manual_seed(seed)
+    z = torch.randn((1, 16, 3, 30, 52), generator=g).to(torch.bfloat16)
+    yy, xx = torch.meshgrid(torch.linspace(0, 3.0, 240), torch.linspace(0, 5.0, 416), indexing="ij")
+    frames = [torch.stack([torch.sin(xx + 0.3 * f + c) * torch.cos(yy - 0.2 * f) for c in range(3)]) for f in range(9)]
+    vid = torch.stack(frames, dim=1)[None] * 0.8 + 0.1 * torch.randn((1, 3, 9, 240, 416), generator=g)
+    return z, vid.clamp(-1, 1).to(torch.bfloat16)
+
+
 FP8_CASES = ((72, 256, 256), (300, 528, 384), (515, 1024, 2048))
 
 

@@ -299,3 +299,18 @@ def test_fp8_model_fn_and_loop_vs_fp8_oracle():
     # CFG x5 over 3 steps amplifies every rounding difference (the bf16 reference itself is 0.153 from fp32 math here):
     # the two fp8 runs must be closer to each other than the fp8 oracle run is to exact math
     assert e_loop < e_ref, f"fp8 3-step loop: HIP vs fp8 oracle {e_loop:.3e} (fp8 oracle vs fp32 math {e_ref:.3e})"
+
+
+def test_time_embedding_sinusoid_on_device_matches_reference_golden():
+    """DIT:68-72 computed on the timestep's device (no host round trip): bit-identical to the reference's CPU result for the
+    fixture's timesteps and for every timestep of the 50-step schedule (bf16-rounded as the pipeline passes it, GF:707)."""
+    from goal_force_amd.dit import sinusoidal_embedding_1d
+    from goal_force_amd.scheduler import FlowMatchScheduler
+    g = _load("g2_ops.npz")
+    ts = torch.tensor([995.9], dtype=BF)                       # the fixture's timestep (make_goldens.py::g2_ops)
+    got = sinusoidal_embedding_1d(256, ts.cuda())
+    assert got.is_cuda and torch.equal(got.cpu(), _bf(g["sinus_bf16"]))
+    sch = FlowMatchScheduler(shift=5, sigma_min=0.0, extra_one_step=True)
+    sch.set_timesteps(50, shift=5.0)
+    t50 = sch.timesteps.to(BF)
+    assert torch.equal(sinusoidal_embedding_1d(256, t50.cuda()).cpu(), wo.sinusoidal_embedding_1d(256, t50))

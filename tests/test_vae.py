@@ -347,3 +347,29 @@ def test_hip_vae_encode_vs_reference_golden():
     a = vae.encode([cv.cuda().permute(3, 0, 1, 2)], tiled=False)
     b = vae.encode([cv.permute(3, 0, 1, 2).contiguous().cuda()], tiled=False)
     assert torch.equal(a, b) and tuple(a.shape) == (1, 16, 3, 8, 8)
+
+
+@pytest.mark.gpu
+def test_hip_vae_production_tile_vs_reference_golden():
+    """The tile geometry the pipeline really runs (GF:733: 30 x 52 latent units = 240 x 416 pixels; first-frame path + frame
+    groups) against g12_vae_tile.npz — the reference's VideoVAE_.decode / .encode on one such tile with 3 latent frames:
+    8192 sampled elements (bar: <= max(1.5e-2, 1.5 x the reference-bf16's own distance from fp32)) and every frame's /
+    channel's energy (sum of squares within 2 %)."""
+    g = np.load(os.path.join(GOLDEN, "g12_vae_tile.npz"))
+    g6 = np.load(os.path.join(GOLDEN, "g6_vae.npz"))
+    sd = gi.vae_decoder_sd(list(g6["names"]), g6["shapes"], seed=61)
+    z, vid = gi.vae_tile_inputs()
+    assert gi.same_checksum(gi.checksum([z, vid]), g["ck_inputs"])
+    vae = _gpu_vae(sd)
+    dec = vae.decode_tile_channels_last(z[0].cuda())[..., :3].permute(3, 0, 1, 2)[None].float().cpu()   # [1,3,9,240,416], raw
+    enc = vae.encode_tile_channels_last(vid[0].cuda()).permute(3, 0, 1, 2)[None].float().cpu()          # [1,16,3,30,52]
+    for name, got in (("decode", dec), ("encode", enc)):
+        assert tuple(got.shape) == tuple(int(v) for v in g[f"{name}_shape"])
+        idx = gi.grad_sample_index(got.numel(), seed=3100 + len(name), k=8192)
+        s32 = torch.from_numpy(g[f"{name}_sample_f32"])
+        sbf = gi.from_u16(g[f"{name}_sample_bf16"]).float()
+        e, e_ref = rel_l2(got.flatten()[idx], s32), rel_l2(sbf, s32)
+        assert e < max(1.5e-2, 1.5 * e_ref), f"{name}: sampled rel-L2 {e:.3e} (reference bf16 {e_ref:.3e})"
+        ss = got.double().pow(2).sum(dim=(0, 3, 4)).numpy()
+        ref = g[f"{name}_sumsq_f32"]
+        assert np.all(np.abs(ss - ref) <= 0.02 * ref + 1e-6), f"{name}: per-(channel, frame) energy off by {np.max(np.abs(ss / ref - 1)):.3e}"
