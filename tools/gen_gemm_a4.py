@@ -30,7 +30,13 @@ Measured and NOT kept (same box, one process, tools/gemm_ab.py; profiles/r02/gem
   * un-permuted source chunks (what a padded instead of XOR-swizzled LDS image would fetch): no difference;
   * two barriers per iteration instead of three (all 16 k-sub-step-1 reads, one barrier, then the 16 pieces two MFMAs apart):
     4 % slower on all three shapes — although a timing-only build WITHOUT barriers is 2.4 / 3.7 / 11 % faster (D->F / D->D /
-    F->D) while one without the counted vmcnt wait gains nothing: the loss is waves waiting for each other, not for memory.
+    F->D) while one without the counted vmcnt wait gains nothing: the loss is waves waiting for each other, not for memory;
+  * a PERSISTENT kernel (one workgroup per CU walking the tiles) that requests the next C tile's first two K tiles before the
+    epilogue of the current one (two asm statements per tile, 8 KiB of epilogue scratch per wave behind the stages, epilogue in
+    four passes): correct, bit-identical, and exactly as fast as one workgroup per tile (±1 %, gemm_ab_persistent_prefetch.txt) —
+    the ~12 us per tile outside the K loop are not request latency or workgroup turnover;
+  * a start-up skew per workgroup on top of it (all CUs otherwise reach their epilogues together): no gain at 32 ns - 0.25 us per
+    workgroup, slower beyond (gemm_ab_startup_skew.txt).
 """
 import os
 
