@@ -29,6 +29,18 @@
 #ifndef GF_ATTN_SCHED
 #define GF_ATTN_SCHED 1
 #endif
+#ifndef GF_K3_CINIT
+#define GF_K3_CINIT 1    // kernel 3: Q carries scale*log2(e) and the QK^T chains start from -max: no scale-and-subtract per score
+#endif
+#ifndef GF_K3_SUMMFMA
+#define GF_K3_SUMMFMA 0  // kernel 3: row sums on the matrix pipe (a ninth "d block" against a ones fragment) instead of 32 v_add_f32
+#endif
+#ifndef GF_K3_RING
+#define GF_K3_RING 2     // kernel 3: operand fragments in flight (registers are the scarce resource at two waves per SIMD)
+#endif
+#ifndef GF_K3_WHATIF
+#define GF_K3_WHATIF 0   // timing-only variants of kernel 3's steady phase (tools/attn_ab.py); 0 in the shipped library
+#endif
 #ifndef GF_ATTN_BUFFER_DMA
 #define GF_ATTN_BUFFER_DMA 1   // 1: K/V staging by buffer_load ... lds with scalar tile offsets; 0: global_load_lds (A/B builds)
 #endif
@@ -917,6 +929,514 @@ __global__ __launch_bounds__(AT2_THREADS, 2) void flash_attn_fwd_kernel2(const A
     }
 }
 
+// ================================================================================================================
+// Kernel 3 (round 2): the same tile pipeline on v_mfma_f32_16x16x32_bf16.
+// Why: on RANDOM operands the chip lowers its clock under an MFMA-dense load, and the 32x32x16 form draws more per FLOP:
+// a bare MFMA loop with every CU busy delivers 1.77 PFLOP/s with 32x32x16 and 2.00 with 16x16x32 (zeros: 2.45 both;
+// tools/probes/mfma_shape_power.hip).  Kernel 2 runs at 1.62 PFLOP/s on all-zero q/k/v and 1.17-1.25 on random data with the
+// SAME instruction stream (tools/microbench.py attn --zeros): it is bound by that clock, not by its issue slots.
+//
+// Layouts (r = lane & 15, g = lane >> 4; a wave still owns 32 query rows = two 16-query blocks qb):
+//   S^T = K Q^T : A = K[16 keys x 32 d] (one ds_read_b128: row 16 kb + r, 16-byte chunk 4 ks + g), B = Q^T (registers),
+//                 D = sc[kb][qb] (f32x4): query 16 qb + r, keys 16 kb + 4 g + j.
+//   The lane's 32 scores of a tile belong to ONE query per qb, spread over the four g-lanes of that query: the running max is
+//   kept identical in those four lanes, the lazy-rescale test `all scores <= max + 6` needs no cross-lane step (it is the same
+//   test on the partial maxima), row sums stay partial per lane until the epilogue; only the rare rescale reduces over g.
+//   O^T += V^T P^T : B = P^T[32 keys x 16 queries] = {sc[2kk][qb][0..3], sc[2kk+1][qb][0..3]} converted in place (lane-local),
+//                 A = V^T[16 d x 32 keys] (one ds_read_b128: row 16 db + r, chunk 4 kk + g of the pre-transposed copy, whose
+//                 keys are stored inside every group of 32 in the B operand's order: position 8 g + i <-> key 4 g + i (i < 4),
+//                 16 + 4 g + i - 4 (i >= 4): gf_transpose_v32), D = oacc[db][qb] (f32x4): query 16 qb + r, d = 16 db + 4 g + j.
+//   Per 64-key tile and wave: 32 + 32 MFMAs of 16 cycles (kernel 2: 16 + 16 of 32), the same 32 fragment reads (each feeds the
+//   two query blocks), the same 32 scores per lane.  K image: 256-byte rows, chunk ^ (row & 15) (conflict-free for the
+//   16-row x 4-chunk fragment read; the 32x32x16 image is 2-way here); V^T image as in kernel 2.
+constexpr int AT3_THREADS = 512;
+constexpr int AT3_V_BASE = 2 * KV_TILE_BYTES;
+constexpr int AT3_LDS = 4 * KV_TILE_BYTES;
+
+__device__ __forceinline__ void mfma16(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(AT3_THREADS, 2) void flash_attn_fwd_kernel3(const AttnArgs p) {
+    constexpr bool CINIT = GF_K3_CINIT != 0, SUMMFMA = GF_K3_SUMMFMA != 0;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    GF_LDS char* lds = (GF_LDS char*)smem;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    int head, qb0;
+    {
+        const int pid = blockIdx.x;
+        if ((p.heads & 7) == 0) {
+            const int xcd = pid & 7, idx = pid >> 3;
+            head = xcd + 8 * (idx / p.n_qblocks);
+            qb0 = idx % p.n_qblocks;
+        } else {
+            head = pid / p.n_qblocks;
+            qb0 = pid % p.n_qblocks;
+        }
+    }
+    const int q0 = qb0 * QB + wave * 32;
+
+    bf16x8 qf[2][4];   // [qb][ks]: Q[q0 + 16 qb + r][32 ks + 8 g .. +8)
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int qr = min(q0 + 16 * qb + r, p.q_len - 1);
+        const u16* qp = p.q + (long)qr * p.q_stride + head * HD + 8 * g;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            // Q carries the softmax scale and log2(e): S' = (c q) k is the score in the exp2 domain, and with the running maximum
+            // as the MFMA's initial accumulator the exponent argument leaves the matrix pipe ready — no scale-and-subtract per
+            // score (32 VALU instructions per tile and wave in a loop that is bound by its issue slots, not by the matrix pipe).
+            const bf16x8 raw = *reinterpret_cast<const bf16x8*>(qp + 32 * ks);
+            if constexpr (CINIT) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) qf[qb][ks][e] = (__bf16)((float)raw[e] * p.scale_log2e);
+            } else {
+                qf[qb][ks] = raw;
+            }
+        }
+    }
+
+    // ---- staging (LDS-DMA, buffer form): wave w fills K row-groups 2w, 2w+1 (4 rows x 256 B; lane L: row L >> 4, physical
+    // chunk L & 15 = logical chunk ^ (row & 15)) and V^T rows 16w .. 16w+15 as two pieces of 8 rows (lane L: row L >> 3,
+    // physical chunk L & 7 = logical chunk ^ ((row >> 1) & 7))
+    const int dma_r = lane >> 4;
+    unsigned k_off[2], vt_off[2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const int row = 4 * (2 * wave + jj) + dma_r;
+        const int lch = (lane & 15) ^ (row & 15);
+        k_off[jj] = ((unsigned)row * (unsigned)p.k_stride + head * HD + lch * 8) * 2u;                 // bytes
+        const int vrow = 16 * wave + 8 * jj + (lane >> 3);
+        const int vch = (lane & 7) ^ ((vrow >> 1) & 7);
+        vt_off[jj] = (unsigned)(((long)head * HD + vrow) * p.kv_pad + vch * 8) * 2u;                   // bytes
+    }
+    const unsigned kstep = KVB * (unsigned)p.k_stride * 2u;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4s;
+    auto make_srd = [](const void* base) {
+        const unsigned long b = (unsigned long)base;
+        u32x4s s;
+        s[0] = (unsigned)b;
+        s[1] = (unsigned)(b >> 32) & 0xffffu;
+        s[2] = 0xffffffffu;
+        s[3] = 0x00020000u;
+        return s;
+    };
+    const u32x4s srd_k = make_srd(p.k), srd_v = make_srd(p.vt);
+    auto dma16b = [&](const u32x4s& srd, unsigned voff_bytes, unsigned soff_bytes, GF_LDS char* l) {
+        unsigned keep;
+        const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)l);
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(voff_bytes), "s"(srd), "s"(dst), "s"(soff_bytes)
+                     : "memory");
+    };
+    auto dma16g = [&](const u16* gp, GF_LDS char* l) {   // 64-bit per-lane address: the clamped rows of a ragged last K tile
+        unsigned keep;
+        const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)l);
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(gp), "s"(dst)
+                     : "memory");
+    };
+    // which = 0: K tile t -> K buffer buf;  which = 1: V^T tile t -> V buffer buf;  jj = which of the wave's two pieces
+    auto stage_piece = [&](int which, int t, int buf, int jj) {
+        GF_LDS char* base = lds + which * AT3_V_BASE + buf * KV_TILE_BYTES + wave * 2048 + jj * 1024;
+        if (which) {
+            dma16b(srd_v, vt_off[jj], (unsigned)t * (KVB * 2u), base);
+        } else if ((t + 1) * KVB <= p.kv_len) {
+            dma16b(srd_k, k_off[jj], (unsigned)t * kstep, base);
+        } else {   // ragged last tile: clamp the row (its scores are masked)
+            const int row = 4 * (2 * wave + jj) + dma_r;
+            const long rr = min(t * KVB + row, p.kv_len - 1);
+            const int lch = (lane & 15) ^ (row & 15);
+            dma16g(p.k + rr * p.k_stride + head * HD + lch * 8, base);
+        }
+    };
+    auto stage = [&](int which, int t, int buf) {
+        stage_piece(which, t, buf, 0);
+        stage_piece(which, t, buf, 1);
+    };
+
+    // ---- fragment read offsets (bytes inside a buffer): K (kb, ks): koff[ks] + kb * 4096;  V^T (db, kk): voff[kk] + db * 2048
+    int koff[4], voff[2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) koff[ks] = 256 * r + 16 * ((4 * ks + g) ^ r);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) voff[kk] = AT3_V_BASE + 128 * r + 16 * ((4 * kk + g) ^ ((r >> 1) & 7));
+
+    // oacc[db][qb], db < 8: O^T;  oacc[8][qb]: the row sums — a ninth "d block" whose V^T fragment is the constant `ones` (row 0
+    // all ones): the matrix pipe adds up the bf16 P it multiplies with anyway (4 MFMAs per tile instead of 32 v_add_f32), and the
+    // sums are rescaled together with O.  sc[tile parity][kb][qb] = S' - m_run (log2 domain).
+    constexpr int NDB = SUMMFMA ? 9 : 8;
+    f32x4 oacc[NDB][2], sc[2][4][2];
+    bf16x8 pf[2][2];                 // P fragments [kk][qb]
+    // CINIT: m_run is the running maximum in the exp2 domain and the scores are kept relative to it; otherwise m_run is the
+    // maximum of the raw scores (times c in the exponent) as in kernel 2.  l_run: per-lane partial row sums (SUMMFMA = 0).
+    float m_run[2] = {CINIT ? 0.f : -1.0e30f, CINIT ? 0.f : -1.0e30f}, alpha_pend[2] = {1.f, 1.f}, l_run[2] = {0.f, 0.f};
+    const float c = CINIT ? 1.0f : p.scale_log2e;
+    f32x4 negm[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};   // -m_run splat: the QK^T chains start from it
+    bool pend = false;               // wave-uniform: O still has to be multiplied by alpha_pend
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) oacc[db][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 ones;
+    {
+        const __bf16 o1 = (__bf16)(r == 0 ? 1.0f : 0.0f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ones[e] = o1;
+    }
+    const int nt = (p.kv_len + KVB - 1) / KVB;
+    const bool ragged = (p.kv_len & (KVB - 1)) != 0;
+    typedef std::integral_constant<int, 0> C0;
+    typedef std::integral_constant<int, 1> C1;
+
+    // ---- unpipelined building blocks (prologue, first and last phase)
+    auto qk_plain = [&](auto par_c) {   // S(par) = K(buffer par) Q^T
+        constexpr int PAR = decltype(par_c)::value;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) sc[PAR][kb][qb] = CINIT ? negm[qb] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                const bf16x8 kf = *(GF_LDS bf16x8*)(lds + koff[ks] + kb * 4096 + PAR * KV_TILE_BYTES);
+                mfma16(sc[PAR][kb][0], kf, qf[0][ks]);
+                mfma16(sc[PAR][kb][1], kf, qf[1][ks]);
+            }
+    };
+    auto pv_plain = [&](auto buf_c) {   // O^T += V(buffer)^T P^T
+        constexpr int BUF = decltype(buf_c)::value;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int db = 0; db < 8; ++db) {
+                const bf16x8 vf = *(GF_LDS bf16x8*)(lds + voff[kk] + db * 2048 + BUF * KV_TILE_BYTES);
+                mfma16(oacc[db][0], vf, pf[kk][0]);
+                mfma16(oacc[db][1], vf, pf[kk][1]);
+            }
+        if constexpr (SUMMFMA) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                mfma16(oacc[NDB - 1][0], ones, pf[kk][0]);
+                mfma16(oacc[NDB - 1][1], ones, pf[kk][1]);
+            }
+        }
+    };
+    auto apply_pending = [&]() {
+        if (pend) {
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) oacc[db][qb][e] *= alpha_pend[qb];
+            pend = false;
+        }
+    };
+    // mx[qb] = this lane's partial maximum of its query's scores in tile PAR, RELATIVE to the running maximum (the scores are
+    // S' - m_run).  Rare path (`first`: always): the running maximum moves to the tile's row maximum; the tile's scores, which the
+    // matrix pipe produced against the old maximum, are corrected here, later tiles start from the new one (negm).
+    auto new_max = [&](auto par_c, float mx0, float mx1, bool first) {
+        constexpr int PAR = decltype(par_c)::value;
+        const bool quiet = CINIT ? __all(mx0 <= 6.0f && mx1 <= 6.0f) : __all((mx0 - m_run[0]) * c <= 6.0f && (mx1 - m_run[1]) * c <= 6.0f);
+        if (first || !quiet) {
+            float mx[2] = {mx0, mx1};
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                float d = mx[qb];                        // reduce over the four g-lanes of the query
+                d = fmaxf(d, __shfl_xor(d, 16));
+                d = fmaxf(d, __shfl_xor(d, 32));
+                float alpha;
+                if constexpr (CINIT) {
+                    if (!first) d = fmaxf(d, 0.f);       // the maximum never moves down (the first tile sets it, whatever its sign)
+                    m_run[qb] += d;
+                    alpha = __builtin_amdgcn_exp2f(-d);
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) sc[PAR][kb][qb][e] -= d;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) negm[qb][e] = -m_run[qb];
+                } else {
+                    const float m_new = fmaxf(m_run[qb], d);
+                    alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * c);
+                    m_run[qb] = m_new;
+                }
+                l_run[qb] *= alpha;
+                alpha_pend[qb] = alpha;   // at most one outstanding: applied at the top of the next phase
+            }
+            pend = !(CINIT && first) || pend;
+            if (CINIT && first) pend = false;
+        }
+    };
+    auto mask_ragged = [&](auto par_c, int t) {
+        constexpr int PAR = decltype(par_c)::value;
+        if (ragged && t == nt - 1) {
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (t * KVB + 16 * kb + 4 * g + j >= p.kv_len) {
+                        sc[PAR][kb][0][j] = -INFINITY;
+                        sc[PAR][kb][1][j] = -INFINITY;
+                    }
+        }
+    };
+    auto softmax_plain = [&](auto par_c, int t) {
+        constexpr int PAR = decltype(par_c)::value;
+        mask_ragged(par_c, t);
+        float mx[2];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            mx[qb] = sc[PAR][0][qb][0];
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mx[qb] = fmaxf(mx[qb], sc[PAR][kb][qb][j]);
+        }
+        new_max(par_c, mx[0], mx[1], t == 0);
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            const float mc = CINIT ? 0.f : m_run[qb] * c;
+            float rs = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float sv = sc[PAR][kb][qb][j];
+                    const float pe = __builtin_amdgcn_exp2f(CINIT ? sv : __builtin_fmaf(sv, c, -mc));
+                    rs += pe;
+                    pf[kb >> 1][qb][(kb & 1) * 4 + j] = (__bf16)pe;
+                }
+            if constexpr (!SUMMFMA) l_run[qb] += rs;
+        }
+    };
+
+    // ---- the steady phase p (1 <= p <= nt-2), PAR = p & 1: 64 matrix slots
+    //   s <  32: PV(p-1)  kk = s >> 4, db = (s >> 1) & 7, qb = s & 1    A = V^T fragment (db, kk) of V buffer 1-PAR
+    //   s >= 32: QK(p+1)  ks = (s-32) >> 3, kb = ((s-32) >> 1) & 3, qb = s & 1    A = K fragment (kb, ks) of K buffer 1-PAR
+    // A fragment serves the two query blocks of a slot pair; fragment f (= slot pair) is read three pairs ahead into ring
+    // entry f & 3.  The partial maxima of S(p) are taken in slots 0-7, the rescale test follows slot 7, its 32 scores are
+    // exponentiated in slots 16-62.
+    constexpr int RING = GF_K3_RING;       // fragment ring entries; a fragment is read RING - 1 slot pairs ahead of its use
+    bf16x8 fr[RING];
+    auto frag_load = [&](auto f_c, auto par_c) {
+        constexpr int F = decltype(f_c)::value, PAR = decltype(par_c)::value;
+        if constexpr (F < 16) {
+            constexpr int kk = F >> 3, db = F & 7;
+            fr[F % RING] = *(GF_LDS bf16x8*)(lds + voff[kk] + db * 2048 + (1 - PAR) * KV_TILE_BYTES);
+        } else if constexpr (F < 32) {
+            constexpr int ks = (F - 16) >> 2, kb = (F - 16) & 3;
+            fr[F % RING] = *(GF_LDS bf16x8*)(lds + koff[ks] + kb * 4096 + (1 - PAR) * KV_TILE_BYTES);
+        }
+    };
+    auto mfma_op = [&](auto s_c, auto par_c) {
+        constexpr int S = decltype(s_c)::value, PAR = decltype(par_c)::value;
+        constexpr int F = S >> 1, qb = S & 1;
+        if constexpr (S < 32) {
+            constexpr int kk = F >> 3, db = F & 7;
+            mfma16(oacc[db][qb], fr[F % RING], pf[kk][qb]);
+        } else {
+            constexpr int ks = (F - 16) >> 2, kb = (F - 16) & 3;
+            if constexpr (ks == 0) {
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                sc[1 - PAR][kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[F % RING], qf[qb][ks], CINIT ? negm[qb] : zero, 0, 0, 0);
+            } else {
+                mfma16(sc[1 - PAR][kb][qb], fr[F % RING], qf[qb][ks]);
+            }
+        }
+    };
+    auto dma_slot = [&](auto s_c, auto par_c, int pidx) {
+        constexpr int S = decltype(s_c)::value, PAR = decltype(par_c)::value;
+        if constexpr (S == 10) stage_piece(1, pidx, PAR, 0);
+        if constexpr (S == 18) stage_piece(1, pidx, PAR, 1);
+        if constexpr (S == 26) { if (pidx + 2 < nt) stage_piece(0, pidx + 2, PAR, 0); }
+        if constexpr (S == 34) { if (pidx + 2 < nt) stage_piece(0, pidx + 2, PAR, 1); }
+    };
+    auto phase = [&](auto par_c, int pidx) {
+        constexpr int PAR = decltype(par_c)::value;
+        apply_pending();
+        static_for<0, RING - 1>([&](auto f_c) { frag_load(f_c, par_c); });
+        float mx[2] = {-INFINITY, -INFINITY};
+        static_for<0, 8>([&](auto s_c) {
+            constexpr int S = decltype(s_c)::value;
+            mfma_op(s_c, par_c);
+            if constexpr ((S & 1) == 0) frag_load(std::integral_constant<int, (S >> 1) + RING - 1>{}, par_c);
+            // partial maxima: slot S takes key block S >> 1 of query block S & 1 (4 scores: one v_max3 + one v_max)
+            {
+                constexpr int kb = S >> 1, qb = S & 1;
+                const f32x4& v = sc[PAR][kb][qb];
+                mx[qb] = fmaxf(fmaxf(mx[qb], v[0]), v[1]);
+                mx[qb] = fmaxf(fmaxf(mx[qb], v[2]), v[3]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        new_max(par_c, mx[0], mx[1], false);
+        const float mc[2] = {CINIT ? 0.f : m_run[0] * c, CINIT ? 0.f : m_run[1] * c};
+        float pe[2], rs[2] = {0.f, 0.f};
+        static_for<8, 64>([&](auto s_c) {
+            constexpr int S = decltype(s_c)::value;
+            mfma_op(s_c, par_c);
+            // the four row-sum MFMAs of PV(p-1) ride in the PV half: after slots 15 / 31 (pf[kk] complete its last use there)
+            if constexpr (SUMMFMA && (S == 15 || S == 31)) {
+                mfma16(oacc[NDB - 1][0], ones, pf[S >> 4][0]);
+                mfma16(oacc[NDB - 1][1], ones, pf[S >> 4][1]);
+            }
+            if constexpr ((S & 1) == 0) frag_load(std::integral_constant<int, (S >> 1) + RING - 1>{}, par_c);
+            dma_slot(s_c, par_c, pidx);
+            // scores of S(p): two per three slots from slot 16 on.  P(p) overwrites pf, which PV(p-1) still reads: pf[0][*] until slot
+            // 15, pf[1][*] until slot 31 — so the scores that land in pf[0] (key blocks 0, 1) come first (slots 16..39) and those
+            // for pf[1] (key blocks 2, 3) from slot 40 on.  e -> kk = e >> 4, qb = (e >> 3) & 1, kb = 2 kk + ((e >> 2) & 1), j = e & 3.
+            if constexpr (S >= 16 && (S - 16) % 3 != 2) {
+                constexpr int e = ((S - 16) / 3) * 2 + (S - 16) % 3;
+                constexpr int kk = e >> 4, qb = (e >> 3) & 1, kb = 2 * kk + ((e >> 2) & 1), j = e & 3;
+                float sv = sc[PAR][kb][qb][j];
+                asm volatile("" : "+v"(sv));
+                pe[e & 1] = __builtin_amdgcn_exp2f(CINIT ? sv : __builtin_fmaf(sv, c, -mc[qb]));
+                if constexpr (!SUMMFMA) rs[qb] += pe[e & 1];
+                if constexpr (e & 1) {
+                    asm volatile("" : "+v"(pe[0]), "+v"(pe[1]), "+v"(rs[qb]));
+                    pf[kk][qb][(kb & 1) * 4 + j - 1] = (__bf16)pe[0];
+                    pf[kk][qb][(kb & 1) * 4 + j] = (__bf16)pe[1];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if constexpr (!SUMMFMA) {
+            l_run[0] += rs[0];
+            l_run[1] += rs[1];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+
+    // ---- prologue: K(0), K(1) staged; S(0)
+    stage(0, 0, 0);
+    if (nt > 1) stage(0, 1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    qk_plain(C0{});
+    __syncthreads();   // every wave has read K(0) before K(2) overwrites its buffer
+    // ---- phase 0 (no PV yet): K(2), V(0) in flight; S(1); softmax(0)
+    if (nt > 2) stage(0, 2, 0);
+    stage(1, 0, 0);
+    if constexpr (CINIT) {
+        softmax_plain(C0{}, 0);          // sets the running maximum (tile 0's row maximum) ...
+        if (nt > 1) qk_plain(C1{});      // ... which S(1) already starts from
+    } else {
+        if (nt > 1) qk_plain(C1{});
+        softmax_plain(C0{}, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // ---- steady phases 1 .. nt-2
+    int pi = 1;
+    for (; pi + 1 <= nt - 2; pi += 2) {
+        phase(C1{}, pi);
+        phase(C0{}, pi + 1);
+    }
+    if (pi <= nt - 2) {
+        phase(C1{}, pi);
+        ++pi;
+    }
+    // ---- last phase p = nt-1 (nt >= 2): V(nt-1) in flight; PV(nt-2); softmax(nt-1)
+    if (nt >= 2) {
+        const int par = (nt - 1) & 1;
+        stage(1, nt - 1, par);
+        apply_pending();
+        if (par) {
+            pv_plain(C0{});
+            softmax_plain(C1{}, nt - 1);
+        } else {
+            pv_plain(C1{});
+            softmax_plain(C0{}, nt - 1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    // ---- PV(nt-1)
+    apply_pending();
+    if ((nt - 1) & 1)
+        pv_plain(C1{});
+    else
+        pv_plain(C0{});
+
+    // ---- epilogue
+    {
+        float inv[2];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            float l;
+            if constexpr (SUMMFMA) {
+                l = __shfl(oacc[NDB - 1][qb][0], r);        // row 0 of the ninth block: lane g == 0 of the query holds it
+            } else {
+                l = l_run[qb];
+                l += __shfl_xor(l, 16);
+                l += __shfl_xor(l, 32);
+            }
+            inv[qb] = 1.0f / l;
+            const int qrow = q0 + 16 * qb + r;
+            if (p.lse && g == 0 && qrow < p.q_len) p.lse[(long)qrow * p.heads + head] = m_run[qb] * c + __builtin_amdgcn_logf(l);
+        }
+        // O leaves through LDS as whole 256-byte rows: the wave's 32 x 256 B image, 16-byte chunk ch of row q at chunk ch ^ (q & 15);
+        // a lane holds the 8-byte pieces d = 16 db + 4 g .. +3 of its two rows.  The K/V tiles are dead at this barrier.
+        __syncthreads();
+        GF_LDS char* ob = lds + wave * 8192;
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int db = 0; db < 8; ++db) {
+                u32x2 pk;
+                pk[0] = pack2bf(oacc[db][qb][0] * inv[qb], oacc[db][qb][1] * inv[qb]);
+                pk[1] = pack2bf(oacc[db][qb][2] * inv[qb], oacc[db][qb][3] * inv[qb]);
+                const int row = 16 * qb + r;
+                *(GF_LDS u32x2*)(ob + row * 256 + (((2 * db + (g >> 1)) ^ (row & 15)) << 4) + 8 * (g & 1)) = pk;
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-local image: LDS is in order, no barrier needed
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = 4 * it + (lane >> 4), ch = lane & 15;
+            const u16x8 v8 = *(GF_LDS u16x8*)(ob + row * 256 + ((ch ^ (row & 15)) << 4));
+            if (q0 + row < p.q_len)
+                *reinterpret_cast<u16x8*>(p.o + (long)(q0 + row) * p.o_stride + head * HD + 8 * ch) = v8;
+        }
+    }
+}
+
+// V [kv_len, heads*128] -> V^T [heads][128][kv_pad] bf16 for kernel 3: keys >= kv_len zero; inside every group of 32 keys position
+// 8 g + i holds key 4 g + i (i < 4) or 16 + 4 g + (i - 4) (i >= 4) — the k order of the 16x16x32 B operand built from two score tiles.
+__global__ __launch_bounds__(256) void transpose_v32_kernel(const u16* __restrict__ v, u16* __restrict__ vt, int kv_len, long kv_pad,
+                                                            long v_stride) {
+    __shared__ u16 tile[KVB][HD + 8];
+    const int t0 = blockIdx.x * KVB, head = blockIdx.y, tid = threadIdx.x;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {                 // 64 rows x 16 chunks of 16 B
+        const int idx = it * 256 + tid, row = idx >> 4, ch = idx & 15;
+        u16x8 val = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (t0 + row < kv_len) val = *reinterpret_cast<const u16x8*>(v + (long)(t0 + row) * v_stride + head * HD + ch * 8);
+        *reinterpret_cast<u16x8*>(&tile[row][ch * 8]) = val;
+    }
+    __syncthreads();
+    const int d = tid >> 1, half = tid & 1;
+    u16* dst = vt + ((long)head * HD + d) * kv_pad + t0 + 32 * half;
+#pragma unroll
+    for (int cg = 0; cg < 4; ++cg) {                 // chunk cg = the 8 positions of lane group g = cg
+        u16x8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int key = 32 * half + (i < 4 ? 4 * cg + i : 16 + 4 * cg + (i - 4));
+            o[i] = tile[key][d];
+        }
+        *reinterpret_cast<u16x8*>(dst + 8 * cg) = o;
+    }
+}
+
 // V [kv_len, heads*128] -> V^T [heads][128][kv_pad] bf16, keys >= kv_len zero; inside every group of 16 keys the order is
 // 0-3, 8-11, 4-7, 12-15 (what a lane half of the 32x32x16 B operand holds).  One workgroup per (64-key tile, head).
 __global__ __launch_bounds__(256) void transpose_v_kernel(const u16* __restrict__ v, u16* __restrict__ vt, int kv_len, long kv_pad,
@@ -1063,4 +1583,68 @@ extern "C" GF_API int gf_flash_attn_fwd_vt(const void* q, const void* k, const v
     GF_CHECK_ARG(heads * HD * kv_pad < (1LL << 31), "gf_flash_attn_fwd_vt: heads*128*kv_pad must stay below 2^31 elements");
     return flash_attn_fwd_impl(q, k, k, o, lse, q_len, kv_len, heads, head_dim, q_stride, k_stride, k_stride, o_stride, scale,
                                stream, vt, kv_pad);
+}
+
+extern "C" GF_API int gf_transpose_v32(const void* v, int64_t v_stride, void* vt, int64_t kv_len, int64_t kv_pad, int64_t heads,
+                                       void* stream) {
+    GF_CHECK_ARG(v && vt, "gf_transpose_v32: null pointer");
+    GF_CHECK_ARG(kv_len > 0 && heads > 0 && kv_pad >= kv_len && kv_pad % KVB == 0 && v_stride % 8 == 0 && v_stride >= heads * HD,
+                 "gf_transpose_v32: kv_pad must be a multiple of 64 covering kv_len; v_stride must cover heads*128");
+    GF_CHECK_ARG(gf_aligned16(v) && gf_aligned16(vt), "gf_transpose_v32: 16-byte alignment required");
+    GF_CHECK_ARG(heads * HD * kv_pad < (1LL << 31), "gf_transpose_v32: heads*128*kv_pad must stay below 2^31 elements");
+    hipLaunchKernelGGL(transpose_v32_kernel, dim3((unsigned)(kv_pad / KVB), (unsigned)heads), dim3(256), 0, (hipStream_t)stream,
+                       (const u16*)v, (u16*)vt, (int)kv_len, (long)kv_pad, (long)v_stride);
+    GF_CHECK_LAUNCH("gf_transpose_v32");
+    return GF_OK;
+}
+
+extern "C" GF_API int gf_flash_attn_fwd_vt32(const void* q, const void* k, const void* vt, void* o, float* lse, int64_t q_len,
+                                             int64_t kv_len, int64_t kv_pad, int64_t heads, int64_t head_dim, int64_t q_stride,
+                                             int64_t k_stride, int64_t o_stride, float scale, void* stream) {
+    GF_CHECK_ARG(q && k && vt && o, "gf_flash_attn_fwd_vt32: null pointer");
+    if (head_dim != HD) {
+        gf_set_error("gf_flash_attn_fwd_vt32: head_dim=%ld unsupported (kernel is built for 128)", (long)head_dim);
+        return GF_ERR_UNSUPPORTED;
+    }
+    GF_CHECK_ARG(q_len >= 0 && kv_len >= 2 * KVB && heads > 0 && q_len < (1 << 30) && kv_len < (1 << 30),
+                 "gf_flash_attn_fwd_vt32: bad lengths q=%ld kv=%ld heads=%ld (kv_len >= 128)", (long)q_len, (long)kv_len, (long)heads);
+    GF_CHECK_ARG(kv_pad >= kv_len && kv_pad % KVB == 0 && heads * HD * kv_pad < (1LL << 31), "gf_flash_attn_fwd_vt32: bad V^T buffer");
+    GF_CHECK_ARG(q_stride % 8 == 0 && k_stride % 8 == 0 && o_stride % 4 == 0 && q_stride >= heads * HD && k_stride >= heads * HD &&
+                     o_stride >= heads * HD,
+                 "gf_flash_attn_fwd_vt32: strides must cover heads*128 and be multiples of 8");
+    GF_CHECK_ARG(gf_aligned16(q) && gf_aligned16(k) && gf_aligned16(vt) && gf_aligned16(o),
+                 "gf_flash_attn_fwd_vt32: 16-byte alignment required");
+    GF_CHECK_ARG((kv_len + 64) * k_stride < (1LL << 31), "gf_flash_attn_fwd_vt32: kv_len*stride must stay below 2^31 elements");
+    if (q_len == 0) return GF_OK;
+    static GfDeviceOnce once;
+    hipError_t e = gf_once_per_device(once, [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_fwd_kernel3),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, AT3_LDS);
+    });
+    if (e != hipSuccess) {
+        gf_set_error("gf_flash_attn_fwd_vt32: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+        return GF_ERR_LAUNCH;
+    }
+    AttnArgs a;
+    a.q = (const u16*)q;
+    a.k = (const u16*)k;
+    a.v = (const u16*)k;
+    a.o = (u16*)o;
+    a.q_len = (int)q_len;
+    a.kv_len = (int)kv_len;
+    a.heads = (int)heads;
+    a.n_qblocks = (int)((q_len + QB - 1) / QB);
+    a.q_stride = q_stride;
+    a.k_stride = k_stride;
+    a.v_stride = k_stride;
+    a.o_stride = o_stride;
+    a.scale_log2e = scale * 1.4426950408889634f;
+    a.lse = lse;
+    a.vt = (const u16*)vt;
+    a.kv_pad = kv_pad;
+    a.dbg = nullptr;
+    hipLaunchKernelGGL(flash_attn_fwd_kernel3, dim3((unsigned)(a.n_qblocks * a.heads)), dim3(AT3_THREADS), AT3_LDS,
+                       (hipStream_t)stream, a);
+    GF_CHECK_LAUNCH("gf_flash_attn_fwd_vt32");
+    return GF_OK;
 }

@@ -193,10 +193,12 @@ def flash_attn(q, k, v, num_heads, out=None, scale=None):
         # long key sequences (the DiT self-attention): hand V over pre-transposed — one LDS read per PV MFMA instead of two;
         # the transpose (0.7 % of the attention's time at S=32760) is inside the timed region
         vt = _vt_workspace(num_heads * 128 * kv_pad, q.device)
-        _lib.check(lib.gf_transpose_v(_ptr(v), v.stride(0), _ptr(vt), skv, kv_pad, num_heads, _stream(q)), "gf_transpose_v")
-        _lib.check(lib.gf_flash_attn_fwd_vt(_ptr(q), _ptr(k), _ptr(vt), _ptr(out), None, sq, skv, kv_pad, num_heads, head_dim,
-                                            q.stride(0), k.stride(0), out.stride(0), float(scale), _stream(q)),
-                   "gf_flash_attn_fwd_vt")
+        # GF_ATTN_KERNEL=2 (read per call: A/B runs) selects the 32x32x16-MFMA kernel 2; default = kernel 3 on 16x16x32 MFMAs
+        k3 = os.environ.get("GF_ATTN_KERNEL", "3") == "3"
+        tr, fa = (lib.gf_transpose_v32, lib.gf_flash_attn_fwd_vt32) if k3 else (lib.gf_transpose_v, lib.gf_flash_attn_fwd_vt)
+        _lib.check(tr(_ptr(v), v.stride(0), _ptr(vt), skv, kv_pad, num_heads, _stream(q)), "gf_transpose_v")
+        _lib.check(fa(_ptr(q), _ptr(k), _ptr(vt), _ptr(out), None, sq, skv, kv_pad, num_heads, head_dim,
+                      q.stride(0), k.stride(0), out.stride(0), float(scale), _stream(q)), "gf_flash_attn_fwd_vt")
     else:
         _lib.check(lib.gf_flash_attn_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), sq, skv, num_heads, head_dim,
                                          q.stride(0), k.stride(0), v.stride(0), out.stride(0), float(scale),
@@ -226,10 +228,11 @@ def flash_attn_lse(q, k, v, num_heads, scale=None):
     kv_pad = -(-skv // 64) * 64
     if skv >= VT_MIN_KV and head_dim == 128 and num_heads * 128 * kv_pad < 2 ** 31:   # as flash_attn: pre-transposed V, same bits
         vt = _vt_workspace(num_heads * 128 * kv_pad, q.device)
-        _lib.check(lib.gf_transpose_v(_ptr(v), v.stride(0), _ptr(vt), skv, kv_pad, num_heads, _stream(q)), "gf_transpose_v")
-        _lib.check(lib.gf_flash_attn_fwd_vt(_ptr(q), _ptr(k), _ptr(vt), _ptr(out), _ptr(lse), sq, skv, kv_pad, num_heads, head_dim,
-                                            q.stride(0), k.stride(0), out.stride(0), float(scale), _stream(q)),
-                   "gf_flash_attn_fwd_vt")
+        k3 = os.environ.get("GF_ATTN_KERNEL", "3") == "3"
+        tr, fa = (lib.gf_transpose_v32, lib.gf_flash_attn_fwd_vt32) if k3 else (lib.gf_transpose_v, lib.gf_flash_attn_fwd_vt)
+        _lib.check(tr(_ptr(v), v.stride(0), _ptr(vt), skv, kv_pad, num_heads, _stream(q)), "gf_transpose_v")
+        _lib.check(fa(_ptr(q), _ptr(k), _ptr(vt), _ptr(out), _ptr(lse), sq, skv, kv_pad, num_heads, head_dim,
+                      q.stride(0), k.stride(0), out.stride(0), float(scale), _stream(q)), "gf_flash_attn_fwd_vt")
         return out, lse
     _lib.check(lib.gf_flash_attn_fwd_lse(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), sq, skv, num_heads, head_dim,
                                          q.stride(0), k.stride(0), v.stride(0), out.stride(0), float(scale),

@@ -138,6 +138,15 @@ GF_API int gf_flash_attn_fwd_vt(const void* q, const void* k, const void* vt, vo
                          int64_t q_len, int64_t kv_len, int64_t kv_pad, int64_t heads, int64_t head_dim,
                          int64_t q_stride, int64_t k_stride, int64_t o_stride, float scale, void* stream);
 
+/* gf_transpose_v32 + gf_flash_attn_fwd_vt32 — the self-attention of the DiT blocks (round 2; kv_len >= 128): the same attention
+ * (DIT:28-61) on v_mfma_f32_16x16x32_bf16, the MFMA shape the chip sustains a higher clock on under random data.  Same
+ * arguments as the pair above; the two V^T copies differ in the key order inside a 64-key tile and are NOT interchangeable
+ * (vt32: inside every group of 32 keys position 8 g + i holds key 4 g + i for i < 4, 16 + 4 g + i - 4 for i >= 4). */
+GF_API int gf_transpose_v32(const void* v, int64_t v_stride, void* vt, int64_t kv_len, int64_t kv_pad, int64_t heads, void* stream);
+GF_API int gf_flash_attn_fwd_vt32(const void* q, const void* k, const void* vt, void* o, float* lse,
+                                  int64_t q_len, int64_t kv_len, int64_t kv_pad, int64_t heads, int64_t head_dim,
+                                  int64_t q_stride, int64_t k_stride, int64_t o_stride, float scale, void* stream);
+
 /* ------------------------------------------------------------------------
  * Training (ControlNet training step): training_loss (GF:180-193) calls loss.backward() through
  * F.scaled_dot_product_attention (DIT:28-61) in every block.

@@ -225,17 +225,63 @@ def test_flash_attn(ops, sq, skv, heads):
 
 
 def test_flash_attn_lse_same_on_both_v_paths(ops, monkeypatch):
-    """flash_attn_lse (training forward) through the pre-transposed-V kernel == through the plain kernel: output and log-sum-exp."""
+    """flash_attn_lse (training forward).  Kernel 2 (32x32x16 MFMA) through the pre-transposed-V path == through the plain path,
+    bit for bit; kernel 3 (16x16x32 MFMA, the default for long key sequences; Q pre-scaled, other summation order) agrees
+    with them to bf16 noise, and its log-sum-exp with an fp32 reference."""
     g = torch.Generator().manual_seed(77)
     sq, skv, heads = 300, 2100, 3
     q, k, v = (dev(torch.randn((n, heads * 128), generator=g).to(BF)) for n in (sq, skv, skv))
-    o1, l1 = ops.flash_attn_lse(q, k, v, heads)                 # skv >= VT_MIN_KV: V^T path
+    o3, l3 = ops.flash_attn_lse(q, k, v, heads)                 # skv >= VT_MIN_KV: kernel 3
+    monkeypatch.setenv("GF_ATTN_KERNEL", "2")
+    o1, l1 = ops.flash_attn_lse(q, k, v, heads)                 # kernel 2, V^T path
     monkeypatch.setattr(ops, "VT_MIN_KV", 1 << 30)
-    o2, l2 = ops.flash_attn_lse(q, k, v, heads)                 # plain path
+    o2, l2 = ops.flash_attn_lse(q, k, v, heads)                 # kernel 2, plain path
     assert torch.equal(o1, o2) and torch.equal(l1, l2)
+    assert rel_l2(o3.float(), o1.float()) < 6e-3 and float((l3 - l1).abs().max()) < 2e-2
     ref = torch.logsumexp((q.float().view(sq, heads, 128).transpose(0, 1) @ k.float().view(skv, heads, 128).permute(1, 2, 0))
                           * (128 ** -0.5), dim=-1).t() * 1.4426950408889634
-    assert float((l1 - ref).abs().max()) < 2e-2
+    assert float((l1 - ref).abs().max()) < 2e-2 and float((l3 - ref).abs().max()) < 2e-2
+
+
+@pytest.mark.parametrize("sq,skv,heads", [(300, 2100, 3), (1000, 4100, 2), (257, 2048, 1), (33, 2368, 4), (512, 2049, 2)])
+def test_flash_attn_kernel3_vs_fp64(ops, sq, skv, heads):
+    """Kernel 3 (the self-attention path: key sequences >= 2048) against the full-tensor fp64 oracle: ragged last key tile,
+    partial last query block, one and several heads.  Same bar as the other attention tests."""
+    g = torch.Generator().manual_seed(sq + skv + heads)
+    q, k, v = (torch.randn((1, n, heads * 128), generator=g).to(BF) for n in (sq, skv, skv))
+    ref = wo.attention_fp64(q, k, v, heads)[0]
+    got = ops.flash_attn(dev(q[0]), dev(k[0]), dev(v[0]), heads).cpu()
+    assert rel_l2(got.float(), ref) < 4e-3
+    assert bool(torch.isfinite(got.float()).all())
+
+
+@pytest.mark.parametrize("case", ["spike_up_mid", "negative_start", "huge_then_small", "all_equal"])
+def test_flash_attn_kernel3_running_maximum_paths(ops, case):
+    """The running maximum of kernel 3 lives in the accumulators' initial value (scores are produced relative to it): force
+    every way it can move.  spike_up_mid: one key far above the rest in the middle of the sweep (rescale of O, the tile's
+    scores corrected in place); negative_start: the first tile's scores are all far below zero (the first maximum is
+    negative); huge_then_small: the first keys dominate, everything after underflows against them; all_equal: constant
+    scores (uniform softmax).  Full-tensor fp64 reference."""
+    g = torch.Generator().manual_seed(5)
+    sq, skv, heads, d = 200, 2560, 2, 128
+    q = (torch.randn((1, sq, heads * d), generator=g) * 0.3).to(BF)
+    k = (torch.randn((1, skv, heads * d), generator=g) * 0.3).to(BF)
+    v = torch.randn((1, skv, heads * d), generator=g).to(BF)
+    qdir = q[0, 7, :d].float()
+    if case == "spike_up_mid":
+        k[0, 1300, :d] = (qdir * 40).to(BF)                      # query 7 of head 0: score jumps by ~ +40 * |q|^2 at tile 20
+        k[0, 1900, d:] = (q[0, 50, d:].float() * 25).to(BF)      # another query / head, later
+    elif case == "negative_start":
+        k[0, :192, :d] = (-qdir * 30).to(BF)                     # the first three tiles score << 0 for query 7
+    elif case == "huge_then_small":
+        k[0, :64, :] = (q[0, 7, :].float() * 50).to(BF)
+    else:
+        k[0, :, :] = 0                                           # every score 0 -> uniform softmax over 2560 keys
+    ref = wo.attention_fp64(q, k, v, heads)[0]
+    got = ops.flash_attn(dev(q[0]), dev(k[0]), dev(v[0]), heads).cpu()
+    assert bool(torch.isfinite(got.float()).all())
+    assert rel_l2(got.float(), ref) < 5e-3, case
+    assert rel_l2(got.float()[7], ref[7]) < 8e-3, case           # the row the case is built around
 
 
 def test_flash_attn_forced_rescale_branch(ops):

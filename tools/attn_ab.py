@@ -29,6 +29,8 @@ def run(s, rounds):
     import torch
     H, D = 40, 5120
     q, k, v = (torch.randn((s, D), device="cuda").to(torch.bfloat16) for _ in range(3))
+    if "--zeros" in sys.argv:
+        q, k, v = (torch.zeros_like(t) for t in (q, k, v))
     kv_pad = -(-s // 64) * 64
     vt = torch.zeros((H * 128 * kv_pad,), dtype=torch.bfloat16, device="cuda")
     vp, i64 = ctypes.c_void_p, ctypes.c_int64
@@ -37,18 +39,22 @@ def run(s, rounds):
     libs, outs = {}, {}
     for path in sorted(glob.glob(os.path.join(OUT, "libgf_*.so"))):
         lib = ctypes.CDLL(path)
-        lib.gf_transpose_v.argtypes = [vp, i64, vp, i64, i64, i64, vp]
-        lib.gf_flash_attn_fwd_vt.argtypes = [vp] * 5 + [i64] * 8 + [ctypes.c_float, vp]
+        for fn in ("gf_transpose_v", "gf_transpose_v32"):
+            getattr(lib, fn).argtypes = [vp, i64, vp, i64, i64, i64, vp]
+        for fn in ("gf_flash_attn_fwd_vt", "gf_flash_attn_fwd_vt32"):
+            getattr(lib, fn).argtypes = [vp] * 5 + [i64] * 8 + [ctypes.c_float, vp]
         libs[os.path.basename(path)[6:-3]] = lib
     best = {n: 1e9 for n in libs}
     for rnd in range(rounds):
         for name, lib in libs.items():
             o = torch.empty_like(q)
 
+            k2 = name.startswith("k2")      # variant names starting with "k2" time kernel 2, everything else kernel 3
+            tr, fa = (lib.gf_transpose_v, lib.gf_flash_attn_fwd_vt) if k2 else (lib.gf_transpose_v32, lib.gf_flash_attn_fwd_vt32)
+
             def call():
-                assert lib.gf_transpose_v(v.data_ptr(), D, vt.data_ptr(), s, kv_pad, H, st) == 0
-                assert lib.gf_flash_attn_fwd_vt(q.data_ptr(), k.data_ptr(), vt.data_ptr(), o.data_ptr(), None, s, s, kv_pad, H, 128,
-                                                D, D, D, 128 ** -0.5, st) == 0
+                assert tr(v.data_ptr(), D, vt.data_ptr(), s, kv_pad, H, st) == 0
+                assert fa(q.data_ptr(), k.data_ptr(), vt.data_ptr(), o.data_ptr(), None, s, s, kv_pad, H, 128, D, D, D, 128 ** -0.5, st) == 0
             call()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--fp8", action="store_true")
     ap.add_argument("--s", type=int, default=S)
+    ap.add_argument("--zeros", action="store_true", help="attn: all-zero q/k/v as well (same instruction stream, no data toggling: "
+                    "how much of the time is the clock the chip grants an MFMA stream on REAL data)")
     ap.add_argument("--ab", action="store_true", help="gemm: interleaved A/B of GF_GEMM_KERNEL=a4 (4 waves, shipped) and ph (8 waves)")
     ap.add_argument("--ref", action="store_true", help="also time torch F.linear (hipBLASLt) on the same shapes: a yardstick, not a product path")
     a = ap.parse_args()
@@ -52,6 +54,24 @@ def main():
         med, mn = timeit(lambda: ops.flash_attn(q, k, v, H, out=o), a.iters)
         fl = 4.0 * s * skv * D
         print(f"flash_attn S={s} Skv={skv} H={H}: median {med:.3f} ms ({fl / med / 1e9:.1f} TFLOP/s), min {mn:.3f} ms ({fl / mn / 1e9:.1f} TFLOP/s)")
+        if a.ab:       # interleaved rounds of kernel 3 (16x16x32 MFMA) and kernel 2 (32x32x16) in this process
+            rounds = {"3": [], "2": []}
+            for _ in range(3):
+                for kern in ("3", "2"):
+                    os.environ["GF_ATTN_KERNEL"] = kern
+                    rounds[kern].append(timeit(lambda: ops.flash_attn(q, k, v, H, out=o), a.iters)[0])
+            os.environ.pop("GF_ATTN_KERNEL")
+            for kern, ts in rounds.items():
+                print(f"   A/B kernel {kern}: medians {', '.join(f'{t:.3f}' for t in ts)} ms -> {fl / min(ts) / 1e9:.1f} TFLOP/s best")
+        if a.zeros:
+            for name, mk in (("zeros", lambda t: torch.zeros_like(t)), ("ones", lambda t: torch.ones_like(t)),
+                             ("random again", lambda t: t)):
+                qq, kk, vv = mk(q), mk(k), mk(v)
+                for kern in ("3", "2"):
+                    os.environ["GF_ATTN_KERNEL"] = kern
+                    med, mn = timeit(lambda: ops.flash_attn(qq, kk, vv, H, out=o), a.iters)
+                    print(f"   {name:13s} kernel {kern}: median {med:.3f} ms ({fl / med / 1e9:.1f} TFLOP/s), min {mn:.3f} ms")
+                os.environ.pop("GF_ATTN_KERNEL")
     elif a.what == "attnbwd":
         q = torch.randn((s, D), device="cuda").to(BF)
         k = torch.randn((s, D), device="cuda").to(BF)

@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 # 1. per-kernel time of one denoise step + VAE decode (the same command as bench.py --steps 1)
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/bench_steps1.json.log 2> $OUT/trace.err
 python3 tools/rocpd_table.py $OUT/trace/bench_results.db 40 > $OUT/bench_steps1_by_kernel_and_grid.md 2>> $OUT/trace.err
-# 2. HBM traffic + matrix-pipe busy of the self-attention launch (transpose_v + flash_attn_fwd_kernel2<true>)
+# 2. HBM traffic + matrix-pipe busy of the self-attention launch (transpose_v32 + flash_attn_fwd_kernel3<true>)
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace -d $OUT/pmc_attn_$c -o a -- python3 tools/microbench.py attn --iters 2 > $OUT/pmc_attn_$c.log 2>&1
 done
