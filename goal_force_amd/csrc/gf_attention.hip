@@ -33,7 +33,7 @@
 #define GF_K3_CINIT 1    // kernel 3: Q carries scale*log2(e) and the QK^T chains start from -max: no scale-and-subtract per score
 #endif
 #ifndef GF_K3_SUMMFMA
-#define GF_K3_SUMMFMA 0  // kernel 3: row sums on the matrix pipe (a ninth "d block" against a ones fragment) instead of 32 v_add_f32
+#define GF_K3_SUMMFMA 1  // kernel 3: row sums on the matrix pipe (a ninth "d block" against a ones fragment) instead of 32 v_add_f32
 #endif
 #ifndef GF_K3_RING
 #define GF_K3_RING 2     // kernel 3: operand fragments in flight (registers are the scarce resource at two waves per SIMD)
@@ -949,7 +949,14 @@ __global__ __launch_bounds__(AT2_THREADS, 2) void flash_attn_fwd_kernel2(const A
 //   Per 64-key tile and wave: 32 + 32 MFMAs of 16 cycles (kernel 2: 16 + 16 of 32), the same 32 fragment reads (each feeds the
 //   two query blocks), the same 32 scores per lane.  K image: 256-byte rows, chunk ^ (row & 15) (conflict-free for the
 //   16-row x 4-chunk fragment read; the 32x32x16 image is 2-way here); V^T image as in kernel 2.
-constexpr int AT3_THREADS = 512;
+// NQ = 16-query blocks per wave: 2 -> 8 waves x 32 rows, two waves per SIMD (256 registers each).
+#ifndef GF_K3_NQ
+#define GF_K3_NQ 2
+#endif
+template <int NQ> struct At3 {
+    static constexpr int WAVES = 16 / NQ, THREADS = 64 * WAVES, ROWS = 16 * NQ, PIECES = NQ;   // PIECES: 1-KiB DMA pieces per wave and tile
+    static constexpr int SLOTS = 32 * NQ;
+};
 constexpr int AT3_V_BASE = 2 * KV_TILE_BYTES;
 constexpr int AT3_LDS = 4 * KV_TILE_BYTES;
 
@@ -957,7 +964,9 @@ __device__ __forceinline__ void mfma16(f32x4& acc, const bf16x8& a, const bf16x8
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
 }
 
-__global__ __launch_bounds__(AT3_THREADS, 2) void flash_attn_fwd_kernel3(const AttnArgs p) {
+template <int NQ>
+__global__ __launch_bounds__(At3<NQ>::THREADS, (NQ == 2 ? 2 : 1)) void flash_attn_fwd_kernel3(const AttnArgs p) {
+    constexpr int NP = At3<NQ>::PIECES, NW = At3<NQ>::WAVES, RW = At3<NQ>::ROWS, NS = At3<NQ>::SLOTS;
     constexpr bool CINIT = GF_K3_CINIT != 0, SUMMFMA = GF_K3_SUMMFMA != 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     GF_LDS char* lds = (GF_LDS char*)smem;
@@ -977,11 +986,11 @@ __global__ __launch_bounds__(AT3_THREADS, 2) void flash_attn_fwd_kernel3(const A
             qb0 = pid % p.n_qblocks;
         }
     }
-    const int q0 = qb0 * QB + wave * 32;
+    const int q0 = qb0 * QB + wave * RW;
 
-    bf16x8 qf[2][4];   // [qb][ks]: Q[q0 + 16 qb + r][32 ks + 8 g .. +8)
+    bf16x8 qf[NQ][4];   // [qb][ks]: Q[q0 + 16 qb + r][32 ks + 8 g .. +8)
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
+    for (int qb = 0; qb < NQ; ++qb) {
         const int qr = min(q0 + 16 * qb + r, p.q_len - 1);
         const u16* qp = p.q + (long)qr * p.q_stride + head * HD + 8 * g;
 #pragma unroll
@@ -999,21 +1008,23 @@ __global__ __launch_bounds__(AT3_THREADS, 2) void flash_attn_fwd_kernel3(const A
         }
     }
 
-    // ---- staging (LDS-DMA, buffer form): wave w fills K row-groups 2w, 2w+1 (4 rows x 256 B; lane L: row L >> 4, physical
-    // chunk L & 15 = logical chunk ^ (row & 15)) and V^T rows 16w .. 16w+15 as two pieces of 8 rows (lane L: row L >> 3,
-    // physical chunk L & 7 = logical chunk ^ ((row >> 1) & 7))
+    // ---- staging (LDS-DMA, buffer form): a tile is 16 pieces of 1 KiB; piece P = NW jj + wave (jj < NP) is staged by `wave`:
+    // K rows 4 P .. 4 P + 3 (lane L: row 4 P + (L >> 4), physical chunk L & 15 = logical chunk ^ (row & 15)), V^T rows 8 P .. 8 P + 7
+    // (lane L: row 8 P + (L >> 3), physical chunk L & 7 = logical chunk ^ ((row >> 1) & 7)).  With this piece order the lane's
+    // swizzle does not depend on jj (row & 15 = 4 wave + (L >> 4)): ONE per-lane offset each for K and V^T, the piece and the tile
+    // position go into the instruction's SGPR offset.
     const int dma_r = lane >> 4;
-    unsigned k_off[2], vt_off[2];
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
-        const int row = 4 * (2 * wave + jj) + dma_r;
+    unsigned k_off0, vt_off0;
+    {
+        const int row = 4 * wave + dma_r;
         const int lch = (lane & 15) ^ (row & 15);
-        k_off[jj] = ((unsigned)row * (unsigned)p.k_stride + head * HD + lch * 8) * 2u;                 // bytes
-        const int vrow = 16 * wave + 8 * jj + (lane >> 3);
+        k_off0 = ((unsigned)row * (unsigned)p.k_stride + head * HD + lch * 8) * 2u;                 // bytes
+        const int vrow = 8 * wave + (lane >> 3);
         const int vch = (lane & 7) ^ ((vrow >> 1) & 7);
-        vt_off[jj] = (unsigned)(((long)head * HD + vrow) * p.kv_pad + vch * 8) * 2u;                   // bytes
+        vt_off0 = (unsigned)(((long)head * HD + vrow) * p.kv_pad + vch * 8) * 2u;                   // bytes
     }
     const unsigned kstep = KVB * (unsigned)p.k_stride * 2u;
+    const unsigned k_piece = 4u * NW * (unsigned)p.k_stride * 2u, vt_piece = 8u * NW * (unsigned)p.kv_pad * 2u;   // bytes between a wave's pieces
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4s;
     auto make_srd = [](const void* base) {
         const unsigned long b = (unsigned long)base;
@@ -1025,7 +1036,7 @@ __global__ __launch_bounds__(AT3_THREADS, 2) void flash_attn_fwd_kernel3(const A
         return s;
     };
     const u32x4s srd_k = make_srd(p.k), srd_v = make_srd(p.vt);
-    auto dma16b = [&](const u32x4s& srd, unsigned voff_bytes, unsigned soff_bytes, GF_LDS char* l) {
+    auto dma16b = [&](const u32x4s& srd, unsigned voff_bytes, unsigned soff_bytes, GF_LDS char* l) __attribute__((always_inline)) {
         unsigned keep;
         const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)l);
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
@@ -1033,7 +1044,7 @@ __global__ __launch_bounds__(AT3_THREADS, 2) void flash_attn_fwd_kernel3(const A
                      : "v"(voff_bytes), "s"(srd), "s"(dst), "s"(soff_bytes)
                      : "memory");
     };
-    auto dma16g = [&](const u16* gp, GF_LDS char* l) {   // 64-bit per-lane address: the clamped rows of a ragged last K tile
+    auto dma16g = [&](const u16* gp, GF_LDS char* l) __attribute__((always_inline)) {   // 64-bit per-lane address: the clamped rows of a ragged last K tile
         unsigned keep;
         const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)l);
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -1041,23 +1052,23 @@ __global__ __launch_bounds__(AT3_THREADS, 2) void flash_attn_fwd_kernel3(const A
                      : "v"(gp), "s"(dst)
                      : "memory");
     };
-    // which = 0: K tile t -> K buffer buf;  which = 1: V^T tile t -> V buffer buf;  jj = which of the wave's two pieces
-    auto stage_piece = [&](int which, int t, int buf, int jj) {
-        GF_LDS char* base = lds + which * AT3_V_BASE + buf * KV_TILE_BYTES + wave * 2048 + jj * 1024;
+    // which = 0: K tile t -> K buffer buf;  which = 1: V^T tile t -> V buffer buf;  jj = which of the wave's NP pieces
+    auto stage_piece = [&](int which, int t, int buf, int jj) __attribute__((always_inline)) {
+        GF_LDS char* base = lds + which * AT3_V_BASE + buf * KV_TILE_BYTES + (NW * jj + wave) * 1024;
         if (which) {
-            dma16b(srd_v, vt_off[jj], (unsigned)t * (KVB * 2u), base);
+            dma16b(srd_v, vt_off0, (unsigned)t * (KVB * 2u) + (unsigned)jj * vt_piece, base);
         } else if ((t + 1) * KVB <= p.kv_len) {
-            dma16b(srd_k, k_off[jj], (unsigned)t * kstep, base);
+            dma16b(srd_k, k_off0, (unsigned)t * kstep + (unsigned)jj * k_piece, base);
         } else {   // ragged last tile: clamp the row (its scores are masked)
-            const int row = 4 * (2 * wave + jj) + dma_r;
+            const int row = 4 * (NW * jj + wave) + dma_r;
             const long rr = min(t * KVB + row, p.kv_len - 1);
             const int lch = (lane & 15) ^ (row & 15);
             dma16g(p.k + rr * p.k_stride + head * HD + lch * 8, base);
         }
     };
-    auto stage = [&](int which, int t, int buf) {
-        stage_piece(which, t, buf, 0);
-        stage_piece(which, t, buf, 1);
+    auto stage = [&](int which, int t, int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int jj = 0; jj < NP; ++jj) stage_piece(which, t, buf, jj);
     };
 
     // ---- fragment read offsets (bytes inside a buffer): K (kb, ks): koff[ks] + kb * 4096;  V^T (db, kk): voff[kk] + db * 2048
@@ -1071,18 +1082,26 @@ __global__ __launch_bounds__(AT3_THREADS, 2) void flash_attn_fwd_kernel3(const A
     // all ones): the matrix pipe adds up the bf16 P it multiplies with anyway (4 MFMAs per tile instead of 32 v_add_f32), and the
     // sums are rescaled together with O.  sc[tile parity][kb][qb] = S' - m_run (log2 domain).
     constexpr int NDB = SUMMFMA ? 9 : 8;
-    f32x4 oacc[NDB][2], sc[2][4][2];
-    bf16x8 pf[2][2];                 // P fragments [kk][qb]
+    f32x4 oacc[NDB][NQ], sc[2][4][NQ];
+    u32x4 pfw[2][NQ];                // P fragments [kk][qb] as four packed bf16 pairs (word w = keys 2w, 2w+1 of the B operand)
+    auto pf = [&](int kk, int qb) __attribute__((always_inline)) { return __builtin_bit_cast(bf16x8, pfw[kk][qb]); };
     // CINIT: m_run is the running maximum in the exp2 domain and the scores are kept relative to it; otherwise m_run is the
     // maximum of the raw scores (times c in the exponent) as in kernel 2.  l_run: per-lane partial row sums (SUMMFMA = 0).
-    float m_run[2] = {CINIT ? 0.f : -1.0e30f, CINIT ? 0.f : -1.0e30f}, alpha_pend[2] = {1.f, 1.f}, l_run[2] = {0.f, 0.f};
+    float m_run[NQ], alpha_pend[NQ], l_run[NQ];
+    f32x4 negm[NQ];                  // -m_run splat: the QK^T chains start from it
+#pragma unroll
+    for (int qb = 0; qb < NQ; ++qb) {
+        m_run[qb] = CINIT ? 0.f : -1.0e30f;
+        alpha_pend[qb] = 1.f;
+        l_run[qb] = 0.f;
+        negm[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     const float c = CINIT ? 1.0f : p.scale_log2e;
-    f32x4 negm[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};   // -m_run splat: the QK^T chains start from it
     bool pend = false;               // wave-uniform: O still has to be multiplied by alpha_pend
 #pragma unroll
     for (int db = 0; db < NDB; ++db)
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb) oacc[db][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int qb = 0; qb < NQ; ++qb) oacc[db][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
     bf16x8 ones;
     {
         const __bf16 o1 = (__bf16)(r == 0 ? 1.0f : 0.0f);
@@ -1094,46 +1113,55 @@ __global__ __launch_bounds__(AT3_THREADS, 2) void flash_attn_fwd_kernel3(const A
     typedef std::integral_constant<int, 0> C0;
     typedef std::integral_constant<int, 1> C1;
 
+    // One wave per SIMD with 64 query rows (NQ = 4: every fragment read feeds four MFMAs, O^T and Q in AGPRs through register-class
+    // constraints on asm MFMAs) was built and measured: 18.7 ms on all-zero inputs against 13.1 ms — a lone wave cannot issue the
+    // phase's ~8 instructions per MFMA pair fast enough; this file keeps the NQ arithmetic but ships and tests NQ = 2 only.
+    static_assert(NQ == 2, "kernel 3 is validated for two query blocks per wave");
+    auto mfma_pv = [&](f32x4& acc, const bf16x8& va, const bf16x8& pb) __attribute__((always_inline)) { mfma16(acc, va, pb); };
+    auto mfma_qk = [&](f32x4& acc, const bf16x8& ka, const bf16x8& qb_) __attribute__((always_inline)) { mfma16(acc, ka, qb_); };
+    auto mfma_qk_first = [&](f32x4& dst, const bf16x8& ka, const bf16x8& qb_, const f32x4& c0) __attribute__((always_inline)) {
+        dst = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qb_, c0, 0, 0, 0);
+    };
+
     // ---- unpipelined building blocks (prologue, first and last phase)
-    auto qk_plain = [&](auto par_c) {   // S(par) = K(buffer par) Q^T
+    auto qk_plain = [&](auto par_c) __attribute__((always_inline)) {   // S(par) = K(buffer par) Q^T
         constexpr int PAR = decltype(par_c)::value;
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-            for (int qb = 0; qb < 2; ++qb) sc[PAR][kb][qb] = CINIT ? negm[qb] : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int qb = 0; qb < NQ; ++qb) sc[PAR][kb][qb] = CINIT ? negm[qb] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) {
                 const bf16x8 kf = *(GF_LDS bf16x8*)(lds + koff[ks] + kb * 4096 + PAR * KV_TILE_BYTES);
-                mfma16(sc[PAR][kb][0], kf, qf[0][ks]);
-                mfma16(sc[PAR][kb][1], kf, qf[1][ks]);
+#pragma unroll
+                for (int qb = 0; qb < NQ; ++qb) mfma_qk(sc[PAR][kb][qb], kf, qf[qb][ks]);
             }
     };
-    auto pv_plain = [&](auto buf_c) {   // O^T += V(buffer)^T P^T
+    auto pv_plain = [&](auto buf_c) __attribute__((always_inline)) {   // O^T += V(buffer)^T P^T
         constexpr int BUF = decltype(buf_c)::value;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int db = 0; db < 8; ++db) {
                 const bf16x8 vf = *(GF_LDS bf16x8*)(lds + voff[kk] + db * 2048 + BUF * KV_TILE_BYTES);
-                mfma16(oacc[db][0], vf, pf[kk][0]);
-                mfma16(oacc[db][1], vf, pf[kk][1]);
+#pragma unroll
+                for (int qb = 0; qb < NQ; ++qb) mfma_pv(oacc[db][qb], vf, pf(kk, qb));
             }
         if constexpr (SUMMFMA) {
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                mfma16(oacc[NDB - 1][0], ones, pf[kk][0]);
-                mfma16(oacc[NDB - 1][1], ones, pf[kk][1]);
-            }
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int qb = 0; qb < NQ; ++qb) mfma_pv(oacc[NDB - 1][qb], ones, pf(kk, qb));
         }
     };
-    auto apply_pending = [&]() {
+    auto apply_pending = [&]() __attribute__((always_inline)) {
         if (pend) {
-#pragma unroll
+    #pragma unroll
             for (int db = 0; db < NDB; ++db)
 #pragma unroll
-                for (int qb = 0; qb < 2; ++qb)
+                for (int qb = 0; qb < NQ; ++qb)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) oacc[db][qb][e] *= alpha_pend[qb];
             pend = false;
@@ -1142,27 +1170,29 @@ __global__ __launch_bounds__(AT3_THREADS, 2) void flash_attn_fwd_kernel3(const A
     // mx[qb] = this lane's partial maximum of its query's scores in tile PAR, RELATIVE to the running maximum (the scores are
     // S' - m_run).  Rare path (`first`: always): the running maximum moves to the tile's row maximum; the tile's scores, which the
     // matrix pipe produced against the old maximum, are corrected here, later tiles start from the new one (negm).
-    auto new_max = [&](auto par_c, float mx0, float mx1, bool first) {
+    auto new_max = [&](auto par_c, const float (&mx)[NQ], bool first) {
         constexpr int PAR = decltype(par_c)::value;
-        const bool quiet = CINIT ? __all(mx0 <= 6.0f && mx1 <= 6.0f) : __all((mx0 - m_run[0]) * c <= 6.0f && (mx1 - m_run[1]) * c <= 6.0f);
-        if (first || !quiet) {
-            float mx[2] = {mx0, mx1};
+        float over = CINIT ? mx[0] : (mx[0] - m_run[0]) * c;        // how far any score of the tile is above its running maximum
 #pragma unroll
-            for (int qb = 0; qb < 2; ++qb) {
+        for (int qb = 1; qb < NQ; ++qb) over = fmaxf(over, CINIT ? mx[qb] : (mx[qb] - m_run[qb]) * c);
+        const bool quiet = __all(over <= 6.0f);
+        if (first || !quiet) {
+#pragma unroll
+            for (int qb = 0; qb < NQ; ++qb) {
                 float d = mx[qb];                        // reduce over the four g-lanes of the query
                 d = fmaxf(d, __shfl_xor(d, 16));
                 d = fmaxf(d, __shfl_xor(d, 32));
                 float alpha;
                 if constexpr (CINIT) {
                     if (!first) d = fmaxf(d, 0.f);       // the maximum never moves down (the first tile sets it, whatever its sign)
-                    m_run[qb] += d;
+                    const float m_new = d - negm[qb][0];     // CINIT: the running maximum is kept as its negative splat only
                     alpha = __builtin_amdgcn_exp2f(-d);
 #pragma unroll
                     for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) sc[PAR][kb][qb][e] -= d;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) negm[qb][e] = -m_run[qb];
+                    for (int e = 0; e < 4; ++e) negm[qb][e] = -m_new;
                 } else {
                     const float m_new = fmaxf(m_run[qb], d);
                     alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * c);
@@ -1175,7 +1205,7 @@ __global__ __launch_bounds__(AT3_THREADS, 2) void flash_attn_fwd_kernel3(const A
             if (CINIT && first) pend = false;
         }
     };
-    auto mask_ragged = [&](auto par_c, int t) {
+    auto mask_ragged = [&](auto par_c, int t) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par_c)::value;
         if (ragged && t == nt - 1) {
 #pragma unroll
@@ -1183,52 +1213,55 @@ __global__ __launch_bounds__(AT3_THREADS, 2) void flash_attn_fwd_kernel3(const A
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (t * KVB + 16 * kb + 4 * g + j >= p.kv_len) {
-                        sc[PAR][kb][0][j] = -INFINITY;
-                        sc[PAR][kb][1][j] = -INFINITY;
+#pragma unroll
+                        for (int qb = 0; qb < NQ; ++qb) sc[PAR][kb][qb][j] = -INFINITY;
                     }
         }
     };
-    auto softmax_plain = [&](auto par_c, int t) {
+    auto softmax_plain = [&](auto par_c, int t) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par_c)::value;
         mask_ragged(par_c, t);
-        float mx[2];
+        float mx[NQ];
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
+        for (int qb = 0; qb < NQ; ++qb) {
             mx[qb] = sc[PAR][0][qb][0];
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) mx[qb] = fmaxf(mx[qb], sc[PAR][kb][qb][j]);
         }
-        new_max(par_c, mx[0], mx[1], t == 0);
+        new_max(par_c, mx, t == 0);
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
+        for (int qb = 0; qb < NQ; ++qb) {
             const float mc = CINIT ? 0.f : m_run[qb] * c;
             float rs = 0.f;
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float sv = sc[PAR][kb][qb][j];
-                    const float pe = __builtin_amdgcn_exp2f(CINIT ? sv : __builtin_fmaf(sv, c, -mc));
-                    rs += pe;
-                    pf[kb >> 1][qb][(kb & 1) * 4 + j] = (__bf16)pe;
+                for (int j = 0; j < 4; j += 2) {
+                    const float s0 = sc[PAR][kb][qb][j], s1 = sc[PAR][kb][qb][j + 1];
+                    const float p0 = __builtin_amdgcn_exp2f(CINIT ? s0 : __builtin_fmaf(s0, c, -mc));
+                    const float p1 = __builtin_amdgcn_exp2f(CINIT ? s1 : __builtin_fmaf(s1, c, -mc));
+                    rs += p0 + p1;
+                    pfw[kb >> 1][qb][(kb & 1) * 2 + (j >> 1)] = pack2bf(p0, p1);
                 }
             if constexpr (!SUMMFMA) l_run[qb] += rs;
         }
     };
 
-    // ---- the steady phase p (1 <= p <= nt-2), PAR = p & 1: 64 matrix slots
-    //   s <  32: PV(p-1)  kk = s >> 4, db = (s >> 1) & 7, qb = s & 1    A = V^T fragment (db, kk) of V buffer 1-PAR
-    //   s >= 32: QK(p+1)  ks = (s-32) >> 3, kb = ((s-32) >> 1) & 3, qb = s & 1    A = K fragment (kb, ks) of K buffer 1-PAR
-    // A fragment serves the two query blocks of a slot pair; fragment f (= slot pair) is read three pairs ahead into ring
-    // entry f & 3.  The partial maxima of S(p) are taken in slots 0-7, the rescale test follows slot 7, its 32 scores are
-    // exponentiated in slots 16-62.
-    constexpr int RING = GF_K3_RING;       // fragment ring entries; a fragment is read RING - 1 slot pairs ahead of its use
+    // ---- the steady phase p (1 <= p <= nt-2), PAR = p & 1: NS = 32 NQ matrix slots; slot s = (fragment f = s / NQ, query block
+    // qb = s % NQ): a fragment read from LDS serves the NQ query blocks of the wave.
+    //   f <  16: PV(p-1)  kk = f >> 3, db = f & 7          A = V^T fragment (db, kk) of V buffer 1-PAR
+    //   f >= 16: QK(p+1)  ks = (f-16) >> 2, kb = (f-16) & 3  A = K fragment (kb, ks) of K buffer 1-PAR
+    // Fragment f is read RING - 1 fragments ahead into ring entry f % RING.  The partial maxima of S(p) are taken in slots
+    // 0 .. 4 NQ - 1, the rescale test follows, its 16 NQ scores per lane are exponentiated in slots 8 NQ .. NS - 1.
+    constexpr int RING = GF_K3_RING;
     bf16x8 fr[RING];
-    auto frag_load = [&](auto f_c, auto par_c) {
+    auto frag_load = [&](auto f_c, auto par_c) __attribute__((always_inline)) {
         constexpr int F = decltype(f_c)::value, PAR = decltype(par_c)::value;
-        if constexpr (F < 16) {
+        if constexpr ((GF_K3_WHATIF & 4) != 0) {
+            if (p.kv_len < 0) fr[F % RING] = *(GF_LDS bf16x8*)(lds + voff[0]);
+        } else if constexpr (F < 16) {
             constexpr int kk = F >> 3, db = F & 7;
             fr[F % RING] = *(GF_LDS bf16x8*)(lds + voff[kk] + db * 2048 + (1 - PAR) * KV_TILE_BYTES);
         } else if constexpr (F < 32) {
@@ -1236,84 +1269,98 @@ __global__ __launch_bounds__(AT3_THREADS, 2) void flash_attn_fwd_kernel3(const A
             fr[F % RING] = *(GF_LDS bf16x8*)(lds + koff[ks] + kb * 4096 + (1 - PAR) * KV_TILE_BYTES);
         }
     };
-    auto mfma_op = [&](auto s_c, auto par_c) {
+    auto mfma_op = [&](auto s_c, auto par_c) __attribute__((always_inline)) {
         constexpr int S = decltype(s_c)::value, PAR = decltype(par_c)::value;
-        constexpr int F = S >> 1, qb = S & 1;
-        if constexpr (S < 32) {
+        constexpr int F = S / NQ, qb = S % NQ;
+        if constexpr (F < 16) {
             constexpr int kk = F >> 3, db = F & 7;
-            mfma16(oacc[db][qb], fr[F % RING], pf[kk][qb]);
+            mfma_pv(oacc[db][qb], fr[F % RING], pf(kk, qb));
         } else {
             constexpr int ks = (F - 16) >> 2, kb = (F - 16) & 3;
             if constexpr (ks == 0) {
                 const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-                sc[1 - PAR][kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[F % RING], qf[qb][ks], CINIT ? negm[qb] : zero, 0, 0, 0);
+                mfma_qk_first(sc[1 - PAR][kb][qb], fr[F % RING], qf[qb][ks], CINIT ? negm[qb] : zero);
             } else {
-                mfma16(sc[1 - PAR][kb][qb], fr[F % RING], qf[qb][ks]);
+                mfma_qk(sc[1 - PAR][kb][qb], fr[F % RING], qf[qb][ks]);
             }
         }
     };
-    auto dma_slot = [&](auto s_c, auto par_c, int pidx) {
+    // staging: the wave's NP V^T pieces of tile p, then its NP K pieces of tile p+2, one every 4 NQ slots from slot 10
+    auto dma_slot = [&](auto s_c, auto par_c, int pidx) __attribute__((always_inline)) {
         constexpr int S = decltype(s_c)::value, PAR = decltype(par_c)::value;
-        if constexpr (S == 10) stage_piece(1, pidx, PAR, 0);
-        if constexpr (S == 18) stage_piece(1, pidx, PAR, 1);
-        if constexpr (S == 26) { if (pidx + 2 < nt) stage_piece(0, pidx + 2, PAR, 0); }
-        if constexpr (S == 34) { if (pidx + 2 < nt) stage_piece(0, pidx + 2, PAR, 1); }
+        if constexpr ((GF_K3_WHATIF & 8) != 0) return;
+        if constexpr (S >= 10 && (S - 10) % (4 * NQ) == 0 && (S - 10) / (4 * NQ) < 2 * NP) {
+            constexpr int i = (S - 10) / (4 * NQ);
+            if constexpr (i < NP) {
+                stage_piece(1, pidx, PAR, i);
+            } else {
+                if (pidx + 2 < nt) stage_piece(0, pidx + 2, PAR, i - NP);
+            }
+        }
     };
-    auto phase = [&](auto par_c, int pidx) {
+    auto phase = [&](auto par_c, int pidx) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par_c)::value;
         apply_pending();
         static_for<0, RING - 1>([&](auto f_c) { frag_load(f_c, par_c); });
-        float mx[2] = {-INFINITY, -INFINITY};
-        static_for<0, 8>([&](auto s_c) {
+        float mx[NQ];
+#pragma unroll
+        for (int qb = 0; qb < NQ; ++qb) mx[qb] = -INFINITY;
+        static_for<0, 4 * NQ>([&](auto s_c) {
             constexpr int S = decltype(s_c)::value;
             mfma_op(s_c, par_c);
-            if constexpr ((S & 1) == 0) frag_load(std::integral_constant<int, (S >> 1) + RING - 1>{}, par_c);
-            // partial maxima: slot S takes key block S >> 1 of query block S & 1 (4 scores: one v_max3 + one v_max)
-            {
-                constexpr int kb = S >> 1, qb = S & 1;
+            if constexpr (S % NQ == 0) frag_load(std::integral_constant<int, S / NQ + RING - 1>{}, par_c);
+            // partial maxima: slot S takes key block S / NQ of query block S % NQ (4 scores: two v_max3)
+            if constexpr ((GF_K3_WHATIF & 16) == 0) {
+                constexpr int kb = S / NQ, qb = S % NQ;
                 const f32x4& v = sc[PAR][kb][qb];
                 mx[qb] = fmaxf(fmaxf(mx[qb], v[0]), v[1]);
                 mx[qb] = fmaxf(fmaxf(mx[qb], v[2]), v[3]);
             }
             __builtin_amdgcn_sched_barrier(0);
         });
-        new_max(par_c, mx[0], mx[1], false);
-        const float mc[2] = {CINIT ? 0.f : m_run[0] * c, CINIT ? 0.f : m_run[1] * c};
-        float pe[2], rs[2] = {0.f, 0.f};
-        static_for<8, 64>([&](auto s_c) {
+        if constexpr ((GF_K3_WHATIF & 16) == 0) new_max(par_c, mx, false);
+        float mc[NQ], pe[2];
+#pragma unroll
+        for (int qb = 0; qb < NQ; ++qb) mc[qb] = CINIT ? 0.f : m_run[qb] * c;
+        static_for<4 * NQ, NS>([&](auto s_c) {
             constexpr int S = decltype(s_c)::value;
             mfma_op(s_c, par_c);
-            // the four row-sum MFMAs of PV(p-1) ride in the PV half: after slots 15 / 31 (pf[kk] complete its last use there)
-            if constexpr (SUMMFMA && (S == 15 || S == 31)) {
-                mfma16(oacc[NDB - 1][0], ones, pf[S >> 4][0]);
-                mfma16(oacc[NDB - 1][1], ones, pf[S >> 4][1]);
+            // the row-sum MFMAs of PV(p-1) ride in the PV half: after the last slot that reads pf[kk]
+            if constexpr (SUMMFMA && (S == 8 * NQ - 1 || S == 16 * NQ - 1)) {
+#pragma unroll
+                for (int qb = 0; qb < NQ; ++qb) mfma_pv(oacc[NDB - 1][qb], ones, pf(S / (8 * NQ), qb));
             }
-            if constexpr ((S & 1) == 0) frag_load(std::integral_constant<int, (S >> 1) + RING - 1>{}, par_c);
+            if constexpr (S % NQ == 0) frag_load(std::integral_constant<int, S / NQ + RING - 1>{}, par_c);
             dma_slot(s_c, par_c, pidx);
-            // scores of S(p): two per three slots from slot 16 on.  P(p) overwrites pf, which PV(p-1) still reads: pf[0][*] until slot
-            // 15, pf[1][*] until slot 31 — so the scores that land in pf[0] (key blocks 0, 1) come first (slots 16..39) and those
-            // for pf[1] (key blocks 2, 3) from slot 40 on.  e -> kk = e >> 4, qb = (e >> 3) & 1, kb = 2 kk + ((e >> 2) & 1), j = e & 3.
-            if constexpr (S >= 16 && (S - 16) % 3 != 2) {
-                constexpr int e = ((S - 16) / 3) * 2 + (S - 16) % 3;
-                constexpr int kk = e >> 4, qb = (e >> 3) & 1, kb = 2 * kk + ((e >> 2) & 1), j = e & 3;
-                float sv = sc[PAR][kb][qb][j];
-                asm volatile("" : "+v"(sv));
-                pe[e & 1] = __builtin_amdgcn_exp2f(CINIT ? sv : __builtin_fmaf(sv, c, -mc[qb]));
-                if constexpr (!SUMMFMA) rs[qb] += pe[e & 1];
-                if constexpr (e & 1) {
-                    asm volatile("" : "+v"(pe[0]), "+v"(pe[1]), "+v"(rs[qb]));
-                    pf[kk][qb][(kb & 1) * 4 + j - 1] = (__bf16)pe[0];
-                    pf[kk][qb][(kb & 1) * 4 + j] = (__bf16)pe[1];
+            // scores of S(p): two per three slots from slot 8 NQ on.  P(p) overwrites pf, which PV(p-1) still reads: pf[0][*] until
+            // slot 8 NQ - 1, pf[1][*] until slot 16 NQ - 1 — so the scores that land in pf[0] (key blocks 0, 1) come first (slots
+            // 8 NQ .. 20 NQ - 1) and those for pf[1] (key blocks 2, 3) from slot 20 NQ on.
+            // e -> kk = e / (8 NQ), qb = (e >> 3) % NQ, kb = 2 kk + ((e >> 2) & 1), j = e & 3.
+            // The exp2 and the pack are inline asm (a compiler-placed exp2 brought a register copy, a wait state and a late pack
+            // per score: 5.8 issue slots per score instead of 2).  v_exp_f32 is a transcendental op: its result may not be read
+            // by the next instruction — the row-sum add of a score sits one slot after its exp2, the pack of a pair in the pair's
+            // third slot, each behind that slot's MFMA.
+            if constexpr (S >= 8 * NQ && (GF_K3_WHATIF & 2) == 0) {
+                constexpr int T = (S - 8 * NQ) % 3, e = ((S - 8 * NQ) / 3) * 2 + (T == 2 ? 1 : T);
+                constexpr int kk = e / (8 * NQ), qb = (e >> 3) % NQ, kb = 2 * kk + ((e >> 2) & 1), j = e & 3;
+                if constexpr (T != 2) {
+                    float arg = sc[PAR][kb][qb][j];
+                    if constexpr (!CINIT) arg = __builtin_fmaf(arg, c, -mc[qb]);
+                    asm volatile("v_exp_f32 %0, %1" : "=v"(pe[T]) : "v"(arg));
+                    if constexpr (!SUMMFMA && T == 1) asm volatile("v_add_f32 %0, %0, %1" : "+v"(l_run[qb]) : "v"(pe[0]));
+                } else {
+                    unsigned w;
+                    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(pe[0]), "v"(pe[1]));
+                    pfw[kk][qb][(kb & 1) * 2 + (j >> 1)] = w;
+                    if constexpr (!SUMMFMA) asm volatile("v_add_f32 %0, %0, %1" : "+v"(l_run[qb]) : "v"(pe[1]));
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
         });
-        if constexpr (!SUMMFMA) {
-            l_run[0] += rs[0];
-            l_run[1] += rs[1];
+        if constexpr ((GF_K3_WHATIF & 1) == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
     };
 
     // ---- prologue: K(0), K(1) staged; S(0)
@@ -1369,9 +1416,9 @@ __global__ __launch_bounds__(AT3_THREADS, 2) void flash_attn_fwd_kernel3(const A
 
     // ---- epilogue
     {
-        float inv[2];
+        float inv[NQ];
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
+        for (int qb = 0; qb < NQ; ++qb) {
             float l;
             if constexpr (SUMMFMA) {
                 l = __shfl(oacc[NDB - 1][qb][0], r);        // row 0 of the ninth block: lane g == 0 of the query holds it
@@ -1382,14 +1429,14 @@ __global__ __launch_bounds__(AT3_THREADS, 2) void flash_attn_fwd_kernel3(const A
             }
             inv[qb] = 1.0f / l;
             const int qrow = q0 + 16 * qb + r;
-            if (p.lse && g == 0 && qrow < p.q_len) p.lse[(long)qrow * p.heads + head] = m_run[qb] * c + __builtin_amdgcn_logf(l);
+            if (p.lse && g == 0 && qrow < p.q_len) p.lse[(long)qrow * p.heads + head] = (CINIT ? -negm[qb][0] : m_run[qb] * c) + __builtin_amdgcn_logf(l);
         }
-        // O leaves through LDS as whole 256-byte rows: the wave's 32 x 256 B image, 16-byte chunk ch of row q at chunk ch ^ (q & 15);
-        // a lane holds the 8-byte pieces d = 16 db + 4 g .. +3 of its two rows.  The K/V tiles are dead at this barrier.
+        // O leaves through LDS as whole 256-byte rows: the wave's RW x 256 B image, 16-byte chunk ch of row q at chunk ch ^ (q & 15);
+        // a lane holds the 8-byte pieces d = 16 db + 4 g .. +3 of its NQ rows.  The K/V tiles are dead at this barrier.
         __syncthreads();
-        GF_LDS char* ob = lds + wave * 8192;
+        GF_LDS char* ob = lds + wave * (RW * 256);
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb)
+        for (int qb = 0; qb < NQ; ++qb)
 #pragma unroll
             for (int db = 0; db < 8; ++db) {
                 u32x2 pk;
@@ -1400,7 +1447,7 @@ __global__ __launch_bounds__(AT3_THREADS, 2) void flash_attn_fwd_kernel3(const A
             }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-local image: LDS is in order, no barrier needed
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
+        for (int it = 0; it < RW / 4; ++it) {
             const int row = 4 * it + (lane >> 4), ch = lane & 15;
             const u16x8 v8 = *(GF_LDS u16x8*)(ob + row * 256 + ((ch ^ (row & 15)) << 4));
             if (q0 + row < p.q_len)
@@ -1618,7 +1665,7 @@ extern "C" GF_API int gf_flash_attn_fwd_vt32(const void* q, const void* k, const
     if (q_len == 0) return GF_OK;
     static GfDeviceOnce once;
     hipError_t e = gf_once_per_device(once, [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_fwd_kernel3),
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_fwd_kernel3<GF_K3_NQ>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, AT3_LDS);
     });
     if (e != hipSuccess) {
@@ -1643,7 +1690,7 @@ extern "C" GF_API int gf_flash_attn_fwd_vt32(const void* q, const void* k, const
     a.vt = (const u16*)vt;
     a.kv_pad = kv_pad;
     a.dbg = nullptr;
-    hipLaunchKernelGGL(flash_attn_fwd_kernel3, dim3((unsigned)(a.n_qblocks * a.heads)), dim3(AT3_THREADS), AT3_LDS,
+    hipLaunchKernelGGL(flash_attn_fwd_kernel3<GF_K3_NQ>, dim3((unsigned)(a.n_qblocks * a.heads)), dim3(At3<GF_K3_NQ>::THREADS), AT3_LDS,
                        (hipStream_t)stream, a);
     GF_CHECK_LAUNCH("gf_flash_attn_fwd_vt32");
     return GF_OK;
