@@ -1035,36 +1035,35 @@ __global__ __launch_bounds__(At3<NQ>::THREADS, (NQ == 2 ? 2 : 1)) void flash_att
         s[3] = 0x00020000u;
         return s;
     };
-    const u32x4s srd_k = make_srd(p.k), srd_v = make_srd(p.vt);
+    const u32x4s srd_v = make_srd(p.vt);
     auto dma16b = [&](const u32x4s& srd, unsigned voff_bytes, unsigned soff_bytes, GF_LDS char* l) __attribute__((always_inline)) {
-        unsigned keep;
+        // M0 (the LDS destination) is ours: nothing else in this kernel uses it, so it is set and not restored
         const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)l);
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds"
+                     :
                      : "v"(voff_bytes), "s"(srd), "s"(dst), "s"(soff_bytes)
-                     : "memory");
+                     : "memory", "m0");
     };
-    auto dma16g = [&](const u16* gp, GF_LDS char* l) __attribute__((always_inline)) {   // 64-bit per-lane address: the clamped rows of a ragged last K tile
-        unsigned keep;
-        const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)l);
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep)
-                     : "v"(gp), "s"(dst)
-                     : "memory");
+    // The K descriptor of tile t starts at the tile and ends with the key sequence (num_records = bytes of the rows that exist,
+    // 0 for a tile past the end): rows of a ragged last tile beyond kv_len, and whole tiles that do not exist, arrive as zeros
+    // with no test in the instruction stream (their scores are masked; a tile past the end is never read).
+    auto srd_k_tile = [&](int t) __attribute__((always_inline)) {
+        const unsigned long bb = (unsigned long)p.k + (unsigned long)(unsigned)t * kstep;
+        const int rem = p.kv_len - t * KVB;
+        u32x4s sd;
+        sd[0] = (unsigned)bb;
+        sd[1] = (unsigned)(bb >> 32) & 0xffffu;
+        sd[2] = rem > 0 ? (unsigned)rem * (unsigned)p.k_stride * 2u : 0u;
+        sd[3] = 0x00020000u;
+        return sd;
     };
     // which = 0: K tile t -> K buffer buf;  which = 1: V^T tile t -> V buffer buf;  jj = which of the wave's NP pieces
     auto stage_piece = [&](int which, int t, int buf, int jj) __attribute__((always_inline)) {
         GF_LDS char* base = lds + which * AT3_V_BASE + buf * KV_TILE_BYTES + (NW * jj + wave) * 1024;
-        if (which) {
+        if (which)
             dma16b(srd_v, vt_off0, (unsigned)t * (KVB * 2u) + (unsigned)jj * vt_piece, base);
-        } else if ((t + 1) * KVB <= p.kv_len) {
-            dma16b(srd_k, k_off0, (unsigned)t * kstep + (unsigned)jj * k_piece, base);
-        } else {   // ragged last tile: clamp the row (its scores are masked)
-            const int row = 4 * (NW * jj + wave) + dma_r;
-            const long rr = min(t * KVB + row, p.kv_len - 1);
-            const int lch = (lane & 15) ^ (row & 15);
-            dma16g(p.k + rr * p.k_stride + head * HD + lch * 8, base);
-        }
+        else
+            dma16b(srd_k_tile(t), k_off0, (unsigned)jj * k_piece, base);
     };
     auto stage = [&](int which, int t, int buf) __attribute__((always_inline)) {
 #pragma unroll
@@ -1294,7 +1293,7 @@ __global__ __launch_bounds__(At3<NQ>::THREADS, (NQ == 2 ? 2 : 1)) void flash_att
             if constexpr (i < NP) {
                 stage_piece(1, pidx, PAR, i);
             } else {
-                if (pidx + 2 < nt) stage_piece(0, pidx + 2, PAR, i - NP);
+                stage_piece(0, pidx + 2, PAR, i - NP);
             }
         }
     };
