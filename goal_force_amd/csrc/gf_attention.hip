@@ -38,6 +38,9 @@
 #ifndef GF_K3_RING
 #define GF_K3_RING 2     // kernel 3: operand fragments in flight (registers are the scarce resource at two waves per SIMD)
 #endif
+#ifndef GF_K3_SNAKE
+#define GF_K3_SNAKE 1    // kernel 3: query-block order reversed on odd fragments (one MFMA operand changes per slot instead of both)
+#endif
 #ifndef GF_K3_WHATIF
 #define GF_K3_WHATIF 0   // timing-only variants of kernel 3's steady phase (tools/attn_ab.py); 0 in the shipped library
 #endif
@@ -1270,7 +1273,7 @@ __global__ __launch_bounds__(At3<NQ>::THREADS, (NQ == 2 ? 2 : 1)) void flash_att
     };
     auto mfma_op = [&](auto s_c, auto par_c) __attribute__((always_inline)) {
         constexpr int S = decltype(s_c)::value, PAR = decltype(par_c)::value;
-        constexpr int F = S / NQ, qb = S % NQ;
+        constexpr int F = S / NQ, qb = (GF_K3_SNAKE && (F & 1)) ? NQ - 1 - S % NQ : S % NQ;
         if constexpr (F < 16) {
             constexpr int kk = F >> 3, db = F & 7;
             mfma_pv(oacc[db][qb], fr[F % RING], pf(kk, qb));
