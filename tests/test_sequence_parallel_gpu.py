@@ -73,9 +73,19 @@ def test_sharded_model_fn_is_bit_identical(tmp_path):
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     want, want_cached = _forward(None)
     assert torch.equal(want, want_cached)
+    # the yardstick is the REFERENCE, not our own unsharded forward: same weights and inputs as golden g5 `model_fn_cn_rand`
+    # (the reference's model_fn_wan_video with its ControlNet, fp32 and bf16 runs; tests/golden/make_goldens.py)
+    import numpy as np
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g5_model_fn.npz"))
+    f32 = torch.from_numpy(g["model_fn_cn_rand_f32"])
+    ref_bf16 = gi.from_u16(g["model_fn_cn_rand_bf16"]).float()
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    e_ref = rel(ref_bf16, f32)
     for r in range(world):
         res = torch.load(os.path.join(tmp_path, f"r{r}.pt"))
         for k in ("out", "cached", "flag"):
+            e = rel(res[k].float(), f32)
+            assert e < 1e-2 and e < 2 * e_ref + 1e-4, f"rank {r} {k}: sharded forward vs reference fp32 {e:.3e} (reference bf16 {e_ref:.3e})"
             assert torch.equal(res[k], want), f"rank {r} {k}: sharded forward differs from the one-GPU forward"
 
 
