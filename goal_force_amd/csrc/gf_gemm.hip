@@ -82,7 +82,7 @@ struct GemmArgs {
     unsigned long long* dbg;
     ConvGeom cv;
     int whatif;   // -DGF_A4_WHATIF diagnostic builds only (tools/gemm_a4_whatif.py)
-    int stagger;  // gemm_a4_kernel: rotate the K loop per column tile (GF_A4_STAGGER=0 turns it off for A/B runs)
+    int stagger;  // gemm_a4_kernel: column tile j starts its K loop at K tile (stagger * j) mod nk (GF_A4_STAGGER, default 2; 0 = off)
 };
 
 __device__ __forceinline__ void glds16(const void* g, GF_LDS char* l) {
@@ -782,7 +782,7 @@ __global__ __launch_bounds__(A4_THREADS, 1) void gemm_a4_kernel(const GemmArgs p
     // operands have the same pitch, so without this every workgroup of the chip walks the SAME few memory channels at the
     // same time (pitch 10 KiB: 16 of 128 channel slots).  The sum over k is only rotated; it depends on the column tile
     // alone, so an output element's bits do not depend on how the rows are cut into tiles or sharded over GPUs.
-    const unsigned k0 = p.stagger ? (unsigned)((2 * (n0 / BN)) % (int)nk) : 0u;
+    const unsigned k0 = p.stagger ? (unsigned)((p.stagger * (n0 / BN)) % (int)nk) : 0u;
     const unsigned kb = (unsigned)p.K * 2u;
 
     // ---- fragment read addresses: (row, chunk) at row * 128 + ((chunk ^ (row & 7)) << 4); sub-step ks reads chunk 4 ks + fq
@@ -1289,8 +1289,8 @@ static int gemm_dispatch(bool fp8, const void* A, int64_t lda, const void* W, in
 #endif
     a.whatif = 0;
     {
-        const char* es = getenv("GF_A4_STAGGER");
-        a.stagger = !(es && es[0] == '0');
+        const char* es = getenv("GF_A4_STAGGER");   // K tiles between the K-loop starts of neighbouring column tiles (0 = off)
+        a.stagger = es ? atoi(es) : 2;
     }
 #ifdef GF_A4_WHATIF
     if (const char* ew = getenv("GF_A4_WHATIF")) a.whatif = atoi(ew);
