@@ -240,7 +240,11 @@ def main():
         achieved = att_flops / (att_ms * 1e-3) / 1e12 if self_att else None
         fwd_per_step = 2 if world == 1 else 1.0 / args.sp   # forwards computed by ONE rank per step
         n_hi = sum(1 for i in step_ids if i < 21)
-        step_flops = [(forward_flops(True) if i < 21 else forward_flops(False)) * fwd_per_step for i in step_ids]
+        # executed FLOPs: with both CFG branches on one GPU the context-independent half of block 0 (self-attention + its four
+        # projections; DiT, and ControlNet on the high-noise steps) is computed once per step, not twice (model_fn: cfg_shared)
+        half0 = 4.0 * S_TOK * S_TOK * DIM + 8.0 * S_TOK * DIM * DIM
+        saved = (lambda i: (2 if i < 21 else 1) * half0) if (world == 1 and pipe.share_cfg_prefix) else (lambda i: 0.0)
+        step_flops = [(forward_flops(True) if i < 21 else forward_flops(False)) * fwd_per_step - saved(i) for i in step_ids]
         out = {
             "metric": "frames_per_sec (81-frame video / (50-step denoise loop + VAE decode), Wan2.2-I2V-A14B 832x480x81f)",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": k, "warmup": args.warmup,
@@ -252,7 +256,7 @@ def main():
                        "schedule": f"FlowMatch 50 steps shift 5, boundary 0.875; timed step ids {step_ids} "
                                    f"({n_hi} high-noise with ControlNet, {k - n_hi} low-noise with the all-zero ControlNet2 elided)",
                        "layers": args.layers,
-                       "parallelism": "1 GPU: sequential CFG" if world == 1 else f"{videos} video(s) x CFG pair, RCCL all-gather of noise_pred per step"
+                       "parallelism": "1 GPU: sequential CFG (block 0's context-independent half shared by the two branches)" if world == 1 else f"{videos} video(s) x CFG pair, RCCL all-gather of noise_pred per step"
                                       + (f"; head-parallel attention degree {args.sp} (RCCL all-to-all over xGMI)" if args.sp > 1 else ""),
                        "vae_decode": "tiled (30,52)/(15,26) decode of [1,16,21,60,104] on the HIP kernels, measured after the "
                                      "timed steps and included in value: frames/s = videos*81 / (50*s_per_step + vae_s)"

@@ -229,17 +229,29 @@ class DiTBlock(nn.Module):
         self.modulation = nn.Parameter(torch.randn(1, 6, dim) / dim ** 0.5)
         self.gate = GateModule()
 
-    def forward(self, x, context, t_mod, freqs, context_kv=None, out=None, sp=None, keep=None):
+    def forward(self, x, context, t_mod, freqs, context_kv=None, out=None, sp=None, keep=None, self_attn_memo=None):
+        """`self_attn_memo` (a dict, optional): x + gate_msa * self_attn(modulate(norm1(x))) — the block's first half — does not
+        depend on the text context.  The two forwards of a CFG step run this block on IDENTICAL x, t_mod and freqs (block 0 of the
+        DiT and of the ControlNet, model_fn_wan_video), so the first stores that half here and the second takes it: same kernels
+        on the same inputs, the same bits, one attention and four projections fewer."""
         if t_mod.dim() == 4:
             raise NotImplementedError("per-token t_mod (seperated_timestep) is outside the Goal-Force path")
         x2 = _tokens2d(x)
         rope = _as_rope(freqs, x.device)
         # rows: shift_msa, 1+scale_msa, gate_msa, shift_mlp, 1+scale_mlp, gate_mlp   (DIT:218-219, 64-65)
         mod = ops.modulation(self.modulation, t_mod.contiguous(), onep_mask=0b010010)
-        h = ops.layernorm_modulate(x2, scale1p=mod[1], shift=mod[0], eps=self.eps)              # DIT:225
-        a = self.self_attn.attend(h, rope, sp, keep)
-        x_new = out if out is not None else torch.empty_like(x2)
-        linear(a, self.self_attn.o, epilogue=ops.EPI_BIAS_GATE_RESID, resid=x2, gate=mod[2], out=x_new)   # DIT:226
+        if self_attn_memo is not None and "x" in self_attn_memo:
+            x_new = self_attn_memo.pop("x")
+            if out is not None:
+                x_new = out.copy_(x_new)
+            h = torch.empty_like(x2)
+        else:
+            h = ops.layernorm_modulate(x2, scale1p=mod[1], shift=mod[0], eps=self.eps)              # DIT:225
+            a = self.self_attn.attend(h, rope, sp, keep)
+            x_new = out if out is not None else torch.empty_like(x2)
+            linear(a, self.self_attn.o, epilogue=ops.EPI_BIAS_GATE_RESID, resid=x2, gate=mod[2], out=x_new)   # DIT:226
+            if self_attn_memo is not None:
+                self_attn_memo["x"] = x_new.clone()      # the rest of the block updates x_new in place
         ops.layernorm_modulate(x_new, weight=self.norm3.weight, bias=self.norm3.bias, eps=self.eps, out=h)
         if context_kv is None:
             context_kv = self.cross_attn.context_kv(_tokens2d(context))

@@ -15,7 +15,11 @@ Differences that do not change results:
   * `use_unified_sequence_parallel` / `sequence_parallel=` run the blocks on this rank's token chunk with head-parallel
     attention (sequence_parallel.py); unlike the reference's USP path the ControlNet tokens are sharded too;
   * `context_cache` (optional) memoises text_embedding(context) and the per-block cross-attention K/V,
-    which are constant over the denoising steps for one (expert, prompt).
+    which are constant over the denoising steps for one (expert, prompt);
+  * `cfg_shared` (optional, a dict owned by the caller for ONE denoising step): the cond and the uncond forward of a step differ
+    only in the text context, which first enters a block at its cross-attention — the self-attention half of block 0 of the DiT
+    and of the ControlNet sees identical inputs in both.  The first forward of the step stores those two tensors in the dict,
+    the second takes them (DiTBlock.forward, `self_attn_memo`): bit-identical results, 2 of 100 self-attentions per step saved.
 """
 from __future__ import annotations
 
@@ -75,6 +79,7 @@ def model_fn_wan_video(
     context_cache: Optional[ContextCache] = None,
     elide_zero_controlnet: bool = True,
     sequence_parallel=None,
+    cfg_shared: Optional[dict] = None,
     **kwargs,
 ):
     for name, val in (("motion_controller", motion_controller), ("vace", vace), ("reference_latents", reference_latents),
@@ -141,12 +146,15 @@ def model_fn_wan_video(
 
     # blocks (GF:1503-1570); ControlNet block i is evaluated right before DiT block i
     for block_id, block in enumerate(dit.blocks):
+        memo_cn = memo_dit = None
+        if cfg_shared is not None and block_id == 0:     # see the module docstring: identical inputs in both CFG branches
+            memo_cn, memo_dit = cfg_shared.setdefault("cn0", {}), cfg_shared.setdefault("dit0", {})
         if block_id < n_cn:
             cb = controlnet.controlnet_dit.blocks[block_id]
             c = cb(c, ctx, t_mod, rope, context_kv=kv_for(context_cache.cn_kv if context_cache else None, cb, block_id),
-                   sp=sp)
+                   sp=sp, self_attn_memo=memo_cn)
         x = block(x, ctx, t_mod, rope, context_kv=kv_for(context_cache.dit_kv if context_cache else None, block, block_id),
-                  sp=sp)
+                  sp=sp, self_attn_memo=memo_dit)
         if block_id < n_cn:
             # x = x + zero_conv(state)   (GF:1565-1570) — Conv1d(k=1) == Linear, fused residual epilogue
             ops.gemm(c, controlnet.zero_conv_weight(block_id), controlnet.controlnet_zero_convs_after[block_id].bias,

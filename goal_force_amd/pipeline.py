@@ -49,6 +49,7 @@ class WanVideoPipeline:
         self.controlnet: Optional[ControlNet] = None
         self.controlnet2: Optional[ControlNet] = None
         self.model_fn = model_fn_wan_video  # GF:161 — the reference's own swap point
+        self.share_cfg_prefix = True        # denoise(): block 0's self-attention half once per CFG step (bit-identical)
         self.vram_management_enabled = False
         self.elide_zero_controlnet = True
         self.num_layers = controlnet_num_layers
@@ -228,10 +229,13 @@ class WanVideoPipeline:
                                      context_cache=caches[key][b])
                 posi, nega = cfg_parallel.exchange(mine)
             else:
-                posi = self.model_fn(**models, **shared, context=context_posi, context_cache=caches[key][0])
+                # both branches on this GPU: the context-independent half of block 0 is computed once (model_fn: cfg_shared)
+                pair = {} if (cfg_scale != 1.0 and self.share_cfg_prefix and self.model_fn is model_fn_wan_video) else None
+                extra = {} if pair is None else {"cfg_shared": pair}
+                posi = self.model_fn(**models, **shared, **extra, context=context_posi, context_cache=caches[key][0])
                 nega = None
                 if cfg_scale != 1.0:
-                    nega = self.model_fn(**models, **shared, context=context_nega, context_cache=caches[key][1])
+                    nega = self.model_fn(**models, **shared, **extra, context=context_nega, context_cache=caches[key][1])
             sigma, sigma_ = self.scheduler.sigma_pair(self.scheduler.timesteps[progress_id])
             # noise_pred = nega + cfg*(posi - nega); latents += noise_pred*(sigma_next - sigma)  (GF:716, FM:81)
             ops.cfg_euler_step(latents, posi.contiguous(), None if nega is None else nega.contiguous(), cfg_scale,

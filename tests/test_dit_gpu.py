@@ -152,6 +152,47 @@ def test_model_fn_with_controlnet_vs_goldens():
             assert cn.all_zero() and torch.equal(out, out_elided) and torch.equal(out, out_none)
 
 
+def test_cfg_pair_shares_block0_self_attention_bit_identically():
+    """model_fn `cfg_shared`: the second forward of a CFG step takes the context-independent half of block 0 (DiT and
+    ControlNet) from the first.  Same bits as two independent forwards, for both branch orders; the dict is drained."""
+    from goal_force_amd.model_fn import model_fn_wan_video
+    inp = {k: v.cuda() for k, v in gi.tiny_inputs().items()}
+    ts = torch.tensor([995.9], dtype=BF).cuda()
+    dit, cn = _tiny_pipeline(False)
+    kw = dict(latents=inp["latents"], timestep=ts, y=inp["y"], controlnet=cn, control_signal_video_latents=inp["control"],
+              elide_zero_controlnet=False)
+    want_p = model_fn_wan_video(dit, context=inp["ctx_posi"], **kw)
+    want_n = model_fn_wan_video(dit, context=inp["ctx_nega"], **kw)
+    assert not torch.equal(want_p, want_n)
+    for first, second, w1, w2 in (("ctx_posi", "ctx_nega", want_p, want_n), ("ctx_nega", "ctx_posi", want_n, want_p)):
+        pair = {}
+        got1 = model_fn_wan_video(dit, context=inp[first], cfg_shared=pair, **kw)
+        assert set(pair) == {"cn0", "dit0"} and all("x" in m for m in pair.values())
+        got2 = model_fn_wan_video(dit, context=inp[second], cfg_shared=pair, **kw)
+        assert torch.equal(got1, w1) and torch.equal(got2, w2)
+        assert all(len(m) == 0 for m in pair.values())
+    # without a ControlNet only the DiT's block 0 is shared
+    pair = {}
+    a = model_fn_wan_video(dit, latents=inp["latents"], timestep=ts, y=inp["y"], context=inp["ctx_posi"], cfg_shared=pair)
+    b = model_fn_wan_video(dit, latents=inp["latents"], timestep=ts, y=inp["y"], context=inp["ctx_nega"], cfg_shared=pair)
+    assert torch.equal(a, model_fn_wan_video(dit, latents=inp["latents"], timestep=ts, y=inp["y"], context=inp["ctx_posi"]))
+    assert torch.equal(b, model_fn_wan_video(dit, latents=inp["latents"], timestep=ts, y=inp["y"], context=inp["ctx_nega"]))
+
+
+def test_denoise_loop_same_bits_with_and_without_shared_prefix():
+    from goal_force_amd.pipeline import WanVideoPipeline
+    inp = {k: v.cuda() for k, v in gi.tiny_inputs().items()}
+    dit1, cn1 = _tiny_pipeline(False)
+    dit2, cn2 = _tiny_pipeline(True, dit_seed=43)
+    pipe = WanVideoPipeline.from_modules(dit1, dit2, cn1, cn2)
+    run = lambda: pipe.denoise(inp["latents"], inp["ctx_posi"], inp["ctx_nega"], inp["y"], inp["control"],
+                               num_inference_steps=3, cfg_scale=5.0, controlnet=True)
+    assert pipe.share_cfg_prefix
+    a = run()
+    pipe.share_cfg_prefix = False
+    assert torch.equal(a, run())
+
+
 def test_three_step_cfg_loop_vs_golden():
     """GF:697-723 at tiny size: expert switch after step 2, CFG 5.0, Euler update; final latents."""
     from goal_force_amd.pipeline import WanVideoPipeline
