@@ -52,7 +52,10 @@ constexpr int GEMM_THREADS = 512;
 constexpr int TILE_BYTES = BM * BK * 2;       // 32 KiB per operand tile
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;   // A + B
 constexpr int GEMM_LDS = 2 * STAGE_BYTES;     // 128 KiB
-constexpr int GROUP_M = 8;
+#ifndef GF_GROUP_M
+#define GF_GROUP_M 8           // 16: -14 % (18 instead of 12 operand slices per K step and XCD), 4: +-2 % (tools/gemm_variants.py)
+#endif
+constexpr int GROUP_M = GF_GROUP_M;
 
 // Implicit-GEMM convolution (CONV = true instantiations of the phased kernel): the A operand is never materialised — row m
 // = output pixel (j, Y, X), column k = (tap, channel) with tap = (dt*ks + dy)*ks + dx, exactly the patch matrix of
@@ -711,7 +714,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs
 //   * same XOR-swizzled 128-byte-row LDS image, swapped operands and fused epilogues (bias / GELU-tanh / SiLU /
 //     gate*+residual / +residual / *multiply, the reference's bf16 rounding sequence) as the other kernels; the epilogue
 //     transposes each wave's 128 x 128 through a private 32 KiB LDS image and stores whole 256-byte row segments.
+#ifdef GF_A4_LOOP_INC          // A/B builds of other generated schedules (tools/gemm_variants.py)
+#include GF_A4_LOOP_INC
+#else
 #include "gf_gemm_a4_loop.inc"
+#endif
 constexpr int A4_THREADS = 256;
 #ifndef GF_A4_NT
 #define GF_A4_NT 1   // the epilogue streams: C stores and residual loads carry the non-temporal hint (D->D +2.6 %, D->F +1.2 %, F->D -0.5 %; 0 for A/B builds)

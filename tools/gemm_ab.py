@@ -24,8 +24,9 @@ def main():
         w = (torch.randn((n, k), device="cuda") / k ** 0.5).to(torch.bfloat16)
         out = torch.empty((S, n), device="cuda", dtype=torch.bfloat16)
         fl = 2.0 * S * n * k
-        variants = [(ln, kern) for ln in libs for kern in ("a4", "ph")] + [("torch", "F.linear")]
-        best = {}
+        kerns = os.environ.get("GEMM_AB_KERNELS", "a4,ph").split(",")
+        variants = [(ln, kern) for ln in libs for kern in kerns] + [("torch", "F.linear")]
+        best, outs = {}, {}
         for rnd in range(4):
             for ln, kern in variants:
                 if ln == "torch":
@@ -43,8 +44,12 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 best[(ln, kern)] = min(best.get((ln, kern), 1e9), e0.elapsed_time(e1) / 6)
+                if ln != "torch" and rnd == 0:
+                    outs[(ln, kern)] = out.clone()
+        first = next(iter(outs.values()))
         for (ln, kern), ms in best.items():
-            print(f"{name}  {ln:10s} {kern:9s} {ms:7.3f} ms  {fl / ms / 1e9:7.1f} TFLOP/s", flush=True)
+            same = "" if ln == "torch" else ("  == first" if torch.equal(outs[(ln, kern)], first) else "  DIFFERS from first")
+            print(f"{name}  {ln:10s} {kern:9s} {ms:7.3f} ms  {fl / ms / 1e9:7.1f} TFLOP/s{same}", flush=True)
 
 
 if __name__ == "__main__":
