@@ -102,7 +102,7 @@ def tensor_digest(torch, t):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fp8", action="store_true", help="BASELINE config 5: block Linears on the fp8_linear contract (e4m3 MFMA)")
@@ -162,7 +162,11 @@ def main():
 
     n_sched = 50
     k = max(1, args.steps)
-    step_ids = sorted({min(n_sched - 1, (i * n_sched) // k) for i in range(k)}) if k < n_sched else list(range(n_sched))
+    # K < 50: the K timed steps sit at the MIDPOINTS of K equal stretches of the schedule, so that their mix of high-noise steps
+    # (21 of 50: both experts' ControlNets run) and low-noise steps follows the schedule (K = 5: 2 of 5, K = 10: 4 of 10);
+    # K = 1 times a high-noise step (the pessimistic choice).  `frames_per_sec_schedule_weighted` is the exact 21/29 weighting.
+    step_ids = (sorted({min(n_sched - 1, ((2 * i + 1) * n_sched) // (2 * k)) for i in range(k)}) if k > 1 else [0]) \
+        if k < n_sched else list(range(n_sched))
     while len(step_ids) < k:  # K > 50: wrap around
         step_ids = step_ids + step_ids[: k - len(step_ids)]
     warm_ids = [step_ids[i % len(step_ids)] for i in range(args.warmup)]
