@@ -748,6 +748,17 @@ __global__ __launch_bounds__(A4_THREADS, 1) void gemm_a4_kernel(const GemmArgs p
     const int wm = wave >> 1, wn = wave & 1;
 
     const int nwg = p.tiles_m * p.tiles_n;
+#if GF_GEMM_STAMP   // diagnostic build: s_memtime at kernel entry / loop entry / loop exit / kernel exit, per workgroup (tools/gemm_a4_stamps.py)
+#define A4STAMP(i)                                                                              \
+    {                                                                                           \
+        unsigned long long t_;                                                                  \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");             \
+        if (p.dbg && threadIdx.x == 0) p.dbg[(long)blockIdx.x * 4 + (i)] = t_;                  \
+    }
+#else
+#define A4STAMP(i)
+#endif
+    A4STAMP(0)
     int v;
     {
         const int pid = blockIdx.x;
@@ -809,7 +820,11 @@ __global__ __launch_bounds__(A4_THREADS, 1) void gemm_a4_kernel(const GemmArgs p
     else if (p.whatif == 128) GF_A4_LOOP_ASM_W128(voffA, voffB, pfA, pfB, rdA0, rdA1, rdB0, rdB1, aLo, aHi, nrA, bLo, bHi, nrB, soA, stA, soB, stB, ldsW, nk, k0, kb);
     else
 #endif
-    GF_A4_LOOP_ASM(voffA, voffB, pfA, pfB, rdA0, rdA1, rdB0, rdB1, aLo, aHi, nrA, bLo, bHi, nrB, soA, stA, soB, stB, ldsW, nk, k0, kb);
+    {
+        A4STAMP(1)
+        GF_A4_LOOP_ASM(voffA, voffB, pfA, pfB, rdA0, rdA1, rdB0, rdB1, aLo, aHi, nrA, bLo, bHi, nrB, soA, stA, soB, stB, ldsW, nk, k0, kb);
+        A4STAMP(2)
+    }
 
 #ifdef GF_A4_WHATIF
     if (p.whatif == 32) return;   // timing only: no epilogue at all
@@ -878,6 +893,10 @@ __global__ __launch_bounds__(A4_THREADS, 1) void gemm_a4_kernel(const GemmArgs p
             }
         }
     }
+#if GF_GEMM_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have left the CU
+    A4STAMP(3)
+#endif
 }
 
 template <int EPI>
