@@ -1040,12 +1040,13 @@ __global__ __launch_bounds__(At3<NQ>::THREADS, (NQ == 2 ? 2 : 1)) void flash_att
     };
     const u32x4s srd_v = make_srd(p.vt);
     auto dma16b = [&](const u32x4s& srd, unsigned voff_bytes, unsigned soff_bytes, GF_LDS char* l) __attribute__((always_inline)) {
-        // M0 (the LDS destination) is ours: nothing else in this kernel uses it, so it is set and not restored
+        // M0 (the LDS destination) is ours: it is a reserved register the compiler never allocates and, on gfx9+, sets itself right
+        // before the few instructions that read it (none in this kernel) — so it is set here and not saved / restored
         const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)l);
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds"
                      :
                      : "v"(voff_bytes), "s"(srd), "s"(dst), "s"(soff_bytes)
-                     : "memory", "m0");
+                     : "memory");
     };
     // The K descriptor of tile t starts at the tile and ends with the key sequence (num_records = bytes of the rows that exist,
     // 0 for a tile past the end): rows of a ragged last tile beyond kv_len, and whole tiles that do not exist, arrive as zeros
