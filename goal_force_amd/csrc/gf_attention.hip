@@ -41,6 +41,10 @@
 #ifndef GF_K3_SNAKE
 #define GF_K3_SNAKE 1    // kernel 3: query-block order reversed on odd fragments (one MFMA operand changes per slot instead of both)
 #endif
+#ifndef GF_K3_DMA0
+#define GF_K3_DMA0 10    // kernel 3: slot of the phase's first staging piece ...
+#define GF_K3_DMAS 8     // ... and the slot distance between pieces (4 per wave and phase)
+#endif
 #ifndef GF_K3_WHATIF
 #define GF_K3_WHATIF 0   // timing-only variants of kernel 3's steady phase (tools/attn_ab.py); 0 in the shipped library
 #endif
@@ -1288,12 +1292,12 @@ __global__ __launch_bounds__(At3<NQ>::THREADS, (NQ == 2 ? 2 : 1)) void flash_att
             }
         }
     };
-    // staging: the wave's NP V^T pieces of tile p, then its NP K pieces of tile p+2, one every 4 NQ slots from slot 10
+    // staging: the wave's NP V^T pieces of tile p, then its NP K pieces of tile p+2, one every GF_K3_DMAS slots from slot GF_K3_DMA0
     auto dma_slot = [&](auto s_c, auto par_c, int pidx) __attribute__((always_inline)) {
         constexpr int S = decltype(s_c)::value, PAR = decltype(par_c)::value;
         if constexpr ((GF_K3_WHATIF & 8) != 0) return;
-        if constexpr (S >= 10 && (S - 10) % (4 * NQ) == 0 && (S - 10) / (4 * NQ) < 2 * NP) {
-            constexpr int i = (S - 10) / (4 * NQ);
+        if constexpr (S >= GF_K3_DMA0 && (S - GF_K3_DMA0) % GF_K3_DMAS == 0 && (S - GF_K3_DMA0) / GF_K3_DMAS < 2 * NP) {
+            constexpr int i = (S - GF_K3_DMA0) / GF_K3_DMAS;
             if constexpr (i < NP) {
                 stage_piece(1, pidx, PAR, i);
             } else {
