@@ -28,11 +28,11 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# HBM bytes per self-attention launch (transpose_v32_kernel + flash_attn_fwd_kernel3<2>) from rocprofv3 --pmc, separate
+# HBM bytes per self-attention launch (flash_attn_fwd_kernel3<2>; its V^T operand comes from the projection GEMM) from rocprofv3 --pmc, separate
 # FETCH_SIZE / WRITE_SIZE passes over tools/microbench.py attn (tools/profile_r02.sh): (2 x FETCH_SIZE [gfx950 reports half of a
 # 16-B/lane stream] + WRITE_SIZE) KiB -> bytes, this round's build.  PMC needs the profiler, so this is a STATIC figure from
 # the named files, not measured by the run that prints it ("traffic_static": true in the JSON line).
-ATTN_TRAFFIC_BYTES = ((2 * 1490960 + 501680) + (2 * 163817 + 327759)) * 1024
+ATTN_TRAFFIC_BYTES = (2 * 1490930 + 501680) * 1024
 ATTN_TRAFFIC_SOURCE = "profiles/r02/pmc/attn_k3_FETCH_SIZE.md + attn_k3_WRITE_SIZE.md"
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md (Chip-level parameters)
 S_TOK, DIM, HEADS, FFN, LTXT = 32760, 5120, 40, 13824, 512
@@ -281,7 +281,7 @@ def main():
             "step_mfma_frac": (sum(step_flops) / elapsed / 1e12) / PEAK_BF16_TFLOPS,
             "frames_per_sec_schedule_weighted": (videos * 81.0 / ((21 * sum(hi) / len(hi) + 29 * sum(lo) / len(lo)) / 1e3 + vae_s)
                                                  if hi and lo else None),
-            "roofline": {"bound": "mfma", "kernel": "flash_attn_fwd_kernel3<2> + transpose_v32_kernel (self-attention, S=32760, 40 heads, d=128)",
+            "roofline": {"bound": "mfma", "kernel": "flash_attn_fwd_kernel3<2> (self-attention, S=32760, 40 heads, d=128; V^T is written by the V projection GEMM, gf_linear_vt32)",
                          "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "peak_note": "dense bf16 MFMA peak = 256 CU x 4096 FLOP/clk x 2.4 GHz (MI355X_MICROARCH.md); under this "
                                       "load the chip holds 1.74-2.05 GHz depending on the box and build (rocprofv3 GRBM_GUI_ACTIVE: 1.84 GHz "
@@ -290,7 +290,7 @@ def main():
                          # HBM bytes per launch from rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes over
                          # tools/microbench.py attn, profiles/r01/pmc/): (2 x FETCH_SIZE [gfx950 reports half of a 16-B/lane
                          # stream] + WRITE_SIZE) KiB -> bytes.  Not collected live: PMC needs the profiler.
-                         # The launch = transpose_v32_kernel + flash_attn_fwd_kernel3<2> (both inside the timed events).
+                         # The launch = flash_attn_fwd_kernel3<2> alone (V^T is written by the V projection, gf_linear_vt32).
                          "traffic": ATTN_TRAFFIC_BYTES, "traffic_static": True,
                          "traffic_source": ATTN_TRAFFIC_SOURCE,
                          "launches": len(self_att), "avg_launch_ms": att_ms if self_att else None,

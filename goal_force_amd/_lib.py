@@ -25,7 +25,7 @@ SYMBOLS = (
     "gf_quant_fp8_rowscale", "gf_cast_fp8", "gf_gemm_fp8",
     "gf_flash_attn_fwd_lse", "gf_flash_attn_bwd",
     "gf_layernorm_bwd", "gf_rmsnorm_rope_bwd", "gf_colsum", "gf_act_bwd", "gf_mse_loss", "gf_adamw_step", "gf_f32_to_bf16", "gf_sumsq",
-    "gf_transpose_v", "gf_flash_attn_fwd_vt", "gf_transpose_v32", "gf_flash_attn_fwd_vt32",
+    "gf_transpose_v", "gf_flash_attn_fwd_vt", "gf_transpose_v32", "gf_flash_attn_fwd_vt32", "gf_linear_vt32",
     "gf_conv3d_bf16",
 )
 
@@ -68,6 +68,7 @@ def _declare(lib):
         "gf_transpose_v": [_vp, _i64, _vp, _i64, _i64, _i64, _vp],
         "gf_flash_attn_fwd_vt": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _vp],
         "gf_transpose_v32": [_vp, _i64, _vp, _i64, _i64, _i64, _vp],
+        "gf_linear_vt32": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _vp],
         "gf_flash_attn_fwd_vt32": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _vp],
         "gf_patchify_im2col": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp],
         "gf_unpatchify": [_vp, _vp, _i64, _i64, _i64, _i64, _vp],

@@ -86,7 +86,13 @@ struct GemmArgs {
     ConvGeom cv;
     int whatif;   // -DGF_A4_WHATIF diagnostic builds only (tools/gemm_a4_whatif.py)
     int stagger;  // gemm_a4_kernel: column tile j starts its K loop at K tile (stagger * j) mod nk (GF_A4_STAGGER, default 2; 0 = off)
+    int wrows;    // gemm_a4_kernel: rows of W that exist (= N except for GF_EPI_VT32, where N = kv_pad covers zero columns past kv_len)
+    int stagger_rows;   // gemm_a4_kernel: the K-loop rotation follows the ROW tile (GF_EPI_VT32: the operands are swapped, see gf_linear_vt32)
 };
+
+// internal epilogue of gf_linear_vt32 (not in goalforce.h's enum): C rows = output features, C columns = keys in kernel 3's
+// order, bias per ROW, columns >= wrows zero
+constexpr int GF_EPI_VT32 = 6;
 
 __device__ __forceinline__ void glds16(const void* g, GF_LDS char* l) {
     __builtin_amdgcn_global_load_lds((const GF_GLOBAL void*)g, (GF_LDS void*)l, 16, 0, 0);
@@ -790,7 +796,8 @@ __global__ __launch_bounds__(A4_THREADS, 1) void gemm_a4_kernel(const GemmArgs p
     const unsigned aLo = (unsigned)baseA, aHi = (unsigned)(baseA >> 32) & 0xffffu;
     const unsigned bLo = (unsigned)baseB, bHi = (unsigned)(baseB >> 32) & 0xffffu;
     const unsigned nrA = (unsigned)(((long)(min(p.M - m0, BM) - 1) * p.lda + p.K) * 2);   // valid bytes from the tile's first row
-    const unsigned nrB = (unsigned)(((long)(min(p.N - n0, BN) - 1) * p.ldw + p.K) * 2);
+    const int wvalid = min(p.wrows - n0, BN);                                              // rows of this W tile that exist
+    const unsigned nrB = wvalid > 0 ? (unsigned)(((long)(wvalid - 1) * p.ldw + p.K) * 2) : 0u;
     const unsigned stA = 8u * (unsigned)p.lda * 2u, stB = 8u * (unsigned)p.ldw * 2u;
     const unsigned soA = (unsigned)wave * 8u * stA, soB = (unsigned)wave * 8u * stB;
     const unsigned ldsW = (unsigned)(unsigned long)lds + (unsigned)wave * 8192u;
@@ -800,7 +807,7 @@ __global__ __launch_bounds__(A4_THREADS, 1) void gemm_a4_kernel(const GemmArgs p
     // operands have the same pitch, so without this every workgroup of the chip walks the SAME few memory channels at the
     // same time (pitch 10 KiB: 16 of 128 channel slots).  The sum over k is only rotated; it depends on the column tile
     // alone, so an output element's bits do not depend on how the rows are cut into tiles or sharded over GPUs.
-    const unsigned k0 = p.stagger ? (unsigned)((p.stagger * (n0 / BN)) % (int)nk) : 0u;
+    const unsigned k0 = p.stagger ? (unsigned)((p.stagger * (p.stagger_rows ? m0 / BM : n0 / BN)) % (int)nk) : 0u;
     const unsigned kb = (unsigned)p.K * 2u;
 
     // ---- fragment read addresses: (row, chunk) at row * 128 + ((chunk ^ (row & 7)) << 4); sub-step ks reads chunk 4 ks + fq
@@ -836,7 +843,7 @@ __global__ __launch_bounds__(A4_THREADS, 1) void gemm_a4_kernel(const GemmArgs p
         constexpr int j = decltype(j_c)::value;
         float bv[4] = {0.f, 0.f, 0.f, 0.f};
         const int n = n0 + wn * 128 + j * 16 + fq * 4;
-        if (p.bias && n < p.N) {   // N % 8 == 0: n .. n+3 are all valid
+        if (EPI != GF_EPI_VT32 && p.bias && n < p.N) {   // N % 8 == 0: n .. n+3 are all valid
             const u16x4 b4 = *reinterpret_cast<const u16x4*>(p.bias + n);
 #pragma unroll
             for (int r = 0; r < 4; ++r) bv[r] = bf2f(b4[r]);
@@ -845,9 +852,16 @@ __global__ __launch_bounds__(A4_THREADS, 1) void gemm_a4_kernel(const GemmArgs p
             constexpr int i = decltype(i_c)::value;
             constexpr int A0 = (i * 8 + j) * 4;
             float y[4] = {a4_acc<A0>(), a4_acc<A0 + 1>(), a4_acc<A0 + 2>(), a4_acc<A0 + 3>()};
+            if constexpr (EPI == GF_EPI_VT32) {   // bias of the ROW (output feature); key columns that do not exist are zero
+                const int mrow = m0 + wm * 128 + i * 16 + frow;
+                const float bm = (p.bias && mrow < p.M) ? bf2f(p.bias[mrow]) : 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                y[r] = gf_epi_act<EPI>(y[r] + bv[r]);
+                for (int r = 0; r < 4; ++r) y[r] = (n + r < p.wrows) ? y[r] + bm : 0.f;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    y[r] = gf_epi_act<EPI>(y[r] + bv[r]);
+                }
             }
             u32x2 pk;
             pk[0] = pack2bf(y[0], y[1]);
@@ -868,7 +882,17 @@ __global__ __launch_bounds__(A4_THREADS, 1) void gemm_a4_kernel(const GemmArgs p
         for (int it = 0; it < 32; ++it) {
             const int row = it * 4 + (lane >> 4);
             const int m = m0 + wm * 128 + row;
-            const u16x8 yv = *(GF_LDS u16x8*)(ep + row * 256 + ((cc ^ (row & 15)) << 4));
+            u16x8 yv;
+            if constexpr (EPI == GF_EPI_VT32) {
+                // positions 8 cc .. 8 cc + 7 of the row = keys 4 g .. 4 g + 3 and 16 + 4 g .. of 32-key group G (cc = 4 G + g): the k
+                // order of the 16x16x32 B operand that kernel 3 builds from two score tiles (gf_transpose_v32)
+                const int G = cc >> 2, g = cc & 3, sw = (row & 15) << 1;
+                const u16x4 lo = *(GF_LDS u16x4*)(ep + row * 256 + (((8 * G + g) ^ sw) << 3));
+                const u16x4 hi = *(GF_LDS u16x4*)(ep + row * 256 + (((8 * G + 4 + g) ^ sw) << 3));
+                yv = u16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            } else {
+                yv = *(GF_LDS u16x8*)(ep + row * 256 + ((cc ^ (row & 15)) << 4));
+            }
             if (m < p.M && n_ok) {
                 u16x8 o = yv;
                 if (EPI == GF_EPI_BIAS_GATE_RESID || EPI == GF_EPI_BIAS_RESID || EPI == GF_EPI_BIAS_MUL) {
@@ -1318,6 +1342,8 @@ static int gemm_dispatch(bool fp8, const void* A, int64_t lda, const void* W, in
         const char* es = getenv("GF_A4_STAGGER");   // K tiles between the K-loop starts of neighbouring column tiles (0 = off)
         a.stagger = es ? atoi(es) : 2;
     }
+    a.wrows = (int)N;
+    a.stagger_rows = 0;
 #ifdef GF_A4_WHATIF
     if (const char* ew = getenv("GF_A4_WHATIF")) a.whatif = atoi(ew);
 #endif
@@ -1347,6 +1373,49 @@ extern "C" GF_API int gf_gemm_fp8(const void* A8, int64_t lda, const void* W8, i
                                   const void* bias, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue,
                                   const void* resid, int64_t ldr, const void* gate, void* stream) {
     return gemm_dispatch(true, A8, lda, W8, ldw, row_scale, bias, C, ldc, M, N, K, epilogue, resid, ldr, gate, stream);
+}
+
+// The V projection of a self-attention written directly as kernel 3's operand: vt[n][pos(s)] = bf16(sum_k x[s,k] w[n,k] + bias[n]),
+// [N rows][kv_pad] with the keys of every 32-group in the order gf_transpose_v32 produces and zeros from kv_len to kv_pad.
+// It is the SAME 4-wave GEMM with the operands swapped (A := w, W := x: C = w x^T is V^T row-major), the bias taken per row, the
+// K-loop rotation taken from the row tile (so every element sums its products in the order gf_gemm_bf16(x, w) uses) and the
+// key permutation applied where the epilogue reads its LDS image: bit-identical to gf_gemm_bf16 + gf_transpose_v32, one
+// kernel and one 2 x 335 MB pass over V less per attention.
+extern "C" GF_API int gf_linear_vt32(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias, void* vt,
+                                     int64_t kv_len, int64_t kv_pad, int64_t N, int64_t K, void* stream) {
+    GF_CHECK_ARG(x && w && vt, "gf_linear_vt32: null x/w/vt");
+    GF_CHECK_ARG(kv_len > 0 && kv_pad >= kv_len && kv_pad % 64 == 0 && kv_pad - kv_len < 64, "gf_linear_vt32: kv_pad = kv_len rounded up to 64");
+    GF_CHECK_ARG(N >= 512 && N % 128 == 0 && K > 0 && K % 64 == 0, "gf_linear_vt32: N=%ld (>= 512, multiple of 128), K=%ld (multiple of 64)", (long)N, (long)K);
+    GF_CHECK_ARG(ldx % 8 == 0 && ldw % 8 == 0 && ldx >= K && ldw >= K, "gf_linear_vt32: leading dimensions must be multiples of 8 covering K");
+    GF_CHECK_ARG(gf_aligned16(x) && gf_aligned16(w) && gf_aligned16(vt) && (!bias || ((uintptr_t)bias & 1u) == 0), "gf_linear_vt32: alignment");
+    GF_CHECK_ARG(N * kv_pad < (1LL << 31) && 256L * ldx * 2 + K * 2L < (1L << 31) && 256L * ldw * 2 + K * 2L < (1L << 31),
+                 "gf_linear_vt32: operand too large for 32-bit staging offsets");
+    GemmArgs a;
+    a.A = (const u16*)w;
+    a.W = (const u16*)x;
+    a.bias = (const u16*)bias;
+    a.C = (u16*)vt;
+    a.R = nullptr;
+    a.gate = nullptr;
+    a.row_scale = nullptr;
+    a.M = (int)N;
+    a.N = (int)kv_pad;
+    a.K = (int)K;
+    a.lda = ldw;
+    a.ldw = ldx;
+    a.ldc = kv_pad;
+    a.ldr = 0;
+    a.tiles_m = (int)((N + BM - 1) / BM);
+    a.tiles_n = (int)((kv_pad + BN - 1) / BN);
+    a.dbg = nullptr;
+    a.whatif = 0;
+    {
+        const char* es = getenv("GF_A4_STAGGER");
+        a.stagger = es ? atoi(es) : 2;
+    }
+    a.wrows = (int)kv_len;
+    a.stagger_rows = 1;
+    return launch_gemm_a4<GF_EPI_VT32>(a, (hipStream_t)stream);
 }
 
 // Causal 3-D / 2-D convolution of the Wan VAE as ONE implicit GEMM (no patch matrix in HBM): out[(j, Y, X), n] =
@@ -1407,6 +1476,8 @@ extern "C" GF_API int gf_conv3d_bf16(const void* src, const void* cache, const v
     a.dbg = nullptr;
     a.whatif = 0;
     a.stagger = 0;
+    a.wrows = (int)N;
+    a.stagger_rows = 0;
     a.cv.src = (const u16*)src;
     a.cv.cache = (const u16*)cache;
     a.cv.zero = conv_zero_page();

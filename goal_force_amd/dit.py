@@ -159,10 +159,17 @@ class SelfAttention(nn.Module):
         group `sp`, x2 and rope are this rank's token chunk and the heads are exchanged over xGMI (usp_attn_forward,
         diffsynth/distributed/xdit_context_parallel.py:109-131).  `keep` (a dict, training): the attention output and the
         rows' log-sum-exp are stored under "attn" / "lse" so that the backward does not run the attention again."""
-        xin = QuantizedInput(x2) if getattr(self.q, "_gf_w8", None) is not None else x2
-        q, k, v = linear(xin, self.q), linear(xin, self.k), linear(xin, self.v)
+        fp8 = getattr(self.q, "_gf_w8", None) is not None
+        xin = QuantizedInput(x2) if fp8 else x2
+        q, k = linear(xin, self.q), linear(xin, self.k)
         ops.rmsnorm_rope(q, self.norm_q.weight, rope.cos, rope.sin, self.head_dim, self.norm_q.eps)
         ops.rmsnorm_rope(k, self.norm_k.weight, rope.cos, rope.sin, self.head_dim, self.norm_k.eps)
+        if sp is None and keep is None and not fp8 and x2.is_cuda and self.v.weight.shape[0] >= 512 \
+                and ops.vt32_ok(x2.shape[0], self.num_heads, self.head_dim):
+            # inference on one GPU: nothing but the attention reads V, so the projection writes it straight in the layout the
+            # attention kernel wants (gf_linear_vt32: same bits as the plain projection + the transpose, one pass over V less)
+            return ops.flash_attn(q, k, None, self.num_heads, vt=ops.linear_vt32(x2, self.v.weight, self.v.bias))
+        v = linear(xin, self.v)
         if sp is not None:
             return sp.attention(q, k, v, self.num_heads)
         if keep is not None:

@@ -168,17 +168,48 @@ def _vt_workspace(numel, device):
     return ws
 
 
-def flash_attn(q, k, v, num_heads, out=None, scale=None):
-    """softmax(q k^T / sqrt(d)) v per head; q [Sq, H*128], k/v [Skv, H*128] (row-strided views OK)."""
-    for n, t in (("q", q), ("k", k), ("v", v)):
+def vt32_ok(skv, num_heads, head_dim):
+    """True when flash_attn would take the pre-transposed-V kernel 3 for this key length (then linear_vt32 can produce its V^T)."""
+    kv_pad = -(-skv // 64) * 64
+    return (skv >= VT_MIN_KV and head_dim == 128 and num_heads * 128 * kv_pad < 2 ** 31
+            and os.environ.get("GF_ATTN_KERNEL", "3") == "3" and os.environ.get("GF_VT_FROM_GEMM", "1") == "1")
+
+
+def linear_vt32(x, weight, bias):
+    """The V projection of a self-attention, written directly as kernel 3's V^T operand (gf_linear_vt32): returns the V^T
+    workspace of this (device, stream) — valid until the next call — for flash_attn(..., vt=...).  Same bits as
+    gemm(x, weight, bias) followed by the transpose inside flash_attn."""
+    _req(x, "linear_vt32.x")
+    _req(weight, "linear_vt32.weight")
+    xv, skv, K, ldx = _rows2d(x, "linear_vt32.x")
+    if weight.dim() != 2 or weight.stride(1) != 1 or weight.shape[1] != K:
+        raise GoalForceError(f"linear_vt32.weight: expected [N, {K}] with contiguous rows")
+    N = weight.shape[0]
+    if bias is not None:
+        _req(bias, "linear_vt32.bias")
+        if bias.numel() != N or not bias.is_contiguous():
+            raise GoalForceError(f"linear_vt32.bias: expected contiguous [{N}]")
+    kv_pad = -(-skv // 64) * 64
+    vt = _vt_workspace(N * kv_pad, x.device)
+    _lib.check(_lib.load().gf_linear_vt32(_ptr(xv), ldx, _ptr(weight), weight.stride(0), _ptr(bias), _ptr(vt), skv, kv_pad, N, K,
+                                          _stream(x)), "gf_linear_vt32")
+    return vt
+
+
+def flash_attn(q, k, v, num_heads, out=None, scale=None, vt=None):
+    """softmax(q k^T / sqrt(d)) v per head; q [Sq, H*128], k/v [Skv, H*128] (row-strided views OK).  `vt` (instead of v): the
+    V^T operand linear_vt32 produced for these keys."""
+    for n, t in (("q", q), ("k", k)) + ((("v", v),) if vt is None else ()):
         _req(t, f"flash_attn.{n}")
         if t.dim() != 2 or t.stride(1) != 1:
             raise GoalForceError(f"flash_attn.{n}: expected 2-D [len, heads*head_dim] with contiguous rows")
     sq, hd_all = q.shape
     skv = k.shape[0]
     head_dim = hd_all // num_heads
-    if k.shape[1] != hd_all or v.shape != k.shape or head_dim * num_heads != hd_all:
+    if k.shape[1] != hd_all or (vt is None and v.shape != k.shape) or head_dim * num_heads != hd_all:
         raise GoalForceError("flash_attn: q/k/v shape mismatch")
+    if vt is not None and not vt32_ok(skv, num_heads, head_dim):
+        raise GoalForceError("flash_attn: a pre-transposed V is only taken by kernel 3 (key length >= VT_MIN_KV, head_dim 128)")
     if out is None:
         out = torch.empty((sq, hd_all), dtype=_BF16, device=q.device)
     if scale is None:
@@ -192,11 +223,14 @@ def flash_attn(q, k, v, num_heads, out=None, scale=None):
     if skv >= VT_MIN_KV and head_dim == 128 and num_heads * 128 * kv_pad < 2 ** 31:
         # long key sequences (the DiT self-attention): hand V over pre-transposed — one LDS read per PV MFMA instead of two;
         # the transpose (0.7 % of the attention's time at S=32760) is inside the timed region
-        vt = _vt_workspace(num_heads * 128 * kv_pad, q.device)
         # GF_ATTN_KERNEL=2 (read per call: A/B runs) selects the 32x32x16-MFMA kernel 2; default = kernel 3 on 16x16x32 MFMAs
         k3 = os.environ.get("GF_ATTN_KERNEL", "3") == "3"
         tr, fa = (lib.gf_transpose_v32, lib.gf_flash_attn_fwd_vt32) if k3 else (lib.gf_transpose_v, lib.gf_flash_attn_fwd_vt)
-        _lib.check(tr(_ptr(v), v.stride(0), _ptr(vt), skv, kv_pad, num_heads, _stream(q)), "gf_transpose_v")
+        if vt is None:
+            vt = _vt_workspace(num_heads * 128 * kv_pad, q.device)
+            _lib.check(tr(_ptr(v), v.stride(0), _ptr(vt), skv, kv_pad, num_heads, _stream(q)), "gf_transpose_v")
+        elif vt.numel() < num_heads * 128 * kv_pad:
+            raise GoalForceError("flash_attn.vt: buffer smaller than heads*128*kv_pad")
         _lib.check(fa(_ptr(q), _ptr(k), _ptr(vt), _ptr(out), None, sq, skv, kv_pad, num_heads, head_dim,
                       q.stride(0), k.stride(0), out.stride(0), float(scale), _stream(q)), "gf_flash_attn_fwd_vt")
     else:

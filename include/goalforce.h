@@ -147,6 +147,15 @@ GF_API int gf_flash_attn_fwd_vt32(const void* q, const void* k, const void* vt, 
                                   int64_t q_len, int64_t kv_len, int64_t kv_pad, int64_t heads, int64_t head_dim,
                                   int64_t q_stride, int64_t k_stride, int64_t o_stride, float scale, void* stream);
 
+/* gf_linear_vt32 — the V projection of SelfAttention.forward (`v = self.v(x)`, DIT:131-146) written DIRECTLY in the layout
+ * gf_flash_attn_fwd_vt32 reads: vt[n * kv_pad + pos(s)] = bf16(sum_k x[s,k] * w[n,k] + bias[n]) for n < N, s < kv_len, positions
+ * kv_len .. kv_pad-1 zero, pos() = the key order of gf_transpose_v32.  Bit-identical to gf_gemm_bf16(x, w, bias) followed by
+ * gf_transpose_v32 (same MFMA kernel with the operands swapped, same summation order); saves the plain V tensor's round trip.
+ *   x [kv_len, ldx] bf16, w [N, ldw] bf16 (nn.Linear layout), bias [N] bf16 or NULL, vt [N * kv_pad] bf16;
+ *   kv_pad = kv_len rounded up to 64, N >= 512 and a multiple of 128, K a multiple of 64. */
+GF_API int gf_linear_vt32(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias, void* vt,
+                          int64_t kv_len, int64_t kv_pad, int64_t N, int64_t K, void* stream);
+
 /* ------------------------------------------------------------------------
  * Training (ControlNet training step): training_loss (GF:180-193) calls loss.backward() through
  * F.scaled_dot_product_attention (DIT:28-61) in every block.

@@ -255,6 +255,48 @@ def test_flash_attn_kernel3_vs_fp64(ops, sq, skv, heads):
     assert bool(torch.isfinite(got.float()).all())
 
 
+@pytest.mark.parametrize("skv,n,k", [(2100, 512, 256), (2048, 640, 320), (4100, 1024, 192), (32760, 5120, 5120)])
+def test_linear_vt32_is_projection_plus_transpose_bit_for_bit(ops, skv, n, k):
+    """gf_linear_vt32 (the V projection written as kernel 3's V^T operand by the GEMM itself, operands swapped) against the path it
+    replaces: gf_gemm_bf16 then gf_transpose_v32.  Same MFMA kernel, same summation order per element: the same bits, including
+    the zero key columns from kv_len to kv_pad."""
+    from goal_force_amd import _lib
+    g = torch.Generator().manual_seed(skv + n)
+    x = dev(torch.randn((skv, k), generator=g).to(BF))
+    w = dev((torch.randn((n, k), generator=g) * 0.05).to(BF))
+    b = dev(torch.randn((n,), generator=g).to(BF))
+    kv_pad = -(-skv // 64) * 64
+    heads = n // 128
+    v = ops.gemm(x, w, b)
+    want = torch.full((n * kv_pad,), 7.0, dtype=BF, device="cuda")
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.gf_transpose_v32(v.data_ptr(), v.stride(0), want.data_ptr(), skv, kv_pad, heads, st) == 0
+    got = ops.linear_vt32(x, w, b)[: n * kv_pad].clone()
+    torch.cuda.synchronize()
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    got2 = ops.linear_vt32(x, w, None)[: n * kv_pad]
+    assert lib.gf_transpose_v32(ops.gemm(x, w, None).data_ptr(), n, want.data_ptr(), skv, kv_pad, heads, st) == 0
+    assert torch.equal(got2.view(torch.int16), want.view(torch.int16))
+
+
+def test_self_attention_same_bits_with_v_transposed_by_the_projection(ops, monkeypatch):
+    """SelfAttention.attend with the V^T-writing projection == with the plain projection + transpose (GF_VT_FROM_GEMM=0)."""
+    from goal_force_amd.dit import RopeTable, SelfAttention
+    torch.manual_seed(3)
+    heads, s = 4, 2100
+    sa = SelfAttention(heads * 128, heads).to(BF).cuda()
+    x = dev((torch.randn((s, heads * 128)) * 0.5).to(BF))
+    pos = torch.arange(s, dtype=torch.float32)[:, None] * torch.arange(1, 65, dtype=torch.float32)[None, :] * 1e-3
+    rope = RopeTable(torch.polar(torch.ones_like(pos), pos), "cuda")
+    assert ops.vt32_ok(s, heads, 128)
+    a = sa.attend(x, rope)
+    monkeypatch.setenv("GF_VT_FROM_GEMM", "0")
+    assert not ops.vt32_ok(s, heads, 128)
+    b = sa.attend(x, rope)
+    assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("case", ["spike_up_mid", "negative_start", "huge_then_small", "all_equal"])
 def test_flash_attn_kernel3_running_maximum_paths(ops, case):
     """The running maximum of kernel 3 lives in the accumulators' initial value (scores are produced relative to it): force
