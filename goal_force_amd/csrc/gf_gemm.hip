@@ -88,6 +88,7 @@ struct GemmArgs {
     int stagger;  // gemm_a4_kernel: column tile j starts its K loop at K tile (stagger * j) mod nk (GF_A4_STAGGER, default 2; 0 = off)
     int wrows;    // gemm_a4_kernel: rows of W that exist (= N except for GF_EPI_VT32, where N = kv_pad covers zero columns past kv_len)
     int stagger_rows;   // gemm_a4_kernel: the K-loop rotation follows the ROW tile (GF_EPI_VT32: the operands are swapped, see gf_linear_vt32)
+    int group_m;        // gemm_a4_kernel: row tiles per workgroup-order group (set by launch_gemm_a4)
 };
 
 // internal epilogue of gf_linear_vt32 (not in goalforce.h's enum): C rows = output features, C columns = keys in kernel 3's
@@ -772,10 +773,11 @@ __global__ __launch_bounds__(A4_THREADS, 1) void gemm_a4_kernel(const GemmArgs p
         const int q = nwg >> 3, r = nwg & 7;
         v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
     }
-    const int per_group = GROUP_M * p.tiles_n;
+    const int gm = p.group_m;                        // row tiles per group (launch_gemm_a4: 8, or 4 for long K loops)
+    const int per_group = gm * p.tiles_n;
     const int group = v / per_group;
-    const int first_m = group * GROUP_M;
-    const int gsz = min(p.tiles_m - first_m, GROUP_M);
+    const int first_m = group * gm;
+    const int gsz = min(p.tiles_m - first_m, gm);
     const int in_group = v - group * per_group;
     const int m0 = (first_m + in_group % gsz) * BM, n0 = (in_group / gsz) * BN;
 
@@ -839,6 +841,27 @@ __global__ __launch_bounds__(A4_THREADS, 1) void gemm_a4_kernel(const GemmArgs p
     // ---- epilogue: a[(i*8+j)*4 + r] = C[m0 + wm*128 + 16 i + frow][n0 + wn*128 + 16 j + 4 fq + r]  (the asm ended on a barrier:
     // every wave is past its LDS reads and every LDS-DMA has landed)
     GF_LDS char* ep = lds + wave * 32768;   // private 128 rows x 256 B; 8-byte slot s of row r at slot s ^ ((r & 15) << 1)
+    // The residual / multiplier operand of the epilogue is requested FIRST, all 32 row pieces of this lane (128 VGPRs: the
+    // fragment registers are free now): its HBM latency passes under the accumulator conversion below.  Loading it inside the
+    // store loop, four pieces in flight, cost the three residual GEMMs of a block 0.12-0.17 ms each (D->D: 1.36 -> 1.2x ms).
+    constexpr bool HAS_R = EPI == GF_EPI_BIAS_GATE_RESID || EPI == GF_EPI_BIAS_RESID || EPI == GF_EPI_BIAS_MUL;
+    u16x8 rres[HAS_R ? 32 : 1];
+    if constexpr (HAS_R) {
+        const int nr = n0 + wn * 128 + (lane & 15) * 8;
+#pragma unroll
+        for (int it = 0; it < 32; ++it) {
+            const int mr = m0 + wm * 128 + it * 4 + (lane >> 4);
+            if (mr < p.M && nr < p.N) {
+#if GF_A4_NT
+                rres[it] = __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(p.R + (long)mr * p.ldr + nr));
+#else
+                rres[it] = *reinterpret_cast<const u16x8*>(p.R + (long)mr * p.ldr + nr);
+#endif
+            } else {
+                rres[it] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+        }
+    }
     a4_static_for<0, 8>([&](auto j_c) {
         constexpr int j = decltype(j_c)::value;
         float bv[4] = {0.f, 0.f, 0.f, 0.f};
@@ -878,7 +901,7 @@ __global__ __launch_bounds__(A4_THREADS, 1) void gemm_a4_kernel(const GemmArgs p
         const bool n_ok = n < p.N;
         u16x8 g8;
         if (EPI == GF_EPI_BIAS_GATE_RESID && n_ok) g8 = *reinterpret_cast<const u16x8*>(p.gate + n);
-#pragma unroll 4
+#pragma unroll
         for (int it = 0; it < 32; ++it) {
             const int row = it * 4 + (lane >> 4);
             const int m = m0 + wm * 128 + row;
@@ -895,12 +918,8 @@ __global__ __launch_bounds__(A4_THREADS, 1) void gemm_a4_kernel(const GemmArgs p
             }
             if (m < p.M && n_ok) {
                 u16x8 o = yv;
-                if (EPI == GF_EPI_BIAS_GATE_RESID || EPI == GF_EPI_BIAS_RESID || EPI == GF_EPI_BIAS_MUL) {
-#if GF_A4_NT
-                    const u16x8 r8 = __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(p.R + (long)m * p.ldr + n));
-#else
-                    const u16x8 r8 = *reinterpret_cast<const u16x8*>(p.R + (long)m * p.ldr + n);
-#endif
+                if constexpr (HAS_R) {
+                    const u16x8 r8 = rres[it];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         float t = bf2f(yv[e]);
@@ -924,7 +943,15 @@ __global__ __launch_bounds__(A4_THREADS, 1) void gemm_a4_kernel(const GemmArgs p
 }
 
 template <int EPI>
-int launch_gemm_a4(const GemmArgs& a, hipStream_t stream) {
+int launch_gemm_a4(const GemmArgs& a0, hipStream_t stream) {
+    GemmArgs a = a0;
+    {
+        // an XCD runs 32 consecutive tiles of the order = group_m row tiles x 32 / group_m column tiles: 8 x 4 and 4 x 8 both stage
+        // 12 operand slices per K step; with the long K loop of F->D (K = 13824) 4 x 8 measured +1.6 %, at K = 5120 8 x 4 +1-2 %
+        const char* eg = getenv("GF_A4_GROUP_M");
+        const int g = eg ? atoi(eg) : 0;
+        a.group_m = g > 0 ? g : (a.K >= 8192 ? 4 : GROUP_M);
+    }
     static GfDeviceOnce once;
     hipError_t e = gf_once_per_device(once, [] {
         return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_a4_kernel<EPI>),
