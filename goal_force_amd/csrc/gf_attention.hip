@@ -1005,13 +1005,8 @@ __global__ __launch_bounds__(At3<NQ>::THREADS, (NQ == 2 ? 2 : 1)) void flash_att
             // Q carries the softmax scale and log2(e): S' = (c q) k is the score in the exp2 domain, and with the running maximum
             // as the MFMA's initial accumulator the exponent argument leaves the matrix pipe ready — no scale-and-subtract per
             // score (32 VALU instructions per tile and wave in a loop that is bound by its issue slots, not by the matrix pipe).
-            const bf16x8 raw = *reinterpret_cast<const bf16x8*>(qp + 32 * ks);
-            if constexpr (CINIT) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) qf[qb][ks][e] = (__bf16)((float)raw[e] * p.scale_log2e);
-            } else {
-                qf[qb][ks] = raw;
-            }
+            // (the loads are issued here; the scaling waits for them below, after the first K tiles have been requested as well)
+            qf[qb][ks] = *reinterpret_cast<const bf16x8*>(qp + 32 * ks);
         }
     }
 
@@ -1373,6 +1368,14 @@ __global__ __launch_bounds__(At3<NQ>::THREADS, (NQ == 2 ? 2 : 1)) void flash_att
     // ---- prologue: K(0), K(1) staged; S(0)
     stage(0, 0, 0);
     if (nt > 1) stage(0, 1, 1);
+    if constexpr (CINIT) {   // Q <- bf16(Q * scale * log2 e), under the latency of the staging just issued
+#pragma unroll
+        for (int qb = 0; qb < NQ; ++qb)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) qf[qb][ks][e] = (__bf16)((float)qf[qb][ks][e] * p.scale_log2e);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     qk_plain(C0{});
