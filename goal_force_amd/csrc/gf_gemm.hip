@@ -820,6 +820,20 @@ __global__ __launch_bounds__(A4_THREADS, 1) void gemm_a4_kernel(const GemmArgs p
     unsigned rdB0 = lbase + (unsigned)(TILE_BYTES + (wn * 128 + frow) * 128 + (((0 + fq) ^ sw) << 4));
     unsigned rdB1 = lbase + (unsigned)(TILE_BYTES + (wn * 128 + frow) * 128 + (((4 + fq) ^ sw) << 4));
 
+    // bias / gate of this lane's columns: requested BEFORE the K loop (16 + 4 VGPRs below the loop's registers), so that the
+    // epilogue does not open with an exposed L2 round trip
+    u16x4 bpre[8];
+    u16x8 gpre = {0, 0, 0, 0, 0, 0, 0, 0};
+    {
+        const int fq_ = lane >> 4;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int n = n0 + wn * 128 + j * 16 + fq_ * 4;
+            bpre[j] = (EPI != GF_EPI_VT32 && p.bias && n < p.N) ? *reinterpret_cast<const u16x4*>(p.bias + n) : u16x4{0, 0, 0, 0};
+        }
+        const int ng = n0 + wn * 128 + (lane & 15) * 8;
+        if (EPI == GF_EPI_BIAS_GATE_RESID && ng < p.N) gpre = *reinterpret_cast<const u16x8*>(p.gate + ng);
+    }
 #ifdef GF_A4_WHATIF   // timing-only variants of the loop (wrong results), selected per launch
     if (p.whatif == 1) GF_A4_LOOP_ASM_W1(voffA, voffB, pfA, pfB, rdA0, rdA1, rdB0, rdB1, aLo, aHi, nrA, bLo, bHi, nrB, soA, stA, soB, stB, ldsW, nk, k0, kb);
     else if (p.whatif == 2) GF_A4_LOOP_ASM_W2(voffA, voffB, pfA, pfB, rdA0, rdA1, rdB0, rdB1, aLo, aHi, nrA, bLo, bHi, nrB, soA, stA, soB, stB, ldsW, nk, k0, kb);
@@ -864,13 +878,8 @@ __global__ __launch_bounds__(A4_THREADS, 1) void gemm_a4_kernel(const GemmArgs p
     }
     a4_static_for<0, 8>([&](auto j_c) {
         constexpr int j = decltype(j_c)::value;
-        float bv[4] = {0.f, 0.f, 0.f, 0.f};
         const int n = n0 + wn * 128 + j * 16 + fq * 4;
-        if (EPI != GF_EPI_VT32 && p.bias && n < p.N) {   // N % 8 == 0: n .. n+3 are all valid
-            const u16x4 b4 = *reinterpret_cast<const u16x4*>(p.bias + n);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) bv[r] = bf2f(b4[r]);
-        }
+        const float bv[4] = {bf2f(bpre[j][0]), bf2f(bpre[j][1]), bf2f(bpre[j][2]), bf2f(bpre[j][3])};   // zeros where there is no bias
         a4_static_for<0, 8>([&](auto i_c) {
             constexpr int i = decltype(i_c)::value;
             constexpr int A0 = (i * 8 + j) * 4;
@@ -899,8 +908,7 @@ __global__ __launch_bounds__(A4_THREADS, 1) void gemm_a4_kernel(const GemmArgs p
         const int cc = lane & 15;                 // 16-byte chunk of the 256-byte row segment
         const int n = n0 + wn * 128 + cc * 8;
         const bool n_ok = n < p.N;
-        u16x8 g8;
-        if (EPI == GF_EPI_BIAS_GATE_RESID && n_ok) g8 = *reinterpret_cast<const u16x8*>(p.gate + n);
+        const u16x8 g8 = gpre;
 #pragma unroll
         for (int it = 0; it < 32; ++it) {
             const int row = it * 4 + (lane >> 4);
