@@ -120,8 +120,8 @@ __global__ __launch_bounds__(ROW_THREADS) void rmsnorm_rope_kernel(
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
                     const float a = y[2 * p], b = y[2 * p + 1];
-                    o[2 * p] = f2bf(a * cs[p] - b * sn[p]);
-                    o[2 * p + 1] = f2bf(a * sn[p] + b * cs[p]);
+                    o[2 * p] = f2bf(__builtin_fmaf(a, cs[p], -(b * sn[p])));      // the wave kernel's explicit contraction
+                    o[2 * p + 1] = f2bf(__builtin_fmaf(a, sn[p], b * cs[p]));
                 }
             } else {
 #pragma unroll
@@ -187,7 +187,10 @@ __global__ __launch_bounds__(64 * WROWS) void layernorm_modulate_wave_kernel(
     }
 }
 
-template <int NCH>
+// ROPE: 0 = no rotation, 1 = head_dim divides 512: a lane's four complex pairs are the same in every 512-element chunk
+// (c0 % head_dim = 8 lane % head_dim), so its cos / sin are loaded ONCE per row instead of once per chunk — 18 loads and ten
+// integer modulo sequences less per row and wave; 2 = any head_dim (per chunk).
+template <int NCH, int ROPE>
 __global__ __launch_bounds__(64 * WROWS) void rmsnorm_rope_wave_kernel(u16* __restrict__ x, const u16* __restrict__ weight,
                                                                          const float* __restrict__ cos_tab,
                                                                          const float* __restrict__ sin_tab, long rows,
@@ -210,6 +213,12 @@ __global__ __launch_bounds__(64 * WROWS) void rmsnorm_rope_wave_kernel(u16* __re
     }
     const float rstd = 1.0f / sqrtf(wave_sum(s) * (1.0f / DIM) + eps);
     const int half = head_dim >> 1;
+    f32x4 cs1 = {0.f, 0.f, 0.f, 0.f}, sn1 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (ROPE == 1) {
+        const int p0 = ((lane * 8) % head_dim) >> 1;
+        cs1 = *reinterpret_cast<const f32x4*>(cos_tab + row * half + p0);
+        sn1 = *reinterpret_cast<const f32x4*>(sin_tab + row * half + p0);
+    }
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int c0 = i * 512 + lane * 8;
@@ -221,15 +230,19 @@ __global__ __launch_bounds__(64 * WROWS) void rmsnorm_rope_wave_kernel(u16* __re
             y[j] = rbf(n * bf2f(w8[j]));                // * weight (bf16 multiply)
         }
         u16x8 o;
-        if (cos_tab) {
-            const int p0 = (c0 % head_dim) >> 1;        // first complex pair of this chunk
-            const f32x4 cs = *reinterpret_cast<const f32x4*>(cos_tab + row * half + p0);
-            const f32x4 sn = *reinterpret_cast<const f32x4*>(sin_tab + row * half + p0);
+        if constexpr (ROPE != 0) {
+            f32x4 cs = cs1, sn = sn1;
+            if constexpr (ROPE == 2) {
+                const int p0 = (c0 % head_dim) >> 1;        // first complex pair of this chunk
+                cs = *reinterpret_cast<const f32x4*>(cos_tab + row * half + p0);
+                sn = *reinterpret_cast<const f32x4*>(sin_tab + row * half + p0);
+            }
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
+                // (a + i b)(cos + i sin); the contraction is written out so that every build and both ROPE modes round alike
                 const float a = y[2 * p], b = y[2 * p + 1];
-                o[2 * p] = f2bf(a * cs[p] - b * sn[p]);
-                o[2 * p + 1] = f2bf(a * sn[p] + b * cs[p]);
+                o[2 * p] = f2bf(__builtin_fmaf(a, cs[p], -(b * sn[p])));
+                o[2 * p + 1] = f2bf(__builtin_fmaf(a, sn[p], b * cs[p]));
             }
         } else {
 #pragma unroll
@@ -377,16 +390,21 @@ extern "C" GF_API int gf_rmsnorm_rope(void* x, const void* weight, const float* 
                      (!cos_tab || (gf_aligned16(cos_tab) && gf_aligned16(sin_tab))),
                  "gf_rmsnorm_rope: 16-byte alignment required");
     if (rows == 0) return GF_OK;
+#define GF_RMS_WAVE_ROPE(NCH, ROPE)                                                                                      \
+    if (rope_ == ROPE)                                                                                                   \
+        hipLaunchKernelGGL((rmsnorm_rope_wave_kernel<NCH, ROPE>), grid_, block_, 0, (hipStream_t)stream, (u16*)x,        \
+                           (const u16*)weight, cos_tab, sin_tab, (long)rows, (int)head_dim, (long)x_stride, eps);
 #define GF_RMS_WAVE(NCH)                                                                                                 \
     if (dim == NCH * 512) {                                                                                              \
-        hipLaunchKernelGGL(rmsnorm_rope_wave_kernel<NCH>, dim3((unsigned)((rows + WROWS - 1) / WROWS)), dim3(64 * WROWS), \
-                           0, (hipStream_t)stream, (u16*)x, (const u16*)weight, cos_tab, sin_tab, (long)rows,            \
-                           (int)head_dim, (long)x_stride, eps);                                                          \
+        const dim3 grid_((unsigned)((rows + WROWS - 1) / WROWS)), block_(64 * WROWS);                                     \
+        const int rope_ = !cos_tab ? 0 : (512 % head_dim == 0 ? 1 : 2);                                                  \
+        GF_RMS_WAVE_ROPE(NCH, 0) GF_RMS_WAVE_ROPE(NCH, 1) GF_RMS_WAVE_ROPE(NCH, 2)                                        \
         GF_CHECK_LAUNCH("gf_rmsnorm_rope");                                                                              \
         return GF_OK;                                                                                                    \
     }
     GF_RMS_WAVE(10) GF_RMS_WAVE(8) GF_RMS_WAVE(3)
 #undef GF_RMS_WAVE
+#undef GF_RMS_WAVE_ROPE
     hipLaunchKernelGGL(rmsnorm_rope_kernel, dim3((unsigned)rows), dim3(ROW_THREADS), 0, (hipStream_t)stream,
                        (u16*)x, (const u16*)weight, cos_tab, sin_tab, (int)dim, (int)head_dim, (long)x_stride, eps);
     GF_CHECK_LAUNCH("gf_rmsnorm_rope");
