@@ -833,6 +833,13 @@ __global__ __launch_bounds__(A4_THREADS, 1) void gemm_a4_kernel(const GemmArgs p
         }
         const int ng = n0 + wn * 128 + (lane & 15) * 8;
         if (EPI == GF_EPI_BIAS_GATE_RESID && ng < p.N) gpre = *reinterpret_cast<const u16x8*>(p.gate + ng);
+        if (EPI == GF_EPI_VT32 && p.bias) {   // the row biases of this lane's eight 16-row blocks travel in bpre[i][0]
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int mrow = m0 + wm * 128 + i * 16 + (lane & 15);
+                if (mrow < p.M) bpre[i][0] = p.bias[mrow];
+            }
+        }
     }
 #ifdef GF_A4_WHATIF   // timing-only variants of the loop (wrong results), selected per launch
     if (p.whatif == 1) GF_A4_LOOP_ASM_W1(voffA, voffB, pfA, pfB, rdA0, rdA1, rdB0, rdB1, aLo, aHi, nrA, bLo, bHi, nrB, soA, stA, soB, stB, ldsW, nk, k0, kb);
@@ -885,8 +892,7 @@ __global__ __launch_bounds__(A4_THREADS, 1) void gemm_a4_kernel(const GemmArgs p
             constexpr int A0 = (i * 8 + j) * 4;
             float y[4] = {a4_acc<A0>(), a4_acc<A0 + 1>(), a4_acc<A0 + 2>(), a4_acc<A0 + 3>()};
             if constexpr (EPI == GF_EPI_VT32) {   // bias of the ROW (output feature); key columns that do not exist are zero
-                const int mrow = m0 + wm * 128 + i * 16 + frow;
-                const float bm = (p.bias && mrow < p.M) ? bf2f(p.bias[mrow]) : 0.f;
+                const float bm = bf2f(bpre[i][0]);       // requested before the K loop (0 where there is no bias / no row)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) y[r] = (n + r < p.wrows) ? y[r] + bm : 0.f;
             } else {
