@@ -948,11 +948,13 @@ __global__ __launch_bounds__(AT2_THREADS, 2) void flash_attn_fwd_kernel2(const A
 //                 D = sc[kb][qb] (f32x4): query 16 qb + r, keys 16 kb + 4 g + j.
 //   The lane's 32 scores of a tile belong to ONE query per qb, spread over the four g-lanes of that query: the running max is
 //   kept identical in those four lanes, the lazy-rescale test `all scores <= max + 6` needs no cross-lane step (it is the same
-//   test on the partial maxima), row sums stay partial per lane until the epilogue; only the rare rescale reduces over g.
+//   test on the partial maxima), row sums are taken on the matrix pipe (GF_K3_SUMMFMA; per lane until the epilogue without it);
+//   only the rare rescale reduces over g.
 //   O^T += V^T P^T : B = P^T[32 keys x 16 queries] = {sc[2kk][qb][0..3], sc[2kk+1][qb][0..3]} converted in place (lane-local),
 //                 A = V^T[16 d x 32 keys] (one ds_read_b128: row 16 db + r, chunk 4 kk + g of the pre-transposed copy, whose
 //                 keys are stored inside every group of 32 in the B operand's order: position 8 g + i <-> key 4 g + i (i < 4),
-//                 16 + 4 g + i - 4 (i >= 4): gf_transpose_v32), D = oacc[db][qb] (f32x4): query 16 qb + r, d = 16 db + 4 g + j.
+//                 16 + 4 g + i - 4 (i >= 4): gf_transpose_v32, or gf_linear_vt32 straight from the V projection), D = oacc[db][qb]
+//                 (f32x4): query 16 qb + r, d = 16 db + 4 g + j.
 //   Per 64-key tile and wave: 32 + 32 MFMAs of 16 cycles (kernel 2: 16 + 16 of 32), the same 32 fragment reads (each feeds the
 //   two query blocks), the same 32 scores per lane.  K image: 256-byte rows, chunk ^ (row & 15) (conflict-free for the
 //   16-row x 4-chunk fragment read; the 32x32x16 image is 2-way here); V^T image as in kernel 2.
