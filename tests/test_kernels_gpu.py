@@ -491,7 +491,8 @@ print("ok")
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
 
 
-A4_SHAPES = [(512, 256, 64), (513, 520, 192), (1000, 768, 1024), (777, 5120, 5120), (2048, 13824, 512), (4096, 264, 13824)]
+A4_SHAPES = [(512, 256, 64), (513, 520, 192), (1000, 768, 1024), (777, 5120, 5120), (2048, 13824, 512), (4096, 264, 13824),
+             (2300, 520, 8192)]   # the last two: K >= 8192 -> tile groups of 4 row tiles (9 row tiles: a ragged last group)
 
 
 @pytest.mark.parametrize("M,N,K", A4_SHAPES)
