@@ -721,6 +721,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs
 //   * same XOR-swizzled 128-byte-row LDS image, swapped operands and fused epilogues (bias / GELU-tanh / SiLU /
 //     gate*+residual / +residual / *multiply, the reference's bf16 rounding sequence) as the other kernels; the epilogue
 //     transposes each wave's 128 x 128 through a private 32 KiB LDS image and stores whole 256-byte row segments.
+#ifndef GF_A4_ROWMAP
+#define GF_A4_ROWMAP 1         // must match the generated loop's PIECE_STEP (tools/gen_gemm_a4.py): 1 <-> 0x1000
+#endif
 #ifdef GF_A4_LOOP_INC          // A/B builds of other generated schedules (tools/gemm_variants.py)
 #include GF_A4_LOOP_INC
 #else
@@ -781,7 +784,8 @@ __global__ __launch_bounds__(A4_THREADS, 1) void gemm_a4_kernel(const GemmArgs p
     const int in_group = v - group * per_group;
     const int m0 = (first_m + in_group % gsz) * BM, n0 = (in_group / gsz) * BN;
 
-    // ---- staging: wave w fills rows [64w, 64w+64) of both operand tiles, 8 pieces of 8 rows x 128 B each; lane l of a piece
+    // ---- staging: wave w fills 64 rows of both operand tiles as 8 pieces of 8 rows x 128 B (GF_A4_ROWMAP: piece p = rows
+    // 32 p + 8 w .., the four waves interleaved; else rows 64 w + 8 p ..); lane l of a piece
     // fills LDS chunk (l & 7) of row (l >> 3) and must fetch logical chunk (l & 7) ^ (row & 7) of that row
     const int srow = lane >> 3;
     unsigned voffA = (unsigned)srow * (unsigned)p.lda * 2u + (unsigned)(((lane & 7) ^ srow) << 4);
@@ -800,9 +804,15 @@ __global__ __launch_bounds__(A4_THREADS, 1) void gemm_a4_kernel(const GemmArgs p
     const unsigned nrA = (unsigned)(((long)(min(p.M - m0, BM) - 1) * p.lda + p.K) * 2);   // valid bytes from the tile's first row
     const int wvalid = min(p.wrows - n0, BN);                                              // rows of this W tile that exist
     const unsigned nrB = wvalid > 0 ? (unsigned)(((long)(wvalid - 1) * p.ldw + p.K) * 2) : 0u;
+#if GF_A4_ROWMAP   // the waves' pieces interleaved: piece p of wave w = rows 32 p + 8 w .. + 7 (the loop generated with A4_PIECE_STEP=0x1000)
+    const unsigned stA = 32u * (unsigned)p.lda * 2u, stB = 32u * (unsigned)p.ldw * 2u;
+    const unsigned soA = (unsigned)wave * 8u * (unsigned)p.lda * 2u, soB = (unsigned)wave * 8u * (unsigned)p.ldw * 2u;
+    const unsigned ldsW = (unsigned)(unsigned long)lds + (unsigned)wave * 1024u;
+#else
     const unsigned stA = 8u * (unsigned)p.lda * 2u, stB = 8u * (unsigned)p.ldw * 2u;
     const unsigned soA = (unsigned)wave * 8u * stA, soB = (unsigned)wave * 8u * stB;
     const unsigned ldsW = (unsigned)(unsigned long)lds + (unsigned)wave * 8192u;
+#endif
     const unsigned nk = (unsigned)(p.K / BK);
     // Staggered K start: the workgroups of column tile j begin their K loop at K tile (2 j) mod nk and wrap around, so
     // that the ~32 column tiles in flight at any time fetch from different 256-byte blocks of their rows.  All rows of the

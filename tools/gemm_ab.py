@@ -27,7 +27,7 @@ def main():
         kerns = os.environ.get("GEMM_AB_KERNELS", "a4,ph").split(",")
         variants = [(ln, kern) for ln in libs for kern in kerns] + [("torch", "F.linear")]
         best, outs = {}, {}
-        for rnd in range(4):
+        for rnd in range(int(os.environ.get("GEMM_AB_ROUNDS", "4"))):
             for ln, kern in variants:
                 if ln == "torch":
                     call = lambda: torch.nn.functional.linear(x, w)
