@@ -14,12 +14,19 @@ LDS: 2 stages x (A tile 256 rows x 128 B | B tile 256 rows x 128 B) = 128 KiB, 1
 Staging: buffer_load_dwordx4 ... offen lds (1 KiB = 8 rows per wave instruction; piece p of wave w = rows 32 p + 8 w .. + 7), descriptor in s[60:63] / s[64:67], the
 piece's row group as an SGPR soffset, the K position in the per-lane voffset: no vector address arithmetic per piece.
 
-Pipeline (tile t multiplies from registers while tile t+1 sits in LDS stage (t+1)&1 and tile t+2 is in flight):
-  iteration t, first half  (64 MFMAs on the k-sub-step-0 fragments): read the k-sub-step-1 fragments of tile t (8 A reads,
-      lgkmcnt(0), barrier B1 -> stage t&1's A region is dead -> 8 DMA pieces of A(t+2) into it; 8 B reads, lgkmcnt(0), barrier
-      B2 -> 8 DMA pieces of B(t+2));
-  second half (64 MFMAs on the k-sub-step-1 fragments): s_waitcnt vmcnt(16) (everything older than this iteration's 16
-      pieces = tile t+1) + barrier B3 -> read the k-sub-step-0 fragments of tile t+1 from the other stage; lgkmcnt(0).
+Pipeline (tile t multiplies from registers while tile t+1 sits in LDS stage (t+1)&1 and tile t+2 is in flight), MFMA slots 0..127:
+  slots 0..7   the 8 A fragments of k-sub-step 1 of tile t (one read per slot); lgkmcnt(0); barrier B1 at slot 11 -> stage t&1's A
+               region is dead;
+  slots 12..   ONE staging piece every 6 MFMAs for the rest of the iteration: the 8 pieces of A(t+2) (12, 18, .. 54), each followed
+               by one B fragment read of sub-step 1; lgkmcnt(0), barrier B2 at slot 60 -> the 8 pieces of B(t+2) (61, 67, .. 103);
+  slot 88      s_waitcnt vmcnt(13): this iteration's 13 pieces issued so far may stay in flight, everything older — all of tile
+               t+1, including the three pieces the previous iteration issued behind ITS wait — has landed; barrier B3 -> the 16
+               fragments of k-sub-step 0 of tile t+1 from the other stage (one read every 2 slots) between the last three pieces.
+  The spacing of the pieces is the single most important number of the schedule (gemm_ab_sched4/5/6.log, 8 interleaved rounds,
+  bit-identical outputs): with all 16 pieces packed into slots 20..69 (one every 3 MFMAs, the round's first version) F->D ran at
+  1.41 PFLOP/s; every 4: 1.46; every 5 with B1 moved up to slot 11: 1.50; every 6 (this): **1.52** (D->F 1.50 -> 1.53, D->D 1.50 ->
+  1.535 = the vendor kernel); every 2: 1.34.  A burst of LDS-DMA instructions stalls the issuing wave and the three that meet it
+  at the next barrier; the vendor kernel spreads its pieces the same way (its counted wait is vmcnt(13) too).
 Tiles past K are staged with num_records = 0 (reads return 0, no memory traffic), so the loop needs no peeled tail.
 
 Measured and NOT kept (same box, one process, tools/gemm_ab.py; profiles/r02/gemm_a4_experiments.md):
@@ -178,6 +185,7 @@ def gen(whatif=0):
     # tile t+2 exists iff remaining > 2
     at(0, f"s_cmp_gt_u32 s{S_CNT}, 2", f"s_cselect_b32 s{SRD_A + 2}, s{S_NRA}, 0")
     at(1, f"s_cselect_b32 s{SRD_B + 2}, s{S_NRB}, 0")
+    last_piece, n_before = 70, 16
     if MERGE_B12:
         # ONE barrier for both operands: all 16 k-sub-step-1 reads first, then the 16 pieces of tile t+2.  (Three barriers per
         # iteration cost the F->D shape 11 % in waves waiting for each other: tools/gemm_a4_whatif.py, whatif 128.)
@@ -193,36 +201,48 @@ def gen(whatif=0):
         for p in range(8):
             at(54 + 2 * p, *dma(1, p))
     else:
+        R1 = int(os.environ.get("A4_RD1_STRIDE", "1"))       # MFMA slots between the sub-step-1 reads of A (1 shipped: B1 at slot 11)
+        b1 = 8 * R1 + 3                                       # B1: behind the last of them (19 at R1 = 2)
         for i in range(8):
-            at(2 * i, rd(A_K1, i, "%[rdA1]"))
-        at(17, f"s_mov_b32 m0, s{S_WR}")
-        at(18, "s_waitcnt lgkmcnt(0)")
-        at(19, "s_barrier")
+            at(R1 * i, rd(A_K1, i, "%[rdA1]"))
+        at(b1 - 2, f"s_mov_b32 m0, s{S_WR}")
+        at(b1 - 1, "s_waitcnt lgkmcnt(0)")
+        at(b1, "s_barrier")
+        DS = int(os.environ.get("A4_DMA_STRIDE", "6"))        # MFMA slots between staging pieces (6 shipped: see the module docstring)
+        b2 = b1 + 1 + DS * 7 + 1 + 5                           # B2: behind the last sub-step-1 read of B (47 at R1 = 2, DS = 3)
+        a_slots = [b1 + 1 + DS * p for p in range(8)]
+        b_slots = [b2 + 1 + DS * p for p in range(8)]
+        b_slots = [x + 2 if x in (WAIT_SLOT, WAIT_SLOT + 1) else x for x in b_slots]    # not between the counted wait and its barrier
         for p in range(8):
             if M0_LATE:
-                at(20 + 3 * p, dma(0, p)[0])
+                at(a_slots[p], dma(0, p)[0])
                 if p < 7:
-                    at(21 + 3 * p, rd(B_K1, p, "%[rdB1]"), dma(0, p)[1])
+                    at(a_slots[p] + 1, rd(B_K1, p, "%[rdB1]"), dma(0, p)[1])
                 else:
-                    at(21 + 3 * p, rd(B_K1, p, "%[rdB1]"))
+                    at(a_slots[p] + 1, rd(B_K1, p, "%[rdB1]"))
             else:
-                at(20 + 3 * p, *dma(0, p))
-                at(21 + 3 * p, rd(B_K1, p, "%[rdB1]"))
-        at(45, f"s_add_u32 m0, s{S_WR}, {B_TILE}")
-        at(46, "s_waitcnt lgkmcnt(0)")
-        at(47, "s_barrier")
+                at(a_slots[p], *dma(0, p))
+                at(a_slots[p] + 1, rd(B_K1, p, "%[rdB1]"))
+        at(b2 - 2, f"s_add_u32 m0, s{S_WR}, {B_TILE}")
+        at(b2 - 1, "s_waitcnt lgkmcnt(0)")
+        at(b2, "s_barrier")
         for p in range(8):
             if M0_LATE:
-                at(48 + 3 * p, dma(1, p)[0])
-                at(49 + 3 * p, dma(1, p)[1])
+                at(b_slots[p], dma(1, p)[0])
+                at(b_slots[p] + 1, dma(1, p)[1])
             else:
-                at(48 + 3 * p, *dma(1, p))
+                at(b_slots[p], *dma(1, p))
+        last_piece = b_slots[7] + (1 if M0_LATE else 0)
+        # pieces of this iteration that are issued before the counted wait: everything older than them (= all of tile t+1, including
+        # the pieces the previous iteration issued behind ITS wait) has landed once vmcnt has dropped to their number
+        n_before = sum(1 for x in a_slots + b_slots if x < WAIT_SLOT)
+        assert last_piece <= 119 and a_slots[7] < WAIT_SLOT, "staging must end before the loop counter's scalar compare"
     at(70, "v_xor_b32 %[rdA0], 0x10000, %[rdA0]", "v_xor_b32 %[rdA1], 0x10000, %[rdA1]")
     at(71, "v_xor_b32 %[rdB0], 0x10000, %[rdB0]", "v_xor_b32 %[rdB1], 0x10000, %[rdB1]")
     at(72, f"s_xor_b32 s{S_WR}, s{S_WR}, {STAGE}")
     # the wait for tile t+1 sits as late as the 16 fragment reads behind it allow: every slot it moves back is lead time for
     # the LDS-DMA (two LDS stages leave it ~1.3 iterations between issue and this wait)
-    at(WAIT_SLOT, "s_waitcnt vmcnt(18)" if (WARM and not (whatif & 8)) else "s_waitcnt vmcnt(16)")
+    at(WAIT_SLOT, "s_waitcnt vmcnt(18)" if (WARM and not (whatif & 8)) else f"s_waitcnt vmcnt({n_before})")
     at(WAIT_SLOT + 1, "s_barrier")
     if B_FIRST:
         # the first 8 MFMAs of an iteration need all of B's sub-step-0 fragments but only A row 0; A row i is first used at slot
@@ -240,9 +260,10 @@ def gen(whatif=0):
             at(WAIT_SLOT + 2 + 2 * i, rd(A_K0, i, "%[rdA0]"))
         for j in range(8):
             at(WAIT_SLOT + 18 + 2 * j, rd(B_K0, j, "%[rdB0]"))
-    at(76, *advance_k()[:2])
-    at(77, *advance_k()[2:])
-    at(80, *ADVANCE_V)
+    adv = max(76, (last_piece + 1) if not MERGE_B12 else 76)   # the staging position moves on only behind the iteration's last piece
+    at(adv, *advance_k()[:2])
+    at(adv + 1, *advance_k()[2:])
+    at(adv + 4, *ADVANCE_V)
     at(124, f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
     at(125, f"s_cmp_eq_u32 s{S_CNT}, 0")
     at(126, "s_waitcnt lgkmcnt(0)")
