@@ -26,7 +26,9 @@ Pipeline (tile t multiplies from registers while tile t+1 sits in LDS stage (t+1
   bit-identical outputs): with all 16 pieces packed into slots 20..69 (one every 3 MFMAs, the round's first version) F->D ran at
   1.41 PFLOP/s; every 4: 1.46; every 5 with B1 moved up to slot 11: 1.50; every 6 (this): **1.52** (D->F 1.50 -> 1.53, D->D 1.50 ->
   1.535 = the vendor kernel); every 2: 1.34.  A burst of LDS-DMA instructions stalls the issuing wave and the three that meet it
-  at the next barrier; the vendor kernel spreads its pieces the same way (its counted wait is vmcnt(13) too).
+  at the next barrier; the vendor kernel spreads its pieces the same way (its counted wait is vmcnt(13) too).  Second: the M0 step
+  that follows a piece sits one MFMA behind it, not directly behind it (the piece still has to read M0): another +1.3 % on all
+  three shapes (gemm_ab_sched7/8.log; 2, 3 or 5 MFMAs behind: the same).
 Tiles past K are staged with num_records = 0 (reads return 0, no memory traffic), so the loop needs no peeled tail.
 
 Measured and NOT kept (same box, one process, tools/gemm_ab.py; profiles/r02/gemm_a4_experiments.md):
@@ -46,8 +48,8 @@ Measured and NOT kept (same box, one process, tools/gemm_ab.py; profiles/r02/gem
     workgroup, slower beyond (gemm_ab_startup_skew.txt);
   * after reading the vendor kernel's loop once more (same 128 MFMA / 32 reads / 16 pieces / 3 barriers, its third barrier at slot
     105 with three pieces behind it, pieces of the four waves interleaved 8 rows at a time): the wait at slot 94 / 100 with the
-    B fragments read first (A4_WAIT_SLOT, A4_B_FIRST), the M0 step one MFMA behind its piece (A4_M0_LATE), the first MFMA source
-    constant over 8 MFMAs (A4_J_OUTER) — each within +-1 % on all three shapes (gemm_ab_sched1/jouter.log); the interleaved row
+    B fragments read first (A4_WAIT_SLOT, A4_B_FIRST), the first MFMA source constant over 8 MFMAs (A4_J_OUTER) — each within
+    +-1 % on all three shapes with the pieces still packed (gemm_ab_sched1/jouter.log); the interleaved row
     map, re-measured over 8 interleaved rounds: +0.5 / +1.1 / +1.3 % and KEPT (gemm_ab_rowmap2.log); an LDS image of 16-byte K-chunk PLANES staged one row per lane (64 lines per instruction, 7 of 8 pieces L1 hits):
     bit-identical and 2.2 x SLOWER (gemm_ab_planes.log); GROUP_M 16: -14 %, 4: +-2 %.
 """
@@ -83,7 +85,7 @@ WAIT_SLOT = int(os.environ.get("A4_WAIT_SLOT", "88"))
 # wave staging its own 64 consecutive rows, 0x400 with GF_A4_ROWMAP=0)
 PIECE_STEP = int(os.environ.get("A4_PIECE_STEP", "0x1000"), 0)
 FRAG_STEP = 2048                                      # LDS bytes between the fragments of consecutive 16-row blocks
-M0_LATE = os.environ.get("A4_M0_LATE", "0") == "1"    # experiment: the M0 step one MFMA after its LDS-DMA instead of right behind it
+M0_LATE = int(os.environ.get("A4_M0_LATE", "1"))      # MFMA slots between an LDS-DMA piece and the M0 step that follows it (0: right behind it)
 B_FIRST = os.environ.get("A4_B_FIRST", "0") == "1"    # experiment: after the wait read B(t+1) sub-step 0 first, A rows 3..7 early in the next iteration
 MERGE_B12 = False     # True: one barrier (instead of two) between the k-sub-step-1 reads and the staging of tile t+2 — measured 4 % SLOWER
 PF_TILES = 6          # L2 warm-up distance beyond the staged tile (K tiles); the instruction offset field holds <= 31
@@ -214,25 +216,18 @@ def gen(whatif=0):
         b_slots = [b2 + 1 + DS * p for p in range(8)]
         b_slots = [x + 2 if x in (WAIT_SLOT, WAIT_SLOT + 1) else x for x in b_slots]    # not between the counted wait and its barrier
         for p in range(8):
-            if M0_LATE:
-                at(a_slots[p], dma(0, p)[0])
-                if p < 7:
-                    at(a_slots[p] + 1, rd(B_K1, p, "%[rdB1]"), dma(0, p)[1])
-                else:
-                    at(a_slots[p] + 1, rd(B_K1, p, "%[rdB1]"))
-            else:
-                at(a_slots[p], *dma(0, p))
-                at(a_slots[p] + 1, rd(B_K1, p, "%[rdB1]"))
+            at(a_slots[p], dma(0, p)[0])
+            at(a_slots[p] + 1, rd(B_K1, p, "%[rdB1]"))
+            if p < 7:
+                at(a_slots[p] + M0_LATE, dma(0, p)[1])        # the M0 step: not glued to the piece that still has to read M0
         at(b2 - 2, f"s_add_u32 m0, s{S_WR}, {B_TILE}")
         at(b2 - 1, "s_waitcnt lgkmcnt(0)")
         at(b2, "s_barrier")
         for p in range(8):
-            if M0_LATE:
-                at(b_slots[p], dma(1, p)[0])
-                at(b_slots[p] + 1, dma(1, p)[1])
-            else:
-                at(b_slots[p], *dma(1, p))
-        last_piece = b_slots[7] + (1 if M0_LATE else 0)
+            at(b_slots[p], dma(1, p)[0])
+            if p < 7:
+                at(b_slots[p] + M0_LATE, dma(1, p)[1])
+        last_piece = b_slots[7]
         # pieces of this iteration that are issued before the counted wait: everything older than them (= all of tile t+1, including
         # the pieces the previous iteration issued behind ITS wait) has landed once vmcnt has dropped to their number
         n_before = sum(1 for x in a_slots + b_slots if x < WAIT_SLOT)
