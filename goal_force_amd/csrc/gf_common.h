@@ -25,8 +25,12 @@ __device__ __forceinline__ u16 f2bf(float f) { return __builtin_bit_cast(u16, (_
 // round an fp32 value to the nearest bf16 and return it as fp32 (the reference's
 // eager bf16 ops round after every elementwise op; we reproduce those roundings)
 __device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
+// two fp32 -> one dword of two bf16 (lo in bits 0-15): the vector conversion lowers to ONE v_cvt_pk_bf16_f32 (round-to-nearest-even,
+// the instruction the scalar casts use too); `f2bf(lo) | f2bf(hi) << 16` compiled to the convert plus an and / shift / or per pair
 __device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
-    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+    typedef __attribute__((ext_vector_type(2))) float f2_t;
+    typedef __attribute__((ext_vector_type(2))) __bf16 b2_t;
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f2_t{lo, hi}, b2_t));
 }
 
 __device__ __forceinline__ float gelu_tanh_f(float x) {
@@ -36,6 +40,22 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
     const float a = -2.0f * 0.7978845608028654f * 1.4426950408889634f, b = a * 0.044715f;
     const float t = __builtin_amdgcn_exp2f(x * __builtin_fmaf(b, x * x, a));   // exp(-2u); inf for very negative x -> -0
     return x * __builtin_amdgcn_rcpf(1.0f + t);
+}
+// four at a time: the same operations as gelu_tanh_f, the multiplies / adds on packed fp32 pairs (v_pk_mul / v_pk_fma / v_pk_add),
+// the four exp2 and the four rcp back to back so that no transcendental result is needed by the very next instruction —
+// bit-identical to four gelu_tanh_f calls, about half the issue slots
+typedef __attribute__((ext_vector_type(2))) float gf_f32x2;
+__device__ __forceinline__ void gelu_tanh_f4(gf_f32x2& x01, gf_f32x2& x23) {
+    const float a = -2.0f * 0.7978845608028654f * 1.4426950408889634f, b = a * 0.044715f;
+    const gf_f32x2 av = {a, a}, bv = {b, b}, one = {1.0f, 1.0f};
+    const gf_f32x2 g01 = x01 * __builtin_elementwise_fma(bv, x01 * x01, av), g23 = x23 * __builtin_elementwise_fma(bv, x23 * x23, av);
+    const float t0 = __builtin_amdgcn_exp2f(g01[0]), t1 = __builtin_amdgcn_exp2f(g01[1]);
+    const float t2 = __builtin_amdgcn_exp2f(g23[0]), t3 = __builtin_amdgcn_exp2f(g23[1]);
+    const gf_f32x2 d01 = one + gf_f32x2{t0, t1}, d23 = one + gf_f32x2{t2, t3};
+    const float r0 = __builtin_amdgcn_rcpf(d01[0]), r1 = __builtin_amdgcn_rcpf(d01[1]);
+    const float r2 = __builtin_amdgcn_rcpf(d23[0]), r3 = __builtin_amdgcn_rcpf(d23[1]);
+    x01 = x01 * gf_f32x2{r0, r1};
+    x23 = x23 * gf_f32x2{r2, r3};
 }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 

@@ -905,6 +905,17 @@ __global__ __launch_bounds__(A4_THREADS, 1) void gemm_a4_kernel(const GemmArgs p
                 const float bm = bf2f(bpre[i][0]);       // requested before the K loop (0 where there is no bias / no row)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) y[r] = (n + r < p.wrows) ? y[r] + bm : 0.f;
+            } else if constexpr (EPI == GF_EPI_BIAS_GELU_TANH) {
+                // the Linear's output rounded to bf16 (one v_cvt_pk per pair, unpacked by a shift and a mask), then GELU on the lane's
+                // four values together — the same operations as gf_epi_act<GELU>, about half the issue slots (FFN1's epilogue cost it 6 %)
+                const unsigned l01 = pack2bf(y[0] + bv[0], y[1] + bv[1]), l23 = pack2bf(y[2] + bv[2], y[3] + bv[3]);
+                gf_f32x2 g01 = {__uint_as_float(l01 << 16), __uint_as_float(l01 & 0xffff0000u)};
+                gf_f32x2 g23 = {__uint_as_float(l23 << 16), __uint_as_float(l23 & 0xffff0000u)};
+                gelu_tanh_f4(g01, g23);
+                y[0] = g01[0];
+                y[1] = g01[1];
+                y[2] = g23[0];
+                y[3] = g23[1];
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
