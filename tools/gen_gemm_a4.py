@@ -126,14 +126,16 @@ def dma(which, p, back_to_back=False):
         (["s_nop 0"] if back_to_back else [])
 
 
-def dma_tile():
-    """16 pieces of one tile back to back (prologue)."""
+def dma_tile(fill=None):
+    """16 pieces of one tile (prologue): back to back, or — `fill`, 16 lists of instructions — each followed by its share of other
+    work (tile 1 is staged between the zeroing of the accumulators: nothing waits for it yet, and a burst of LDS-DMA instructions
+    is expensive, see the module docstring)."""
     out = [f"s_mov_b32 m0, s{S_WR}", "s_nop 0"]
     for p in range(8):
-        out += dma(0, p, True)
+        out += dma(0, p, fill is None) + ([] if fill is None else fill[p])
     out += [f"s_add_u32 m0, s{S_WR}, {B_TILE}", "s_nop 0"]
     for p in range(8):
-        out += dma(1, p, True)
+        out += dma(1, p, fill is None) + ([] if fill is None else fill[8 + p])
     out += advance_k() + ADVANCE_V
     return out
 
@@ -167,10 +169,15 @@ def gen(whatif=0):
     L += [f"s_xor_b32 s{S_WR}, s{S_WR}, {STAGE}",
           f"s_cmp_gt_u32 s{S_CNT}, 1", f"s_cselect_b32 s{SRD_A + 2}, s{S_NRA}, 0", f"s_cselect_b32 s{SRD_B + 2}, s{S_NRB}, 0",
           "s_nop 1"]
-    L += dma_tile()                                                   # tile 1 -> stage 1 (zeros past K)
-    L += [f"s_xor_b32 s{S_WR}, s{S_WR}, {STAGE}"]
-    for r in range(256):                                              # zeroed under the latency of the first two tiles
-        L.append(f"v_accvgpr_write_b32 a{r}, 0")
+    if os.environ.get("A4_PROLOGUE_DENSE", "0") == "1":               # the round's first version: 32 pieces back to back, then the zeroing
+        L += dma_tile()                                               # tile 1 -> stage 1 (zeros past K)
+        L += [f"s_xor_b32 s{S_WR}, s{S_WR}, {STAGE}"]
+        for r in range(256):
+            L.append(f"v_accvgpr_write_b32 a{r}, 0")
+    else:
+        # tile 1 -> stage 1 (zeros past K), one piece per 16 accumulator registers zeroed (under the latency of tile 0)
+        L += dma_tile([[f"v_accvgpr_write_b32 a{16 * q + r}, 0" for r in range(16)] for q in range(16)])
+        L += [f"s_xor_b32 s{S_WR}, s{S_WR}, {STAGE}"]
     L += ["s_waitcnt vmcnt(16)", "s_barrier"]
     for i in range(8):
         L.append(rd(A_K0, i, "%[rdA0]"))
