@@ -20,7 +20,7 @@ def main():
     st = torch.cuda.current_stream().cuda_stream
     res = torch.randn((S, D), device="cuda").to(BF)
     gate = torch.randn((D,), device="cuda").to(BF)
-    cases = {"D->D bias": (D, D, 0), "D->D gate*+resid": (D, D, 2), "D->D +resid": (D, D, 3), "D->F GELU": (D, F, 1), "F->D gate*+resid": (F, D, 2)}
+    cases = {"D->D bias": (D, D, 0), "D->D gate*+resid": (D, D, 2), "D->D +resid": (D, D, 3), "D->F bias": (D, F, 0), "D->F GELU": (D, F, 1), "F->D bias": (F, D, 0), "F->D gate*+resid": (F, D, 2)}
     for name, (k, n, epi) in cases.items():
         x = torch.randn((S, k), device="cuda").to(BF)
         w = (torch.randn((n, k), device="cuda") * 0.02).to(BF)
