@@ -729,6 +729,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs
 #else
 #include "gf_gemm_a4_loop.inc"
 #endif
+#include "gf_gemm_a4f8_loop.inc"   // the fp8 K loop (tools/gen_gemm_a4f8.py)
 constexpr int A4_THREADS = 256;
 #ifndef GF_A4_NT
 #define GF_A4_NT 1   // the epilogue streams: C stores and residual loads carry the non-temporal hint (D->D +2.6 %, D->F +1.2 %, F->D -0.5 %; 0 for A/B builds)
@@ -748,8 +749,13 @@ __device__ __forceinline__ void a4_static_for(F&& f) {
     }
 }
 
-template <int EPI>
+// FP8 = true (gf_gemm_fp8, the reference's fp8_linear contract VRAM:115-151): the operands are OCP e4m3 bytes, a K tile is still
+// 128 bytes per row (= 128 elements, one k step of v_mfma_f32_16x16x128_f8f6f4), the loop is gf_gemm_a4f8_loop.inc (two barriers
+// per tile, staging by half tiles: tools/gen_gemm_a4f8.py) and the epilogue multiplies each row by its activation scale first.
+// p.lda / p.ldw / p.K are in ELEMENTS of the operand type.
+template <int EPI, bool FP8 = false>
 __global__ __launch_bounds__(A4_THREADS, 1) void gemm_a4_kernel(const GemmArgs p) {
+    constexpr unsigned ESZ = FP8 ? 1u : 2u;    // bytes per operand element
     extern __shared__ __attribute__((aligned(16))) char smem[];
     GF_LDS char* lds = (GF_LDS char*)smem;
     const int tid = threadIdx.x;
@@ -788,39 +794,41 @@ __global__ __launch_bounds__(A4_THREADS, 1) void gemm_a4_kernel(const GemmArgs p
     // 32 p + 8 w .., the four waves interleaved; else rows 64 w + 8 p ..); lane l of a piece
     // fills LDS chunk (l & 7) of row (l >> 3) and must fetch logical chunk (l & 7) ^ (row & 7) of that row
     const int srow = lane >> 3;
-    unsigned voffA = (unsigned)srow * (unsigned)p.lda * 2u + (unsigned)(((lane & 7) ^ srow) << 4);
-    unsigned voffB = (unsigned)srow * (unsigned)p.ldw * 2u + (unsigned)(((lane & 7) ^ srow) << 4);
+    unsigned voffA = (unsigned)srow * (unsigned)p.lda * ESZ + (unsigned)(((lane & 7) ^ srow) << 4);
+    unsigned voffB = (unsigned)srow * (unsigned)p.ldw * ESZ + (unsigned)(((lane & 7) ^ srow) << 4);
 #ifdef GF_A4_WHATIF
-    if (p.whatif == 16) {   // timing only: un-permuted source chunks (what a padded, un-swizzled LDS image would fetch)
+    if (!FP8 && p.whatif == 16) {   // timing only: un-permuted source chunks (what a padded, un-swizzled LDS image would fetch)
         voffA = (unsigned)srow * (unsigned)p.lda * 2u + (unsigned)((lane & 7) << 4);
         voffB = (unsigned)srow * (unsigned)p.ldw * 2u + (unsigned)((lane & 7) << 4);
     }
 #endif
     // L2 warm-up loads (one line per lane): lane l = row l of this wave's 64 staging rows
-    unsigned pfA = (unsigned)lane * (unsigned)p.lda * 2u, pfB = (unsigned)lane * (unsigned)p.ldw * 2u;
-    const unsigned long baseA = (unsigned long)(p.A + (long)m0 * p.lda), baseB = (unsigned long)(p.W + (long)n0 * p.ldw);
+    unsigned pfA = (unsigned)lane * (unsigned)p.lda * ESZ, pfB = (unsigned)lane * (unsigned)p.ldw * ESZ;
+    const unsigned long baseA = (unsigned long)((const char*)p.A + (long)m0 * p.lda * ESZ);
+    const unsigned long baseB = (unsigned long)((const char*)p.W + (long)n0 * p.ldw * ESZ);
     const unsigned aLo = (unsigned)baseA, aHi = (unsigned)(baseA >> 32) & 0xffffu;
     const unsigned bLo = (unsigned)baseB, bHi = (unsigned)(baseB >> 32) & 0xffffu;
-    const unsigned nrA = (unsigned)(((long)(min(p.M - m0, BM) - 1) * p.lda + p.K) * 2);   // valid bytes from the tile's first row
-    const int wvalid = min(p.wrows - n0, BN);                                              // rows of this W tile that exist
-    const unsigned nrB = wvalid > 0 ? (unsigned)(((long)(wvalid - 1) * p.ldw + p.K) * 2) : 0u;
+    const unsigned nrA = (unsigned)(((long)(min(p.M - m0, BM) - 1) * p.lda + p.K) * ESZ);   // valid bytes from the tile's first row
+    const int wvalid = min(p.wrows - n0, BN);                                                // rows of this W tile that exist
+    const unsigned nrB = wvalid > 0 ? (unsigned)(((long)(wvalid - 1) * p.ldw + p.K) * ESZ) : 0u;
 #if GF_A4_ROWMAP   // the waves' pieces interleaved: piece p of wave w = rows 32 p + 8 w .. + 7 (the loop generated with A4_PIECE_STEP=0x1000)
-    const unsigned stA = 32u * (unsigned)p.lda * 2u, stB = 32u * (unsigned)p.ldw * 2u;
-    const unsigned soA = (unsigned)wave * 8u * (unsigned)p.lda * 2u, soB = (unsigned)wave * 8u * (unsigned)p.ldw * 2u;
+    const unsigned stA = 32u * (unsigned)p.lda * ESZ, stB = 32u * (unsigned)p.ldw * ESZ;
+    const unsigned soA = (unsigned)wave * 8u * (unsigned)p.lda * ESZ, soB = (unsigned)wave * 8u * (unsigned)p.ldw * ESZ;
     const unsigned ldsW = (unsigned)(unsigned long)lds + (unsigned)wave * 1024u;
 #else
+    static_assert(!FP8, "the fp8 loop is generated for the interleaved row map");
     const unsigned stA = 8u * (unsigned)p.lda * 2u, stB = 8u * (unsigned)p.ldw * 2u;
     const unsigned soA = (unsigned)wave * 8u * stA, soB = (unsigned)wave * 8u * stB;
     const unsigned ldsW = (unsigned)(unsigned long)lds + (unsigned)wave * 8192u;
 #endif
-    const unsigned nk = (unsigned)(p.K / BK);
+    const unsigned nk = (unsigned)(p.K * (int)ESZ / 128);       // K tiles of 128 bytes per row
     // Staggered K start: the workgroups of column tile j begin their K loop at K tile (2 j) mod nk and wrap around, so
     // that the ~32 column tiles in flight at any time fetch from different 256-byte blocks of their rows.  All rows of the
     // operands have the same pitch, so without this every workgroup of the chip walks the SAME few memory channels at the
     // same time (pitch 10 KiB: 16 of 128 channel slots).  The sum over k is only rotated; it depends on the column tile
     // alone, so an output element's bits do not depend on how the rows are cut into tiles or sharded over GPUs.
     const unsigned k0 = p.stagger ? (unsigned)((p.stagger * (p.stagger_rows ? m0 / BM : n0 / BN)) % (int)nk) : 0u;
-    const unsigned kb = (unsigned)p.K * 2u;
+    const unsigned kb = (unsigned)p.K * ESZ;
 
     // ---- fragment read addresses: (row, chunk) at row * 128 + ((chunk ^ (row & 7)) << 4); sub-step ks reads chunk 4 ks + fq
     const int frow = lane & 15, fq = lane >> 4, sw = frow & 7;
@@ -851,6 +859,22 @@ __global__ __launch_bounds__(A4_THREADS, 1) void gemm_a4_kernel(const GemmArgs p
             }
         }
     }
+    // fp8: the activation scales of this lane's eight rows (one per 16-row block), requested before the K loop as well
+    float rsc[FP8 ? 8 : 1];
+    if constexpr (FP8) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) rsc[i] = p.row_scale[min(m0 + wm * 128 + i * 16 + (lane & 15), p.M - 1)];
+    }
+    if constexpr (FP8) {
+        A4STAMP(1)
+#ifdef GF_A4_WHATIF
+        if (p.whatif == 1) GF_A4F8_LOOP_ASM_W1(voffA, voffB, rdA0, rdA1, rdB0, rdB1, aLo, aHi, nrA, bLo, bHi, nrB, soA, stA, soB, stB, ldsW, nk, k0, kb);
+        else if (p.whatif == 4) GF_A4F8_LOOP_ASM_W4(voffA, voffB, rdA0, rdA1, rdB0, rdB1, aLo, aHi, nrA, bLo, bHi, nrB, soA, stA, soB, stB, ldsW, nk, k0, kb);
+        else
+#endif
+        GF_A4F8_LOOP_ASM(voffA, voffB, rdA0, rdA1, rdB0, rdB1, aLo, aHi, nrA, bLo, bHi, nrB, soA, stA, soB, stB, ldsW, nk, k0, kb);
+        A4STAMP(2)
+    } else
 #ifdef GF_A4_WHATIF   // timing-only variants of the loop (wrong results), selected per launch
     if (p.whatif == 1) GF_A4_LOOP_ASM_W1(voffA, voffB, pfA, pfB, rdA0, rdA1, rdB0, rdB1, aLo, aHi, nrA, bLo, bHi, nrB, soA, stA, soB, stB, ldsW, nk, k0, kb);
     else if (p.whatif == 2) GF_A4_LOOP_ASM_W2(voffA, voffB, pfA, pfB, rdA0, rdA1, rdB0, rdB1, aLo, aHi, nrA, bLo, bHi, nrB, soA, stA, soB, stB, ldsW, nk, k0, kb);
@@ -901,6 +925,10 @@ __global__ __launch_bounds__(A4_THREADS, 1) void gemm_a4_kernel(const GemmArgs p
             constexpr int i = decltype(i_c)::value;
             constexpr int A0 = (i * 8 + j) * 4;
             float y[4] = {a4_acc<A0>(), a4_acc<A0 + 1>(), a4_acc<A0 + 2>(), a4_acc<A0 + 3>()};
+            if constexpr (FP8) {   // x scale_a of the row, + bias: the same expression as the 8-wave fp8 kernel (gemm_kernel<EPI, true>)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[r] = y[r] * rsc[i] + bv[r];
+            }
             if constexpr (EPI == GF_EPI_VT32) {   // bias of the ROW (output feature); key columns that do not exist are zero
                 const float bm = bf2f(bpre[i][0]);       // requested before the K loop (0 where there is no bias / no row)
 #pragma unroll
@@ -908,7 +936,8 @@ __global__ __launch_bounds__(A4_THREADS, 1) void gemm_a4_kernel(const GemmArgs p
             } else if constexpr (EPI == GF_EPI_BIAS_GELU_TANH) {
                 // the Linear's output rounded to bf16 (one v_cvt_pk per pair, unpacked by a shift and a mask), then GELU on the lane's
                 // four values together — the same operations as gf_epi_act<GELU>, about half the issue slots (FFN1's epilogue cost it 6 %)
-                const unsigned l01 = pack2bf(y[0] + bv[0], y[1] + bv[1]), l23 = pack2bf(y[2] + bv[2], y[3] + bv[3]);
+                const unsigned l01 = FP8 ? pack2bf(y[0], y[1]) : pack2bf(y[0] + bv[0], y[1] + bv[1]);
+                const unsigned l23 = FP8 ? pack2bf(y[2], y[3]) : pack2bf(y[2] + bv[2], y[3] + bv[3]);
                 gf_f32x2 g01 = {__uint_as_float(l01 << 16), __uint_as_float(l01 & 0xffff0000u)};
                 gf_f32x2 g23 = {__uint_as_float(l23 << 16), __uint_as_float(l23 & 0xffff0000u)};
                 gelu_tanh_f4(g01, g23);
@@ -919,7 +948,7 @@ __global__ __launch_bounds__(A4_THREADS, 1) void gemm_a4_kernel(const GemmArgs p
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    y[r] = gf_epi_act<EPI>(y[r] + bv[r]);
+                    y[r] = gf_epi_act<EPI>(FP8 ? y[r] : y[r] + bv[r]);
                 }
             }
             u32x2 pk;
@@ -977,7 +1006,7 @@ __global__ __launch_bounds__(A4_THREADS, 1) void gemm_a4_kernel(const GemmArgs p
 #endif
 }
 
-template <int EPI>
+template <int EPI, bool FP8 = false>
 int launch_gemm_a4(const GemmArgs& a0, hipStream_t stream) {
     GemmArgs a = a0;
     {
@@ -985,19 +1014,19 @@ int launch_gemm_a4(const GemmArgs& a0, hipStream_t stream) {
         // 12 operand slices per K step; with the long K loop of F->D (K = 13824) 4 x 8 measured +1.6 %, at K = 5120 8 x 4 +1-2 %
         const char* eg = getenv("GF_A4_GROUP_M");
         const int g = eg ? atoi(eg) : 0;
-        a.group_m = g > 0 ? g : (a.K >= 8192 ? 4 : GROUP_M);
+        a.group_m = g > 0 ? g : (a.K * (FP8 ? 1 : 2) >= 16384 ? 4 : GROUP_M);   // by the K loop's length in bytes per row
     }
     static GfDeviceOnce once;
     hipError_t e = gf_once_per_device(once, [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_a4_kernel<EPI>),
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_a4_kernel<EPI, FP8>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
     });
     if (e != hipSuccess) {
         gf_set_error("gf_gemm: hipFuncSetAttribute(%d B LDS) failed: %s", GEMM_LDS, hipGetErrorString(e));
         return GF_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL((gemm_a4_kernel<EPI>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(A4_THREADS), GEMM_LDS, stream, a);
-    GF_CHECK_LAUNCH("gf_gemm_bf16");
+    hipLaunchKernelGGL((gemm_a4_kernel<EPI, FP8>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(A4_THREADS), GEMM_LDS, stream, a);
+    GF_CHECK_LAUNCH(FP8 ? "gf_gemm_fp8" : "gf_gemm_bf16");
     return GF_OK;
 }
 
@@ -1287,6 +1316,13 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
         if (use_a4 && a.M >= 512 && a.K % 64 == 0 && 256L * a.lda * 2 + a.K * 2L < (1L << 31) &&
             256L * a.ldw * 2 + a.K * 2L < (1L << 31))
             return launch_gemm_a4<EPI>(a, stream);
+    }
+    if constexpr (FP8) {
+        // the 4-wave fp8 kernel for the large shapes (GF_GEMM_KERNEL=ph selects the 8-wave one-barrier kernel below: A/B runs)
+        const char* ek4 = getenv("GF_GEMM_KERNEL");
+        const bool use_a4 = !(ek4 && ek4[0] == 'p');
+        if (use_a4 && a.M >= 512 && a.K % 128 == 0 && 256L * a.lda + a.K < (1L << 31) && 256L * a.ldw + a.K < (1L << 31))
+            return launch_gemm_a4<EPI, true>(a, stream);
     }
     // bf16 ships the phased kernel (+5..11 % at the DiT shapes); fp8 ships the one-barrier-per-K-tile kernel (at 254
     // VGPRs the phased fp8 variant measured 10-15 % slower).  GF_GEMM_V1=0/1 overrides for A/B tuning.

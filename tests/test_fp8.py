@@ -161,3 +161,97 @@ def test_hip_fp8_dit_block_vs_fp8_oracle_block():
     enable_fp8(blk, False)
     got_bf = blk(x.cuda(), ctx.cuda(), t_mod.cuda(), rope).cpu()
     assert rel_l2(got_bf.float(), exact) < 5e-3
+
+
+# ------------------------------------------------------------------ the 4-wave fp8 kernel (gemm_a4_kernel<EPI, true>, M >= 512)
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(700, 520, 384), (512, 256, 128), (1000, 1024, 256), (2300, 264, 1280)])
+def test_hip_fp8_a4_exact_integer_layout(M, N, K):
+    """Small-integer e4m3 operands (every product and fp32 sum exact, so the MFMA's internal order cannot matter): any fragment /
+    chunk-pairing / half-tile / register-set mistake of the asm loop is a hard mismatch.  K = 128 (one tile: the body's second tile
+    multiplies a zero tile), 384 (odd tile count), ragged M and N tiles; rows scaled by exact powers of two."""
+    from goal_force_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randint(-3, 4, (M, K), generator=g).float()
+    w = torch.randint(-2, 3, (N, K), generator=g).float()
+    w[:, 0] += (torch.arange(N) % 3).float()            # asymmetric
+    a[:, K - 1] += (torch.arange(M) % 2).float()
+    bias = torch.randint(-4, 5, (N,), generator=g).float()
+    rs = (2.0 ** torch.randint(0, 3, (M,), generator=g)).float()
+    ref = (a @ w.t()) * rs[:, None] + bias
+    assert ref.abs().max() < 2048
+    ref = ref.to(BF)                                     # |ref| may exceed 256: the kernel's only rounding is the final one
+    a8, w8 = a.cuda().to(torch.float8_e4m3fn), w.cuda().to(torch.float8_e4m3fn)
+    assert torch.equal(a8.float().cpu(), a) and torch.equal(w8.float().cpu(), w)
+    got = ops.gemm_fp8(a8, rs.cuda(), w8, bias.to(BF).cuda())
+    assert torch.equal(got.cpu(), ref), f"{int((got.cpu() != ref).sum())} of {ref.numel()} elements differ"
+    os.environ["GF_GEMM_KERNEL"] = "ph"                  # the 8-wave kernel on the same operands: same exact result
+    try:
+        assert torch.equal(ops.gemm_fp8(a8, rs.cuda(), w8, bias.to(BF).cuda()).cpu(), ref)
+    finally:
+        os.environ.pop("GF_GEMM_KERNEL")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(1000, 5120, 5120), (700, 520, 384), (2300, 264, 13824), (513, 13824, 256)])
+def test_hip_fp8_a4_vs_8wave_kernel(M, N, K):
+    """Random data, every fused epilogue: the 4-wave kernel against the 8-wave one-barrier kernel.  Both add the same exact e4m3
+    products in fp32; the order differs (k chunks paired (c, c + 4) instead of (2c, 2c + 1), rotated K start), so: <= 1 bf16 ulp
+    on all but a sliver.  A row's bits do not depend on the M tiling; strided A and C."""
+    from goal_force_amd import ops
+    g = torch.Generator().manual_seed(M + 3 * N + K)
+    x = (torch.randn((M, K), generator=g) * 2).to(BF).cuda()
+    w8 = ops.cast_fp8((torch.randn((N, K), generator=g) / math.sqrt(K)).to(BF).cuda())
+    bias = (0.1 * torch.randn(N, generator=g)).to(BF).cuda()
+    resid = torch.randn((M, N), generator=g).to(BF).cuda()
+    gate = torch.randn(N, generator=g).to(BF).cuda()
+    x8, s = ops.quant_fp8_rowscale(x)
+    cases = [dict(), dict(epilogue=ops.EPI_BIAS_GELU_TANH), dict(epilogue=ops.EPI_BIAS_SILU),
+             dict(epilogue=ops.EPI_BIAS_RESID, resid=resid), dict(epilogue=ops.EPI_BIAS_GATE_RESID, resid=resid, gate=gate),
+             dict(epilogue=ops.EPI_BIAS_MUL, resid=resid)]
+    try:
+        for kw in cases:
+            os.environ["GF_GEMM_KERNEL"] = "ph"
+            want = ops.gemm_fp8(x8, s, w8, bias, **kw)
+            os.environ["GF_GEMM_KERNEL"] = "a4"
+            got = ops.gemm_fp8(x8, s, w8, bias, **kw)
+            bad, e = _ulp_stats(got.cpu(), want.cpu())
+            assert bad < 2e-3 and e < 1e-3, f"{kw.get('epilogue')}: >1ulp frac {bad:.2e}, rel-L2 {e:.3e}"
+        os.environ["GF_GEMM_KERNEL"] = "a4"
+        full = ops.gemm_fp8(x8, s, w8, bias)
+        assert torch.equal(ops.gemm_fp8(x8, s, w8, None), ops.gemm_fp8(x8, s, w8, torch.zeros_like(bias)))
+        assert torch.equal(ops.gemm_fp8(x8[M - 512:], s[M - 512:].contiguous(), w8, bias), full[M - 512:])
+        wide = torch.zeros((M, K + 128), dtype=torch.float8_e4m3fn, device="cuda")
+        wide[:, 128:] = x8
+        big = torch.zeros((M, N + 16), dtype=BF, device="cuda")
+        ops.gemm_fp8(wide[:, 128:], s, w8, bias, out=big[:, 8:8 + N])
+        assert torch.equal(big[:, 8:8 + N], full)
+        assert float(big[:, :8].abs().sum()) == 0 and float(big[:, 8 + N:].abs().sum()) == 0
+    finally:
+        os.environ.pop("GF_GEMM_KERNEL", None)
+
+
+@pytest.mark.gpu
+def test_hip_fp8_a4_full_size_vs_torch_scaled_mm():
+    """BASELINE config 5's GEMM shapes at S = 32760 (ragged last M tile): the 4-wave kernel against torch._scaled_mm run live
+    through the reference's call sequence — quantiser bit-exact, outputs within 1 bf16 ulp, every row finite."""
+    import sys
+    from conftest import GOLDEN
+    sys.path.insert(0, GOLDEN)
+    from make_fp8_golden_gpu import scaled_mm_linear
+    from goal_force_amd import ops
+    g = torch.Generator().manual_seed(11)
+    S = 32760
+    for (N, K) in ((5120, 5120), (13824, 5120), (5120, 13824)):
+        x = (torch.randn((S, K), generator=g) * 1.5).to(BF).cuda()
+        x[77, 5] = 2000.0                                 # one row with scale_a > 1
+        w = (torch.randn((N, K), generator=g) / math.sqrt(K)).to(BF).cuda()
+        b = (0.1 * torch.randn(N, generator=g)).to(BF).cuda()
+        ref, r8, rs, rw8 = scaled_mm_linear(x, w, b)
+        x8, s = ops.quant_fp8_rowscale(x)
+        assert torch.equal(x8.view(torch.uint8), r8.view(torch.uint8)) and torch.equal(s, rs.flatten())
+        got = ops.gemm_fp8(x8, s, ops.cast_fp8(w), b)
+        assert bool(torch.isfinite(got.float().norm(dim=1)).all())
+        bad, e = _ulp_stats(got.cpu(), ref.cpu())
+        assert bad < 1e-3 and e < 1e-3, f"[{S},{K}]x[{N},{K}]^T vs torch._scaled_mm: >1ulp frac {bad:.2e}, rel-L2 {e:.3e}"
+        del x, w, ref, r8, x8, got

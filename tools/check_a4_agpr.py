@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Build-time check of the accumulator hand-off in gemm_a4_kernel (gf_gemm.hip).
+
+The K loop is one asm statement that leaves the 256 fp32 accumulators in a[0:255]; the epilogue fetches them with separate
+`v_accvgpr_read_b32` asm statements.  Between the two the compiler sees the AGPRs as free, so a future hipcc could legally park
+a spill or a load result in one of them and silently corrupt an accumulator.  This script compiles gf_gemm.hip to gfx950
+assembly and verifies for EVERY gemm_a4_kernel instantiation that between the end of the loop's asm block and the last
+accumulator read the ONLY instructions that mention an AGPR are those reads, each register read exactly once.
+
+    python tools/check_a4_agpr.py            # exit code 0 = safe; called by __graft_entry__.build() and tests/test_host_cpu.py
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "goal_force_amd", "csrc", "gf_gemm.hip")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+AGPR = re.compile(r"\ba\d+\b|\ba\[(?:0x[0-9a-f]+|\d+)(?::\d+)?\]")
+
+
+def device_asm():
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "gemm.s")
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", f"-I{ROOT}/include", f"-I{ROOT}/goal_force_amd/csrc",
+               "-DGF_BUILD", "--cuda-device-only", "-S", "-o", out, SRC]
+        subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+        return open(out).read()
+
+
+def check(text):
+    """Returns {kernel: number of accumulator reads}; raises AssertionError on a violation."""
+    res = {}
+    kernels = re.findall(r"^(_ZN\S*gemm_a4_kernel\S*):[^\n]*\n(.*?)^\.Lfunc_end", text, re.S | re.M)
+    assert kernels, "no gemm_a4_kernel instantiation found in the device assembly"
+    for name, body in kernels:
+        lines = [l.split(";")[0].strip() for l in body.splitlines()]
+        lines = [l for l in lines if l and not l.startswith((".", "//"))]
+        # the loop's asm block ends with: s_waitcnt vmcnt(0) / s_nop 7 ... / s_mov_b32 m0, s52 / s_barrier
+        ends = [i for i, l in enumerate(lines) if re.match(r"s_mov_b32 m0, s52$", l)]
+        assert len(ends) >= 1, f"{name}: end of the K loop's asm block not found"
+        start = ends[-1] + 1
+        reads = [i for i, l in enumerate(lines) if l.startswith("v_accvgpr_read_b32") and i > start]
+        assert reads, f"{name}: no accumulator reads behind the loop"
+        seen = set()
+        for i in range(start, reads[-1] + 1):
+            l = lines[i]
+            if not AGPR.search(l):
+                continue
+            m = re.match(r"v_accvgpr_read_b32 v\d+, a\[?(0x[0-9a-f]+|\d+)\]?$", l)
+            assert m, f"{name}: `{l}` touches an AGPR between the K loop and the last accumulator read"
+            r = int(m.group(1), 0)
+            assert r not in seen, f"{name}: a{r} is read twice"
+            seen.add(r)
+        assert seen == set(range(256)), f"{name}: {len(seen)} of 256 accumulators are read"
+        # and nothing before the loop may leave a value in an AGPR that the loop does not overwrite: the loop zeroes all 256
+        res[name] = len(seen)
+    return res
+
+
+def main():
+    res = check(device_asm())
+    for k, n in res.items():
+        print(f"ok  {k}: {n} accumulator reads, no other AGPR access between the loop and the last read")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
