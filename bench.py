@@ -35,6 +35,7 @@ sys.path.insert(0, ROOT)
 ATTN_TRAFFIC_BYTES = (2 * 1490930 + 501680) * 1024
 ATTN_TRAFFIC_SOURCE = "profiles/r02/pmc/attn_k3_FETCH_SIZE.md + attn_k3_WRITE_SIZE.md"
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md (Chip-level parameters)
+PEAK_FP8_TFLOPS = 5000.0   # dense fp8 MFMA peak (same table): the denominator of the GEMM entries under --fp8 (config 5)
 S_TOK, DIM, HEADS, FFN, LTXT = 32760, 5120, 40, 13824, 512
 
 
@@ -304,8 +305,10 @@ def main():
                 return None
             avg = sum(ms) / len(ms)
             fl = 2.0 * (S_TOK // args.sp) * n * kk
-            return {"bound": "mfma", "kernel": name, "achieved": fl / (avg * 1e-3) / 1e12, "peak": PEAK_BF16_TFLOPS,
-                    "unit": "TFLOP/s", "frac": fl / (avg * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, "traffic": None,
+            peak = PEAK_FP8_TFLOPS if args.fp8 else PEAK_BF16_TFLOPS
+            return {"bound": "mfma", "kernel": name + (" — e4m3 operands, v_mfma_f32_16x16x128_f8f6f4" if args.fp8 else ""),
+                    "achieved": fl / (avg * 1e-3) / 1e12, "peak": peak,
+                    "unit": "TFLOP/s", "frac": fl / (avg * 1e-3) / 1e12 / peak, "traffic": None,
                     "launches": len(ms), "avg_launch_ms": avg, "algorithmic_flops_per_launch": fl}
         out["roofline_gemm"] = [e for e in (gemm_entry(FFN, DIM, "gemm_a4_kernel<GELU> FFN1 [S,5120]x[13824,5120]^T"),
                                             gemm_entry(DIM, FFN, "gemm_a4_kernel<gate*+resid> FFN2 [S,13824]x[5120,13824]^T"),

@@ -3,7 +3,7 @@
 #include <cstdarg>
 #include <cstdio>
 
-#define GF_ABI_VERSION 7
+#define GF_ABI_VERSION 8
 
 static thread_local char g_err[512] = "";
 

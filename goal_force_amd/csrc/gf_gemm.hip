@@ -89,6 +89,7 @@ struct GemmArgs {
     int wrows;    // gemm_a4_kernel: rows of W that exist (= N except for GF_EPI_VT32, where N = kv_pad covers zero columns past kv_len)
     int stagger_rows;   // gemm_a4_kernel: the K-loop rotation follows the ROW tile (GF_EPI_VT32: the operands are swapped, see gf_linear_vt32)
     int group_m;        // gemm_a4_kernel: row tiles per workgroup-order group (set by launch_gemm_a4)
+    int halftile;       // gemm_a4_kernel, bf16: the half-tile K loop (gf_gemm_a4h_loop.inc) instead of the k-sub-step loop (A/B: GF_A4_LOOP=h)
 };
 
 // internal epilogue of gf_linear_vt32 (not in goalforce.h's enum): C rows = output features, C columns = keys in kernel 3's
@@ -730,6 +731,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs
 #include "gf_gemm_a4_loop.inc"
 #endif
 #include "gf_gemm_a4f8_loop.inc"   // the fp8 K loop (tools/gen_gemm_a4f8.py)
+#include "gf_gemm_a4h_loop.inc"    // the fp8 loop's half-tile schedule with bf16 MFMAs (A4F8_BF16=1 tools/gen_gemm_a4f8.py)
 constexpr int A4_THREADS = 256;
 #ifndef GF_A4_NT
 #define GF_A4_NT 1   // the epilogue streams: C stores and residual loads carry the non-temporal hint (D->D +2.6 %, D->F +1.2 %, F->D -0.5 %; 0 for A/B builds)
@@ -884,7 +886,11 @@ __global__ __launch_bounds__(A4_THREADS, 1) void gemm_a4_kernel(const GemmArgs p
     else if (p.whatif == 128) GF_A4_LOOP_ASM_W128(voffA, voffB, pfA, pfB, rdA0, rdA1, rdB0, rdB1, aLo, aHi, nrA, bLo, bHi, nrB, soA, stA, soB, stB, ldsW, nk, k0, kb);
     else
 #endif
-    {
+    if (p.halftile) {
+        A4STAMP(1)
+        GF_A4H_LOOP_ASM(voffA, voffB, rdA0, rdA1, rdB0, rdB1, aLo, aHi, nrA, bLo, bHi, nrB, soA, stA, soB, stB, ldsW, nk, k0, kb);
+        A4STAMP(2)
+    } else {
         A4STAMP(1)
         GF_A4_LOOP_ASM(voffA, voffB, pfA, pfB, rdA0, rdA1, rdB0, rdB1, aLo, aHi, nrA, bLo, bHi, nrB, soA, stA, soB, stB, ldsW, nk, k0, kb);
         A4STAMP(2)
@@ -1015,6 +1021,8 @@ int launch_gemm_a4(const GemmArgs& a0, hipStream_t stream) {
         const char* eg = getenv("GF_A4_GROUP_M");
         const int g = eg ? atoi(eg) : 0;
         a.group_m = g > 0 ? g : (a.K * (FP8 ? 1 : 2) >= 16384 ? 4 : GROUP_M);   // by the K loop's length in bytes per row
+        const char* el = getenv("GF_A4_LOOP");
+        a.halftile = (el && el[0] == 'h') ? 1 : 0;
     }
     static GfDeviceOnce once;
     hipError_t e = gf_once_per_device(once, [] {

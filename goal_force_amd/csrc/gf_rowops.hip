@@ -303,6 +303,80 @@ __global__ __launch_bounds__(ROW_THREADS) void quant_fp8_rowscale_kernel(const u
     }
 }
 
+// LayerNorm(+affine)(+modulate) whose consumer is an fp8 Linear (BASELINE config 5): the bf16 row the reference would hand to
+// fp8_linear never goes to HBM — the wave that normalised it takes its row maximum (wave shuffles), forms scale_a and writes the
+// e4m3 bytes + the scale.  Same arithmetic, in the same order, as layernorm_modulate_wave_kernel followed by
+// quant_fp8_rowscale_kernel (bit-identical: tests/test_fp8.py), one 335 MB write and one 335 MB read less per use.
+template <int NCH>
+__global__ __launch_bounds__(64 * WROWS) void layernorm_modulate_fp8_wave_kernel(
+    const u16* __restrict__ x, unsigned char* __restrict__ out8, float* __restrict__ scale, const u16* __restrict__ weight,
+    const u16* __restrict__ bias, const u16* __restrict__ scale1p, const u16* __restrict__ shift, long rows, long x_stride,
+    long out_stride, float eps) {
+    constexpr int DIM = NCH * 512;
+    const long row = (long)blockIdx.x * WROWS + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const u16* xr = x + row * x_stride + lane * 8;
+    u16x8 v[NCH];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        v[i] = *reinterpret_cast<const u16x8*>(xr + i * 512);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += bf2f(v[i][j]);
+    }
+    const float mean = wave_sum(s) * (1.0f / DIM);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float d = bf2f(v[i][j]) - mean;
+            q += d * d;
+        }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / DIM) + eps);
+    float mx = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c0 = i * 512 + lane * 8;
+        u16x8 w8, b8, sc8, sh8;
+        if (weight) w8 = *reinterpret_cast<const u16x8*>(weight + c0);
+        if (bias) b8 = *reinterpret_cast<const u16x8*>(bias + c0);
+        if (scale1p) sc8 = *reinterpret_cast<const u16x8*>(scale1p + c0);
+        if (shift) sh8 = *reinterpret_cast<const u16x8*>(shift + c0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float y = (bf2f(v[i][j]) - mean) * rstd;
+            if (weight) y = y * bf2f(w8[j]);
+            if (bias) y = y + bf2f(b8[j]);
+            y = rbf(y);                                   // .type_as(x)
+            if (scale1p) y = rbf(y * bf2f(sc8[j]));       // x * (1 + scale)
+            if (shift) y = rbf(y + bf2f(sh8[j]));         // + shift
+            v[i][j] = f2bf(y);                            // the bf16 row fp8_linear receives (kept in registers)
+            mx = fmaxf(mx, fabsf(y));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    const float sc = fmaxf(rbf(mx / 448.0f), 1.0f);      // x_max is bf16 in the reference: x_max / 448 rounds to bf16 before the clamp
+    if (lane == 0) scale[row] = sc;
+    const float den = sc + 1e-8f;
+    const bool unit = den == 1.0f;                       // wave-uniform; 1 + 1e-8 IS 1 in fp32, so x / den = x exactly
+    unsigned char* orow = out8 + row * out_stride + lane * 8;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = unit ? bf2f(v[i][j]) : bf2f(v[i][j]) / den;
+        unsigned w0 = 0, w1 = 0;
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], w0, false);
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w0, true);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], w1, false);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], w1, true);
+        *reinterpret_cast<u32x2*>(orow + i * 512) = u32x2{w0, w1};
+    }
+}
+
 // plain bf16 -> e4m3 cast (the weight side of fp8_linear: `weight.to(float8_e4m3fn)`, unit scale, VRAM:138)
 __global__ __launch_bounds__(256) void cast_fp8_kernel(const u16* __restrict__ x, unsigned char* __restrict__ out, long n8) {
     const long stride = (long)gridDim.x * 256;
@@ -373,6 +447,32 @@ extern "C" GF_API int gf_layernorm_modulate(const void* x, void* out, const void
                        (hipStream_t)stream, (const u16*)x, (u16*)out, (const u16*)weight, (const u16*)bias,
                        (const u16*)scale1p, (const u16*)shift, (int)dim, (long)x_stride, (long)out_stride, eps);
     GF_CHECK_LAUNCH("gf_layernorm_modulate");
+    return GF_OK;
+}
+
+extern "C" GF_API int gf_layernorm_modulate_fp8(const void* x, void* out8, float* scale, const void* weight, const void* bias,
+                                                const void* scale1p, const void* shift, int64_t rows, int64_t dim,
+                                                int64_t x_stride, int64_t out_stride, float eps, void* stream) {
+    GF_CHECK_ARG(x && out8 && scale, "gf_layernorm_modulate_fp8: null x/out8/scale");
+    GF_CHECK_ARG(rows >= 0 && (dim == 5120 || dim == 4096 || dim == 1536),
+                 "gf_layernorm_modulate_fp8: dim=%ld is not one of the wave-per-row widths (5120, 4096, 1536); use "
+                 "gf_layernorm_modulate + gf_quant_fp8_rowscale", (long)dim);
+    GF_CHECK_ARG(x_stride % 8 == 0 && out_stride % 8 == 0 && gf_aligned16(x) && (((uintptr_t)out8) & 7u) == 0,
+                 "gf_layernorm_modulate_fp8: rows must be 16-byte (x) / 8-byte (out8) aligned");
+    GF_CHECK_ARG((!weight || gf_aligned16(weight)) && (!bias || gf_aligned16(bias)) &&
+                     (!scale1p || gf_aligned16(scale1p)) && (!shift || gf_aligned16(shift)),
+                 "gf_layernorm_modulate_fp8: vectors must be 16-byte aligned");
+    if (rows == 0) return GF_OK;
+#define GF_LN8_WAVE(NCH)                                                                                                 \
+    if (dim == NCH * 512) {                                                                                              \
+        hipLaunchKernelGGL(layernorm_modulate_fp8_wave_kernel<NCH>, dim3((unsigned)((rows + WROWS - 1) / WROWS)),        \
+                           dim3(64 * WROWS), 0, (hipStream_t)stream, (const u16*)x, (unsigned char*)out8, scale,          \
+                           (const u16*)weight, (const u16*)bias, (const u16*)scale1p, (const u16*)shift, (long)rows,     \
+                           (long)x_stride, (long)out_stride, eps);                                                       \
+    }
+    GF_LN8_WAVE(10) GF_LN8_WAVE(8) GF_LN8_WAVE(3)
+#undef GF_LN8_WAVE
+    GF_CHECK_LAUNCH("gf_layernorm_modulate_fp8");
     return GF_OK;
 }
 

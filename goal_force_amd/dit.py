@@ -90,8 +90,21 @@ def param_key(*tensors):
 class QuantizedInput:
     """Row-quantised activation (e4m3 bytes + per-row scale) shared by the GEMMs that read the same input."""
 
-    def __init__(self, x2):
-        self.x8, self.scale = ops.quant_fp8_rowscale(x2)
+    def __init__(self, x2=None, x8=None, scale=None):
+        self.x8, self.scale = ops.quant_fp8_rowscale(x2) if x2 is not None else (x8, scale)
+
+    @classmethod
+    def layernorm(cls, x2, **kw):
+        """LayerNorm(+affine)(+modulate) of x2 delivered as an fp8_linear input (ops.layernorm_modulate_fp8)."""
+        return cls(None, *ops.layernorm_modulate_fp8(x2, **kw))
+
+    @property
+    def shape(self):
+        return self.x8.shape
+
+    @property
+    def is_cuda(self):
+        return self.x8.is_cuda
 
 
 def linear(x2, lin: nn.Linear, epilogue=ops.EPI_BIAS, resid=None, gate=None, out=None):
@@ -160,7 +173,7 @@ class SelfAttention(nn.Module):
         diffsynth/distributed/xdit_context_parallel.py:109-131).  `keep` (a dict, training): the attention output and the
         rows' log-sum-exp are stored under "attn" / "lse" so that the backward does not run the attention again."""
         fp8 = getattr(self.q, "_gf_w8", None) is not None
-        xin = QuantizedInput(x2) if fp8 else x2
+        xin = (x2 if isinstance(x2, QuantizedInput) else QuantizedInput(x2)) if fp8 else x2
         q, k = linear(xin, self.q), linear(xin, self.k)
         ops.rmsnorm_rope(q, self.norm_q.weight, rope.cos, rope.sin, self.head_dim, self.norm_q.eps)
         ops.rmsnorm_rope(k, self.norm_k.weight, rope.cos, rope.sin, self.head_dim, self.norm_k.eps)
@@ -247,24 +260,35 @@ class DiTBlock(nn.Module):
         rope = _as_rope(freqs, x.device)
         # rows: shift_msa, 1+scale_msa, gate_msa, shift_mlp, 1+scale_mlp, gate_mlp   (DIT:218-219, 64-65)
         mod = ops.modulation(self.modulation, t_mod.contiguous(), onep_mask=0b010010)
+        # config 5: every Linear of the block on the fp8_linear contract — all of them or none (enable_fp8)
+        fp8 = getattr(self.ffn[0], "_gf_w8", None) is not None
         if self_attn_memo is not None and "x" in self_attn_memo:
             x_new = self_attn_memo.pop("x")
             if out is not None:
                 x_new = out.copy_(x_new)
-            h = torch.empty_like(x2)
+            h = None if fp8 else torch.empty_like(x2)
         else:
-            h = ops.layernorm_modulate(x2, scale1p=mod[1], shift=mod[0], eps=self.eps)              # DIT:225
+            if fp8:                              # the normalised row goes straight to e4m3 + scale_a (never to HBM as bf16)
+                h = QuantizedInput.layernorm(x2, scale1p=mod[1], shift=mod[0], eps=self.eps)
+            else:
+                h = ops.layernorm_modulate(x2, scale1p=mod[1], shift=mod[0], eps=self.eps)          # DIT:225
             a = self.self_attn.attend(h, rope, sp, keep)
             x_new = out if out is not None else torch.empty_like(x2)
             linear(a, self.self_attn.o, epilogue=ops.EPI_BIAS_GATE_RESID, resid=x2, gate=mod[2], out=x_new)   # DIT:226
             if self_attn_memo is not None:
                 self_attn_memo["x"] = x_new.clone()      # the rest of the block updates x_new in place
-        ops.layernorm_modulate(x_new, weight=self.norm3.weight, bias=self.norm3.bias, eps=self.eps, out=h)
+        if fp8:
+            h = QuantizedInput.layernorm(x_new, weight=self.norm3.weight, bias=self.norm3.bias, eps=self.eps)
+        else:
+            ops.layernorm_modulate(x_new, weight=self.norm3.weight, bias=self.norm3.bias, eps=self.eps, out=h)
         if context_kv is None:
             context_kv = self.cross_attn.context_kv(_tokens2d(context))
         a = self.cross_attn.attend(h, context_kv)
         linear(a, self.cross_attn.o, epilogue=ops.EPI_BIAS_RESID, resid=x_new, out=x_new)               # DIT:227
-        ops.layernorm_modulate(x_new, scale1p=mod[4], shift=mod[3], eps=self.eps, out=h)         # DIT:228
+        if fp8:
+            h = QuantizedInput.layernorm(x_new, scale1p=mod[4], shift=mod[3], eps=self.eps)
+        else:
+            ops.layernorm_modulate(x_new, scale1p=mod[4], shift=mod[3], eps=self.eps, out=h)     # DIT:228
         f1 = linear(h, self.ffn[0], epilogue=ops.EPI_BIAS_GELU_TANH)
         linear(f1, self.ffn[2], epilogue=ops.EPI_BIAS_GATE_RESID, resid=x_new, gate=mod[5], out=x_new)  # DIT:229
         return x_new.view(x.shape)

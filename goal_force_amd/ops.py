@@ -556,6 +556,30 @@ def quant_fp8_rowscale(x):
     return out, scale
 
 
+LN_FP8_WIDTHS = (5120, 4096, 1536)     # gf_layernorm_modulate_fp8's wave-per-row widths
+
+
+def layernorm_modulate_fp8(x, weight=None, bias=None, scale1p=None, shift=None, eps=1e-6):
+    """LayerNorm(+affine)(+modulate) straight into the fp8_linear input format: (x8 [M,K] float8_e4m3fn, scale_a [M] fp32) —
+    gf_layernorm_modulate_fp8 at the DiT widths (the bf16 row never reaches HBM), elsewhere the two kernels it fuses; the same
+    bits either way."""
+    _req(x, "layernorm_modulate_fp8.x")
+    xv, rows, dim, xs = _rows2d(x, "layernorm_modulate_fp8.x")
+    if dim not in LN_FP8_WIDTHS:
+        return quant_fp8_rowscale(layernorm_modulate(x, weight=weight, bias=bias, scale1p=scale1p, shift=shift, eps=eps))
+    for n, t in (("weight", weight), ("bias", bias), ("scale1p", scale1p), ("shift", shift)):
+        if t is not None:
+            _req(t, f"layernorm_modulate_fp8.{n}")
+            if t.numel() != dim or not t.is_contiguous():
+                raise GoalForceError(f"layernorm_modulate_fp8.{n}: expected contiguous [{dim}]")
+    out = torch.empty((rows, dim), dtype=_FP8, device=x.device)
+    scale = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().gf_layernorm_modulate_fp8(_ptr(xv), _ptr(out), _ptr(scale), _ptr(weight), _ptr(bias), _ptr(scale1p),
+                                                     _ptr(shift), rows, dim, xs, dim, float(eps), _stream(x)),
+               "gf_layernorm_modulate_fp8")
+    return out, scale
+
+
 def cast_fp8(w):
     """bf16 -> float8_e4m3fn, elementwise (weights; unit scale)."""
     _req(w, "cast_fp8.w")
@@ -593,9 +617,16 @@ def gemm_fp8(a8, row_scale, w8, bias=None, epilogue=EPI_BIAS, resid=None, gate=N
             _req(t, f"gemm_fp8.{n}")
             if t.numel() != N or not t.is_contiguous():
                 raise GoalForceError(f"gemm_fp8.{n}: expected contiguous [{N}]")
+    prof = PROFILE_GEMM
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.check(_lib.load().gf_gemm_fp8(_ptr(a8), a8.stride(0), _ptr(w8), w8.stride(0), _ptr(row_scale), _ptr(bias),
                                        _ptr(ov), ldc, M, N, K, int(epilogue), _ptr(resid), ldr, _ptr(gate), _stream(a8)),
                "gf_gemm_fp8")
+    if prof is not None:
+        e1.record()
+        prof.append((e0, e1, M, N, K, int(epilogue)))
     return out
 
 

@@ -348,11 +348,19 @@ GF_API int gf_vae_tile_finalize(void* values, const void* weight, int64_t planes
 GF_API int gf_quant_fp8_rowscale(const void* x, void* out8, float* scale, int64_t rows, int64_t dim,
                                  int64_t x_stride, int64_t out_stride, void* stream);
 
+/* gf_layernorm_modulate_fp8 — gf_layernorm_modulate whose consumer is an fp8 Linear: the normalised (+affine, +modulate) bf16
+ * row stays in registers, its row maximum gives scale_a and only the e4m3 bytes + scale are written — bit-identical to
+ * gf_layernorm_modulate followed by gf_quant_fp8_rowscale (DIT:206-208, 225-228 feeding VRAM:124-137).
+ * dim must be one of the wave-per-row widths 5120 / 4096 / 1536; other widths: call the two functions. */
+GF_API int gf_layernorm_modulate_fp8(const void* x, void* out8, float* scale, const void* weight, const void* bias,
+                                     const void* scale1p, const void* shift, int64_t rows, int64_t dim,
+                                     int64_t x_stride, int64_t out_stride, float eps, void* stream);
+
 /* gf_cast_fp8 — bf16 -> e4m3 elementwise (weight.to(float8_e4m3fn), VRAM:138); n % 8 == 0. */
 GF_API int gf_cast_fp8(const void* x, void* out8, int64_t n, void* stream);
 
 /* gf_gemm_fp8 — C = epilogue((A8 · W8^T) * row_scale[m] + bias); A8 [M,K], W8 [N,K] e4m3 bytes (K contiguous),
- * fp32 accumulate on v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales (2x the bf16 MFMA rate);
+ * fp32 accumulate on v_mfma_f32_16x16x128_f8f6f4 (2x the bf16 MFMA rate; M >= 512: the 4-wave asm K loop);
  * same epilogues / residual / gate semantics as gf_gemm_bf16 (torch._scaled_mm, VRAM:141-148).
  * K % 128 == 0, lda/ldw % 16 == 0. */
 GF_API int gf_gemm_fp8(const void* A8, int64_t lda, const void* W8, int64_t ldw, const float* row_scale,

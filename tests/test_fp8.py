@@ -255,3 +255,31 @@ def test_hip_fp8_a4_full_size_vs_torch_scaled_mm():
         bad, e = _ulp_stats(got.cpu(), ref.cpu())
         assert bad < 1e-3 and e < 1e-3, f"[{S},{K}]x[{N},{K}]^T vs torch._scaled_mm: >1ulp frac {bad:.2e}, rel-L2 {e:.3e}"
         del x, w, ref, r8, x8, got
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim", [5120, 4096, 1536])
+@pytest.mark.parametrize("kind", ["modulate", "affine", "plain"])
+def test_hip_layernorm_fp8_fusion_is_bit_identical(dim, kind):
+    """gf_layernorm_modulate_fp8 (the normalised row quantised in the registers of the wave that normalised it) against the two
+    kernels it fuses — e4m3 bytes and scales bit-identical, including a row whose maximum exceeds 448 (scale_a > 1) and a
+    constant row (variance 0)."""
+    from goal_force_amd import ops
+    g = torch.Generator().manual_seed(dim)
+    M = 777
+    x = (torch.randn((M, dim), generator=g) * 2).to(BF)
+    x[5, 17] = 3000.0
+    x[9] = 1.25
+    kw = {}
+    if kind == "modulate":
+        kw = dict(scale1p=(1 + 0.3 * torch.randn(dim, generator=g)).to(BF).cuda(), shift=(0.2 * torch.randn(dim, generator=g)).to(BF).cuda())
+        kw["scale1p"][3] = 400.0         # drives one output column of every row far up: row maxima above 448 (scale_a > 1)
+    elif kind == "affine":
+        kw = dict(weight=(1 + 0.2 * torch.randn(dim, generator=g)).to(BF).cuda(), bias=(0.1 * torch.randn(dim, generator=g)).to(BF).cuda())
+    xd = x.cuda()
+    want8, wants = ops.quant_fp8_rowscale(ops.layernorm_modulate(xd, **kw))
+    got8, gots = ops.layernorm_modulate_fp8(xd, **kw)
+    assert torch.equal(gots, wants) and float(wants.max()) >= 1.0
+    assert torch.equal(got8.view(torch.uint8), want8.view(torch.uint8))
+    if kind == "modulate":
+        assert float(wants.max()) > 1.0, "the case must exercise scale_a > 1"

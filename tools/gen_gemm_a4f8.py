@@ -56,6 +56,8 @@ FRAG_STEP = 2048                                      # LDS bytes between the fr
 CLOBBER_S = list(range(36, 60)) + list(range(60, 70))
 LO_P, HI_P = (0, 1, 4, 5), (2, 3, 6, 7)               # pieces (32-row groups of the 256-row tile) of the waves' lo / hi 64-row halves
 
+BF16 = os.environ.get("A4F8_BF16", "0") == "1"        # the SAME schedule for bf16 operands (a K tile = 64 elements): every fp8 MFMA
+                                                      # becomes the two 16x16x32 bf16 MFMAs of k-sub-steps 0 / 1 -> gf_gemm_a4h_loop.inc
 SCALED = os.environ.get("A4F8_SCALED", "0") == "1"    # 1: v_mfma_scale_... with unit E8M0 scales in a VGPR (16-byte encoding)
 M_SLOT = int(os.environ.get("A4F8_M_SLOT", "28"))     # counted wait of barrier M (the barrier one slot later)
 E_SLOT = int(os.environ.get("A4F8_E_SLOT", "58"))
@@ -76,6 +78,10 @@ def acc(i, j):
 def mfma(i, j, aset, bset):
     """D = W_frag x A_frag (operands swapped as in the bf16 kernel: a lane ends up with 4 consecutive n of one m)."""
     a, b = v8(aset, i & 3), v8(bset, j & 3)
+    if BF16:
+        ra, rb = aset + 8 * (i & 3), bset + 8 * (j & 3)
+        return [f"v_mfma_f32_16x16x32_bf16 {acc(i, j)}, v[{rb + 4 * ks}:{rb + 4 * ks + 3}], v[{ra + 4 * ks}:{ra + 4 * ks + 3}], {acc(i, j)}"
+                for ks in range(2)]
     if SCALED:
         return f"v_mfma_scale_f32_16x16x128_f8f6f4 {acc(i, j)}, {b}, {a}, {acc(i, j)}, v{V_RD - 1}, v{V_RD - 1} op_sel_hi:[0,0,0]"
     return f"v_mfma_f32_16x16x128_f8f6f4 {acc(i, j)}, {b}, {a}, {acc(i, j)}"
@@ -178,8 +184,18 @@ def tile_events(par, whatif=0):
             for j in range(4):
                 order.append((4 * ah + i, 4 * bh + j, XA if ah == 0 else YA, B0 if bh == 0 else B1))
     out = []
-    for s, (i, j, aset, bset) in enumerate(order):
-        out.append(mfma(i, j, aset, bset))
+    if BF16:
+        # per A block: k-sub-step 0 of its four accumulators, then k-sub-step 1 (an accumulator's two MFMAs four apart); a "slot" of
+        # the schedule = two MFMAs = the 32 cycles of one fp8 MFMA
+        flat = []
+        for g in range(0, 64, 4):
+            pairs = [mfma(*order[g + q]) for q in range(4)]
+            flat += [pr[0] for pr in pairs] + [pr[1] for pr in pairs]
+        slots = [flat[2 * s: 2 * s + 2] for s in range(64)]
+    else:
+        slots = [[mfma(*order[s])] for s in range(64)]
+    for s in range(64):
+        out += slots[s]
         for ins in ev.get(s, []):
             if (whatif & 1) and (ins == "s_barrier" or ins.startswith("s_waitcnt vmcnt")):
                 continue
@@ -264,6 +280,7 @@ def check(lines, nbodies=3):
     tile_of_stage = {0: 0, 1: 1}      # tile currently being staged INTO each stage: advanced when its 16th piece is issued
     pieces_in_tile = {0: 0, 1: 0}
     mf_count = 0
+    ks_seen = {}
     lgkm_clean = True
     scc_from_cmp = False
     for ins in stream + ["s_cbranch_scc1 1b"]:
@@ -342,25 +359,30 @@ def check(lines, nbodies=3):
             if region[key]["reads"] == 8:
                 region[key]["read_done"] = True
             continue
-        m = re.match(r"v_mfma\S* a\[(\d+):\d+\], v\[(\d+):\d+\], v\[(\d+):\d+\], a\[(\d+):", ins)
+        m = re.match(r"v_mfma\S* a\[(\d+):\d+\], v\[(\d+):(\d+)\], v\[(\d+):\d+\], a\[(\d+):", ins)
         if m:
-            a0, vb, va, c0 = (int(x) for x in m.groups())
+            a0, vb, vbe, va, c0 = (int(x) for x in m.groups())
             assert a0 == c0
             i, j = divmod(a0 // 4, 8)
-            tile = mf_count // 64
+            per_tile = 128 if BF16 else 64
+            tile = mf_count // per_tile
             mf_count += 1
-            for (base, op, blk) in ((va, 0, i), (vb, 1, j)):
-                for chunk in range(2):
+            chunks = (0, 1) if vbe - vb == 7 else ((vb % 8) // 4,)
+            if BF16:      # an accumulator takes k-sub-step 0 of a tile before k-sub-step 1 (the bf16 kernels' summation order)
+                assert ks_seen.get((a0, tile), -1) == chunks[0] - 1, f"acc({i},{j}) tile {tile}: k-sub-steps out of order"
+                ks_seen[(a0, tile)] = chunks[0]
+            for (base, op, blk) in ((va - va % 8, 0, i), (vb - vb % 8, 1, j)):
+                for chunk in chunks:
                     got = frag.get(base + 4 * chunk)
                     assert got == (tile, op, blk, chunk), f"MFMA #{mf_count - 1} acc({i},{j}) of tile {tile}: v{base + 4 * chunk} holds {got}"
             continue
-    assert mf_count == 64 * 2 * nbodies
+    assert mf_count == (128 if BF16 else 64) * 2 * nbodies
     return True
 
 
 def emit(name, lines):
     n_mfma = sum(1 for l in lines if l.startswith("v_mfma"))
-    assert n_mfma == 128, n_mfma
+    assert n_mfma == (256 if BF16 else 128), n_mfma
     body = "\n".join(f'    "{l}\\n\\t"' for l in lines)
     vclob = ", ".join(f'"v{r}"' for r in range(V_RD - 1, 256))
     aclob = ", ".join(f'"a{r}"' for r in range(256))
@@ -388,10 +410,13 @@ def emit(name, lines):
 def main():
     lines = gen()
     check(lines)
-    text = emit("GF_A4F8_LOOP_ASM", lines)
-    # timing-only variants behind -DGF_A4_WHATIF (never in the shipped library): 1 = no barriers / counted waits, 4 = no staging
-    text += "#ifdef GF_A4_WHATIF\n" + "".join(emit(f"GF_A4F8_LOOP_ASM_W{w}", gen(w)) for w in (1, 4)) + "#endif\n"
-    out = os.environ.get("A4F8_OUT", OUT)
+    if BF16:
+        text = emit("GF_A4H_LOOP_ASM", lines).replace("gemm_a4_kernel<EPI, FP8 = true>", "gemm_a4_kernel<EPI> (bf16, half-tile schedule)")
+    else:
+        text = emit("GF_A4F8_LOOP_ASM", lines)
+        # timing-only variants behind -DGF_A4_WHATIF (never in the shipped library): 1 = no barriers / counted waits, 4 = no staging
+        text += "#ifdef GF_A4_WHATIF\n" + "".join(emit(f"GF_A4F8_LOOP_ASM_W{w}", gen(w)) for w in (1, 4)) + "#endif\n"
+    out = os.environ.get("A4F8_OUT", OUT.replace("a4f8", "a4h") if BF16 else OUT)
     with open(out, "w") as f:
         f.write(text)
     print(f"wrote {out} (schedule checked)")
