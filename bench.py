@@ -27,6 +27,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# RCCL's intra-node transport needs dmabuf IPC handles on this driver (goal_force_amd/distributed.py::ensure_ipc_env); ROCr reads
+# the variable when the process first touches the GPU, so it is set before torch is imported.  setdefault: the launcher's choice wins.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 # HBM bytes per self-attention launch (flash_attn_fwd_kernel3<2>; its V^T operand comes from the projection GEMM) from rocprofv3 --pmc, separate
 # FETCH_SIZE / WRITE_SIZE passes over tools/microbench.py attn (tools/profile_r02.sh): (2 x FETCH_SIZE [gfx950 reports half of a
@@ -109,7 +112,14 @@ def main():
     ap.add_argument("--fp8", action="store_true", help="BASELINE config 5: block Linears on the fp8_linear contract (e4m3 MFMA)")
     ap.add_argument("--sp", type=int, default=1, help="head-parallel (Ulysses) degree inside each forward: world = videos x 2 x sp "
                     "(latency mode; the default 1 is the CFG-pair x sample layout the driver's scaling runs use)")
+    ap.add_argument("--inputs", choices=["randn", "example"], default="randn",
+                    help="conditioning of the timed run: seeded N(0,1) tensors (default, SURVEY §8d config 2) or the reference's pendulum "
+                         "example (tests/golden/example_pendulum.npz): image conditioning y and force-map control latents are VAE "
+                         "encodings of the real first frame and of the rendered goal-force map (the kernels' speed depends on the data)")
+    ap.add_argument("--peaky", type=float, default=1.0, help="multiply every self-attention norm_q weight by this factor (8: attention "
+                    "logits x 8, near-one-hot softmax rows) — data-sensitivity runs only")
     ap.add_argument("--layers", type=int, default=40, help=argparse.SUPPRESS)  # debugging only; 40 = the real model
+    ap.add_argument("--sample-offset", type=int, default=0, help=argparse.SUPPRESS)  # tests: the N=1 run of video #k (seeds follow the sample id)
     args = ap.parse_args()
 
     import torch
@@ -129,7 +139,7 @@ def main():
         raise SystemExit(f"--sp {args.sp} needs --gpus = videos x 2 x sp")
     cfgp = CfgPairParallel(rank, world, sp_size=args.sp) if world > 1 else None
     seqp = None if cfgp is None else cfgp.sequence_parallel()
-    sample = 0 if cfgp is None else cfgp.sample
+    sample = args.sample_offset + (0 if cfgp is None else cfgp.sample)
 
     cfg = dict(A14B_CONFIG)
     cfg["num_layers"] = args.layers
@@ -160,6 +170,29 @@ def main():
     ctx_p[:, 40:] = 0
     ctx_n[:, 40:] = 0  # prompter zeroes past the prompt length (wan_prompter.py:99-109)
     ctx_p, ctx_n = ctx_p.to(torch.bfloat16).to(dev), ctx_n.to(torch.bfloat16).to(dev)
+    if args.inputs == "example":
+        # structured conditioning: the reference's pendulum example through the pipeline's own pre-loop units (random-init VAE)
+        import numpy as np
+        from PIL import Image
+        from goal_force_amd.force_map import plan_control_video, render_control_video
+        ex = np.load(os.path.join(ROOT, "tests", "golden", "example_pendulum.npz"))
+        v = dict(zip([str(k) for k in ex["fields"]], [float(x) for x in ex["values"]]))
+        masses = {"projectile": v["projectile_mass"], "target": v["target_mass"], "distractors": []}
+        coords = {"projectile": [int(v["projectile_coordx"]), int(v["projectile_coordy"])],
+                  "target": [int(v["target_coordx"]), int(v["target_coordy"])], "distractors": []}
+        plan = plan_control_video(v["projectile_force_magnitude"], v["projectile_force_angle"], v["projectile_coordx"] / v["width"],
+                                  v["projectile_coordy"] / v["height"], v["target_indirect_force_magnitude"],
+                                  v["target_indirect_force_angle"], v["target_coordx"] / v["width"], v["target_coordy"] / v["height"],
+                                  81, 480, 832, masses, coords, 30.0, 400.0, 30.0, 400.0, 1.0, 4.0, 0.0, 0.0, 0.0)   # INF:137-146
+        cv = render_control_video(plan, dev)
+        control = pipe.embed_control_video(cv, True, (30, 52), (15, 26))          # [1,16,21,60,104]
+        y = pipe.embed_image(Image.fromarray(ex["image"]), 81, 480, 832, True, (30, 52), (15, 26))
+        assert tuple(y.shape) == (1, 20, 21, 60, 104) and tuple(control.shape) == (1, 16, 21, 60, 104), (y.shape, control.shape)
+    if args.peaky != 1.0:
+        for m in (dit, dit2, cn, cn2):
+            for blk in m.modules():
+                if hasattr(blk, "self_attn") and hasattr(blk.self_attn, "norm_q"):
+                    blk.self_attn.norm_q.weight.data.mul_(args.peaky)
 
     n_sched = 50
     k = max(1, args.steps)
@@ -213,8 +246,10 @@ def main():
         raise SystemExit(f"rank {rank}: non-finite decoded frames")
     u8 = pipe.frames_uint8(frames)                      # [81,480,832,3] uint8, 97 MB (what the reference saves, GF:735)
     frames_digest = tensor_digest(torch, u8)
-    # end-of-run all-gather of every sample's frames over the world group: 1 warm-up + 1 timed
+    # end-of-run all-gather of every sample's frames among the samples' lead ranks (one contributor per sample, the
+    # other ranks send nothing): 1 warm-up + 1 timed.  Rank 0 is a lead and ends up with every video's frames.
     gather_s, n_gathered = 0.0, 1
+    sample_digests = [{"sample": sample, "latents_sha256": lat_digest["sha256"], "frames_uint8_sha256": frames_digest["sha256"]}]
     if cfgp is not None:
         cfgp.gather_frames(u8, tuple(u8.shape), torch.uint8, dev)
         torch.cuda.synchronize()
@@ -223,9 +258,17 @@ def main():
         allf = cfgp.gather_frames(u8, tuple(u8.shape), torch.uint8, dev)
         torch.cuda.synchronize()
         gather_s = time.perf_counter() - tg
-        n_gathered = len(allf)
-        if not torch.equal(allf[cfgp.sample], u8):
-            raise SystemExit(f"rank {rank}: the gathered frames of sample {cfgp.sample} differ from the local decode")
+        if cfgp.is_lead:
+            n_gathered = len(allf)
+            if not torch.equal(allf[cfgp.sample], u8):
+                raise SystemExit(f"rank {rank}: the gathered frames of sample {cfgp.sample} differ from the local decode")
+        # every video's checksums on rank 0: frames from the gathered tensors themselves, latents from their owners
+        lat_all = [None] * world
+        dist.all_gather_object(lat_all, (sample, cfgp.is_lead, lat_digest["sha256"]))
+        if rank == 0:
+            lat_by_sample = {sm: h for sm, lead, h in lat_all if lead}
+            sample_digests = [{"sample": args.sample_offset + i, "latents_sha256": lat_by_sample[args.sample_offset + i],
+                               "frames_uint8_sha256": tensor_digest(torch, f)["sha256"]} for i, f in enumerate(allf)]
     if world > 1:
         t = torch.tensor([elapsed, vae_s, gather_s], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -258,6 +301,9 @@ def main():
             "config": {"workload": "Goal-Force denoise step: cond+uncond model_fn (40 DiT + 10 ControlNet blocks, "
                                    "A14B dims) + CFG + Euler, latents [1,16,21,60,104] = 32760 tokens, 512 text tokens; "
                                    "random-init bf16 weights, both experts + both ControlNets resident",
+                       "inputs": ("seeded N(0,1) conditioning tensors" if args.inputs == "randn" else
+                                  "pendulum example of the reference (first frame + rendered goal-force map) through the pre-loop VAE encodes")
+                                 + ("" if args.peaky == 1.0 else f"; self-attention logits x {args.peaky:g}"),
                        "schedule": f"FlowMatch 50 steps shift 5, boundary 0.875; timed step ids {step_ids} "
                                    f"({n_hi} high-noise with ControlNet, {k - n_hi} low-noise with the all-zero ControlNet2 elided)",
                        "layers": args.layers,
@@ -271,9 +317,10 @@ def main():
             "distributed": {"world": world, "backend": dist.get_backend() if world > 1 else None,
                             "rccl_ranks": world if (world > 1 and dist.get_backend() == "nccl") else 0,
                             "collectives": None if world == 1 else "per step: all-gather of the 4.19 MB noise prediction inside each "
-                                           "CFG pair; VAE tiles broadcast inside the pair; end of run: world all-gather of the "
-                                           "uint8 frames (97 MB per sample), timed as frame_allgather_s and included in value"},
+                                           "CFG pair; VAE tiles broadcast inside the pair; end of run: all-gather of the uint8 frames (97 MB "
+                                           "per sample) among the samples' lead ranks, timed as frame_allgather_s and included in value"},
             "self_check": {"latents_finite": True, "frames_finite": True, "latents": lat_digest, "frames_uint8": frames_digest,
+                           "per_sample": sample_digests,
                            "note": "latents = output of the K timed steps of rank 0's sample (finite, std in (1e-3,1e3) or the run "
                                    "aborts); frames = tiled VAE decode of those latents -> uint8 as the reference saves them"},
             "frames_per_sec_denoise_only": videos * 81.0 / loop_s,

@@ -89,7 +89,7 @@ struct GemmArgs {
     int wrows;    // gemm_a4_kernel: rows of W that exist (= N except for GF_EPI_VT32, where N = kv_pad covers zero columns past kv_len)
     int stagger_rows;   // gemm_a4_kernel: the K-loop rotation follows the ROW tile (GF_EPI_VT32: the operands are swapped, see gf_linear_vt32)
     int group_m;        // gemm_a4_kernel: row tiles per workgroup-order group (set by launch_gemm_a4)
-    int halftile;       // gemm_a4_kernel, bf16: the half-tile K loop (gf_gemm_a4h_loop.inc) instead of the k-sub-step loop (A/B: GF_A4_LOOP=h)
+    int halftile;       // -DGF_A4_HALFTILE_AB builds only: the half-tile K loop instead of the k-sub-step loop for bf16 (GF_A4_LOOP=h)
 };
 
 // internal epilogue of gf_linear_vt32 (not in goalforce.h's enum): C rows = output features, C columns = keys in kernel 3's
@@ -731,7 +731,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs
 #include "gf_gemm_a4_loop.inc"
 #endif
 #include "gf_gemm_a4f8_loop.inc"   // the fp8 K loop (tools/gen_gemm_a4f8.py)
-#include "gf_gemm_a4h_loop.inc"    // the fp8 loop's half-tile schedule with bf16 MFMAs (A4F8_BF16=1 tools/gen_gemm_a4f8.py)
+#ifdef GF_A4_HALFTILE_AB           // A/B builds only (tools/gemm_loop_ab.py): the fp8 loop's half-tile schedule with bf16 MFMAs
+#include GF_A4_HALFTILE_AB         // (A4F8_BF16=1 tools/gen_gemm_a4f8.py) — bit-identical to the k-sub-step loop and equally fast
+#endif                             // (profiles/r03/gemm_loop_ab_halftile.log), so the shipped library carries one bf16 loop
 constexpr int A4_THREADS = 256;
 #ifndef GF_A4_NT
 #define GF_A4_NT 1   // the epilogue streams: C stores and residual loads carry the non-temporal hint (D->D +2.6 %, D->F +1.2 %, F->D -0.5 %; 0 for A/B builds)
@@ -886,11 +888,14 @@ __global__ __launch_bounds__(A4_THREADS, 1) void gemm_a4_kernel(const GemmArgs p
     else if (p.whatif == 128) GF_A4_LOOP_ASM_W128(voffA, voffB, pfA, pfB, rdA0, rdA1, rdB0, rdB1, aLo, aHi, nrA, bLo, bHi, nrB, soA, stA, soB, stB, ldsW, nk, k0, kb);
     else
 #endif
+#ifdef GF_A4_HALFTILE_AB
     if (p.halftile) {
         A4STAMP(1)
         GF_A4H_LOOP_ASM(voffA, voffB, rdA0, rdA1, rdB0, rdB1, aLo, aHi, nrA, bLo, bHi, nrB, soA, stA, soB, stB, ldsW, nk, k0, kb);
         A4STAMP(2)
-    } else {
+    } else
+#endif
+    {
         A4STAMP(1)
         GF_A4_LOOP_ASM(voffA, voffB, pfA, pfB, rdA0, rdA1, rdB0, rdB1, aLo, aHi, nrA, bLo, bHi, nrB, soA, stA, soB, stB, ldsW, nk, k0, kb);
         A4STAMP(2)

@@ -311,12 +311,12 @@ class WanVideoPipeline:
         video = self.vae.decode(latents, device=self.device, tiled=tiled, tile_size=tile_size, tile_stride=tile_stride,
                                 tile_group=None if cfg_parallel is None else cfg_parallel.pair_group)
         if gather_frames:
-            # end-of-run all-gather of every sample's decoded frames over the world group (RCCL / xGMI),
+            # end-of-run all-gather of every sample's decoded frames among the samples' lead ranks (RCCL / xGMI), then one broadcast inside each sample's group,
             # 81x480x832x3 uint8 = 97 MB per sample -> list (one [T,H,W,3] uint8 tensor per sample) on every rank
             if cfg_parallel is None:
                 return [self.frames_uint8(video)]
             u8 = self.frames_uint8(video)
-            return cfg_parallel.gather_frames(u8, tuple(u8.shape), torch.uint8, u8.device)
+            return cfg_parallel.gather_frames(u8, tuple(u8.shape), torch.uint8, u8.device, everywhere=True)
         return video if output_type == "pt" else self.vae_output_to_video(video)
 
     # ---------------------------------------------------------------- pre-loop units that use the VAE encoder

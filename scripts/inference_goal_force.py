@@ -17,6 +17,8 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+# dmabuf IPC for RCCL on this driver (goal_force_amd/distributed.py::ensure_ipc_env): set before anything touches the GPU
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 CONTROLNET_NUM_LAYERS = 10   # INF:27-32
 NUM_FRAMES = 81

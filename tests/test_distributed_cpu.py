@@ -57,8 +57,12 @@ def _worker(rank, world, port, out):
         posi, nega = cp.exchange(mine)
         assert float(posi[0, 0]) == 2 * cp.sample and float(nega[0, 0]) == 2 * cp.sample + 1
         lat = _run_loop(cp, seed=100 + cp.sample)
-        frames = cp.gather_frames(lat if cp.branch == 0 else None, lat.shape, lat.dtype, "cpu")
+        lead_only = cp.gather_frames(lat if cp.branch == 0 else None, lat.shape, lat.dtype, "cpu")
+        assert (lead_only is None) == (cp.branch == 1), "only the samples' lead ranks take part in the frame all-gather"
+        frames = cp.gather_frames(lat if cp.branch == 0 else None, lat.shape, lat.dtype, "cpu", everywhere=True)
         assert len(frames) == world // 2
+        if lead_only is not None:
+            assert all(torch.equal(a, b) for a, b in zip(lead_only, frames))
         torch.save({"lat": lat, "frames": frames}, os.path.join(out, f"r{rank}.pt"))
     finally:
         dist.destroy_process_group()

@@ -4,7 +4,7 @@ RCCL backend itself initialises in this environment and accepts every collective
 forms and tensor kinds it issues them with (a one-rank world: each collective degenerates to a copy):
 
   distributed.CfgPairParallel.exchange       all_gather (list form) of the bf16 noise prediction in a new_group
-  distributed.CfgPairParallel.gather_frames  world all_gather of uint8 frames
+  distributed.CfgPairParallel.gather_frames  all_gather of uint8 frames in the leads-only group + broadcast in the sample group
   sequence_parallel.SequenceParallel         all_to_all_single (async) + all_gather_into_tensor
   vae tiled decode over a CFG pair           broadcast
   bench.py                                   barrier, all_reduce(MAX)
@@ -70,6 +70,8 @@ def test_rccl_backend_accepts_every_collective_of_the_package():
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
+    # HSA_ENABLE_IPC_MODE_LEGACY=0: dmabuf IPC, the only form this pool's host driver supports (distributed.ensure_ipc_env sets
+    # it by default; spelled out here because the child initialises the GPU before it imports the package)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GF_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, f"stdout: {r.stdout[-2000:]}\nstderr: {r.stderr[-4000:]}"

@@ -100,7 +100,7 @@ def _layout_worker(rank, world, port, sp_size, out):
         b0 = 2 * sp_size * cp.sample + cp.sp_rank
         assert float(posi[0]) == b0 and float(nega[0]) == b0 + sp_size
         frames = cp.gather_frames(torch.full((3,), float(cp.sample + 1)) if (cp.branch == 0 and cp.sp_rank == 0) else None,
-                                  (3,), torch.float32, "cpu")
+                                  (3,), torch.float32, "cpu", everywhere=True)
         assert [float(f[0]) for f in frames] == [float(s + 1) for s in range(cp.num_samples)]
         open(os.path.join(out, f"ok{rank}"), "w").close()
     finally:

@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """A/B of the two bf16 K loops of gemm_a4_kernel in ONE process (interleaved rounds): the k-sub-step loop (three barriers per K
 tile, tools/gen_gemm_a4.py) against the half-tile loop (two barriers, staging by halves: the fp8 loop's schedule with bf16 MFMAs,
-A4F8_BF16=1 tools/gen_gemm_a4f8.py), selected per launch with GF_A4_LOOP.  Checks that both produce the same bits."""
+A4F8_BF16=1 tools/gen_gemm_a4f8.py), selected per launch with GF_A4_LOOP.  Checks that both produce the same bits.
+Needs a library built with the second loop compiled in (the shipped one carries only the first):
+    A4F8_BF16=1 A4F8_OUT=build/ab/a4h_loop.inc python tools/gen_gemm_a4f8.py
+    make -C goal_force_amd/csrc CXXFLAGS+='-DGF_A4_HALFTILE_AB=\"$PWD/build/ab/a4h_loop.inc\"'     (then rebuild plainly)
+Result (profiles/r03/gemm_loop_ab_halftile.log): bit-identical, and within 0.5 % on all three shapes — not shipped."""
 import os
 import sys
 

@@ -54,6 +54,24 @@ def main():
         med, mn = timeit(lambda: ops.flash_attn(q, k, v, H, out=o), a.iters)
         fl = 4.0 * s * skv * D
         print(f"flash_attn S={s} Skv={skv} H={H}: median {med:.3f} ms ({fl / med / 1e9:.1f} TFLOP/s), min {mn:.3f} ms ({fl / mn / 1e9:.1f} TFLOP/s)")
+        if a.ref:      # yardstick only: torch's F.scaled_dot_product_attention — the backend the reference falls back to on this
+            # stack (DIT:55-60: no flash_attn / sageattention packages) — same box, same process, interleaved rounds
+            import torch.nn.functional as TF
+            hd = D // H
+            q4, k4, v4 = (t.view(1, -1, H, hd).transpose(1, 2) for t in (q, k, v))       # the reference's 'b s (n d) -> b n s d'
+            try:
+                ref_o = TF.scaled_dot_product_attention(q4, k4, v4)
+                torch.cuda.synchronize()
+                err = float((ref_o.transpose(1, 2).reshape(s, D).float() - ops.flash_attn(q, k, v, H).float()).norm() / ref_o.float().norm())
+                ours, theirs = [], []
+                for _ in range(3):
+                    ours.append(timeit(lambda: ops.flash_attn(q, k, v, H, out=o), a.iters)[0])
+                    theirs.append(timeit(lambda: TF.scaled_dot_product_attention(q4, k4, v4), a.iters)[0])
+                print(f"   yardstick F.scaled_dot_product_attention: medians {', '.join(f'{t:.3f}' for t in theirs)} ms -> "
+                      f"{fl / min(theirs) / 1e9:.1f} TFLOP/s best;  ours interleaved: {', '.join(f'{t:.3f}' for t in ours)} ms -> "
+                      f"{fl / min(ours) / 1e9:.1f} TFLOP/s best;  rel-L2 between the two outputs {err:.2e}")
+            except Exception as e:      # noqa: BLE001 — a yardstick that cannot run is reported, not fatal
+                print(f"   yardstick F.scaled_dot_product_attention failed: {type(e).__name__}: {str(e)[:200]}")
         if a.ab:       # interleaved rounds of kernel 3 (16x16x32 MFMA) and kernel 2 (32x32x16) in this process
             rounds = {"3": [], "2": []}
             for _ in range(3):
