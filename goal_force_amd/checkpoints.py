@@ -13,6 +13,7 @@ from the tensor shapes, so the A14B files and small synthetic checkpoints go thr
 """
 from __future__ import annotations
 
+import contextlib
 import glob
 import os
 from typing import Optional
@@ -76,6 +77,39 @@ def load_state_dict(path, torch_dtype=None, device="cpu"):
     return sd
 
 
+@contextlib.contextmanager
+def params_on_meta():
+    """Modules built inside allocate no parameter storage and run no random initialisation: every parameter is moved to the
+    meta device the moment it is registered (what the reference's `init_weights_on_device(torch.device("meta"))` does,
+    diffsynth/models/model_manager.py:71-75).  Buffers and plain tensor attributes (RoPE tables, VAE statistics) stay real.
+    The checkpoint's tensors are then ADOPTED with `load_state_dict(assign=True)` instead of being copied into a second,
+    randomly initialised fp32 copy of the model — for an A14B expert that copy would be 57 GB of host memory and minutes of
+    CPU random-number generation."""
+    old = torch.nn.Module.register_parameter
+
+    def register(module, name, param):
+        old(module, name, param)
+        if param is not None:
+            p = module._parameters[name]
+            module._parameters[name] = torch.nn.Parameter(p.detach().to("meta"), requires_grad=p.requires_grad)
+
+    torch.nn.Module.register_parameter = register
+    try:
+        yield
+    finally:
+        torch.nn.Module.register_parameter = old
+
+
+def _adopt(module, sd, what):
+    """strict load that takes over the checkpoint's tensors; a parameter the file does not provide would stay on the meta
+    device — strict=True names it first."""
+    module.load_state_dict(sd, strict=True, assign=True)
+    left = [n for n, p in module.named_parameters() if p.is_meta]
+    if left:
+        raise GoalForceError(f"{what}: parameters without checkpoint data: {left[:4]}")
+    return module
+
+
 def model_kind(sd) -> Optional[str]:
     if "model_state" in sd and isinstance(sd["model_state"], dict):
         sd = sd["model_state"]
@@ -109,9 +143,9 @@ def build_dit(sd, head_dim=128):
                out_dim=int(sd["head.head.weight"].shape[0]) // (int(pw.shape[2]) * int(pw.shape[3]) * int(pw.shape[4])),
                num_heads=dim // head_dim, num_layers=_count(sd, "blocks.{}.self_attn.q.weight"), eps=1e-6,
                require_clip_embedding=False)
-    m = WanModel(**cfg)
-    m.load_state_dict(sd, strict=True)
-    return m
+    with params_on_meta():
+        m = WanModel(**cfg)
+    return _adopt(m, sd, "wan_video_dit")
 
 
 def build_text_encoder(sd, head_dim=64):
@@ -121,11 +155,11 @@ def build_text_encoder(sd, head_dim=64):
     dim_attn = int(sd["blocks.0.attn.q.weight"].shape[0])
     shared = "pos_embedding.embedding.weight" in sd
     pe = sd["pos_embedding.embedding.weight" if shared else "blocks.0.pos_embedding.embedding.weight"]
-    m = WanTextEncoder(vocab=vocab, dim=dim, dim_attn=dim_attn, dim_ffn=int(sd["blocks.0.ffn.fc1.weight"].shape[0]),
-                       num_heads=int(pe.shape[1]), num_layers=_count(sd, "blocks.{}.attn.q.weight"),
-                       num_buckets=int(pe.shape[0]), shared_pos=shared)
-    m.load_state_dict(sd, strict=True)
-    return m
+    with params_on_meta():
+        m = WanTextEncoder(vocab=vocab, dim=dim, dim_attn=dim_attn, dim_ffn=int(sd["blocks.0.ffn.fc1.weight"].shape[0]),
+                           num_heads=int(pe.shape[1]), num_layers=_count(sd, "blocks.{}.attn.q.weight"),
+                           num_buckets=int(pe.shape[0]), shared_pos=shared)
+    return _adopt(m, sd, "wan_video_text_encoder")
 
 
 def build_vae(sd):
@@ -134,9 +168,9 @@ def build_vae(sd):
     from .vae import WanVideoVAE
     if "model_state" in sd:
         sd = sd["model_state"]
-    m = WanVideoVAE()
-    m.load_state_dict({("model." + k): v for k, v in sd.items()}, strict=True)
-    return m
+    with params_on_meta():
+        m = WanVideoVAE()
+    return _adopt(m, {("model." + k): v for k, v in sd.items()}, "wan_video_vae")
 
 
 BUILDERS = {"wan_video_dit": build_dit, "wan_video_text_encoder": build_text_encoder, "wan_video_vae": build_vae}
@@ -149,11 +183,15 @@ def load_model(model_config: ModelConfig, torch_dtype=torch.bfloat16, device="cu
     path = model_config.path
     if isinstance(path, str) and os.path.isdir(path):
         path = sorted(glob.glob(os.path.join(path, "*.safetensors"))) or sorted(glob.glob(os.path.join(path, "*.pth")))
-    sd = load_state_dict(path)
+    # every tensor is cast to torch_dtype as it is read and lands on `device` directly (safetensors reads straight into device
+    # memory): the host never holds more than one tensor of the model.  ModelConfig.offload_device / offload_dtype are accepted
+    # and unused — nothing is offloaded on a 288 GB part.
+    sd = load_state_dict(path, torch_dtype=torch_dtype, device=device)
     kind = model_kind(sd)
     if kind is None:
         some = ", ".join(list(sd)[:4])
         raise NotImplementedError(f"checkpoint {model_config.path}: not a Wan DiT expert, umT5 encoder or Wan VAE "
                                   f"(first keys: {some}); the other DiffSynth model families are out of scope")
     module = BUILDERS[kind](sd)
-    return kind, module.to(dtype=torch_dtype).to(device)
+    del sd
+    return kind, module.to(device=device, dtype=torch_dtype)     # parameters are there already; this moves the (few) buffers

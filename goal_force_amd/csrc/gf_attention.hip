@@ -1554,10 +1554,7 @@ static int flash_attn_fwd_impl(const void* q, const void* k, const void* v, void
                  "gf_flash_attn_fwd: kv_len*stride must stay below 2^31 elements");
     if (q_len == 0) return GF_OK;
     // tuning switch: GF_ATTN_KERNEL=1 = the phase-serial kernel, otherwise the slot-pipelined kernel 2
-    static const bool use_k2 = [] {
-        const char* ev = getenv("GF_ATTN_KERNEL");
-        return !(ev && ev[0] == '1');
-    }();
+    static const bool use_k2 = !gf_options().attn_kernel1.load(std::memory_order_relaxed);   // fixed at the first launch
     static GfDeviceOnce once;
     hipError_t e = gf_once_per_device(once, [] {
         hipError_t r = hipFuncSetAttribute(use_k2 ? reinterpret_cast<const void*>(flash_attn_fwd_kernel2<false>)

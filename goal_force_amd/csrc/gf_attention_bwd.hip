@@ -364,11 +364,7 @@ extern "C" GF_API int gf_flash_attn_bwd(const void* q, const void* k, const void
     const unsigned nqb = (unsigned)((q_len + DQ_ROWS - 1) / DQ_ROWS), nkb = (unsigned)((kv_len + DKV_ROWS - 1) / DKV_ROWS);
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(nqb * (unsigned)heads), dim3(DQ_THREADS), lds_bytes, s, a);
     // GF_ATTN_BWD_FUSED_DKV=1: dK and dV in one pass at one wave per SIMD (the first version, A/B)
-    static int fused = -1;
-    if (fused < 0) {
-        const char* ev = getenv("GF_ATTN_BWD_FUSED_DKV");
-        fused = (ev && ev[0] == '1') ? 1 : 0;
-    }
+    const int fused = gf_options().bwd_fused_dkv.load(std::memory_order_relaxed);
     if (fused) {
         hipLaunchKernelGGL(attn_bwd_dkv_kernel<0>, dim3(nkb * (unsigned)heads), dim3(DKV_THREADS), lds_bytes, s, a);
     } else {

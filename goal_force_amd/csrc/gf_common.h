@@ -98,6 +98,26 @@ void gf_set_error(const char* fmt, ...);
     } while (0)
 static inline bool gf_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
+// A/B and diagnostic knobs of the launchers (GF_GEMM_KERNEL, GF_A4_STAGGER, ...).  They are read from the environment ONCE per
+// process (first use) into atomics and validated there; the launch path only does relaxed loads — no getenv per launch (getenv
+// is not thread-safe against setenv, and a forward makes ~1000 launches).  A process that changes one of the variables at run
+// time (tests, tools/*_ab.py) calls gf_reload_options() afterwards.  Defaults = the shipped configuration.
+#include <atomic>
+struct GfOptions {
+    std::atomic<int> gemm_kernel{0};    // GF_GEMM_KERNEL: 0 = shipped (a4 for M >= 512), 1 = "ph" (8-wave kernels), 2 = "sl", 3 = "sl8"
+    std::atomic<int> gemm_v1{-1};       // GF_GEMM_V1: -1 = per dtype default, 0 / 1 forced
+    std::atomic<int> a4_stagger{2};     // GF_A4_STAGGER: K tiles between the K-loop starts of neighbouring column tiles (>= 0; 0 = off)
+    std::atomic<int> a4_group_m{0};     // GF_A4_GROUP_M: 0 = by K
+    std::atomic<int> a4_loop_h{0};      // GF_A4_LOOP=h (-DGF_A4_HALFTILE_AB builds only)
+    std::atomic<int> a4_whatif{0};      // GF_A4_WHATIF (-DGF_A4_WHATIF builds only)
+    std::atomic<int> attn_kernel1{0};   // GF_ATTN_KERNEL=1: gf_flash_attn_fwd on the phase-serial kernel 1
+    std::atomic<int> bwd_fused_dkv{0};  // GF_ATTN_BWD_FUSED_DKV=1
+    std::atomic<int> conv_nb{0};        // GF_CONV_NB: 0 = by Cout, 1 / 2 forced
+    std::atomic<int> conv_gather{0};    // GF_CONV_GATHER=1: the general gather
+};
+const GfOptions& gf_options();          // gf_abi.hip
+extern "C" GF_API void gf_reload_options(void);
+
 // One-time, per-DEVICE, thread-safe launcher setup (hipFuncSetAttribute is a property of the function on the current
 // device: a process that drives a second GPU must set it there too).  `f()` runs at most once per device and returns
 // a hipError_t; a failure is not latched (the next call retries).

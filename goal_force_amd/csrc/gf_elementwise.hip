@@ -75,6 +75,53 @@ __global__ __launch_bounds__(EW_THREADS) void add_kernel(const u16* __restrict__
     }
 }
 
+// modulate (DIT:64-65) as the reference's eager bf16 graph: t = bf16(1 + scale); y = bf16(x * t); out = bf16(y + shift);
+// scale / shift are [dim] vectors (the reference's [B, 1, D] operands at B = 1).  dim % 8 == 0.
+__global__ __launch_bounds__(EW_THREADS) void modulate_kernel(const u16* __restrict__ x, u16* __restrict__ out,
+                                                              const u16* __restrict__ scale, const u16* __restrict__ shift,
+                                                              long rows, int dim, long x_stride, long out_stride) {
+    const int cpr = dim >> 3;
+    const long total = rows * cpr;
+    const long stride = (long)gridDim.x * EW_THREADS;
+    for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += stride) {
+        const long r = i / cpr;
+        const int c = (int)(i - r * cpr) << 3;
+        const u16x8 xv = *reinterpret_cast<const u16x8*>(x + r * x_stride + c);
+        const u16x8 sc = *reinterpret_cast<const u16x8*>(scale + c);
+        const u16x8 sh = *reinterpret_cast<const u16x8*>(shift + c);
+        u16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = f2bf(rbf(bf2f(xv[j]) * rbf(1.0f + bf2f(sc[j]))) + bf2f(sh[j]));
+        *reinterpret_cast<u16x8*>(out + r * out_stride + c) = o;
+    }
+}
+
+// rope_apply (DIT:92-97) alone: adjacent pairs of every head rotated by the token's phases (fp32 cos / sin tables [rows, head_dim/2];
+// the reference multiplies in complex128 and rounds once to bf16).  The fused form on the hot path is gf_rmsnorm_rope.
+__global__ __launch_bounds__(EW_THREADS) void rope_apply_kernel(const u16* __restrict__ x, u16* __restrict__ out,
+                                                                const float* __restrict__ cos_tab, const float* __restrict__ sin_tab,
+                                                                long rows, int dim, int head_dim, long x_stride, long out_stride) {
+    const int cpr = dim >> 3, half = head_dim >> 1;
+    const long total = rows * cpr;
+    const long stride = (long)gridDim.x * EW_THREADS;
+    for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += stride) {
+        const long r = i / cpr;
+        const int c = (int)(i - r * cpr) << 3;
+        const u16x8 xv = *reinterpret_cast<const u16x8*>(x + r * x_stride + c);
+        const int p0 = (c % head_dim) >> 1;
+        const f32x4 cs = *reinterpret_cast<const f32x4*>(cos_tab + r * half + p0);
+        const f32x4 sn = *reinterpret_cast<const f32x4*>(sin_tab + r * half + p0);
+        u16x8 o;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const float a = bf2f(xv[2 * p]), b = bf2f(xv[2 * p + 1]);
+            o[2 * p] = f2bf(__builtin_fmaf(a, cs[p], -(b * sn[p])));
+            o[2 * p + 1] = f2bf(__builtin_fmaf(a, sn[p], b * cs[p]));
+        }
+        *reinterpret_cast<u16x8*>(out + r * out_stride + c) = o;
+    }
+}
+
 // out[i, :] = bf16(param[i, :] + t[i % t_rows, :]); rows whose bit is set in onep_mask become bf16(1 + .)
 __global__ __launch_bounds__(EW_THREADS) void modulation_kernel(const u16* __restrict__ param,
                                                                 const u16* __restrict__ t, u16* __restrict__ out,
@@ -208,6 +255,31 @@ extern "C" GF_API int gf_add_bf16(const void* a, const void* b, void* out, int64
     hipLaunchKernelGGL(add_kernel, dim3(ew_grid(n >> 3)), dim3(EW_THREADS), 0, (hipStream_t)stream, (const u16*)a,
                        (const u16*)b, (u16*)out, (long)n);
     GF_CHECK_LAUNCH("gf_add_bf16");
+    return GF_OK;
+}
+
+extern "C" GF_API int gf_modulate(const void* x, void* out, const void* scale, const void* shift, int64_t rows, int64_t dim,
+                                  int64_t x_stride, int64_t out_stride, void* stream) {
+    GF_CHECK_ARG(x && out && scale && shift && rows >= 0, "gf_modulate: null pointer");
+    GF_CHECK_ARG(dim > 0 && dim % 8 == 0 && x_stride % 8 == 0 && out_stride % 8 == 0 && gf_aligned16(x) && gf_aligned16(out) &&
+                     gf_aligned16(scale) && gf_aligned16(shift), "gf_modulate: dim %% 8 == 0 and 16-byte aligned rows / vectors required");
+    if (rows == 0) return GF_OK;
+    hipLaunchKernelGGL(modulate_kernel, dim3(ew_grid(rows * (dim >> 3))), dim3(EW_THREADS), 0, (hipStream_t)stream, (const u16*)x,
+                       (u16*)out, (const u16*)scale, (const u16*)shift, (long)rows, (int)dim, (long)x_stride, (long)out_stride);
+    GF_CHECK_LAUNCH("gf_modulate");
+    return GF_OK;
+}
+
+extern "C" GF_API int gf_rope_apply(const void* x, void* out, const float* cos_tab, const float* sin_tab, int64_t rows,
+                                    int64_t dim, int64_t head_dim, int64_t x_stride, int64_t out_stride, void* stream) {
+    GF_CHECK_ARG(x && out && cos_tab && sin_tab && rows >= 0, "gf_rope_apply: null pointer");
+    GF_CHECK_ARG(dim > 0 && head_dim > 0 && head_dim % 8 == 0 && dim % head_dim == 0, "gf_rope_apply: head_dim must be a multiple of 8 dividing dim");
+    GF_CHECK_ARG(x_stride % 8 == 0 && out_stride % 8 == 0 && gf_aligned16(x) && gf_aligned16(out) && gf_aligned16(cos_tab) &&
+                     gf_aligned16(sin_tab), "gf_rope_apply: 16-byte alignment required");
+    if (rows == 0) return GF_OK;
+    hipLaunchKernelGGL(rope_apply_kernel, dim3(ew_grid(rows * (dim >> 3))), dim3(EW_THREADS), 0, (hipStream_t)stream, (const u16*)x,
+                       (u16*)out, cos_tab, sin_tab, (long)rows, (int)dim, (int)head_dim, (long)x_stride, (long)out_stride);
+    GF_CHECK_LAUNCH("gf_rope_apply");
     return GF_OK;
 }
 

@@ -1023,11 +1023,9 @@ int launch_gemm_a4(const GemmArgs& a0, hipStream_t stream) {
     {
         // an XCD runs 32 consecutive tiles of the order = group_m row tiles x 32 / group_m column tiles: 8 x 4 and 4 x 8 both stage
         // 12 operand slices per K step; with the long K loop of F->D (K = 13824) 4 x 8 measured +1.6 %, at K = 5120 8 x 4 +1-2 %
-        const char* eg = getenv("GF_A4_GROUP_M");
-        const int g = eg ? atoi(eg) : 0;
+        const int g = gf_options().a4_group_m.load(std::memory_order_relaxed);
         a.group_m = g > 0 ? g : (a.K * (FP8 ? 1 : 2) >= 16384 ? 4 : GROUP_M);   // by the K loop's length in bytes per row
-        const char* el = getenv("GF_A4_LOOP");
-        a.halftile = (el && el[0] == 'h') ? 1 : 0;
+        a.halftile = gf_options().a4_loop_h.load(std::memory_order_relaxed);
     }
     static GfDeviceOnce once;
     hipError_t e = gf_once_per_device(once, [] {
@@ -1315,33 +1313,28 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
     if constexpr (!FP8) {
         // bf16: GF_GEMM_KERNEL=sl selects the experimental slot-scheduled kernel (A/B); its DMA offsets are 32-bit byte
         // offsets from the operand base
-        static int use_sl = -1;
-        if (use_sl < 0) {
-            const char* ek = getenv("GF_GEMM_KERNEL");
-            use_sl = (ek && ek[0] == 's') ? ((ek[1] == 'l' && ek[2] == '8') ? 8 : 4) : 0;   // "sl" / "sl8"
-        }
+        const int gk = gf_options().gemm_kernel.load(std::memory_order_relaxed);
+        const int use_sl = gk == 3 ? 8 : (gk == 2 ? 4 : 0);                                  // "sl8" / "sl"
         if (use_sl && (long)a.M * a.lda < (1L << 31) && (long)a.N * a.ldw < (1L << 31))
             return use_sl == 8 ? launch_gemm_sl<EPI, 8>(a, stream) : launch_gemm_sl<EPI, 4>(a, stream);
         // the 4-wave kernel for the large shapes (every Linear of a DiT block at S >= 512): GF_GEMM_KERNEL=ph selects the
         // 8-wave phased kernel instead (A/B runs).  Its 32-bit staging offsets cover 256 rows of either operand.
-        const char* ek4 = getenv("GF_GEMM_KERNEL");   // read per call: A/B runs toggle it inside one process
-        const bool use_a4 = !(ek4 && ek4[0] == 'p');
+        const bool use_a4 = gk != 1;                  // A/B runs toggle it inside one process (gf_reload_options)
         if (use_a4 && a.M >= 512 && a.K % 64 == 0 && 256L * a.lda * 2 + a.K * 2L < (1L << 31) &&
             256L * a.ldw * 2 + a.K * 2L < (1L << 31))
             return launch_gemm_a4<EPI>(a, stream);
     }
     if constexpr (FP8) {
         // the 4-wave fp8 kernel for the large shapes (GF_GEMM_KERNEL=ph selects the 8-wave one-barrier kernel below: A/B runs)
-        const char* ek4 = getenv("GF_GEMM_KERNEL");
-        const bool use_a4 = !(ek4 && ek4[0] == 'p');
+        const bool use_a4 = gf_options().gemm_kernel.load(std::memory_order_relaxed) != 1;
         if (use_a4 && a.M >= 512 && a.K % 128 == 0 && 256L * a.lda + a.K < (1L << 31) && 256L * a.ldw + a.K < (1L << 31))
             return launch_gemm_a4<EPI, true>(a, stream);
     }
     // bf16 ships the phased kernel (+5..11 % at the DiT shapes); fp8 ships the one-barrier-per-K-tile kernel (at 254
     // VGPRs the phased fp8 variant measured 10-15 % slower).  GF_GEMM_V1=0/1 overrides for A/B tuning.
-    static const bool use_v1 = [] {
-        const char* ev = getenv("GF_GEMM_V1");
-        return ev ? (ev[0] == '1') : FP8;
+    static const bool use_v1 = [] {     // fixed at the first launch: it selects which kernel gets its LDS attribute set
+        const int v = gf_options().gemm_v1.load(std::memory_order_relaxed);
+        return v < 0 ? FP8 : v == 1;
     }();
     static GfDeviceOnce once;   // per instantiation
     hipError_t e = gf_once_per_device(once, [] {
@@ -1449,14 +1442,13 @@ static int gemm_dispatch(bool fp8, const void* A, int64_t lda, const void* W, in
     a.dbg = nullptr;
 #endif
     a.whatif = 0;
-    {
-        const char* es = getenv("GF_A4_STAGGER");   // K tiles between the K-loop starts of neighbouring column tiles (0 = off)
-        a.stagger = es ? atoi(es) : 2;
-    }
+    // K tiles between the K-loop starts of neighbouring column tiles (0 = off).  The rotation changes the ORDER of the sum over k
+    // (not the sum): a4 outputs match the unrotated kernels (M < 512: the 8-wave path) to fp32 rounding, not bit for bit.
+    a.stagger = gf_options().a4_stagger.load(std::memory_order_relaxed);
     a.wrows = (int)N;
     a.stagger_rows = 0;
 #ifdef GF_A4_WHATIF
-    if (const char* ew = getenv("GF_A4_WHATIF")) a.whatif = atoi(ew);
+    a.whatif = gf_options().a4_whatif.load(std::memory_order_relaxed);
 #endif
     hipStream_t s = (hipStream_t)stream;
 #define GF_GEMM_CASE(E) case E: return fp8 ? launch_gemm<E, true>(a, s) : launch_gemm<E, false>(a, s);
@@ -1520,10 +1512,7 @@ extern "C" GF_API int gf_linear_vt32(const void* x, int64_t ldx, const void* w, 
     a.tiles_n = (int)((kv_pad + BN - 1) / BN);
     a.dbg = nullptr;
     a.whatif = 0;
-    {
-        const char* es = getenv("GF_A4_STAGGER");
-        a.stagger = es ? atoi(es) : 2;
-    }
+    a.stagger = gf_options().a4_stagger.load(std::memory_order_relaxed);
     a.wrows = (int)kv_len;
     a.stagger_rows = 1;
     return launch_gemm_a4<GF_EPI_VT32>(a, (hipStream_t)stream);
@@ -1576,11 +1565,7 @@ extern "C" GF_API int gf_conv3d_bf16(const void* src, const void* cache, const v
     a.ldc = ldc;
     a.ldr = ldr;
     // Cout <= 128 (the 96-channel level, the RGB head): the 256 x 128 tile; GF_CONV_NB=2 forces the 256 x 256 tile (A/B timing)
-    static int force_nb = -1;
-    if (force_nb < 0) {
-        const char* ev = getenv("GF_CONV_NB");
-        force_nb = ev ? atoi(ev) : 0;
-    }
+    const int force_nb = gf_options().conv_nb.load(std::memory_order_relaxed);
     const bool narrow = force_nb ? force_nb == 1 : N <= 128;
     a.tiles_m = (int)((M + BM - 1) / BM);
     a.tiles_n = narrow ? (int)((N + 127) / 128) : (int)((N + BN - 1) / BN);
@@ -1613,11 +1598,7 @@ extern "C" GF_API int gf_conv3d_bf16(const void* src, const void* cache, const v
     hipStream_t s = (hipStream_t)stream;
     a.cv.hist_front = (kt == 3 && !cache) ? 1 : 0;
     // contiguous source frames and stride-1 taps: the pointer-per-row gather (GF_CONV_GATHER=1 forces the general one, A/B)
-    static int force_g = -1;
-    if (force_g < 0) {
-        const char* ev = getenv("GF_CONV_GATHER");
-        force_g = ev ? atoi(ev) : 0;
-    }
+    const int force_g = gf_options().conv_gather.load(std::memory_order_relaxed);
     const bool fast = force_g != 1 && mode == 0 && (kt == 1 || !cache);
 #define GF_CONV_CASE(E, NBV, CV) return launch_conv<E, NBV, CV>(a, s)
     if (fast) {

@@ -80,11 +80,55 @@ def sinusoidal_embedding_1d(dim, position):
     return torch.cat([torch.cos(sinusoid), torch.sin(sinusoid)], dim=1).to(position.dtype)
 
 
+# ------------------------------------------------------------------ B3: the reference's module-level functions (DIT:28, 64, 92)
+def flash_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: int, compatibility_mode=False):
+    """DIT:28-61 — q, k, v [B, S, num_heads * head_dim] (`b s (n d)`) -> [B, Sq, num_heads * head_dim]: softmax(q k^T / sqrt(d)) v
+    per head, no mask, on the HIP flash-attention kernels (gf_flash_attn_fwd).  `compatibility_mode` only chooses among the
+    reference's backends (flash-attn 3 / 2, sageattention, torch SDPA); there is one backend here, so it is accepted and ignored."""
+    if q.dim() != 3 or k.dim() != 3 or v.dim() != 3 or not (q.shape[0] == k.shape[0] == v.shape[0]):
+        raise GoalForceError("flash_attention: q, k, v must be [B, S, num_heads * head_dim] with equal B")
+    return torch.stack([ops.flash_attn(q[b].contiguous(), k[b].contiguous(), v[b].contiguous(), num_heads) for b in range(q.shape[0])])
+
+
+def modulate(x: torch.Tensor, shift: torch.Tensor, scale: torch.Tensor):
+    """DIT:64-65 — x * (1 + scale) + shift with x [B, S, D] and shift / scale broadcastable [B or 1, 1, D] (or [D]), computed in
+    the reference's eager bf16 rounding sequence by gf_modulate."""
+    if x.dim() == 2:
+        return ops.modulate(x, shift.reshape(-1).contiguous(), scale.reshape(-1).contiguous())
+    d = x.shape[-1]
+    sh, sc = (t.reshape(-1, d) if t.numel() != d else t.reshape(1, d) for t in (shift, scale))
+    if sh.shape[0] not in (1, x.shape[0]) or sc.shape[0] not in (1, x.shape[0]):
+        raise GoalForceError("modulate: shift / scale must be [B or 1, 1, D] (per-token modulation is outside the Goal-Force path)")
+    return torch.stack([ops.modulate(x[b].contiguous(), sh[b if sh.shape[0] > 1 else 0].contiguous(),
+                                     sc[b if sc.shape[0] > 1 else 0].contiguous()) for b in range(x.shape[0])])
+
+
+def rope_apply(x: torch.Tensor, freqs, num_heads: int):
+    """DIT:92-97 — x [B, S, num_heads * head_dim], freqs the reference's complex [S, 1, head_dim / 2] table (or a RopeTable):
+    adjacent pairs of every head rotated by the token's phases (gf_rope_apply, fp32 math, one rounding to bf16)."""
+    rope = _as_rope(freqs, x.device)
+    hd = x.shape[-1] // num_heads
+    return torch.stack([ops.rope_apply(x[b].contiguous(), rope.cos, rope.sin, hd) for b in range(x.shape[0])])
+
+
+_CACHE_EPOCH = [0]
+
+
+def invalidate_caches():
+    """Every copy derived from a parameter (K-padded patch weights, fp8 weight copies, the ControlNet's all-zero flag, memoised
+    context projections) is rebuilt on its next use.  Needed only for changes param_key cannot see: a raw-pointer write to a
+    weight, or an in-place edit of an inference tensor."""
+    _CACHE_EPOCH[0] += 1
+
+
 def param_key(*tensors):
-    """Identity + modification state of parameters a derived copy was built from: (storage address, autograd version) per
-    tensor.  Optimiser steps (ops.adamw_step bumps the version), load_state_dict, .to() and in-place edits all change it,
-    so a cache that compares keys can never serve weights captured before an update."""
-    return tuple((t.data_ptr(), t._version) for t in tensors)
+    """Identity + modification state of parameters a derived copy was built from: (object id, device, storage address, autograd
+    version) per tensor.  Optimiser steps (ops.adamw_step bumps the version), load_state_dict, .to() and in-place edits all change
+    it, so a cache that compares keys can never serve weights captured before an update.  Inference tensors (a pipeline built
+    under torch.inference_mode()) carry no version counter — reading `_version` raises there — so their key is identity +
+    address only: after an in-place edit of such a weight (or a raw-pointer write to any weight) call `invalidate_caches()`,
+    the hook for changes the key cannot see."""
+    return (_CACHE_EPOCH[0],) + tuple((id(t), str(t.device), t.data_ptr(), None if t.is_inference() else t._version) for t in tensors)
 
 
 class QuantizedInput:

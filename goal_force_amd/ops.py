@@ -114,6 +114,35 @@ def rmsnorm_rope(x, weight, cos=None, sin=None, head_dim=128, eps=1e-6):
     return x
 
 
+def modulate(x, shift, scale):
+    """x * (1 + scale) + shift in the reference's eager bf16 rounding sequence (DIT:64-65) — gf_modulate; shift / scale [dim]."""
+    _req(x, "modulate.x")
+    xv, rows, dim, xs = _rows2d(x, "modulate.x")
+    for n, t in (("shift", shift), ("scale", scale)):
+        _req(t, f"modulate.{n}")
+        if t.numel() != dim or not t.is_contiguous():
+            raise GoalForceError(f"modulate.{n}: expected contiguous [{dim}] (batch 1)")
+    out = torch.empty(x.shape, dtype=_BF16, device=x.device)
+    ov, _, _, os_ = _rows2d(out, "modulate.out")
+    _lib.check(_lib.load().gf_modulate(_ptr(xv), _ptr(ov), _ptr(scale), _ptr(shift), rows, dim, xs, os_, _stream(x)), "gf_modulate")
+    return out
+
+
+def rope_apply(x, cos, sin, head_dim):
+    """Rotary embedding alone (DIT:92-97) — gf_rope_apply; x [S, H*head_dim] bf16, cos / sin [S, head_dim/2] fp32 -> new tensor."""
+    _req(x, "rope_apply.x")
+    xv, rows, dim, xs = _rows2d(x, "rope_apply.x")
+    for n, t in (("cos", cos), ("sin", sin)):
+        _req(t, f"rope_apply.{n}", torch.float32)
+        if tuple(t.shape) != (rows, head_dim // 2) or not t.is_contiguous():
+            raise GoalForceError(f"rope_apply.{n}: expected contiguous [{rows}, {head_dim // 2}] fp32")
+    out = torch.empty(x.shape, dtype=_BF16, device=x.device)
+    ov, _, _, os_ = _rows2d(out, "rope_apply.out")
+    _lib.check(_lib.load().gf_rope_apply(_ptr(xv), _ptr(ov), _ptr(cos), _ptr(sin), rows, dim, head_dim, xs, os_, _stream(x)),
+               "gf_rope_apply")
+    return out
+
+
 def gemm(a, w, bias=None, epilogue=EPI_BIAS, resid=None, gate=None, out=None):
     """out[M,N] = epilogue(a[M,K] @ w[N,K]^T + bias) — gf_gemm_bf16."""
     _req(a, "gemm.a")
@@ -155,6 +184,40 @@ def gemm(a, w, bias=None, epilogue=EPI_BIAS, resid=None, gate=None, out=None):
 
 
 VT_MIN_KV = int(os.environ.get("GF_ATTN_VT_MIN_KV", "2048"))   # key sequences at least this long go through the pre-transposed-V kernel
+# A/B knobs of this module, read once (like the library's own: gf_reload_options); reload_options() re-reads both sides
+_OPT = {"attn_k3": os.environ.get("GF_ATTN_KERNEL", "3") == "3", "vt_from_gemm": os.environ.get("GF_VT_FROM_GEMM", "1") == "1"}
+
+
+def reload_options():
+    """Re-read the A/B / diagnostic environment knobs (GF_GEMM_KERNEL, GF_A4_STAGGER, GF_ATTN_KERNEL, GF_VT_FROM_GEMM, ...): the
+    launch paths read them once per process, so a process that changes os.environ at run time (tests, tools) calls this."""
+    _OPT["attn_k3"] = os.environ.get("GF_ATTN_KERNEL", "3") == "3"
+    _OPT["vt_from_gemm"] = os.environ.get("GF_VT_FROM_GEMM", "1") == "1"
+    _lib.load().gf_reload_options()
+
+
+class env_options:
+    """`with ops.env_options(GF_GEMM_KERNEL="ph"): ...` — set (None: unset) knobs for a block and restore them afterwards."""
+
+    def __init__(self, **kv):
+        self.kv, self.old = kv, {}
+
+    def _apply(self, kv):
+        for k, v in kv.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = str(v)
+        reload_options()
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        self._apply(self.kv)
+        return self
+
+    def __exit__(self, *exc):
+        self._apply(self.old)
+        return False
 _VT_WS = {}
 
 
@@ -172,7 +235,7 @@ def vt32_ok(skv, num_heads, head_dim):
     """True when flash_attn would take the pre-transposed-V kernel 3 for this key length (then linear_vt32 can produce its V^T)."""
     kv_pad = -(-skv // 64) * 64
     return (skv >= VT_MIN_KV and head_dim == 128 and num_heads * 128 * kv_pad < 2 ** 31
-            and os.environ.get("GF_ATTN_KERNEL", "3") == "3" and os.environ.get("GF_VT_FROM_GEMM", "1") == "1")
+            and _OPT["attn_k3"] and _OPT["vt_from_gemm"])
 
 
 def linear_vt32(x, weight, bias):
@@ -224,7 +287,7 @@ def flash_attn(q, k, v, num_heads, out=None, scale=None, vt=None):
         # long key sequences (the DiT self-attention): hand V over pre-transposed — one LDS read per PV MFMA instead of two;
         # the transpose (0.7 % of the attention's time at S=32760) is inside the timed region
         # GF_ATTN_KERNEL=2 (read per call: A/B runs) selects the 32x32x16-MFMA kernel 2; default = kernel 3 on 16x16x32 MFMAs
-        k3 = os.environ.get("GF_ATTN_KERNEL", "3") == "3"
+        k3 = _OPT["attn_k3"]
         tr, fa = (lib.gf_transpose_v32, lib.gf_flash_attn_fwd_vt32) if k3 else (lib.gf_transpose_v, lib.gf_flash_attn_fwd_vt)
         if vt is None:
             vt = _vt_workspace(num_heads * 128 * kv_pad, q.device)
@@ -262,7 +325,7 @@ def flash_attn_lse(q, k, v, num_heads, scale=None):
     kv_pad = -(-skv // 64) * 64
     if skv >= VT_MIN_KV and head_dim == 128 and num_heads * 128 * kv_pad < 2 ** 31:   # as flash_attn: pre-transposed V, same bits
         vt = _vt_workspace(num_heads * 128 * kv_pad, q.device)
-        k3 = os.environ.get("GF_ATTN_KERNEL", "3") == "3"
+        k3 = _OPT["attn_k3"]
         tr, fa = (lib.gf_transpose_v32, lib.gf_flash_attn_fwd_vt32) if k3 else (lib.gf_transpose_v, lib.gf_flash_attn_fwd_vt)
         _lib.check(tr(_ptr(v), v.stride(0), _ptr(vt), skv, kv_pad, num_heads, _stream(q)), "gf_transpose_v")
         _lib.check(fa(_ptr(q), _ptr(k), _ptr(vt), _ptr(out), _ptr(lse), sq, skv, kv_pad, num_heads, head_dim,

@@ -48,6 +48,9 @@ typedef enum {
 GF_API const char* gf_version(void);      /* "goalforce-hip <semver> gfx950" */
 GF_API const char* gf_last_error(void);   /* thread-local message of the last failure */
 GF_API int gf_abi_version(void);          /* bumped on any signature change */
+/* The launchers' A/B and diagnostic knobs (GF_GEMM_KERNEL, GF_A4_STAGGER, GF_ATTN_KERNEL, GF_CONV_NB, ...) are read from the
+ * environment once per process and validated; a process that changes one of them at run time calls this afterwards. */
+GF_API void gf_reload_options(void);
 
 /* ------------------------------------------------------------------------
  * gf_layernorm_modulate — LayerNorm over the last dim (fp32 math, one
@@ -335,6 +338,17 @@ GF_API int gf_vae_tile_blend(void* values, void* weight, const void* tile, int64
                              void* stream);
 /* clamp1 != 0: clamp to [-1,1] (decode); 0: no clamp (tiled_encode, VAE:1155-1203). */
 GF_API int gf_vae_tile_finalize(void* values, const void* weight, int64_t planes, int64_t hw, int clamp1, void* stream);
+
+/* gf_modulate — the reference's module-level `modulate(x, shift, scale)` (DIT:64-65) in its eager bf16 rounding sequence:
+ * out = bf16(bf16(x * bf16(1 + scale)) + shift); scale / shift [dim] bf16; x, out [rows, dim] bf16.  (On the hot path the
+ * modulation is fused into gf_layernorm_modulate; this entry point backs the B3 drop-in name.) */
+GF_API int gf_modulate(const void* x, void* out, const void* scale, const void* shift, int64_t rows, int64_t dim,
+                       int64_t x_stride, int64_t out_stride, void* stream);
+
+/* gf_rope_apply — the reference's module-level `rope_apply(x, freqs, num_heads)` (DIT:92-97) alone: adjacent pairs of every
+ * head rotated by cos / sin [rows, head_dim/2] fp32.  (Hot path: fused into gf_rmsnorm_rope.) */
+GF_API int gf_rope_apply(const void* x, void* out, const float* cos_tab, const float* sin_tab, int64_t rows, int64_t dim,
+                         int64_t head_dim, int64_t x_stride, int64_t out_stride, void* stream);
 
 /* ========================================================================
  * fp8 Linear — the contract of AutoWrappedLinear.fp8_linear (VRAM:115-151):

@@ -68,6 +68,44 @@ def test_tiny_block_and_submodules_vs_goldens():
     assert torch.equal(xg.cpu(), x)
 
 
+def test_b3_module_level_functions_vs_reference_goldens():
+    """the reference's module-level names with its signatures — `rope_apply(x, freqs, num_heads)` (DIT:92),
+    `modulate(x, shift, scale)` (DIT:64), `flash_attention(q, k, v, num_heads, compatibility_mode=False)` (DIT:28) — exported by
+    goal_force_amd.dit and run on the HIP kernels, against what the reference's own functions produced (g2)."""
+    from goal_force_amd import ops
+    from goal_force_amd.dit import flash_attention, modulate, rope_apply
+    g = _load("g2_ops.npz")
+    cfg = gi.TINY
+    nh = cfg["num_heads"]
+    sd = gi.block_sd(torch.Generator().manual_seed(11), cfg["dim"], cfg["ffn_dim"], "", BF)
+    x, ctx, t_mod = gi.block_inputs(cfg["dim"], 72, gi.TINY_CTX_LEN, seed=12)
+    xg = x.cuda()
+    # rope_apply with the reference's complex [S, 1, d/2] table: one bf16 rounding of an exact rotation -> <= 1 ulp from the golden
+    freqs = torch.complex(torch.from_numpy(g["freqs_re"]), torch.from_numpy(g["freqs_im"])).reshape(72, 1, 64)
+    got = rope_apply(xg, freqs, nh).cpu()
+    ref = _bf(g["rope_bf16"])
+    assert got.shape == ref.shape
+    d = (got.view(torch.int16).int() - ref.view(torch.int16).int()).abs()
+    assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 2e-3 and rel_l2(got.float(), torch.from_numpy(g["rope_f32"])) < 3e-3
+    # modulate(norm1(x), shift, scale) == the fused LayerNorm+modulate kernel's output, and the reference's bf16 result
+    mod = (sd["modulation"] + t_mod).chunk(6, dim=1)                       # bf16 add, as DIT:218
+    ln = ops.layernorm_modulate(xg[0], eps=cfg["eps"]).unsqueeze(0)
+    got = modulate(ln, mod[0].cuda(), mod[1].cuda())
+    fused = ops.layernorm_modulate(xg[0], scale1p=(1 + mod[1]).reshape(-1).cuda(), shift=mod[0].reshape(-1).contiguous().cuda(), eps=cfg["eps"])
+    assert torch.equal(got[0], fused)
+    ref = _bf(g["ln_mod_bf16"])
+    d = (got.cpu().view(torch.int16).int() - ref.view(torch.int16).int()).abs()
+    assert float((d > 1).float().mean()) < 2e-3 and rel_l2(got.cpu().float(), torch.from_numpy(g["ln_mod_f32"])) < 4e-3
+    # flash_attention on [B, S, n d] with B = 2 (two different batches) vs the fp64 attention of the oracle
+    gq = torch.Generator().manual_seed(5)
+    q, k, v = (torch.randn((2, 300, nh * 128), generator=gq).to(BF) for _ in range(3))
+    got = flash_attention(q.cuda(), k[:, :200].cuda(), v[:, :200].cuda(), num_heads=nh)
+    got_c = flash_attention(q.cuda(), k[:, :200].cuda(), v[:, :200].cuda(), nh, compatibility_mode=True)
+    assert tuple(got.shape) == (2, 300, nh * 128) and torch.equal(got, got_c)
+    ref = wo.attention_fp64(q, k[:, :200], v[:, :200], nh)
+    assert rel_l2(got.cpu().float(), ref.float()) < 4e-3
+
+
 def test_block_accepts_reference_complex_freqs():
     cfg = gi.TINY
     sd = gi.block_sd(torch.Generator().manual_seed(11), cfg["dim"], cfg["ffn_dim"], "", BF)

@@ -185,11 +185,8 @@ def test_hip_fp8_a4_exact_integer_layout(M, N, K):
     assert torch.equal(a8.float().cpu(), a) and torch.equal(w8.float().cpu(), w)
     got = ops.gemm_fp8(a8, rs.cuda(), w8, bias.to(BF).cuda())
     assert torch.equal(got.cpu(), ref), f"{int((got.cpu() != ref).sum())} of {ref.numel()} elements differ"
-    os.environ["GF_GEMM_KERNEL"] = "ph"                  # the 8-wave kernel on the same operands: same exact result
-    try:
+    with ops.env_options(GF_GEMM_KERNEL="ph"):           # the 8-wave kernel on the same operands: same exact result
         assert torch.equal(ops.gemm_fp8(a8, rs.cuda(), w8, bias.to(BF).cuda()).cpu(), ref)
-    finally:
-        os.environ.pop("GF_GEMM_KERNEL")
 
 
 @pytest.mark.gpu
@@ -209,26 +206,21 @@ def test_hip_fp8_a4_vs_8wave_kernel(M, N, K):
     cases = [dict(), dict(epilogue=ops.EPI_BIAS_GELU_TANH), dict(epilogue=ops.EPI_BIAS_SILU),
              dict(epilogue=ops.EPI_BIAS_RESID, resid=resid), dict(epilogue=ops.EPI_BIAS_GATE_RESID, resid=resid, gate=gate),
              dict(epilogue=ops.EPI_BIAS_MUL, resid=resid)]
-    try:
-        for kw in cases:
-            os.environ["GF_GEMM_KERNEL"] = "ph"
+    for kw in cases:
+        with ops.env_options(GF_GEMM_KERNEL="ph"):
             want = ops.gemm_fp8(x8, s, w8, bias, **kw)
-            os.environ["GF_GEMM_KERNEL"] = "a4"
-            got = ops.gemm_fp8(x8, s, w8, bias, **kw)
-            bad, e = _ulp_stats(got.cpu(), want.cpu())
-            assert bad < 2e-3 and e < 1e-3, f"{kw.get('epilogue')}: >1ulp frac {bad:.2e}, rel-L2 {e:.3e}"
-        os.environ["GF_GEMM_KERNEL"] = "a4"
-        full = ops.gemm_fp8(x8, s, w8, bias)
-        assert torch.equal(ops.gemm_fp8(x8, s, w8, None), ops.gemm_fp8(x8, s, w8, torch.zeros_like(bias)))
-        assert torch.equal(ops.gemm_fp8(x8[M - 512:], s[M - 512:].contiguous(), w8, bias), full[M - 512:])
-        wide = torch.zeros((M, K + 128), dtype=torch.float8_e4m3fn, device="cuda")
-        wide[:, 128:] = x8
-        big = torch.zeros((M, N + 16), dtype=BF, device="cuda")
-        ops.gemm_fp8(wide[:, 128:], s, w8, bias, out=big[:, 8:8 + N])
-        assert torch.equal(big[:, 8:8 + N], full)
-        assert float(big[:, :8].abs().sum()) == 0 and float(big[:, 8 + N:].abs().sum()) == 0
-    finally:
-        os.environ.pop("GF_GEMM_KERNEL", None)
+        got = ops.gemm_fp8(x8, s, w8, bias, **kw)
+        bad, e = _ulp_stats(got.cpu(), want.cpu())
+        assert bad < 2e-3 and e < 1e-3, f"{kw.get('epilogue')}: >1ulp frac {bad:.2e}, rel-L2 {e:.3e}"
+    full = ops.gemm_fp8(x8, s, w8, bias)
+    assert torch.equal(ops.gemm_fp8(x8, s, w8, None), ops.gemm_fp8(x8, s, w8, torch.zeros_like(bias)))
+    assert torch.equal(ops.gemm_fp8(x8[M - 512:], s[M - 512:].contiguous(), w8, bias), full[M - 512:])
+    wide = torch.zeros((M, K + 128), dtype=torch.float8_e4m3fn, device="cuda")
+    wide[:, 128:] = x8
+    big = torch.zeros((M, N + 16), dtype=BF, device="cuda")
+    ops.gemm_fp8(wide[:, 128:], s, w8, bias, out=big[:, 8:8 + N])
+    assert torch.equal(big[:, 8:8 + N], full)
+    assert float(big[:, :8].abs().sum()) == 0 and float(big[:, 8 + N:].abs().sum()) == 0
 
 
 @pytest.mark.gpu

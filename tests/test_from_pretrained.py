@@ -157,3 +157,39 @@ def test_pipeline_from_checkpoints_end_to_end_tiny(tmp_path):
     lat2 = pipe(context_posi=ctx_p, context_nega=ctx_n, y=y, control_signal_video_latents=cl, num_frames=9, height=64,
                 width=96, seed=3, controlnet=True, num_inference_steps=3, output_type="latent")
     assert torch.equal(lat, lat2)
+
+
+def test_load_model_adopts_checkpoint_tensors_without_a_second_copy(tmp_path):
+    """checkpoints.load_model builds the module with its parameters on the meta device (no storage, no random init) and takes
+    over the tensors read from the files (`load_state_dict(assign=True)`), each cast to torch_dtype as it is read — not a random
+    fp32 model that the checkpoint is then copied into (for an A14B expert: 57 GB and minutes of CPU RNG).  fp32 shards in,
+    bf16 parameters out; a file that lacks a parameter fails by name."""
+    from safetensors.torch import save_file
+    from goal_force_amd import checkpoints as ck
+    from goal_force_amd.dit import WanModel
+    with ck.params_on_meta():
+        m = WanModel(has_image_input=False, require_clip_embedding=False, **gi.TINY)
+    assert all(p.is_meta for p in m.parameters()) and not any(f.is_meta for f in m.freqs), "parameters on meta, RoPE tables real"
+    sd = {k: v.float() for k, v in gi.dit_sd(gi.TINY, seed=41).items()}
+    path = os.path.join(tmp_path, "dit.safetensors")
+    save_file(sd, path)
+    seen = {}
+    real = ck.load_state_dict
+
+    def spy(*a, **kw):
+        seen["sd"] = real(*a, **kw)
+        return seen["sd"]
+
+    ck.load_state_dict = spy
+    try:
+        kind, mod = ck.load_model(ck.ModelConfig(path=path), torch_dtype=BF, device="cpu")
+    finally:
+        ck.load_state_dict = real
+    assert kind == "wan_video_dit" and all(p.dtype == BF and not p.is_meta for p in mod.parameters())
+    w = mod.blocks[0].ffn[0].weight
+    assert w.data_ptr() == seen["sd"]["blocks.0.ffn.0.weight"].data_ptr(), "the parameter IS the tensor read from the file"
+    assert torch.equal(w, sd["blocks.0.ffn.0.weight"].to(BF))
+    del sd["blocks.1.ffn.2.bias"]
+    save_file(sd, path)
+    with pytest.raises(RuntimeError, match="blocks.1.ffn.2.bias"):
+        ck.load_model(ck.ModelConfig(path=path), torch_dtype=BF, device="cpu")

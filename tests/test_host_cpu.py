@@ -104,3 +104,31 @@ def test_pipeline_call_signature_matches_reference_kwargs():
                           ("rand_device", "cpu"), ("height", 480), ("width", 832), ("num_frames", 81),
                           ("tiled", True), ("controlnet", False), ("control_signal_video", None)):
         assert name in params and params[name].default == default, name
+
+
+def test_param_key_survives_inference_tensors_and_sees_edits():
+    """dit.param_key keys every derived weight copy: it must not raise on inference tensors (no version counter), must change
+    on in-place edits of ordinary tensors and on invalidate_caches()."""
+    import torch
+    from goal_force_amd import dit
+    w = torch.zeros(8)
+    k0 = dit.param_key(w)
+    w.add_(1)
+    assert dit.param_key(w) != k0
+    with torch.inference_mode():
+        wi = torch.ones(8)
+    ki = dit.param_key(wi)                      # used to raise: "Inference tensors do not track version counter"
+    assert ki == dit.param_key(wi)
+    dit.invalidate_caches()
+    assert dit.param_key(wi) != ki
+
+
+def test_a4_accumulator_handoff_is_clean_in_the_built_kernel():
+    """tools/check_a4_agpr.py on the shipped source: between the asm K loop and the last v_accvgpr_read of every
+    gemm_a4_kernel instantiation nothing but those reads touches an AGPR (the compiler sees them as free there)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_a4_agpr.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("ok  ") >= 13

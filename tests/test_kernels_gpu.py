@@ -511,28 +511,26 @@ def test_gemm_a4_vs_phased_kernel(ops, M, N, K):
     cases = [dict(), dict(epilogue=ops.EPI_BIAS_GELU_TANH), dict(epilogue=ops.EPI_BIAS_SILU),
              dict(epilogue=ops.EPI_BIAS_RESID, resid=resid), dict(epilogue=ops.EPI_BIAS_GATE_RESID, resid=resid, gate=gate),
              dict(epilogue=ops.EPI_BIAS_MUL, resid=resid)]
-    try:
-        for kw in cases:
-            os.environ["GF_GEMM_KERNEL"] = "ph"
+    with ops.env_options(GF_A4_STAGGER="0"):
+        want0 = ops.gemm(a, w, bias)
+    for kw in cases:
+        with ops.env_options(GF_GEMM_KERNEL="ph"):
             want = ops.gemm(a, w, bias, **kw)
-            os.environ["GF_GEMM_KERNEL"] = "a4"
-            os.environ["GF_A4_STAGGER"] = "0"
+        with ops.env_options(GF_GEMM_KERNEL="a4", GF_A4_STAGGER="0"):
             got = ops.gemm(a, w, bias, **kw)
-            assert torch.equal(got, want), f"{kw.get('epilogue')}: {int((got != want).sum())} elements differ"
-            os.environ.pop("GF_A4_STAGGER")
-            rot = ops.gemm(a, w, bias, **kw)
-            assert ulp_mismatch_frac(rot, want, ulps=1) < 2e-3 and rel_l2(rot.float(), want.float()) < 1e-3
-        os.environ["GF_GEMM_KERNEL"] = "a4"
-        assert torch.equal(ops.gemm(a, w, None), ops.gemm(a, w, torch.zeros_like(bias)))
-        # rows keep their bits when the M tiling changes (what the sharded forwards rely on)
-        full = ops.gemm(a, w, bias)
-        assert torch.equal(ops.gemm(a[M - 512:], w, bias), full[M - 512:])
-        # strided A (a column slice of a wider activation) and a strided output
-        wide = dev(torch.randn((M, K + 64), generator=g).to(BF))
-        big = torch.zeros((M, N + 16), dtype=BF, device="cuda")
-        ops.gemm(wide[:, 64:], w, bias, out=big[:, 8:8 + N])
-        assert torch.equal(big[:, 8:8 + N], ops.gemm(wide[:, 64:].contiguous(), w, bias))
-        assert float(big[:, :8].abs().sum()) == 0 and float(big[:, 8 + N:].abs().sum()) == 0
-    finally:
-        os.environ.pop("GF_GEMM_KERNEL", None)
-        os.environ.pop("GF_A4_STAGGER", None)
+        assert torch.equal(got, want), f"{kw.get('epilogue')}: {int((got != want).sum())} elements differ"
+        rot = ops.gemm(a, w, bias, **kw)
+        assert ulp_mismatch_frac(rot, want, ulps=1) < 2e-3 and rel_l2(rot.float(), want.float()) < 1e-3
+    assert torch.equal(ops.gemm(a, w, None), ops.gemm(a, w, torch.zeros_like(bias)))
+    # rows keep their bits when the M tiling changes (what the sharded forwards rely on)
+    full = ops.gemm(a, w, bias)
+    assert torch.equal(ops.gemm(a[M - 512:], w, bias), full[M - 512:])
+    # strided A (a column slice of a wider activation) and a strided output
+    wide = dev(torch.randn((M, K + 64), generator=g).to(BF))
+    big = torch.zeros((M, N + 16), dtype=BF, device="cuda")
+    ops.gemm(wide[:, 64:], w, bias, out=big[:, 8:8 + N])
+    assert torch.equal(big[:, 8:8 + N], ops.gemm(wide[:, 64:].contiguous(), w, bias))
+    assert float(big[:, :8].abs().sum()) == 0 and float(big[:, 8 + N:].abs().sum()) == 0
+    # a negative stagger is clamped to 0 (it used to turn into a huge K offset): same bits as the unrotated kernel
+    with ops.env_options(GF_A4_STAGGER="-3"):
+        assert torch.equal(ops.gemm(a, w, bias), want0)

@@ -41,6 +41,7 @@ def run():
         for rnd in range(3):
             for m in NAMES:
                 os.environ["GF_A4_WHATIF"] = str(m)
+                lib.gf_reload_options()    # the library reads its knobs once per process
                 for _ in range(2):
                     call()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

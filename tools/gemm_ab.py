@@ -33,6 +33,7 @@ def main():
                     call = lambda: torch.nn.functional.linear(x, w)
                 else:
                     os.environ["GF_GEMM_KERNEL"] = kern
+                    libs[ln].gf_reload_options()       # the library reads its knobs once; tell it the environment changed
                     lib = libs[ln]
                     call = lambda: lib.gf_gemm_bf16(x.data_ptr(), k, w.data_ptr(), k, None, out.data_ptr(), n, S, n, k, 0, None, 0, None, st)
                 for _ in range(2):

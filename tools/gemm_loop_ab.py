@@ -32,8 +32,10 @@ def main():
         for rnd in range(rounds):
             for vn, env in variants:
                 os.environ.pop("GF_A4_LOOP", None)
+                ops.reload_options()       # the launch paths read the knobs once per process
                 if env:
                     os.environ["GF_A4_LOOP"] = env
+                    ops.reload_options()       # the launch paths read the knobs once per process
                 call = (lambda: torch.nn.functional.linear(x, w, b)) if vn == "torch" else (lambda: ops.gemm(x, w, b, out=out))
                 for _ in range(2):
                     call()
@@ -47,6 +49,7 @@ def main():
                 if vn != "torch" and rnd == 0:
                     outs[vn] = out.clone()
         os.environ.pop("GF_A4_LOOP", None)
+        ops.reload_options()       # the launch paths read the knobs once per process
         same = torch.equal(outs["ksub"], outs["half"])
         for vn, ms in best.items():
             print(f"{name}  {vn:6s} {ms:7.3f} ms  {fl / ms / 1e9:7.1f} TFLOP/s" + ("" if vn == "torch" else f"  bits {'==' if same else 'DIFFER'}"), flush=True)

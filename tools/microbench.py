@@ -77,8 +77,10 @@ def main():
             for _ in range(3):
                 for kern in ("3", "2"):
                     os.environ["GF_ATTN_KERNEL"] = kern
+                    ops.reload_options()       # the launch paths read the knobs once per process
                     rounds[kern].append(timeit(lambda: ops.flash_attn(q, k, v, H, out=o), a.iters)[0])
             os.environ.pop("GF_ATTN_KERNEL")
+            ops.reload_options()       # the launch paths read the knobs once per process
             for kern, ts in rounds.items():
                 print(f"   A/B kernel {kern}: medians {', '.join(f'{t:.3f}' for t in ts)} ms -> {fl / min(ts) / 1e9:.1f} TFLOP/s best")
         if a.zeros:
@@ -87,9 +89,11 @@ def main():
                 qq, kk, vv = mk(q), mk(k), mk(v)
                 for kern in ("3", "2"):
                     os.environ["GF_ATTN_KERNEL"] = kern
+                    ops.reload_options()       # the launch paths read the knobs once per process
                     med, mn = timeit(lambda: ops.flash_attn(qq, kk, vv, H, out=o), a.iters)
                     print(f"   {name:13s} kernel {kern}: median {med:.3f} ms ({fl / med / 1e9:.1f} TFLOP/s), min {mn:.3f} ms")
                 os.environ.pop("GF_ATTN_KERNEL")
+                ops.reload_options()       # the launch paths read the knobs once per process
     elif a.what == "attnbwd":
         q = torch.randn((s, D), device="cuda").to(BF)
         k = torch.randn((s, D), device="cuda").to(BF)
@@ -116,8 +120,10 @@ def main():
                 for _ in range(3):
                     for kern in ("a4", "ph"):
                         os.environ["GF_GEMM_KERNEL"] = kern
+                        ops.reload_options()       # the launch paths read the knobs once per process
                         rounds[kern].append(timeit(lambda: ops.gemm(inp, w, b, out=out), a.iters)[0])
                 os.environ.pop("GF_GEMM_KERNEL")
+                ops.reload_options()       # the launch paths read the knobs once per process
                 for kern, ts in rounds.items():
                     print(f"   A/B {kern} {name}: medians {', '.join(f'{t:.3f}' for t in ts)} ms -> {fl / min(ts) / 1e9:.1f} TFLOP/s best")
             if n == D:
