@@ -14,6 +14,7 @@
 // Round-1 shape: tiles double buffered (the DMA of tile t+1 flies during the products of tile t, one barrier per tile),
 // plain per-tile product order — the forward's slot pipeline is the template for the next step.
 #include "gf_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -115,6 +116,23 @@ __device__ __forceinline__ void zero16(f32x16& a) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) a[e] = 0.f;
 }
+__device__ __forceinline__ void splat16(f32x16& a, float v) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) a[e] = v;
+}
+// 8 fp32 -> one bf16x8 fragment, two values per v_cvt_pk_bf16_f32
+__device__ __forceinline__ bf16x8 pack8(const float (&x)[8]) {
+    const u32x4 w = {pack2bf(x[0], x[1]), pack2bf(x[2], x[3]), pack2bf(x[4], x[5]), pack2bf(x[6], x[7])};
+    return __builtin_bit_cast(bf16x8, w);
+}
+// operand pre-scaled by c = scale * log2(e) (one rounding to bf16, as the forward's kernel 3 does with Q): the score accumulator
+// is then directly the base-2 exponent
+__device__ __forceinline__ bf16x8 scale8(const bf16x8& v, float c) {
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = (float)v[j] * c;
+    return pack8(x);
+}
 
 // transposed accumulator acc[d][e] (lane = owned row, register e of block d = column 32d + (e&3) + 8(e>>2) + 4h) -> row of out
 __device__ __forceinline__ void store_rows(u16* rowp, const f32x16 (&acc)[4], float mul, int h) {
@@ -153,7 +171,11 @@ __global__ __launch_bounds__(DQ_THREADS, 2) void attn_bwd_dq_kernel(const BwdArg
     }
     const float lse = p.lse[(long)qr * p.heads + head];
     const float dl = p.delta[(long)qr * p.heads + head];
-    const float c = p.scale_log2e;
+    // Q pre-scaled by c = scale log2 e: S' = (c Q) K^T accumulated ON TOP OF -lse (the chain's initial accumulator) is the exponent
+    // itself, and dP accumulated on top of -delta is (dP - delta): p = exp2(S'), dS = p * dP' — per score one v_exp_f32, one multiply
+    // and half a v_cvt_pk instead of fma / exp2 / subtract / multiply / compare / select / convert
+#pragma unroll
+    for (int kd = 0; kd < 8; ++kd) qf[kd] = scale8(qf[kd], p.scale_log2e);
     const FragOffsets fo = frag_offsets(lane);
     f32x16 dq[4];
 #pragma unroll
@@ -165,41 +187,54 @@ __global__ __launch_bounds__(DQ_THREADS, 2) void attn_bwd_dq_kernel(const BwdArg
         stage_tile<8>(p.k + head * HD, p.k_stride, t * KVB, p.kv_len, b, wave, lane);
         stage_tile<8>(p.v + head * HD, p.v_stride, t * KVB, p.kv_len, b + TILE_BYTES, wave, lane);
     };
-    stage(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int t = 0; t < nt; ++t) {
-        if (t + 1 < nt) stage(t + 1);          // lands while this tile is multiplied; its buffer was released by the last barrier
+    // MASKED: the last tile when kv_len is not a multiple of 64 (its staged rows past the end are clamped copies: their p is 0)
+    auto tile = [&](int t, auto masked) {
+        constexpr bool MASKED = decltype(masked)::value;
         GF_LDS char* kbuf = lds + (t & 1) * 2 * TILE_BYTES;
         GF_LDS char* vbuf = kbuf + TILE_BYTES;
-        f32x16 sc[2], dp[2];
-        zero16(sc[0]); zero16(sc[1]); zero16(dp[0]); zero16(dp[1]);
-#pragma unroll
-        for (int kd = 0; kd < 8; ++kd) {
-            const bf16x8 k0 = *(GF_LDS bf16x8*)(kbuf + fo.row[kd]);
-            const bf16x8 k1 = *(GF_LDS bf16x8*)(kbuf + fo.row[kd] + 32 * 256);
-            const bf16x8 v0 = *(GF_LDS bf16x8*)(vbuf + fo.row[kd]);
-            const bf16x8 v1 = *(GF_LDS bf16x8*)(vbuf + fo.row[kd] + 32 * 256);
-            mfma32(sc[0], k0, qf[kd]);      // S^T[key, query]
-            mfma32(sc[1], k1, qf[kd]);
-            mfma32(dp[0], v0, dof[kd]);     // dP^T[key, query] = V dO^T
-            mfma32(dp[1], v1, dof[kd]);
-        }
+        // one 32-key half at a time: only 32 score / dP accumulators are live beside dQ^T, Q and dO (the kernel sits at the
+        // 256-register line of two waves per SIMD)
         bf16x8 dsf[2][2];
 #pragma unroll
-        for (int half = 0; half < 2; ++half)
+        for (int half = 0; half < 2; ++half) {
+            f32x16 sc, dp;
+            splat16(sc, -lse);
+            splat16(dp, -dl);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int key = t * KVB + 32 * half + (e & 3) + 8 * (e >> 2) + 4 * h;
-                const float pr = key < p.kv_len ? __builtin_amdgcn_exp2f(__builtin_fmaf(sc[half][e], c, -lse)) : 0.f;
-                dsf[half][e >> 3][e & 7] = (__bf16)(pr * (dp[half][e] - dl));
+            for (int kd = 0; kd < 8; ++kd) {
+                const bf16x8 kk = *(GF_LDS bf16x8*)(kbuf + fo.row[kd] + half * 32 * 256);
+                const bf16x8 vv = *(GF_LDS bf16x8*)(vbuf + fo.row[kd] + half * 32 * 256);
+                mfma32(sc, kk, qf[kd]);      // S'^T[key, query] = c K Q^T - lse
+                mfma32(dp, vv, dof[kd]);     // dP'^T[key, query] = V dO^T - delta
             }
+#pragma unroll
+            for (int s8 = 0; s8 < 2; ++s8) {
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int e = 8 * s8 + j;
+                    float pr = __builtin_amdgcn_exp2f(sc[e]);
+                    if constexpr (MASKED) pr = (t * KVB + 32 * half + (e & 3) + 8 * (e >> 2) + 4 * h < p.kv_len) ? pr : 0.f;
+                    x[j] = pr * dp[e];
+                }
+                dsf[half][s8] = pack8(x);
+            }
+        }
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
                 for (int d = 0; d < 4; ++d) mfma32(dq[d], tr_frag(kbuf, fo, d, kt, s), dsf[kt][s]);   // dQ^T += K^T dS^T
+    };
+    stage(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const bool ragged = (p.kv_len % KVB) != 0;
+    for (int t = 0; t < nt; ++t) {
+        if (t + 1 < nt) stage(t + 1);          // lands while this tile is multiplied; its buffer was released by the last barrier
+        if (ragged && t == nt - 1) tile(t, std::true_type{});
+        else tile(t, std::false_type{});
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
@@ -235,7 +270,10 @@ __global__ __launch_bounds__(DKV_THREADS, PART == 0 ? 1 : 2) void attn_bwd_dkv_k
             if constexpr (DO_K) vf[kd] = *reinterpret_cast<const bf16x8*>(vp + 16 * kd);
         }
     }
-    const float c = p.scale_log2e;
+    // K pre-scaled by c = scale log2 e (this wave's own 32 keys, once): with -lse of the tile's queries as the initial accumulator the
+    // score chain ends on the exponent itself; dP starts from -delta.  (The UNSCALED keys are not needed: dK = scale dS^T Q.)
+#pragma unroll
+    for (int kd = 0; kd < 8; ++kd) kf[kd] = scale8(kf[kd], p.scale_log2e);
     const FragOffsets fo = frag_offsets(lane);
     f32x16 dk[4], dv[4];
 #pragma unroll
@@ -255,48 +293,52 @@ __global__ __launch_bounds__(DKV_THREADS, PART == 0 ? 1 : 2) void attn_bwd_dkv_k
         stage_tile<4>(p.q + head * HD, p.q_stride, t * KVB, p.q_len, b, wave, lane);
         stage_tile<4>(p.dout + head * HD, p.do_stride, t * KVB, p.q_len, b + TILE_BYTES, wave, lane);
     };
-    stage(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int t = 0; t < nt; ++t) {
-        if (t + 1 < nt) stage(t + 1);
+    auto tile = [&](int t, auto masked) {
+        constexpr bool MASKED = decltype(masked)::value;   // the last query tile when q_len % 64 != 0: clamped copies get p = 0
         GF_LDS char* qbuf = lds + (t & 1) * 2 * TILE_BYTES;
         GF_LDS char* dobuf = qbuf + TILE_BYTES;
         GF_LDS float* lse_s = scal + (t & 1) * 2 * KVB;
         GF_LDS float* dl_s = lse_s + KVB;
-        f32x16 sc[2], dp[2];
-        zero16(sc[0]); zero16(sc[1]); zero16(dp[0]); zero16(dp[1]);
-#pragma unroll
-        for (int kd = 0; kd < 8; ++kd) {
-            const bf16x8 q0f = *(GF_LDS bf16x8*)(qbuf + fo.row[kd]);
-            const bf16x8 q1f = *(GF_LDS bf16x8*)(qbuf + fo.row[kd] + 32 * 256);
-            mfma32(sc[0], q0f, kf[kd]);     // S[query, key]: lane = key, registers = queries
-            mfma32(sc[1], q1f, kf[kd]);
-            if constexpr (DO_K) {
-                const bf16x8 d0f = *(GF_LDS bf16x8*)(dobuf + fo.row[kd]);
-                const bf16x8 d1f = *(GF_LDS bf16x8*)(dobuf + fo.row[kd] + 32 * 256);
-                mfma32(dp[0], d0f, vf[kd]);     // dP[query, key] = dO V^T
-                mfma32(dp[1], d1f, vf[kd]);
-            }
-        }
         bf16x8 pf[2][2], dsf[2][2];
 #pragma unroll
-        for (int half = 0; half < 2; ++half)
+        for (int half = 0; half < 2; ++half) {      // one 32-query half at a time (register pressure, as in the dQ kernel)
+            f32x16 sc, dp;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int qi = 32 * half + 8 * g + 4 * h;      // 4 consecutive queries of registers 4g..4g+3
                 const f32x4 l4 = *(GF_LDS f32x4*)(lse_s + qi);
-                f32x4 d4 = {0.f, 0.f, 0.f, 0.f};
-                if constexpr (DO_K) d4 = *(GF_LDS f32x4*)(dl_s + qi);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int e = 4 * g + i;
-                    const bool ok = t * KVB + qi + i < p.q_len;
-                    const float pr = ok ? __builtin_amdgcn_exp2f(__builtin_fmaf(sc[half][e], c, -l4[i])) : 0.f;
-                    if constexpr (DO_V) pf[half][e >> 3][e & 7] = (__bf16)pr;
-                    if constexpr (DO_K) dsf[half][e >> 3][e & 7] = (__bf16)(pr * (dp[half][e] - d4[i]));
+                for (int i = 0; i < 4; ++i) sc[4 * g + i] = -l4[i];
+                if constexpr (DO_K) {
+                    const f32x4 d4 = *(GF_LDS f32x4*)(dl_s + qi);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dp[4 * g + i] = -d4[i];
                 }
             }
+#pragma unroll
+            for (int kd = 0; kd < 8; ++kd) {
+                const bf16x8 qq = *(GF_LDS bf16x8*)(qbuf + fo.row[kd] + half * 32 * 256);
+                mfma32(sc, qq, kf[kd]);     // S'[query, key] = c Q K^T - lse: lane = key, registers = queries
+                if constexpr (DO_K) {
+                    const bf16x8 dd = *(GF_LDS bf16x8*)(dobuf + fo.row[kd] + half * 32 * 256);
+                    mfma32(dp, dd, vf[kd]);     // dP'[query, key] = dO V^T - delta
+                }
+            }
+#pragma unroll
+            for (int s8 = 0; s8 < 2; ++s8) {
+                float xp[8], xs[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int e = 8 * s8 + j;
+                    float pr = __builtin_amdgcn_exp2f(sc[e]);
+                    if constexpr (MASKED) pr = (t * KVB + 32 * half + 8 * (e >> 2) + 4 * h + (e & 3) < p.q_len) ? pr : 0.f;
+                    xp[j] = pr;
+                    if constexpr (DO_K) xs[j] = pr * dp[e];
+                }
+                if constexpr (DO_V) pf[half][s8] = pack8(xp);
+                if constexpr (DO_K) dsf[half][s8] = pack8(xs);
+            }
+        }
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -306,6 +348,15 @@ __global__ __launch_bounds__(DKV_THREADS, PART == 0 ? 1 : 2) void attn_bwd_dkv_k
                     if constexpr (DO_V) mfma32(dv[d], tr_frag(dobuf, fo, d, kt, s), pf[kt][s]);    // dV^T += dO^T P
                     if constexpr (DO_K) mfma32(dk[d], tr_frag(qbuf, fo, d, kt, s), dsf[kt][s]);    // dK^T += Q^T dS
                 }
+    };
+    stage(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const bool ragged = (p.q_len % KVB) != 0;
+    for (int t = 0; t < nt; ++t) {
+        if (t + 1 < nt) stage(t + 1);
+        if (ragged && t == nt - 1) tile(t, std::true_type{});
+        else tile(t, std::false_type{});
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }

@@ -162,5 +162,5 @@ def model_fn_wan_video(
 
     x = dit.head(x.unsqueeze(0), t)          # GF:1581
     if sp is not None:
-        x = sp.gather_tokens(x[0]).unsqueeze(0)   # GF:1582-1585
+        x = sp.gather_tokens(x[0], total=f * h * w).unsqueeze(0)   # GF:1582-1585; pad rows of a ragged split cut off (xdit:103)
     return dit.unpatchify(x, (f, h, w))      # GF:1590

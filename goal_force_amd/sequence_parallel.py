@@ -19,8 +19,11 @@ single-GPU forward.
 
 Traffic per attention and rank: 4 x (S/P) x D x 2 B x (P-1)/P  (= 147 MB at S=32760, D=5120, P=8), point to point over
 xGMI: RCCL's all-to-all keeps all P-1 links of a GPU busy at once, which is the pattern xGMI is good at (no ring).
-The token count must divide by P (32760 = 8 x 4095; the reference zero-pads instead and lets the pad rows take part in the
-attention as keys — a quirk that is not reproduced).
+Token counts that do not divide by P follow the reference (xdit_context_parallel.py:15-40, 75-79, 103): `torch.chunk` cuts
+chunks of ceil(S / P) tokens, the short last chunk is padded with ZERO rows, their RoPE phases are padded with ones (no
+rotation), the pad rows run through every block like tokens — in the self-attention they are keys like any other — and are cut
+off after the final token all-gather.  A sharded forward then equals the one-GPU forward over the padded sequence (tested),
+not the one-GPU forward over S tokens; 32760 divides by 2, 4 and 8, so BASELINE config 3 never pads.
 """
 from __future__ import annotations
 
@@ -45,32 +48,48 @@ class SequenceParallel:
 
     # ---- token sharding -------------------------------------------------------------------------------------------
     def local_tokens(self, total: int) -> int:
-        if total % self.size:
-            raise GoalForceError(f"sequence parallel: {total} tokens do not divide by {self.size} ranks")
-        return total // self.size
+        """Tokens per rank = torch.chunk's chunk size ceil(total / P) (xdit_context_parallel.py:75).  Like the reference, a split
+        that would leave a rank without any real token is refused (torch.chunk returns fewer than P chunks there and the
+        reference's `chunks[rank]` raises)."""
+        sl = -(-total // self.size)
+        if sl * (self.size - 1) >= total and self.size > 1:
+            raise GoalForceError(f"sequence parallel: {total} tokens leave rank {self.size - 1} of {self.size} without a token")
+        return sl
 
     def shard_tokens(self, x2: torch.Tensor) -> torch.Tensor:
-        """[S, D] -> this rank's contiguous chunk [S/P, D] (a view; torch.chunk order as in the reference, GF:1528-1531)."""
+        """[S, D] -> this rank's contiguous chunk [ceil(S/P), D] (torch.chunk order as in the reference, GF:1528-1531); a short
+        last chunk is padded with zero rows (xdit_context_parallel.py:76-79).  A view when nothing has to be padded."""
         sl = self.local_tokens(x2.shape[0])
-        return x2[self.rank * sl:(self.rank + 1) * sl]
+        part = x2[self.rank * sl:(self.rank + 1) * sl]
+        if part.shape[0] == sl:
+            return part
+        out = torch.zeros((sl,) + tuple(x2.shape[1:]), dtype=x2.dtype, device=x2.device)
+        out[:part.shape[0]] = part
+        return out
 
     def shard_rope(self, rope):
-        """RoPE phases of this rank's tokens (xdit_context_parallel.py:36-37)."""
+        """RoPE phases of this rank's tokens (xdit_context_parallel.py:36-37); pad rows get the unit phase (pad_freqs pads the
+        complex table with ones, xdit:15-25): cos 1, sin 0."""
         from .dit import RopeTable
         sl = self.local_tokens(rope.tokens)
         out = RopeTable.__new__(RopeTable)
-        out.cos = rope.cos[self.rank * sl:(self.rank + 1) * sl].contiguous()
-        out.sin = rope.sin[self.rank * sl:(self.rank + 1) * sl].contiguous()
+        cos, sin = rope.cos[self.rank * sl:(self.rank + 1) * sl], rope.sin[self.rank * sl:(self.rank + 1) * sl]
+        if cos.shape[0] < sl:
+            pad = sl - cos.shape[0]
+            cos = torch.cat([cos, torch.ones((pad, cos.shape[1]), dtype=cos.dtype, device=cos.device)])
+            sin = torch.cat([sin, torch.zeros((pad, sin.shape[1]), dtype=sin.dtype, device=sin.device)])
+        out.cos, out.sin = cos.contiguous(), sin.contiguous()
         out.tokens = sl
         return out
 
-    def gather_tokens(self, x_local: torch.Tensor) -> torch.Tensor:
-        """[S/P, C] per rank -> [S, C] on every rank (get_sp_group().all_gather(x, dim=1), GF:1584)."""
+    def gather_tokens(self, x_local: torch.Tensor, total: Optional[int] = None) -> torch.Tensor:
+        """[ceil(S/P), C] per rank -> [S, C] on every rank (get_sp_group().all_gather(x, dim=1), GF:1584); `total` = S cuts the
+        pad rows off again (xdit_context_parallel.py:103)."""
         x_local = x_local.contiguous()
         out = torch.empty((x_local.shape[0] * self.size,) + tuple(x_local.shape[1:]), dtype=x_local.dtype,
                           device=x_local.device)
         dist.all_gather_into_tensor(out, x_local, group=self.group)
-        return out
+        return out if total is None or total == out.shape[0] else out[:total]
 
     # ---- attention ------------------------------------------------------------------------------------------------
     def attention(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: int) -> torch.Tensor:

@@ -232,10 +232,10 @@ def test_flash_attn_lse_same_on_both_v_paths(ops, monkeypatch):
     sq, skv, heads = 300, 2100, 3
     q, k, v = (dev(torch.randn((n, heads * 128), generator=g).to(BF)) for n in (sq, skv, skv))
     o3, l3 = ops.flash_attn_lse(q, k, v, heads)                 # skv >= VT_MIN_KV: kernel 3
-    monkeypatch.setenv("GF_ATTN_KERNEL", "2")
-    o1, l1 = ops.flash_attn_lse(q, k, v, heads)                 # kernel 2, V^T path
-    monkeypatch.setattr(ops, "VT_MIN_KV", 1 << 30)
-    o2, l2 = ops.flash_attn_lse(q, k, v, heads)                 # kernel 2, plain path
+    with ops.env_options(GF_ATTN_KERNEL="2"):                   # (the knobs are read once per process: env_options reloads them)
+        o1, l1 = ops.flash_attn_lse(q, k, v, heads)             # kernel 2, V^T path
+        monkeypatch.setattr(ops, "VT_MIN_KV", 1 << 30)
+        o2, l2 = ops.flash_attn_lse(q, k, v, heads)             # kernel 2, plain path
     assert torch.equal(o1, o2) and torch.equal(l1, l2)
     assert rel_l2(o3.float(), o1.float()) < 6e-3 and float((l3 - l1).abs().max()) < 2e-2
     ref = torch.logsumexp((q.float().view(sq, heads, 128).transpose(0, 1) @ k.float().view(skv, heads, 128).permute(1, 2, 0))
@@ -291,9 +291,9 @@ def test_self_attention_same_bits_with_v_transposed_by_the_projection(ops, monke
     rope = RopeTable(torch.polar(torch.ones_like(pos), pos), "cuda")
     assert ops.vt32_ok(s, heads, 128)
     a = sa.attend(x, rope)
-    monkeypatch.setenv("GF_VT_FROM_GEMM", "0")
-    assert not ops.vt32_ok(s, heads, 128)
-    b = sa.attend(x, rope)
+    with ops.env_options(GF_VT_FROM_GEMM="0"):
+        assert not ops.vt32_ok(s, heads, 128)
+        b = sa.attend(x, rope)
     assert torch.equal(a, b)
 
 

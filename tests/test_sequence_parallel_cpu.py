@@ -63,8 +63,7 @@ def _worker(rank, world, port, out):
         rl = sp.shard_rope(rope)
         sl = tokens // world
         assert rl.tokens == sl and torch.equal(rl.cos, rope.cos[rank * sl:(rank + 1) * sl])
-        with pytest.raises(Exception):
-            sp.local_tokens(tokens + 1)
+        assert sp.local_tokens(tokens + 1) == -(-(tokens + 1) // world)      # ragged splits: torch.chunk's ceil(S / P)
         torch.save({"o_local": o_local, "o_full": o_full}, os.path.join(out, f"r{rank}.pt"))
     finally:
         dist.destroy_process_group()
@@ -145,3 +144,48 @@ def test_data_parallel_gradient_average(tmp_path):
     world = 2
     mp.spawn(_ddp_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert all(os.path.exists(os.path.join(tmp_path, f"ddp{r}")) for r in range(world))
+
+
+def _ragged_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from goal_force_amd import ops
+        from goal_force_amd.dit import RopeTable
+        from goal_force_amd.sequence_parallel import SequenceParallel
+        ops.flash_attn = _attn_standin
+        sp = SequenceParallel()
+        heads, tokens = 4, 23                                   # 23 tokens over 4 ranks: chunks of 6, the last one 5 + 1 pad row
+        sl = sp.local_tokens(tokens)
+        assert sl == 6
+        q, k, v = _qkv(tokens, heads, seed=9)
+        ql, kl, vl = (sp.shard_tokens(t).contiguous() for t in (q, k, v))
+        assert ql.shape[0] == sl
+        if rank == world - 1:
+            assert float(ql[5].abs().sum()) == 0 and torch.equal(ql[:5], q[18:])      # zero pad row (xdit:76-79)
+        rope = RopeTable(torch.polar(torch.ones(tokens, 1, 4, dtype=torch.float64),
+                                     torch.arange(tokens * 4, dtype=torch.float64).view(tokens, 1, 4)), "cpu")
+        rl = sp.shard_rope(rope)
+        if rank == world - 1:
+            assert torch.equal(rl.cos[5], torch.ones(4)) and torch.equal(rl.sin[5], torch.zeros(4))   # pad_freqs: ones
+        o = sp.gather_tokens(sp.attention(ql, kl, vl, heads), total=tokens)
+        assert o.shape[0] == tokens
+        torch.save(o, os.path.join(out, f"r{rank}.pt"))
+        with pytest.raises(Exception):
+            sp.local_tokens(9)                                  # 9 tokens / 4 ranks: chunks of 3 leave rank 3 empty (torch.chunk gives 3 chunks)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ulysses_ragged_token_count_follows_the_reference_padding(tmp_path):
+    """S % P != 0 (xdit_context_parallel.py:15-40, 75-79, 103): chunks of ceil(S/P), zero pad rows, unit RoPE phases for them, the
+    pad rows take part in the attention as keys, and the gathered output is cut back to S — i.e. the sharded attention equals
+    FULL attention over the zero-padded sequence, rows [:S]."""
+    world = 4
+    mp.spawn(_ragged_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    q, k, v = _qkv(23, 4, seed=9)
+    pad = lambda t: torch.cat([t, torch.zeros((1, t.shape[1]), dtype=t.dtype)])
+    want = _attn_standin(pad(q), pad(k), pad(v), 4)[:23]
+    for r in range(world):
+        assert torch.equal(torch.load(os.path.join(tmp_path, f"r{r}.pt")), want)
+    assert not torch.equal(want, _attn_standin(q, k, v, 4)), "the pad row IS a key: the result differs from attention over 23 tokens"

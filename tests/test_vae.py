@@ -66,11 +66,13 @@ def test_oracle_encode_matches_reference():
 
 
 @pytest.fixture(autouse=True)
-def _unrotated_yardstick_gemm(monkeypatch):
+def _unrotated_yardstick_gemm():
     """The convolution is compared BIT FOR BIT with `gf_vae_im2col + gf_gemm_bf16`: pin that yardstick GEMM to the K order
     the implicit-GEMM convolution uses (k tiles 0, 1, 2, ...).  The 4-wave GEMM kernel that large dense shapes go through by
     default starts each column tile's K loop at a staggered tile (same sum, rotated order: test_kernels_gpu.py)."""
-    monkeypatch.setenv("GF_A4_STAGGER", "0")
+    from goal_force_amd import ops
+    with ops.env_options(GF_A4_STAGGER="0"):       # the launchers read their knobs once per process: env_options reloads them
+        yield
 
 
 def _gpu_vae(sd):
