@@ -118,6 +118,9 @@ def main():
                          "encodings of the real first frame and of the rendered goal-force map (the kernels' speed depends on the data)")
     ap.add_argument("--peaky", type=float, default=1.0, help="multiply every self-attention norm_q weight by this factor (8: attention "
                     "logits x 8, near-one-hot softmax rows) — data-sensitivity runs only")
+    ap.add_argument("--no-launch-events", action="store_true", help="do not record the per-launch HIP events behind `roofline` / "
+                    "`roofline_gemm` in the timed region (they are then null): measures what those ~900 event pairs per forward cost "
+                    "(profiles/r03/README.md: below 0.1 %)")
     ap.add_argument("--layers", type=int, default=40, help=argparse.SUPPRESS)  # debugging only; 40 = the real model
     ap.add_argument("--sample-offset", type=int, default=0, help=argparse.SUPPRESS)  # tests: the N=1 run of video #k (seeds follow the sample id)
     args = ap.parse_args()
@@ -215,15 +218,15 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ops.PROFILE_ATTN, ops.PROFILE_GEMM = [], []
+    ops.PROFILE_ATTN, ops.PROFILE_GEMM = (None, None) if args.no_launch_events else ([], [])
     t0 = time.perf_counter()
     final = run(step_ids, record=True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    prof, ops.PROFILE_ATTN = ops.PROFILE_ATTN, None
-    gprof, ops.PROFILE_GEMM = ops.PROFILE_GEMM, None
+    prof, ops.PROFILE_ATTN = ops.PROFILE_ATTN or [], None
+    gprof, ops.PROFILE_GEMM = ops.PROFILE_GEMM or [], None
     # ---- self-check of what the timed steps produced: a forward that overflowed would time the same
     if not bool(torch.isfinite(final.float()).all()):
         raise SystemExit(f"rank {rank}: non-finite latents after the timed steps")

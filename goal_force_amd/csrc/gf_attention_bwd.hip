@@ -16,6 +16,24 @@
 #include "gf_common.h"
 #include <type_traits>
 
+// Variant switches of the tile bodies (tools/attnbwd_ab.py builds the combinations side by side; round 3, S = 32760 x 40 heads,
+// one process, profiles/r03/attnbwd_ab1.log):
+//   GF_BWD_SEED   1: the score / dP accumulator chains START from -lse / -delta and the register-resident operand is pre-scaled by
+//                    scale log2 e (p = exp2(acc), dS = p * dP': one exp2, one multiply and half a pack per score instead of fma /
+//                    exp2 / subtract / multiply / convert); 0: zero start, p = exp2(fma(S, c, -lse)), dS = p * (dP - delta).
+//                    MEASURED SLOWER (100 ms against 86): the 32 seeded accumulators are live before their chains start, which
+//                    pushes the dQ kernel over the 256 registers of two waves per SIMD (26 spilled dwords reloaded every tile).
+//   GF_BWD_HALVES 1: the tile's two 32-row halves one after the other (32 score / dP accumulators live instead of 64): 88 ms
+//                    against 86 — the compiler re-interleaves the halves anyway and the pressure stays.
+// The ragged last tile is the only one that pays for the bounds compare / select (no effect on the time either: 86.1 against
+// 85.4 ms for round 2's loop) — the kernels are not VALU-bound; what they lack is the forward's pinned tile pipeline.
+#ifndef GF_BWD_SEED
+#define GF_BWD_SEED 0
+#endif
+#ifndef GF_BWD_HALVES
+#define GF_BWD_HALVES 0
+#endif
+
 namespace {
 
 constexpr int KVB = 64, HD = 128;
@@ -174,8 +192,12 @@ __global__ __launch_bounds__(DQ_THREADS, 2) void attn_bwd_dq_kernel(const BwdArg
     // Q pre-scaled by c = scale log2 e: S' = (c Q) K^T accumulated ON TOP OF -lse (the chain's initial accumulator) is the exponent
     // itself, and dP accumulated on top of -delta is (dP - delta): p = exp2(S'), dS = p * dP' — per score one v_exp_f32, one multiply
     // and half a v_cvt_pk instead of fma / exp2 / subtract / multiply / compare / select / convert
+#if GF_BWD_SEED
 #pragma unroll
     for (int kd = 0; kd < 8; ++kd) qf[kd] = scale8(qf[kd], p.scale_log2e);
+#endif
+    const float c = p.scale_log2e;
+    (void)c;
     const FragOffsets fo = frag_offsets(lane);
     f32x16 dq[4];
 #pragma unroll
@@ -192,14 +214,44 @@ __global__ __launch_bounds__(DQ_THREADS, 2) void attn_bwd_dq_kernel(const BwdArg
         constexpr bool MASKED = decltype(masked)::value;
         GF_LDS char* kbuf = lds + (t & 1) * 2 * TILE_BYTES;
         GF_LDS char* vbuf = kbuf + TILE_BYTES;
-        // one 32-key half at a time: only 32 score / dP accumulators are live beside dQ^T, Q and dO (the kernel sits at the
-        // 256-register line of two waves per SIMD)
         bf16x8 dsf[2][2];
+        auto softmax_half = [&](int half, const f32x16& sc, const f32x16& dp) {
+#pragma unroll
+            for (int s8 = 0; s8 < 2; ++s8) {
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int e = 8 * s8 + j;
+#if GF_BWD_SEED
+                    float pr = __builtin_amdgcn_exp2f(sc[e]);
+#else
+                    float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[e], c, -lse));
+#endif
+                    if constexpr (MASKED) pr = (t * KVB + 32 * half + (e & 3) + 8 * (e >> 2) + 4 * h < p.kv_len) ? pr : 0.f;
+#if GF_BWD_SEED
+                    x[j] = pr * dp[e];
+#else
+                    x[j] = pr * (dp[e] - dl);
+#endif
+                }
+                dsf[half][s8] = pack8(x);
+            }
+        };
+        auto init = [&](f32x16& sc, f32x16& dp) {
+#if GF_BWD_SEED
+            splat16(sc, -lse);
+            splat16(dp, -dl);
+#else
+            zero16(sc);
+            zero16(dp);
+#endif
+        };
+#if GF_BWD_HALVES
+        // one 32-key half at a time: only 32 score / dP accumulators are live beside dQ^T, Q and dO
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             f32x16 sc, dp;
-            splat16(sc, -lse);
-            splat16(dp, -dl);
+            init(sc, dp);
 #pragma unroll
             for (int kd = 0; kd < 8; ++kd) {
                 const bf16x8 kk = *(GF_LDS bf16x8*)(kbuf + fo.row[kd] + half * 32 * 256);
@@ -207,19 +259,28 @@ __global__ __launch_bounds__(DQ_THREADS, 2) void attn_bwd_dq_kernel(const BwdArg
                 mfma32(sc, kk, qf[kd]);      // S'^T[key, query] = c K Q^T - lse
                 mfma32(dp, vv, dof[kd]);     // dP'^T[key, query] = V dO^T - delta
             }
-#pragma unroll
-            for (int s8 = 0; s8 < 2; ++s8) {
-                float x[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int e = 8 * s8 + j;
-                    float pr = __builtin_amdgcn_exp2f(sc[e]);
-                    if constexpr (MASKED) pr = (t * KVB + 32 * half + (e & 3) + 8 * (e >> 2) + 4 * h < p.kv_len) ? pr : 0.f;
-                    x[j] = pr * dp[e];
-                }
-                dsf[half][s8] = pack8(x);
-            }
+            softmax_half(half, sc, dp);
         }
+#else
+        {
+            f32x16 sc[2], dp[2];
+            init(sc[0], dp[0]);
+            init(sc[1], dp[1]);
+#pragma unroll
+            for (int kd = 0; kd < 8; ++kd) {
+                const bf16x8 k0 = *(GF_LDS bf16x8*)(kbuf + fo.row[kd]);
+                const bf16x8 k1 = *(GF_LDS bf16x8*)(kbuf + fo.row[kd] + 32 * 256);
+                const bf16x8 v0 = *(GF_LDS bf16x8*)(vbuf + fo.row[kd]);
+                const bf16x8 v1 = *(GF_LDS bf16x8*)(vbuf + fo.row[kd] + 32 * 256);
+                mfma32(sc[0], k0, qf[kd]);
+                mfma32(sc[1], k1, qf[kd]);
+                mfma32(dp[0], v0, dof[kd]);
+                mfma32(dp[1], v1, dof[kd]);
+            }
+            softmax_half(0, sc[0], dp[0]);
+            softmax_half(1, sc[1], dp[1]);
+        }
+#endif
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -272,8 +333,12 @@ __global__ __launch_bounds__(DKV_THREADS, PART == 0 ? 1 : 2) void attn_bwd_dkv_k
     }
     // K pre-scaled by c = scale log2 e (this wave's own 32 keys, once): with -lse of the tile's queries as the initial accumulator the
     // score chain ends on the exponent itself; dP starts from -delta.  (The UNSCALED keys are not needed: dK = scale dS^T Q.)
+#if GF_BWD_SEED
 #pragma unroll
     for (int kd = 0; kd < 8; ++kd) kf[kd] = scale8(kf[kd], p.scale_log2e);
+#endif
+    const float c = p.scale_log2e;
+    (void)c;
     const FragOffsets fo = frag_offsets(lane);
     f32x16 dk[4], dv[4];
 #pragma unroll
@@ -300,21 +365,67 @@ __global__ __launch_bounds__(DKV_THREADS, PART == 0 ? 1 : 2) void attn_bwd_dkv_k
         GF_LDS float* lse_s = scal + (t & 1) * 2 * KVB;
         GF_LDS float* dl_s = lse_s + KVB;
         bf16x8 pf[2][2], dsf[2][2];
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {      // one 32-query half at a time (register pressure, as in the dQ kernel)
-            f32x16 sc, dp;
+        auto init = [&](int half, f32x16& sc, f32x16& dp, f32x16& lsev, f32x16& dlv) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int qi = 32 * half + 8 * g + 4 * h;      // 4 consecutive queries of registers 4g..4g+3
                 const f32x4 l4 = *(GF_LDS f32x4*)(lse_s + qi);
+                f32x4 d4 = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (DO_K) d4 = *(GF_LDS f32x4*)(dl_s + qi);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) sc[4 * g + i] = -l4[i];
-                if constexpr (DO_K) {
-                    const f32x4 d4 = *(GF_LDS f32x4*)(dl_s + qi);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) dp[4 * g + i] = -d4[i];
+                for (int i = 0; i < 4; ++i) {
+#if GF_BWD_SEED
+                    sc[4 * g + i] = -l4[i];
+                    dp[4 * g + i] = -d4[i];
+#else
+                    sc[4 * g + i] = 0.f;
+                    dp[4 * g + i] = 0.f;
+                    (void)l4;
+                    (void)d4;
+                    (void)lsev;
+                    (void)dlv;
+#endif
                 }
             }
+        };
+        auto softmax_half = [&](int half, const f32x16& sc, const f32x16& dp, const f32x16& lsev, const f32x16& dlv) {
+#pragma unroll
+            for (int s8 = 0; s8 < 2; ++s8) {
+                float xp[8], xs[8];
+#if !GF_BWD_SEED     // the rows' lse / delta are read where they are used (4 queries per ds_read_b128), not held across the chains
+                f32x4 l4[2], d4[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2) {
+                    const int qi = 32 * half + 8 * (2 * s8 + g2) + 4 * h;
+                    l4[g2] = *(GF_LDS f32x4*)(lse_s + qi);
+                    if constexpr (DO_K) d4[g2] = *(GF_LDS f32x4*)(dl_s + qi);
+                }
+#endif
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int e = 8 * s8 + j;
+#if GF_BWD_SEED
+                    float pr = __builtin_amdgcn_exp2f(sc[e]);
+#else
+                    float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[e], c, -l4[j >> 2][j & 3]));
+#endif
+                    if constexpr (MASKED) pr = (t * KVB + 32 * half + 8 * (e >> 2) + 4 * h + (e & 3) < p.q_len) ? pr : 0.f;
+                    xp[j] = pr;
+#if GF_BWD_SEED
+                    if constexpr (DO_K) xs[j] = pr * dp[e];
+#else
+                    if constexpr (DO_K) xs[j] = pr * (dp[e] - d4[j >> 2][j & 3]);
+#endif
+                }
+                if constexpr (DO_V) pf[half][s8] = pack8(xp);
+                if constexpr (DO_K) dsf[half][s8] = pack8(xs);
+            }
+        };
+#if GF_BWD_HALVES
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {      // one 32-query half at a time (register pressure, as in the dQ kernel)
+            f32x16 sc, dp, lsev, dlv;
+            init(half, sc, dp, lsev, dlv);
 #pragma unroll
             for (int kd = 0; kd < 8; ++kd) {
                 const bf16x8 qq = *(GF_LDS bf16x8*)(qbuf + fo.row[kd] + half * 32 * 256);
@@ -324,21 +435,30 @@ __global__ __launch_bounds__(DKV_THREADS, PART == 0 ? 1 : 2) void attn_bwd_dkv_k
                     mfma32(dp, dd, vf[kd]);     // dP'[query, key] = dO V^T - delta
                 }
             }
-#pragma unroll
-            for (int s8 = 0; s8 < 2; ++s8) {
-                float xp[8], xs[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int e = 8 * s8 + j;
-                    float pr = __builtin_amdgcn_exp2f(sc[e]);
-                    if constexpr (MASKED) pr = (t * KVB + 32 * half + 8 * (e >> 2) + 4 * h + (e & 3) < p.q_len) ? pr : 0.f;
-                    xp[j] = pr;
-                    if constexpr (DO_K) xs[j] = pr * dp[e];
-                }
-                if constexpr (DO_V) pf[half][s8] = pack8(xp);
-                if constexpr (DO_K) dsf[half][s8] = pack8(xs);
-            }
+            softmax_half(half, sc, dp, lsev, dlv);
         }
+#else
+        {
+            f32x16 sc[2], dp[2], lsev[2], dlv[2];
+            init(0, sc[0], dp[0], lsev[0], dlv[0]);
+            init(1, sc[1], dp[1], lsev[1], dlv[1]);
+#pragma unroll
+            for (int kd = 0; kd < 8; ++kd) {
+                const bf16x8 q0f = *(GF_LDS bf16x8*)(qbuf + fo.row[kd]);
+                const bf16x8 q1f = *(GF_LDS bf16x8*)(qbuf + fo.row[kd] + 32 * 256);
+                mfma32(sc[0], q0f, kf[kd]);
+                mfma32(sc[1], q1f, kf[kd]);
+                if constexpr (DO_K) {
+                    const bf16x8 d0f = *(GF_LDS bf16x8*)(dobuf + fo.row[kd]);
+                    const bf16x8 d1f = *(GF_LDS bf16x8*)(dobuf + fo.row[kd] + 32 * 256);
+                    mfma32(dp[0], d0f, vf[kd]);
+                    mfma32(dp[1], d1f, vf[kd]);
+                }
+            }
+            softmax_half(0, sc[0], dp[0], lsev[0], dlv[0]);
+            softmax_half(1, sc[1], dp[1], lsev[1], dlv[1]);
+        }
+#endif
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll

@@ -187,6 +187,155 @@ __global__ __launch_bounds__(64 * WROWS) void layernorm_modulate_wave_kernel(
     }
 }
 
+// ---- the same wave-per-row LayerNorm, specialised (round 3).  The kernel above decides per ELEMENT which of weight / bias / scale /
+// shift exist (166 v_cndmask per row and lane) and rounds every value on its own (one v_cvt_pk_bf16_f32 + a shift per value and
+// rounding): 1847 vector instructions per row and lane = 23 per element — enough to hold an HBM-bound kernel at 5.0 TB/s.  Here
+// the operand set is a template parameter and values go through the roundings in PAIRS (one v_cvt_pk_bf16_f32 per pair, unpacked
+// by a shift and a mask; multiplies / adds on float2 so that the packed-math forms can be used): the same operations in the same
+// order on every value, so the same bits, at about half the instructions.
+//   MODE 0: LayerNorm                      (norm without affine, no modulation)
+//   MODE 1: LayerNorm * a + b              (a = weight, b = bias: norm3)
+//   MODE 2: modulate(LayerNorm, b, a)      (a = 1 + scale, b = shift: norm1 / norm2 / head, the reference's three bf16 roundings)
+//   FP8: the result is quantised in registers for an fp8_linear consumer (layernorm_modulate_fp8_wave_kernel's contract).
+__device__ __forceinline__ gf_f32x2 unpack2bf(unsigned u) { return gf_f32x2{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)}; }
+#ifndef GF_LN2_PK
+#define GF_LN2_PK 1     // 0 (diagnostic builds): the pair arithmetic as scalar instructions pinned by inline asm instead of v_pk_*_f32
+#endif
+__device__ __forceinline__ gf_f32x2 ln2_fma(gf_f32x2 a, gf_f32x2 b, gf_f32x2 c) {
+#if GF_LN2_PK
+    return __builtin_elementwise_fma(a, b, c);
+#else
+    gf_f32x2 r;
+    asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r[0]) : "v"(a[0]), "v"(b[0]), "v"(c[0]));
+    asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r[1]) : "v"(a[1]), "v"(b[1]), "v"(c[1]));
+    return r;
+#endif
+}
+// (contract off: a product must stay a product — the roundings of the reference's separate ops are the point)
+__device__ __forceinline__ gf_f32x2 ln2_mul(gf_f32x2 a, gf_f32x2 b) {
+#pragma clang fp contract(off)
+#if GF_LN2_PK
+    return a * b;
+#else
+    gf_f32x2 r;
+    asm volatile("v_mul_f32 %0, %1, %2" : "=v"(r[0]) : "v"(a[0]), "v"(b[0]));
+    asm volatile("v_mul_f32 %0, %1, %2" : "=v"(r[1]) : "v"(a[1]), "v"(b[1]));
+    return r;
+#endif
+}
+__device__ __forceinline__ gf_f32x2 ln2_add(gf_f32x2 a, gf_f32x2 b) {
+#pragma clang fp contract(off)
+#if GF_LN2_PK
+    return a + b;
+#else
+    gf_f32x2 r;
+    asm volatile("v_add_f32 %0, %1, %2" : "=v"(r[0]) : "v"(a[0]), "v"(b[0]));
+    asm volatile("v_add_f32 %0, %1, %2" : "=v"(r[1]) : "v"(a[1]), "v"(b[1]));
+    return r;
+#endif
+}
+
+template <int NCH, int MODE, bool FP8>
+__global__ __launch_bounds__(64 * WROWS) void layernorm_wave2_kernel(const u16* __restrict__ x, void* __restrict__ outp,
+                                                                     float* __restrict__ scale_out, const u16* __restrict__ avec,
+                                                                     const u16* __restrict__ bvec, long rows, long x_stride,
+                                                                     long out_stride, float eps) {
+    constexpr int DIM = NCH * 512;
+    const long row = (long)blockIdx.x * WROWS + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const u16* xr = x + row * x_stride + lane * 8;
+    u32x4 v[NCH];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        v[i] = *reinterpret_cast<const u32x4*>(xr + i * 512);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {           // element order 0..7 of the chunk, as the per-element kernel adds them
+            const gf_f32x2 f = unpack2bf(v[i][p]);
+            s += f[0];
+            s += f[1];
+        }
+    }
+    // x - mean as ONE fma on the row total, fma(total, -1/DIM, x), and the variance as fma(sum, 1/DIM, eps): what the per-element
+    // kernel's expressions contract to (hipcc's default fp-contract), written out so that both kernels round alike
+    const float tot = wave_sum(s);
+    const gf_f32x2 tot2 = {tot, tot}, ninv2 = {-1.0f / DIM, -1.0f / DIM};
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const gf_f32x2 d = ln2_fma(tot2, ninv2, unpack2bf(v[i][p]));
+            q = __builtin_fmaf(d[0], d[0], q);
+            q = __builtin_fmaf(d[1], d[1], q);
+        }
+    const float rstd = 1.0f / sqrtf(__builtin_fmaf(wave_sum(q), 1.0f / DIM, eps));
+    const gf_f32x2 rstd2 = {rstd, rstd};
+    __attribute__((ext_vector_type(2))) unsigned short mxb = {0, 0};
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c0 = i * 512 + lane * 8;
+        u32x4 a8 = {0, 0, 0, 0}, b8 = {0, 0, 0, 0};
+        if constexpr (MODE != 0) {
+            a8 = *reinterpret_cast<const u32x4*>(avec + c0);
+            b8 = *reinterpret_cast<const u32x4*>(bvec + c0);
+        }
+        u32x4 o;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            gf_f32x2 y = ln2_mul(ln2_fma(tot2, ninv2, unpack2bf(v[i][p])), rstd2);
+            unsigned r;
+            if constexpr (MODE == 1) {
+                y = ln2_add(ln2_mul(y, unpack2bf(a8[p])), unpack2bf(b8[p]));   // * weight, + bias: two roundings, as the per-element kernel
+                r = pack2bf(y[0], y[1]);                                         // (its selects keep the compiler from fusing them); .type_as(x)
+            } else if constexpr (MODE == 2) {
+                r = pack2bf(y[0], y[1]);                                                 // .type_as(x)
+                y = ln2_mul(unpack2bf(r), unpack2bf(a8[p]));                             // x * (1 + scale)
+                r = pack2bf(y[0], y[1]);
+                y = ln2_add(unpack2bf(r), unpack2bf(b8[p]));                             // + shift
+                r = pack2bf(y[0], y[1]);
+            } else {
+                r = pack2bf(y[0], y[1]);
+            }
+            o[p] = r;
+            if constexpr (FP8) {   // |bf16| orders like its 15-bit pattern: the row maximum on the packed pairs (one and + one v_pk_max_u16)
+                typedef __attribute__((ext_vector_type(2))) unsigned short us2;
+                mxb = __builtin_elementwise_max(mxb, __builtin_bit_cast(us2, r & 0x7fff7fffu));
+            }
+        }
+        if constexpr (FP8) v[i] = o;            // the bf16 row fp8_linear receives, kept in registers
+        else *reinterpret_cast<u32x4*>((u16*)outp + row * out_stride + lane * 8 + i * 512) = o;
+    }
+    if constexpr (FP8) {
+        float mx = bf2f(mxb[0] > mxb[1] ? mxb[0] : mxb[1]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        const float sc = fmaxf(rbf(mx / 448.0f), 1.0f);      // x_max is bf16 in the reference: x_max / 448 rounds to bf16 before the clamp
+        if (lane == 0) scale_out[row] = sc;
+        const float den = sc + 1e-8f;
+        const bool unit = den == 1.0f;                       // wave-uniform; 1 + 1e-8 IS 1 in fp32, so x / den = x exactly
+        unsigned char* orow = (unsigned char*)outp + row * out_stride + lane * 8;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            unsigned w[2];
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                gf_f32x2 f0 = unpack2bf(v[i][2 * h2]), f1 = unpack2bf(v[i][2 * h2 + 1]);
+                if (!unit) {
+                    f0 = gf_f32x2{f0[0] / den, f0[1] / den};
+                    f1 = gf_f32x2{f1[0] / den, f1[1] / den};
+                }
+                unsigned t = 0;
+                t = __builtin_amdgcn_cvt_pk_fp8_f32(f0[0], f0[1], t, false);
+                t = __builtin_amdgcn_cvt_pk_fp8_f32(f1[0], f1[1], t, true);
+                w[h2] = t;
+            }
+            *reinterpret_cast<u32x2*>(orow + i * 512) = u32x2{w[0], w[1]};
+        }
+    }
+}
+
 // ROPE: 0 = no rotation, 1 = head_dim divides 512: a lane's four complex pairs are the same in every 512-element chunk
 // (c0 % head_dim = 8 lane % head_dim), so its cos / sin are loaded ONCE per row instead of once per chunk — 18 loads and ten
 // integer modulo sequences less per row and wave; 2 = any head_dim (per chunk).
@@ -432,6 +581,22 @@ extern "C" GF_API int gf_layernorm_modulate(const void* x, void* out, const void
                      (!scale1p || gf_aligned16(scale1p)) && (!shift || gf_aligned16(shift)),
                  "gf_layernorm_modulate: vectors must be 16-byte aligned");
     if (rows == 0) return GF_OK;
+    {   // the three operand sets of the DiT (plain, weight + bias, scale + shift) at the wave-per-row widths: the specialised kernel
+        const int mode = (!weight && !bias && !scale1p && !shift) ? 0 : (weight && bias && !scale1p && !shift) ? 1
+                         : (!weight && !bias && scale1p && shift) ? 2 : -1;
+        const void* av = mode == 1 ? weight : scale1p;
+        const void* bv = mode == 1 ? bias : shift;
+        const dim3 grid_((unsigned)((rows + WROWS - 1) / WROWS)), block_(64 * WROWS);
+#define GF_LN2(NCH, M)                                                                                                   \
+    if (dim == NCH * 512 && mode == M) {                                                                                 \
+        hipLaunchKernelGGL((layernorm_wave2_kernel<NCH, M, false>), grid_, block_, 0, (hipStream_t)stream, (const u16*)x, out,     \
+                           (float*)nullptr, (const u16*)av, (const u16*)bv, (long)rows, (long)x_stride, (long)out_stride, eps);     \
+        GF_CHECK_LAUNCH("gf_layernorm_modulate");                                                                        \
+        return GF_OK;                                                                                                    \
+    }
+        GF_LN2(10, 0) GF_LN2(10, 1) GF_LN2(10, 2) GF_LN2(8, 0) GF_LN2(8, 1) GF_LN2(8, 2) GF_LN2(3, 0) GF_LN2(3, 1) GF_LN2(3, 2)
+#undef GF_LN2
+    }
 #define GF_LN_WAVE(NCH)                                                                                                  \
     if (dim == NCH * 512) {                                                                                              \
         hipLaunchKernelGGL(layernorm_modulate_wave_kernel<NCH>, dim3((unsigned)((rows + WROWS - 1) / WROWS)),            \
@@ -463,6 +628,22 @@ extern "C" GF_API int gf_layernorm_modulate_fp8(const void* x, void* out8, float
                      (!scale1p || gf_aligned16(scale1p)) && (!shift || gf_aligned16(shift)),
                  "gf_layernorm_modulate_fp8: vectors must be 16-byte aligned");
     if (rows == 0) return GF_OK;
+    {
+        const int mode = (!weight && !bias && !scale1p && !shift) ? 0 : (weight && bias && !scale1p && !shift) ? 1
+                         : (!weight && !bias && scale1p && shift) ? 2 : -1;
+        const void* av = mode == 1 ? weight : scale1p;
+        const void* bv = mode == 1 ? bias : shift;
+        const dim3 grid_((unsigned)((rows + WROWS - 1) / WROWS)), block_(64 * WROWS);
+#define GF_LN2(NCH, M)                                                                                                   \
+    if (dim == NCH * 512 && mode == M) {                                                                                 \
+        hipLaunchKernelGGL((layernorm_wave2_kernel<NCH, M, true>), grid_, block_, 0, (hipStream_t)stream, (const u16*)x, out8,     \
+                           scale, (const u16*)av, (const u16*)bv, (long)rows, (long)x_stride, (long)out_stride, eps);   \
+        GF_CHECK_LAUNCH("gf_layernorm_modulate_fp8");                                                                    \
+        return GF_OK;                                                                                                    \
+    }
+        GF_LN2(10, 0) GF_LN2(10, 1) GF_LN2(10, 2) GF_LN2(8, 0) GF_LN2(8, 1) GF_LN2(8, 2) GF_LN2(3, 0) GF_LN2(3, 1) GF_LN2(3, 2)
+#undef GF_LN2
+    }
 #define GF_LN8_WAVE(NCH)                                                                                                 \
     if (dim == NCH * 512) {                                                                                              \
         hipLaunchKernelGGL(layernorm_modulate_fp8_wave_kernel<NCH>, dim3((unsigned)((rows + WROWS - 1) / WROWS)),        \

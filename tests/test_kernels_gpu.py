@@ -534,3 +534,32 @@ def test_gemm_a4_vs_phased_kernel(ops, M, N, K):
     # a negative stagger is clamped to 0 (it used to turn into a huge K offset): same bits as the unrotated kernel
     with ops.env_options(GF_A4_STAGGER="-3"):
         assert torch.equal(ops.gemm(a, w, bias), want0)
+
+
+@pytest.mark.parametrize("dim", [5120, 4096, 1536])
+def test_layernorm_specialised_kernel_matches_the_general_one(ops, dim):
+    """gf_layernorm_modulate at the wave-per-row widths runs layernorm_wave2_kernel<MODE> for the three operand sets of the DiT
+    (plain / weight + bias / scale + shift: values rounded in pairs, packed fp32 math, operand set a template parameter).  With
+    all four operands given the per-element kernel runs instead; weight = 1 / bias = 0 (resp. scale1p = 1 / shift = 0) make it
+    compute the same chain.  Same operations in the same order: the outputs agree except for about one value in 10^7 that sits
+    within two fp32 ulps of a bf16 rounding boundary (tools/ln_diag.py: 0 / 1 / 3 of 20.5 M for modulate / plain / affine, the
+    same with the pair arithmetic issued as scalar instructions, and both kernels equally far from torch's fp32 layer_norm) —
+    bar: <= 1 bf16 ulp on <= 2e-6 of the values."""
+    g = torch.Generator().manual_seed(dim + 1)
+    M = 515
+    x = dev((torch.randn((M, dim), generator=g) * 3 + 0.5).to(BF))
+    x[7] = 2.5                                                       # a constant row (variance 0)
+    a = dev((1 + 0.3 * torch.randn(dim, generator=g)).to(BF))
+    b = dev((0.4 * torch.randn(dim, generator=g)).to(BF))
+    one, zero = torch.ones_like(a), torch.zeros_like(a)
+
+    def close(new, old):
+        d = (new.view(torch.int16).int() - old.view(torch.int16).int()).abs()
+        return int(d.max()) <= 1 and float((d > 0).float().mean()) <= 2e-6
+
+    assert close(ops.layernorm_modulate(x, scale1p=a, shift=b), ops.layernorm_modulate(x, weight=one, bias=zero, scale1p=a, shift=b))
+    assert close(ops.layernorm_modulate(x, weight=a, bias=b), ops.layernorm_modulate(x, weight=a, bias=b, scale1p=one, shift=zero))
+    assert close(ops.layernorm_modulate(x), ops.layernorm_modulate(x, weight=one, bias=zero, scale1p=one, shift=zero))
+    big = torch.zeros((M, dim + 64), dtype=BF, device="cuda")           # strided output
+    ops.layernorm_modulate(x, scale1p=a, shift=b, out=big[:, 32:32 + dim])
+    assert torch.equal(big[:, 32:32 + dim], ops.layernorm_modulate(x, scale1p=a, shift=b)) and float(big[:, :32].abs().sum()) == 0

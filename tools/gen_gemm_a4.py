@@ -31,7 +31,7 @@ Pipeline (tile t multiplies from registers while tile t+1 sits in LDS stage (t+1
   three shapes (gemm_ab_sched7/8.log; 2, 3 or 5 MFMAs behind: the same).
 Tiles past K are staged with num_records = 0 (reads return 0, no memory traffic), so the loop needs no peeled tail.
 
-Measured and NOT kept (same box, one process, tools/gemm_ab.py; profiles/r02/gemm_a4_experiments.md):
+Measured and NOT kept (same box, one process, tools/gemm_ab.py; logs profiles/r02/gemm_ab_*.txt|log, write-up EXPERIMENTS.md):
   * rings of 3 A stages + 2 B stages in all 160 KiB of LDS (A tile t+3 / B tile t+2 in flight, loop unrolled 6 x): F->D +2.3 %,
     but D->D -4 % and D->F -5.5 %;
   * L2 warm-up loads, one 128-byte line per LANE six K tiles ahead: 1.43 -> 1.08 PFLOP/s (64 line look-ups per instruction
