@@ -114,7 +114,11 @@ struct GfOptions {
     std::atomic<int> bwd_fused_dkv{0};  // GF_ATTN_BWD_FUSED_DKV=1
     std::atomic<int> conv_nb{0};        // GF_CONV_NB: 0 = by Cout, 1 / 2 forced
     std::atomic<int> conv_gather{0};    // GF_CONV_GATHER=1: the general gather
+    std::atomic<int> conv_direct{1};    // GF_CONV_DIRECT=0: the 96-channel 3x3x3 convolutions on the implicit GEMM instead of gf_conv_direct.hip
 };
+// gf_conv_direct.hip: direct convolution of the 96-channel level; GF_ERR_UNSUPPORTED = shape not covered (caller falls back)
+int gf_conv3d_direct_c96(const void* src_walk, const void* Wm, int64_t ldw, const void* bias, void* out, int64_t T_out, int64_t H,
+                         int64_t W, int epilogue, const void* resid, const void* zero_page, void* stream);
 const GfOptions& gf_options();          // gf_abi.hip
 extern "C" GF_API void gf_reload_options(void);
 

@@ -1,0 +1,326 @@
+// gf_conv_direct.hip — direct 3x3x3 causal convolution for the 96-channel full-resolution level of the Wan VAE (decoder
+// ResidualBlocks and the encoder's first level: CausalConv3d VAE:33-52 inside ResidualBlock VAE:267-301), the layers that sat
+// furthest below their roofline: as an implicit GEMM (gf_conv3d_bf16 -> gemm_ph_kernel<CONV = 2>) every input pixel is fetched 27
+// times through L2 (once per tap), a 128-wide N tile is three quarters full at Cout = 96, and the 192-byte pixel pitch straddles
+// 128-byte lines: 7.6 ms for 3.97 TFLOP (0.52 PFLOP/s) per convolution of a 240 x 416 x 80 tile.
+//
+// Here a workgroup (8 waves, two per SIMD) owns an 8 x 32 patch of output pixels x all 96 output channels and WALKS THE FRAMES:
+//   * the (8+2) x (32+2) halo of ONE input frame is staged into LDS once (LDS-DMA, 224-byte pixel pitch = 192 + 32: the
+//     16-pixel x 32-channel MFMA fragments are conflict-free ds_read_b128s, and a tap (dy, dx) is a constant address offset);
+//   * an input frame g contributes to THREE output frames (g - dt, temporal tap dt = 0, 1, 2), so three accumulator sets are live
+//     and the frame's 27 taps all run against the one staged halo: the input is fetched once, not 27 (nor 3) times.  The sets are
+//     named by temporal tap and move up one place per frame by register moves, so the frame loop is ONE code path (three
+//     instantiations selected by g mod 3 made hipcc spill accumulators);
+//   * wave w = (pixel group w >> 1: two rows = four 16-pixel blocks) x (channel half w & 1: three 16-channel blocks): 3 sets x 12
+//     tiles x 4 = 144 accumulator registers, so two waves fit a SIMD and cover each other's LDS latencies and barrier waits (the
+//     first version, 4 waves x 3 blocks x 6 channel blocks at one wave per SIMD, ran at 0.71 PFLOP/s; hipcc spills at the 288
+//     accumulators a 4-wave 8 x 32 patch would need);
+//   * the weights of one tap (96 x 96 bf16, rows at the same 224-byte pitch) stream through a 3-stage LDS ring, two taps ahead
+//     (an LDS-DMA piece needs ~1.1 us to land under load: one tap ahead left every tap waiting), one barrier per tap; per tap and wave 36 v_mfma_f32_16x16x32_bf16 (operands swapped as in the GEMM: a lane ends with 4
+//     consecutive output channels of one pixel) on 12 A + 9 B fragment reads;
+//   * when an output frame is complete (after its third input frame) its accumulators go through a wave-private LDS image and
+//     leave as 96-byte half pixels, 16 bytes per lane (bias, optional residual with the GEMM epilogue's rounding sequence); that
+//     epilogue runs while the next input frame's halo is in flight.
+// Every output element sums its products in the order of the implicit GEMM (taps (dt, dy, dx) in sequence, 32 channels per MFMA):
+// the results are BIT-IDENTICAL to gemm_ph_kernel<CONV> (tests/test_vae.py).  Frames are cut into segments so that a launch has a
+// few workgroups per CU; a segment's first two input frames only feed the later temporal taps.
+#include "gf_common.h"
+#include <type_traits>
+
+namespace {
+
+#ifndef CD_WHATIF
+#define CD_WHATIF 0
+#endif
+constexpr int CD_C = 96;
+constexpr int CD_TH = 8, CD_TW = 32, CD_HH = CD_TH + 2, CD_HW = CD_TW + 2;
+constexpr int CD_WAVES = 8, CD_THREADS = 64 * CD_WAVES;
+constexpr int CD_PITCH = 224, CD_SLOTS = 14;                                          // 16-byte slots per pixel / weight row: 12 data + 2 pad
+constexpr int CD_HALO_INSTR = (CD_HH * CD_HW * CD_SLOTS + 63) / 64;                  // 75 wave-instructions of 1 KiB
+constexpr int CD_HALO_BYTES = CD_HALO_INSTR * 1024;                                  // 76800
+constexpr int CD_W_INSTR = CD_C * CD_SLOTS / 64;                                     // 21
+constexpr int CD_W_BYTES = CD_W_INSTR * 1024;                                        // 21504
+constexpr int CD_STAGES = 3;                                                         // weight ring: the tap running, the next one, the one after
+constexpr int CD_EP_BYTES = 16 * 96;                                                 // per wave and pass: 16 pixels x its 48 channels (in the free ring stage)
+constexpr int CD_LDS = CD_HALO_BYTES + CD_STAGES * CD_W_BYTES;                       // 141312
+constexpr int CD_HK = (CD_HALO_INSTR + CD_WAVES - 1) / CD_WAVES, CD_WK = (CD_W_INSTR + CD_WAVES - 1) / CD_WAVES;   // 10, 3
+
+struct CdArgs {
+    const u16* src;     // input frame 0 of the walk = the frame output 0 reads with dt = 0 (history included): [*, H, W, 96]
+    const u16* w;       // [96, ldw], K order (dt, dy, dx, cin)
+    const u16* bias;    // [96] or null
+    u16* out;           // [T_out, H, W, 96]
+    const u16* resid;   // [T_out, H, W, 96] (EPI_BIAS_RESID)
+    const u16* zero;    // >= 16 zero bytes
+    int H, W, T_out, tseg, tiles_x, tiles_y;
+    long frame;         // H * W * 96
+    long ldw;
+};
+
+// One asm statement: counted wait for this wave's own LDS-DMA requests + its LDS reads, then the workgroup barrier.  NOT
+// __syncthreads(): its fence makes hipcc wait for vmcnt(0) — every request in flight, the newest weight prefetch included —
+// which turns a ring that is two taps deep into one that is one tap deep.
+#define CD_WAIT_BARRIER(N) asm volatile("s_waitcnt vmcnt(" #N ")\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+__device__ __forceinline__ void cd_glds16(const void* g, GF_LDS char* l) {
+    __builtin_amdgcn_global_load_lds((const GF_GLOBAL void*)g, (GF_LDS void*)l, 16, 0, 0);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(CD_THREADS, 2) void conv3d_c96_kernel(const CdArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    GF_LDS char* lds = (GF_LDS char*)smem;
+    GF_LDS char* halo = lds;
+    GF_LDS char* wbuf = lds + CD_HALO_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = wave >> 1, wc = wave & 1;               // pixel group (rows 2 wp, 2 wp + 1), channel half (blocks 3 wc ..)
+    const int l15 = lane & 15, kc = lane >> 4;
+
+    const int spatial = p.tiles_x * p.tiles_y;
+    const int seg = blockIdx.x / spatial, sp = blockIdx.x - seg * spatial;
+    const int y0 = (sp / p.tiles_x) * CD_TH, x0 = (sp % p.tiles_x) * CD_TW;
+    const int j0 = seg * p.tseg, j1 = min(p.T_out, j0 + p.tseg);
+
+    // ---- DMA sources.  The weight rows' offsets (3 per lane) are kept; a halo slot's place (pixel, 16-byte piece) does not depend
+    // on the frame either, but keeping 10 per-lane offsets and the 64-bit addresses made from them alive across the frame loop
+    // costs more registers than the ~25 integer instructions per DMA instruction that recompute them (one frame = 27 taps x 36
+    // MFMAs per wave): `lane_v` is made opaque once per frame so that the compiler does not hoist the arithmetic out of the loop.
+    int woff[CD_WK];
+#pragma unroll
+    for (int k = 0; k < CD_WK; ++k) {
+        const int slot = (wave + CD_WAVES * k) * 64 + lane;
+        const int n = min(slot / CD_SLOTS, CD_C - 1), sl = min(slot % CD_SLOTS, 11);     // pad slots fetch valid bytes nobody reads
+        woff[k] = (int)(n * p.ldw * 2) + sl * 16;
+    }
+    auto issue_w = [&](int tap, int stage_off) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < CD_WK; ++k) {
+            const int i = wave + CD_WAVES * k;
+            if (i < CD_W_INSTR) cd_glds16((const char*)p.w + woff[k] + tap * (CD_C * 2), wbuf + stage_off + i * 1024);
+        }
+    };
+    const bool three = wave + CD_WAVES * 2 < CD_W_INSTR;   // this wave issues 3 (else 2) DMA instructions per tap
+    auto issue_halo = [&](int g, int lane_v) __attribute__((always_inline)) {
+        const char* base = (const char*)(p.src + (long)g * p.frame);
+#pragma unroll
+        for (int k = 0; k < CD_HK; ++k) {
+            const int i = wave + CD_WAVES * k;
+            if (i < CD_HALO_INSTR) {
+                const int slot = i * 64 + lane_v;
+                const int px = slot / CD_SLOTS, sl = slot - px * CD_SLOTS;
+                const int hy = px / CD_HW, hx = px - hy * CD_HW;
+                const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+                const bool ok = px < CD_HH * CD_HW && sl < 12 && y >= 0 && y < p.H && x >= 0 && x < p.W;
+                cd_glds16(ok ? base + (long)((y * p.W + x) * (CD_C * 2) + sl * 16) : (const char*)p.zero, halo + i * 1024);
+            }
+        }
+    };
+
+    // fragment read bases: lane (row l15, k chunk kc) of a 16-row x 32-channel fragment
+    const int lane_off = l15 * CD_PITCH + kc * 16;
+    GF_LDS char* const a_base = halo + lane_off + 2 * wp * CD_HW * CD_PITCH;
+    GF_LDS char* const b_base = wbuf + lane_off + 3 * wc * 16 * CD_PITCH;
+
+    f32x4 acc[3][4][3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int cb = 0; cb < 3; ++cb) acc[s][b][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // The weight ring: three stages.  An LDS-DMA piece takes ~1.1 us from issue to landing under load — two taps of this
+    // workgroup's MFMA time — so a tap's weights are requested TWO taps ahead and the counted wait at a tap's start leaves the
+    // newest request in flight (with a 2-stage ring and vmcnt(0) every tap waited ~1 us: 5.6 ms per convolution, measured).
+    int st_cur = 0, st_nxt = CD_W_BYTES, st_free = 2 * CD_W_BYTES;     // byte offsets of the stages holding tap t, t + 1 and the free one
+    int tap_next2 = 2;                                                  // the tap (0..26, wrapping into the next frame) two ahead
+    // one temporal tap dt of input frame g into accumulator set dt (= output frame g - dt): nine spatial taps
+    auto tap_group = [&](auto set_c, bool valid, bool first) __attribute__((always_inline)) {
+        constexpr int SET = decltype(set_c)::value;
+#pragma unroll 1
+        for (int s = 0; s < 9; ++s) {
+            if (!(first && s == 0)) {                      // (the frame's first tap: the halo wait did this already)
+                // weights of this tap landed (the newest request, 3 or 2 instructions of this wave, stays in flight); every wave is
+                // past the previous tap
+#if CD_WHATIF & 1       // timing-only builds (wrong results): 1 = no counted wait, 2 = no barrier, 4 = no weight requests
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#elif CD_WHATIF & 2
+                asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+#else
+                if (three) CD_WAIT_BARRIER(3);
+                else CD_WAIT_BARRIER(2);
+#endif
+            }
+#if !(CD_WHATIF & 4)
+            issue_w(tap_next2, st_free);                   // the stage the previous tap has just been read out of
+#endif
+            tap_next2 = tap_next2 == 26 ? 0 : tap_next2 + 1;
+            if (valid) {
+                const int dy = (s * 11) >> 5, dx = s - 3 * dy;
+                GF_LDS char* const aaddr = a_base + (dy * CD_HW + dx) * CD_PITCH;
+                GF_LDS char* const baddr = b_base + st_cur;
+                // fragments of k step ks + 1 are requested before the 12 MFMAs of k step ks (two register sets; the scheduling
+                // barriers keep hipcc from sinking each read next to its use behind an lgkmcnt(0))
+                bf16x8 af[2][4], bfr[2][3];
+                auto load = [&](int ks, int set) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) af[set][b] = *(GF_LDS bf16x8*)(aaddr + ((b >> 1) * CD_HW + (b & 1) * 16) * CD_PITCH + ks * 64);
+#pragma unroll
+                    for (int cb = 0; cb < 3; ++cb) bfr[set][cb] = *(GF_LDS bf16x8*)(baddr + cb * 16 * CD_PITCH + ks * 64);
+                };
+                load(0, 0);
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) {
+                    if (ks < 2) load(ks + 1, (ks + 1) & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+#pragma unroll
+                        for (int cb = 0; cb < 3; ++cb)
+                            acc[SET][b][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks & 1][cb], af[ks & 1][b], acc[SET][b][cb], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            const int t = st_cur;
+            st_cur = st_nxt;
+            st_nxt = st_free;
+            st_free = t;
+        }
+    };
+    // this lane's bias values: channels (3 wc + cb) * 16 + 4 kc .. + 3
+    u16x4 bias4[3];
+#pragma unroll
+    for (int cb = 0; cb < 3; ++cb) bias4[cb] = p.bias ? *reinterpret_cast<const u16x4*>(p.bias + (3 * wc + cb) * 16 + kc * 4) : u16x4{0, 0, 0, 0};
+    // Output frame j is complete in set 2: bias (+ residual), out.  Four passes of one 16-pixel block x this wave's 48 channels through
+    // the FREE stage of the weight ring (nothing is requested into it before the frame's first tap).  The residual pieces are
+    // requested FIRST and the next halo's DMA behind them (`after_loads`): vmcnt retires in order, so a load issued behind the DMA
+    // would make the epilogue wait for the whole halo.
+    auto epilogue = [&](int j, auto&& after_loads) __attribute__((always_inline)) {
+        GF_LDS char* ep = wbuf + st_free + wave * CD_EP_BYTES;
+        u16x8 rres[4][2];
+        long offs[4][2];
+        bool okk[4][2];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int y = y0 + 2 * wp + (b >> 1), xb = x0 + (b & 1) * 16;
+            const long blkbase = (((long)j * p.H + y) * p.W + xb) * CD_C + wc * 48;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int s = i * 64 + lane;                          // 16-byte piece s of the block image: pixel s / 6, piece s % 6 of its 96 bytes
+                const int px = s / 6, sl = s - px * 6;
+                okk[b][i] = s < 96 && y < p.H && xb + px < p.W;
+                offs[b][i] = blkbase + (long)px * CD_C + sl * 8;
+                if constexpr (EPI == GF_EPI_BIAS_RESID) {
+                    if (okk[b][i]) rres[b][i] = *reinterpret_cast<const u16x8*>(p.resid + offs[b][i]);
+                }
+            }
+        }
+        after_loads();
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+#pragma unroll
+            for (int cb = 0; cb < 3; ++cb) {
+                const f32x4 a = acc[2][b][cb];
+                u32x2 pk;
+                pk[0] = pack2bf(a[0] + bf2f(bias4[cb][0]), a[1] + bf2f(bias4[cb][1]));
+                pk[1] = pack2bf(a[2] + bf2f(bias4[cb][2]), a[3] + bf2f(bias4[cb][3]));
+                *(GF_LDS u32x2*)(ep + l15 * 96 + cb * 32 + kc * 8) = pk;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // wave-private image
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (okk[b][i]) {
+                    const u16x8 v = *(GF_LDS u16x8*)(ep + (i * 64 + lane) * 16);
+                    u16x8 o = v;
+                    if constexpr (EPI == GF_EPI_BIAS_RESID) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(rres[b][i][e]) + bf2f(v[e]));
+                    }
+                    *reinterpret_cast<u16x8*>(p.out + offs[b][i]) = o;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the image is rewritten by the next block
+        }
+    };
+    // The sets are named by temporal tap: set dt collects output frame g - dt while input frame g is processed.  At the start of a
+    // frame step set 2 holds the output completed by the previous frame: it is stored (under the new halo's DMA), then the sets
+    // move up one place (register moves: 96 per frame and lane against 972 MFMAs) and set 0 starts the new output frame from 0.
+    auto rotate = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int cb = 0; cb < 3; ++cb) {
+                acc[2][b][cb] = acc[1][b][cb];
+                acc[1][b][cb] = acc[0][b][cb];
+                acc[0][b][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+    };
+    issue_w(0, 0);
+    issue_w(1, CD_W_BYTES);
+#pragma unroll 1
+    for (int g = j0; g < j1 + 2; ++g) {                    // input frame g of the walk: output j reads g = j, j + 1, j + 2
+        CD_WAIT_BARRIER(0);                                // every wave is done with the previous frame's halo (and its last tap)
+        int lane_v = lane;
+        asm volatile("" : "+v"(lane_v));                   // opaque: see issue_halo
+        if (g - 3 >= j0) epilogue(g - 3, [&]() __attribute__((always_inline)) { issue_halo(g, lane_v); });   // completed a frame ago, stored under the DMA
+        else issue_halo(g, lane_v);
+        rotate();
+        CD_WAIT_BARRIER(0);                                // halo g (and the weights of its first two taps) landed
+        tap_group(std::integral_constant<int, 0>{}, g >= j0 && g < j1, true);
+        tap_group(std::integral_constant<int, 1>{}, g - 1 >= j0 && g - 1 < j1, false);
+        tap_group(std::integral_constant<int, 2>{}, g - 2 >= j0 && g - 2 < j1, false);
+    }
+    CD_WAIT_BARRIER(0);                                    // the ring's last prefetches (never read) must not outlive the workgroup's LDS
+    epilogue(j1 - 1, []() {});                             // the segment's last output frame finished with input j1 + 1 (set 2)
+}
+
+template <int EPI>
+int launch_cd(const CdArgs& a, unsigned grid, hipStream_t stream) {
+    static GfDeviceOnce once;
+    hipError_t e = gf_once_per_device(once, [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_c96_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, CD_LDS);
+    });
+    if (e != hipSuccess) {
+        gf_set_error("gf_conv3d_bf16 (direct): hipFuncSetAttribute(%d B LDS) failed: %s", CD_LDS, hipGetErrorString(e));
+        return GF_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL((conv3d_c96_kernel<EPI>), dim3(grid), dim3(CD_THREADS), CD_LDS, stream, a);
+    GF_CHECK_LAUNCH("gf_conv3d_bf16 (direct)");
+    return GF_OK;
+}
+
+}  // namespace
+
+// Called by gf_conv3d_bf16 (gf_gemm.hip) for: kt = ks = 3, stride 1, no resampling, history in front of src, C = N = 96, contiguous
+// out / resid rows.  `src_walk` = the frame output 0 reads with its FIRST temporal tap.  Returns GF_ERR_UNSUPPORTED when the shape
+// is outside what the kernel covers (the caller then takes the implicit GEMM).
+int gf_conv3d_direct_c96(const void* src_walk, const void* Wm, int64_t ldw, const void* bias, void* out, int64_t T_out, int64_t H,
+                         int64_t W, int epilogue, const void* resid, const void* zero_page, void* stream) {
+    if (H * W * CD_C * 2 >= (1LL << 31) || ldw * 2 * CD_C >= (1LL << 31) || T_out <= 0) return GF_ERR_UNSUPPORTED;
+    CdArgs a;
+    a.src = (const u16*)src_walk;
+    a.w = (const u16*)Wm;
+    a.bias = (const u16*)bias;
+    a.out = (u16*)out;
+    a.resid = (const u16*)resid;
+    a.zero = (const u16*)zero_page;
+    a.H = (int)H;
+    a.W = (int)W;
+    a.T_out = (int)T_out;
+    a.tiles_x = (int)((W + CD_TW - 1) / CD_TW);
+    a.tiles_y = (int)((H + CD_TH - 1) / CD_TH);
+    a.frame = H * W * CD_C;
+    a.ldw = ldw;
+    // segments of frames: enough workgroups for a few rounds over the 256 CUs, segments not shorter than 4 frames (each pays two
+    // input frames of lead-in)
+    const long spatial = (long)a.tiles_x * a.tiles_y;
+    long nseg = (4 * 256 + spatial - 1) / spatial;
+    if (nseg > (T_out + 3) / 4) nseg = (T_out + 3) / 4;
+    if (nseg < 1) nseg = 1;
+    a.tseg = (int)((T_out + nseg - 1) / nseg);
+    nseg = (T_out + a.tseg - 1) / a.tseg;
+    const unsigned grid = (unsigned)(spatial * nseg);
+    hipStream_t s = (hipStream_t)stream;
+    return epilogue == GF_EPI_BIAS_RESID ? launch_cd<GF_EPI_BIAS_RESID>(a, grid, s) : launch_cd<GF_EPI_BIAS>(a, grid, s);
+}

@@ -1597,6 +1597,14 @@ extern "C" GF_API int gf_conv3d_bf16(const void* src, const void* cache, const v
     a.cv.inv_ks2 = 1.0f / (float)(ks * ks);
     hipStream_t s = (hipStream_t)stream;
     a.cv.hist_front = (kt == 3 && !cache) ? 1 : 0;
+    // the 96-channel full-resolution level (ResidualBlock convolutions with their history in front of src): direct convolution,
+    // bit-identical to the implicit GEMM below (gf_conv_direct.hip; GF_CONV_DIRECT=0 switches it off)
+    if (kt == 3 && ks == 3 && mode == 0 && !cache && t_stride == 1 && C == 96 && N == 96 && ldc == 96 &&
+        (epilogue == GF_EPI_BIAS || ldr == 96) && gf_options().conv_direct.load(std::memory_order_relaxed)) {
+        const u16* walk = (const u16*)src + (long)(t_off - 2) * H * W * C;
+        const int rc = gf_conv3d_direct_c96(walk, Wm, ldw, bias, out, T_out, H, W, epilogue, resid, a.cv.zero, stream);
+        if (rc != GF_ERR_UNSUPPORTED) return rc;
+    }
     // contiguous source frames and stride-1 taps: the pointer-per-row gather (GF_CONV_GATHER=1 forces the general one, A/B)
     const int force_g = gf_options().conv_gather.load(std::memory_order_relaxed);
     const bool fast = force_g != 1 && mode == 0 && (kt == 1 || !cache);

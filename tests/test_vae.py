@@ -159,7 +159,7 @@ def test_hip_implicit_conv_bit_identical_to_im2col_gemm(case):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("T,H,W,C,N,ks", [(3, 9, 11, 96, 96, 3), (5, 18, 20, 96, 8, 3), (2, 6, 5, 32, 64, 1), (4, 13, 7, 192, 192, 3),
-                                          (1, 5, 5, 16, 24, 3)])
+                                          (1, 5, 5, 16, 24, 3), (9, 20, 70, 96, 96, 3), (22, 13, 33, 96, 96, 3), (1, 6, 32, 96, 96, 3)])
 def test_hip_conv_history_in_front_bit_identical(T, H, W, C, N, ks):
     """The pointer-per-row gather (history frames in front of src, one buffer) == the general gather with a separate cache
     == gf_vae_im2col + gf_gemm_bf16, bit for bit, with and without a residual."""
@@ -182,6 +182,33 @@ def test_hip_conv_history_in_front_bit_identical(T, H, W, C, N, ks):
     from goal_force_amd._lib import GoalForceError
     with pytest.raises(GoalForceError):
         ops.vae_conv3d(x.clone(), None, w, b, 3, ks, history_in_front=True)        # no room in front of a fresh tensor
+
+
+@pytest.mark.gpu
+def test_hip_direct_conv_c96_equals_implicit_gemm_at_tile_size():
+    """The 96-channel level of a production tile's first frames (240 x 416; C = N = 96, 3x3x3, history in front): the direct
+    convolution (gf_conv_direct.hip: 6 x 32 pixel patches walking the frames, input halo staged once per frame, three
+    accumulator sets) against the implicit GEMM it replaces (GF_CONV_DIRECT=0) — bit for bit, with and without the residual, over
+    several frame segments."""
+    from goal_force_amd import ops
+    g = torch.Generator().manual_seed(96)
+    T, H, W, C = 7, 240, 416, 96
+    k = 27 * C
+    kpad = -(-k // 64) * 64
+    buf = (torch.randn((T + 2, H, W, C), generator=g) * 0.7).to(BF).cuda()
+    x = buf[2:]
+    w = torch.zeros((C, kpad), dtype=BF)
+    w[:, :k] = (torch.randn((C, k), generator=g) / k ** 0.5).to(BF)
+    w = w.cuda()
+    b = torch.randn((C,), generator=g).to(BF).cuda()
+    resid = torch.randn((T * H * W, C), generator=g).to(BF).cuda()
+    with ops.env_options(GF_CONV_DIRECT="0"):
+        ref = ops.vae_conv3d(x, None, w, b, 3, 3, history_in_front=True)
+        ref_r = ops.vae_conv3d(x, None, w, b, 3, 3, resid=resid, history_in_front=True)
+    got = ops.vae_conv3d(x, None, w, b, 3, 3, history_in_front=True)
+    assert torch.equal(got, ref), f"{int((got != ref).sum())} of {ref.numel()} differ"
+    assert torch.equal(ops.vae_conv3d(x, None, w, b, 3, 3, resid=resid, history_in_front=True), ref_r)
+    assert float(ref.float().abs().max()) > 0.5
 
 
 @pytest.mark.gpu

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""The 96-channel 3x3x3 convolution of one production VAE tile (80 frames of 240 x 416, history in front): direct kernel
+(gf_conv_direct.hip) against the implicit GEMM (GF_CONV_DIRECT=0), interleaved in one process; 3.97 TFLOP per launch."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from goal_force_amd import ops
+
+BF = torch.bfloat16
+
+
+def main():
+    T, H, W, C = int(os.environ.get("CONV_T", "80")), 240, 416, 96
+    torch.manual_seed(0)
+    buf = (torch.randn((T + 2, H, W, C), device="cuda") * 0.7).to(BF)
+    x = buf[2:]
+    k = 27 * C
+    kpad = -(-k // 64) * 64
+    w = torch.zeros((C, kpad), dtype=BF, device="cuda")
+    w[:, :k] = (torch.randn((C, k), device="cuda") / k ** 0.5).to(BF)
+    b = torch.randn((C,), device="cuda").to(BF)
+    resid = torch.randn((T * H * W, C), device="cuda").to(BF)
+    fl = 2.0 * T * H * W * k * C
+    best = {}
+    for rnd in range(3):
+        for name, env in (("implicit", "0"), ("direct", "1")):
+            with ops.env_options(GF_CONV_DIRECT=env):
+                for kind, kw in (("bias", {}), ("resid", dict(resid=resid))):
+                    ops.vae_conv3d(x, None, w, b, 3, 3, history_in_front=True, **kw)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(3):
+                        ops.vae_conv3d(x, None, w, b, 3, 3, history_in_front=True, **kw)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    key = f"{name} {kind}"
+                    best[key] = min(best.get(key, 1e9), e0.elapsed_time(e1) / 3)
+    for key, ms in best.items():
+        print(f"{key:16s} {ms:7.3f} ms  {fl / ms / 1e9:7.1f} TFLOP/s", flush=True)
+    # timing-only what-if builds of the direct kernel (-DCD_WHATIF=n: 1 no counted wait, 2 no barrier, 4 no weight requests; wrong
+    # results): build/whatif/libcd_w<n>.so = gf_conv_direct.hip + gf_gemm.hip + gf_abi.hip
+    import ctypes
+    import glob
+    vp, i64, ci = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
+    out = torch.empty((T * H * W, C), dtype=BF, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    for path in sorted(glob.glob(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build", "whatif", "libcd_w*.so"))):
+        lib = ctypes.CDLL(path)
+        lib.gf_conv3d_bf16.argtypes = [vp, vp, vp, i64, vp, vp, i64, i64, i64, i64, i64, i64, ci, ci, ci, ci, ci, i64, i64, ci, vp, i64, vp]
+
+        def call():
+            assert lib.gf_conv3d_bf16(x.data_ptr(), None, w.data_ptr(), kpad, b.data_ptr(), out.data_ptr(), C, T, T, H, W, C, 3, 3, 0, 1, 0,
+                                      C, kpad, 0, None, 0, st) == 0
+        call()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            call()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 3
+        print(f"what-if {os.path.basename(path)[7:-3]:4s} {ms:7.3f} ms  {fl / ms / 1e9:7.1f} TFLOP/s-equivalent", flush=True)
+
+
+if __name__ == "__main__":
+    main()
