@@ -32,11 +32,11 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 # HBM bytes per self-attention launch (flash_attn_fwd_kernel3<2>; its V^T operand comes from the projection GEMM) from rocprofv3 --pmc, separate
-# FETCH_SIZE / WRITE_SIZE passes over tools/microbench.py attn (tools/profile_r02.sh): (2 x FETCH_SIZE [gfx950 reports half of a
+# FETCH_SIZE / WRITE_SIZE passes over tools/microbench.py attn (tools/profile_r03.sh): (2 x FETCH_SIZE [gfx950 reports half of a
 # 16-B/lane stream] + WRITE_SIZE) KiB -> bytes, this round's build.  PMC needs the profiler, so this is a STATIC figure from
 # the named files, not measured by the run that prints it ("traffic_static": true in the JSON line).
-ATTN_TRAFFIC_BYTES = (2 * 1490930 + 501680) * 1024
-ATTN_TRAFFIC_SOURCE = "profiles/r02/pmc/attn_k3_FETCH_SIZE.md + attn_k3_WRITE_SIZE.md"
+ATTN_TRAFFIC_BYTES = (2 * 1490380 + 501680) * 1024
+ATTN_TRAFFIC_SOURCE = "profiles/r03/pmc/attn_FETCH_SIZE.md + attn_WRITE_SIZE.md (tools/profile_r03.sh, this round's build)"
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md (Chip-level parameters)
 PEAK_FP8_TFLOPS = 5000.0   # dense fp8 MFMA peak (same table): the denominator of the GEMM entries under --fp8 (config 5)
 S_TOK, DIM, HEADS, FFN, LTXT = 32760, 5120, 40, 13824, 512
@@ -336,7 +336,7 @@ def main():
                          "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "peak_note": "dense bf16 MFMA peak = 256 CU x 4096 FLOP/clk x 2.4 GHz (MI355X_MICROARCH.md); under this "
                                       "load the chip holds 1.74-2.05 GHz depending on the box and build (rocprofv3 GRBM_GUI_ACTIVE: 1.84 GHz "
-                                      "at 75 % MFMA-busy in profiles/r02/pmc/attn_k3_SQ.md), i.e. 1.8-2.1 PFLOP/s",
+                                      "at 75 % MFMA-busy in profiles/r03/pmc/attn_SQ.md: 1.87 GHz), i.e. 1.8-2.1 PFLOP/s",
                          "frac": None if achieved is None else achieved / PEAK_BF16_TFLOPS,
                          # HBM bytes per launch from rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes over
                          # tools/microbench.py attn, profiles/r01/pmc/): (2 x FETCH_SIZE [gfx950 reports half of a 16-B/lane

@@ -22,7 +22,7 @@ SYMBOLS = (
     "gf_force_map",
     "gf_vae_prep_latent", "gf_vae_im2col", "gf_vae_finish_latent", "gf_vae_rmsnorm_silu", "gf_softmax_rows", "gf_transpose_pad",
     "gf_vae_tile_blend", "gf_vae_tile_finalize",
-    "gf_quant_fp8_rowscale", "gf_cast_fp8", "gf_gemm_fp8", "gf_layernorm_modulate_fp8", "gf_modulate", "gf_rope_apply",
+    "gf_quant_fp8_rowscale", "gf_cast_fp8", "gf_gemm_fp8", "gf_layernorm_modulate_fp8", "gf_modulate", "gf_rope_apply", "gf_linear_vt32_fp8",
     "gf_flash_attn_fwd_lse", "gf_flash_attn_bwd",
     "gf_layernorm_bwd", "gf_rmsnorm_rope_bwd", "gf_colsum", "gf_act_bwd", "gf_mse_loss", "gf_adamw_step", "gf_f32_to_bf16", "gf_sumsq",
     "gf_transpose_v", "gf_flash_attn_fwd_vt", "gf_transpose_v32", "gf_flash_attn_fwd_vt32", "gf_linear_vt32",
@@ -90,6 +90,7 @@ def _declare(lib):
         "gf_vae_tile_finalize": [_vp, _vp, _i64, _i64, _int, _vp],
         "gf_quant_fp8_rowscale": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp],
         "gf_modulate": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp],
+        "gf_linear_vt32_fp8": [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _vp],
         "gf_rope_apply": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp],
         "gf_layernorm_modulate_fp8": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _vp],
         "gf_cast_fp8": [_vp, _vp, _i64, _vp],

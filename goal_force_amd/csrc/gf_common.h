@@ -118,7 +118,7 @@ struct GfOptions {
 };
 // gf_conv_direct.hip: direct convolution of the 96-channel level; GF_ERR_UNSUPPORTED = shape not covered (caller falls back)
 int gf_conv3d_direct_c96(const void* src_walk, const void* Wm, int64_t ldw, const void* bias, void* out, int64_t T_out, int64_t H,
-                         int64_t W, int epilogue, const void* resid, const void* zero_page, void* stream);
+                         int64_t W, int64_t N, int epilogue, const void* resid, const void* zero_page, void* stream);
 const GfOptions& gf_options();          // gf_abi.hip
 extern "C" GF_API void gf_reload_options(void);
 

@@ -38,12 +38,19 @@ constexpr int CD_WAVES = 8, CD_THREADS = 64 * CD_WAVES;
 constexpr int CD_PITCH = 224, CD_SLOTS = 14;                                          // 16-byte slots per pixel / weight row: 12 data + 2 pad
 constexpr int CD_HALO_INSTR = (CD_HH * CD_HW * CD_SLOTS + 63) / 64;                  // 75 wave-instructions of 1 KiB
 constexpr int CD_HALO_BYTES = CD_HALO_INSTR * 1024;                                  // 76800
-constexpr int CD_W_INSTR = CD_C * CD_SLOTS / 64;                                     // 21
-constexpr int CD_W_BYTES = CD_W_INSTR * 1024;                                        // 21504
 constexpr int CD_STAGES = 3;                                                         // weight ring: the tap running, the next one, the one after
 constexpr int CD_EP_BYTES = 16 * 96;                                                 // per wave and pass: 16 pixels x its 48 channels (in the free ring stage)
-constexpr int CD_LDS = CD_HALO_BYTES + CD_STAGES * CD_W_BYTES;                       // 141312
-constexpr int CD_HK = (CD_HALO_INSTR + CD_WAVES - 1) / CD_WAVES, CD_WK = (CD_W_INSTR + CD_WAVES - 1) / CD_WAVES;   // 10, 3
+constexpr int CD_HK = (CD_HALO_INSTR + CD_WAVES - 1) / CD_WAVES;                     // halo DMA instructions per wave: 10
+// NCB = 16-channel blocks of output: 6 (Cout = 96: wave = pixel group w >> 1 x channel half w & 1) or 1 (Cout <= 16, the decoder's RGB
+// head: wave = pixel row w, two 16-pixel blocks; weight rows past Cout come from the zero page)
+template <int NCB> struct CdShape {
+    static constexpr int ROWS = NCB * 16;                                            // weight rows staged per tap
+    static constexpr int W_INSTR = (ROWS * CD_SLOTS + 63) / 64;                      // 21 / 4 wave-instructions per tap
+    static constexpr int W_BYTES = W_INSTR * 1024;                                   // 21504 / 4096
+    static constexpr int WK = (W_INSTR + CD_WAVES - 1) / CD_WAVES;                   // per wave: 3 / 1
+    static constexpr int PB = NCB == 6 ? 4 : 2, CB = NCB == 6 ? 3 : 1;               // per wave: pixel blocks x channel blocks
+    static constexpr int LDS = CD_HALO_BYTES + CD_STAGES * W_BYTES;                  // 141312 / 89088
+};
 
 struct CdArgs {
     const u16* src;     // input frame 0 of the walk = the frame output 0 reads with dt = 0 (history included): [*, H, W, 96]
@@ -53,6 +60,7 @@ struct CdArgs {
     const u16* resid;   // [T_out, H, W, 96] (EPI_BIAS_RESID)
     const u16* zero;    // >= 16 zero bytes
     int H, W, T_out, tseg, tiles_x, tiles_y;
+    int N;              // output channels (96, or <= 16 for the NCB = 1 kernel; out / resid rows are N wide)
     long frame;         // H * W * 96
     long ldw;
 };
@@ -66,15 +74,19 @@ __device__ __forceinline__ void cd_glds16(const void* g, GF_LDS char* l) {
     __builtin_amdgcn_global_load_lds((const GF_GLOBAL void*)g, (GF_LDS void*)l, 16, 0, 0);
 }
 
-template <int EPI>
+template <int EPI, int NCB>
 __global__ __launch_bounds__(CD_THREADS, 2) void conv3d_c96_kernel(const CdArgs p) {
+    using SH = CdShape<NCB>;
+    constexpr int PB = SH::PB, CB = SH::CB, CD_W_INSTR = SH::W_INSTR, CD_W_BYTES = SH::W_BYTES, CD_WK = SH::WK;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     GF_LDS char* lds = (GF_LDS char*)smem;
     GF_LDS char* halo = lds;
     GF_LDS char* wbuf = lds + CD_HALO_BYTES;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wp = wave >> 1, wc = wave & 1;               // pixel group (rows 2 wp, 2 wp + 1), channel half (blocks 3 wc ..)
+    // NCB = 6: pixel group wp (rows 2 wp, 2 wp + 1), channel half wc (blocks 3 wc ..); NCB = 1: pixel row wp = wave, one channel block
+    const int wp = NCB == 6 ? wave >> 1 : wave, wc = NCB == 6 ? wave & 1 : 0;
+    const int row0 = NCB == 6 ? 2 * wp : wp;
     const int l15 = lane & 15, kc = lane >> 4;
 
     const int spatial = p.tiles_x * p.tiles_y;
@@ -90,17 +102,19 @@ __global__ __launch_bounds__(CD_THREADS, 2) void conv3d_c96_kernel(const CdArgs 
 #pragma unroll
     for (int k = 0; k < CD_WK; ++k) {
         const int slot = (wave + CD_WAVES * k) * 64 + lane;
-        const int n = min(slot / CD_SLOTS, CD_C - 1), sl = min(slot % CD_SLOTS, 11);     // pad slots fetch valid bytes nobody reads
-        woff[k] = (int)(n * p.ldw * 2) + sl * 16;
+        const int n = slot / CD_SLOTS, sl = min(slot % CD_SLOTS, 11);                    // pad slots fetch valid bytes nobody reads
+        woff[k] = n < p.N ? (int)(n * p.ldw * 2) + sl * 16 : -1;                         // rows past Cout: zeros
     }
     auto issue_w = [&](int tap, int stage_off) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < CD_WK; ++k) {
             const int i = wave + CD_WAVES * k;
-            if (i < CD_W_INSTR) cd_glds16((const char*)p.w + woff[k] + tap * (CD_C * 2), wbuf + stage_off + i * 1024);
+            if (i < CD_W_INSTR)
+                cd_glds16(woff[k] < 0 ? (const char*)p.zero : (const char*)p.w + woff[k] + tap * (CD_C * 2), wbuf + stage_off + i * 1024);
         }
     };
-    const bool three = wave + CD_WAVES * 2 < CD_W_INSTR;   // this wave issues 3 (else 2) DMA instructions per tap
+    // DMA instructions this wave issues per tap: 3 or 2 (NCB = 6), 1 or 0 (NCB = 1) — what the counted wait leaves in flight
+    const bool more = wave + CD_WAVES * (CD_WK - 1) < CD_W_INSTR;
     auto issue_halo = [&](int g, int lane_v) __attribute__((always_inline)) {
         const char* base = (const char*)(p.src + (long)g * p.frame);
 #pragma unroll
@@ -119,16 +133,18 @@ __global__ __launch_bounds__(CD_THREADS, 2) void conv3d_c96_kernel(const CdArgs 
 
     // fragment read bases: lane (row l15, k chunk kc) of a 16-row x 32-channel fragment
     const int lane_off = l15 * CD_PITCH + kc * 16;
-    GF_LDS char* const a_base = halo + lane_off + 2 * wp * CD_HW * CD_PITCH;
-    GF_LDS char* const b_base = wbuf + lane_off + 3 * wc * 16 * CD_PITCH;
+    GF_LDS char* const a_base = halo + lane_off + row0 * CD_HW * CD_PITCH;
+    GF_LDS char* const b_base = wbuf + lane_off + CB * wc * 16 * CD_PITCH;
+    // pixel block b of this wave inside the halo image: NCB = 6: row b >> 1, x (b & 1) * 16; NCB = 1: x 16 b
+    auto blk_off = [](int b) { return NCB == 6 ? ((b >> 1) * CD_HW + (b & 1) * 16) * CD_PITCH : b * 16 * CD_PITCH; };
 
-    f32x4 acc[3][4][3];
+    f32x4 acc[3][PB][CB];
 #pragma unroll
     for (int s = 0; s < 3; ++s)
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < PB; ++b)
 #pragma unroll
-            for (int cb = 0; cb < 3; ++cb) acc[s][b][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int cb = 0; cb < CB; ++cb) acc[s][b][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // The weight ring: three stages.  An LDS-DMA piece takes ~1.1 us from issue to landing under load — two taps of this
     // workgroup's MFMA time — so a tap's weights are requested TWO taps ahead and the counted wait at a tap's start leaves the
@@ -148,8 +164,13 @@ __global__ __launch_bounds__(CD_THREADS, 2) void conv3d_c96_kernel(const CdArgs 
 #elif CD_WHATIF & 2
                 asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
 #else
-                if (three) CD_WAIT_BARRIER(3);
-                else CD_WAIT_BARRIER(2);
+                if constexpr (NCB == 6) {
+                    if (more) CD_WAIT_BARRIER(3);
+                    else CD_WAIT_BARRIER(2);
+                } else {
+                    if (more) CD_WAIT_BARRIER(1);
+                    else CD_WAIT_BARRIER(0);
+                }
 #endif
             }
 #if !(CD_WHATIF & 4)
@@ -162,12 +183,12 @@ __global__ __launch_bounds__(CD_THREADS, 2) void conv3d_c96_kernel(const CdArgs 
                 GF_LDS char* const baddr = b_base + st_cur;
                 // fragments of k step ks + 1 are requested before the 12 MFMAs of k step ks (two register sets; the scheduling
                 // barriers keep hipcc from sinking each read next to its use behind an lgkmcnt(0))
-                bf16x8 af[2][4], bfr[2][3];
+                bf16x8 af[2][PB], bfr[2][CB];
                 auto load = [&](int ks, int set) __attribute__((always_inline)) {
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) af[set][b] = *(GF_LDS bf16x8*)(aaddr + ((b >> 1) * CD_HW + (b & 1) * 16) * CD_PITCH + ks * 64);
+                    for (int b = 0; b < PB; ++b) af[set][b] = *(GF_LDS bf16x8*)(aaddr + blk_off(b) + ks * 64);
 #pragma unroll
-                    for (int cb = 0; cb < 3; ++cb) bfr[set][cb] = *(GF_LDS bf16x8*)(baddr + cb * 16 * CD_PITCH + ks * 64);
+                    for (int cb = 0; cb < CB; ++cb) bfr[set][cb] = *(GF_LDS bf16x8*)(baddr + cb * 16 * CD_PITCH + ks * 64);
                 };
                 load(0, 0);
 #pragma unroll
@@ -175,9 +196,9 @@ __global__ __launch_bounds__(CD_THREADS, 2) void conv3d_c96_kernel(const CdArgs 
                     if (ks < 2) load(ks + 1, (ks + 1) & 1);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int b = 0; b < 4; ++b)
+                    for (int b = 0; b < PB; ++b)
 #pragma unroll
-                        for (int cb = 0; cb < 3; ++cb)
+                        for (int cb = 0; cb < CB; ++cb)
                             acc[SET][b][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks & 1][cb], af[ks & 1][b], acc[SET][b][cb], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -188,15 +209,51 @@ __global__ __launch_bounds__(CD_THREADS, 2) void conv3d_c96_kernel(const CdArgs 
             st_free = t;
         }
     };
-    // this lane's bias values: channels (3 wc + cb) * 16 + 4 kc .. + 3
-    u16x4 bias4[3];
+    // this lane's bias values: channels (CB wc + cb) * 16 + 4 kc .. + 3
+    u16x4 bias4[CB];
 #pragma unroll
-    for (int cb = 0; cb < 3; ++cb) bias4[cb] = p.bias ? *reinterpret_cast<const u16x4*>(p.bias + (3 * wc + cb) * 16 + kc * 4) : u16x4{0, 0, 0, 0};
-    // Output frame j is complete in set 2: bias (+ residual), out.  Four passes of one 16-pixel block x this wave's 48 channels through
-    // the FREE stage of the weight ring (nothing is requested into it before the frame's first tap).  The residual pieces are
-    // requested FIRST and the next halo's DMA behind them (`after_loads`): vmcnt retires in order, so a load issued behind the DMA
-    // would make the epilogue wait for the whole halo.
+    for (int cb = 0; cb < CB; ++cb) {
+        const int n = (CB * wc + cb) * 16 + kc * 4;
+        bias4[cb] = (p.bias && n < p.N) ? *reinterpret_cast<const u16x4*>(p.bias + n) : u16x4{0, 0, 0, 0};
+    }
+    // Output frame j is complete in set 2: bias (+ residual), out.
+    //   NCB = 6: four passes of one 16-pixel block x this wave's 48 channels through the FREE stage of the weight ring (nothing is
+    //   requested into it before the frame's first tap), out as 16-byte pieces.  The residual pieces are requested FIRST and the
+    //   next halo's DMA behind them (`after_loads`): vmcnt retires in order, so a load issued behind the DMA would make the epilogue
+    //   wait for the whole halo.
+    //   NCB = 1: a lane holds channels 4 kc .. 4 kc + 3 of its pixel — 8 bytes of the pixel's N-channel row, stored as they are.
     auto epilogue = [&](int j, auto&& after_loads) __attribute__((always_inline)) {
+        if constexpr (NCB == 1) {
+            u32x2 rr[PB];
+            long offs[PB];
+            bool okk[PB];
+#pragma unroll
+            for (int b = 0; b < PB; ++b) {
+                const int y = y0 + wp, x = x0 + b * 16 + l15;
+                okk[b] = y < p.H && x < p.W && kc * 4 < p.N;
+                offs[b] = (((long)j * p.H + y) * p.W + x) * p.N + kc * 4;
+                if constexpr (EPI == GF_EPI_BIAS_RESID) {
+                    if (okk[b]) rr[b] = *reinterpret_cast<const u32x2*>(p.resid + offs[b]);
+                }
+            }
+            after_loads();
+#pragma unroll
+            for (int b = 0; b < PB; ++b) {
+                const f32x4 a = acc[2][b][0];
+                u32x2 pk;
+                pk[0] = pack2bf(a[0] + bf2f(bias4[0][0]), a[1] + bf2f(bias4[0][1]));
+                pk[1] = pack2bf(a[2] + bf2f(bias4[0][2]), a[3] + bf2f(bias4[0][3]));
+                if constexpr (EPI == GF_EPI_BIAS_RESID) {
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        const float lo = bf2f((u16)(rr[b][h2] & 0xffffu)) + bf2f((u16)(pk[h2] & 0xffffu));
+                        const float hi = bf2f((u16)(rr[b][h2] >> 16)) + bf2f((u16)(pk[h2] >> 16));
+                        pk[h2] = pack2bf(lo, hi);
+                    }
+                }
+                if (okk[b]) *reinterpret_cast<u32x2*>(p.out + offs[b]) = pk;
+            }
+        } else {
         GF_LDS char* ep = wbuf + st_free + wave * CD_EP_BYTES;
         u16x8 rres[4][2];
         long offs[4][2];
@@ -242,15 +299,16 @@ __global__ __launch_bounds__(CD_THREADS, 2) void conv3d_c96_kernel(const CdArgs 
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the image is rewritten by the next block
         }
+        }
     };
     // The sets are named by temporal tap: set dt collects output frame g - dt while input frame g is processed.  At the start of a
     // frame step set 2 holds the output completed by the previous frame: it is stored (under the new halo's DMA), then the sets
     // move up one place (register moves: 96 per frame and lane against 972 MFMAs) and set 0 starts the new output frame from 0.
     auto rotate = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < PB; ++b)
 #pragma unroll
-            for (int cb = 0; cb < 3; ++cb) {
+            for (int cb = 0; cb < CB; ++cb) {
                 acc[2][b][cb] = acc[1][b][cb];
                 acc[1][b][cb] = acc[0][b][cb];
                 acc[0][b][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -275,29 +333,32 @@ __global__ __launch_bounds__(CD_THREADS, 2) void conv3d_c96_kernel(const CdArgs 
     epilogue(j1 - 1, []() {});                             // the segment's last output frame finished with input j1 + 1 (set 2)
 }
 
-template <int EPI>
+template <int EPI, int NCB>
 int launch_cd(const CdArgs& a, unsigned grid, hipStream_t stream) {
     static GfDeviceOnce once;
     hipError_t e = gf_once_per_device(once, [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_c96_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, CD_LDS);
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_c96_kernel<EPI, NCB>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   CdShape<NCB>::LDS);
     });
     if (e != hipSuccess) {
-        gf_set_error("gf_conv3d_bf16 (direct): hipFuncSetAttribute(%d B LDS) failed: %s", CD_LDS, hipGetErrorString(e));
+        gf_set_error("gf_conv3d_bf16 (direct): hipFuncSetAttribute(%d B LDS) failed: %s", CdShape<NCB>::LDS, hipGetErrorString(e));
         return GF_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL((conv3d_c96_kernel<EPI>), dim3(grid), dim3(CD_THREADS), CD_LDS, stream, a);
+    hipLaunchKernelGGL((conv3d_c96_kernel<EPI, NCB>), dim3(grid), dim3(CD_THREADS), CdShape<NCB>::LDS, stream, a);
     GF_CHECK_LAUNCH("gf_conv3d_bf16 (direct)");
     return GF_OK;
 }
 
 }  // namespace
 
-// Called by gf_conv3d_bf16 (gf_gemm.hip) for: kt = ks = 3, stride 1, no resampling, history in front of src, C = N = 96, contiguous
-// out / resid rows.  `src_walk` = the frame output 0 reads with its FIRST temporal tap.  Returns GF_ERR_UNSUPPORTED when the shape
-// is outside what the kernel covers (the caller then takes the implicit GEMM).
+// Called by gf_conv3d_bf16 (gf_gemm.hip) for: kt = ks = 3, stride 1, no resampling, history in front of src, C = 96, N = 96 or
+// N <= 16 (the decoder's RGB head), contiguous out / resid rows of N channels.  `src_walk` = the frame output 0 reads with its
+// FIRST temporal tap.  Returns GF_ERR_UNSUPPORTED when the shape is outside what the kernels cover (the caller then takes the
+// implicit GEMM).
 int gf_conv3d_direct_c96(const void* src_walk, const void* Wm, int64_t ldw, const void* bias, void* out, int64_t T_out, int64_t H,
-                         int64_t W, int epilogue, const void* resid, const void* zero_page, void* stream) {
+                         int64_t W, int64_t N, int epilogue, const void* resid, const void* zero_page, void* stream) {
     if (H * W * CD_C * 2 >= (1LL << 31) || ldw * 2 * CD_C >= (1LL << 31) || T_out <= 0) return GF_ERR_UNSUPPORTED;
+    if (!(N == CD_C || (N <= 16 && N % 4 == 0))) return GF_ERR_UNSUPPORTED;
     CdArgs a;
     a.src = (const u16*)src_walk;
     a.w = (const u16*)Wm;
@@ -308,6 +369,7 @@ int gf_conv3d_direct_c96(const void* src_walk, const void* Wm, int64_t ldw, cons
     a.H = (int)H;
     a.W = (int)W;
     a.T_out = (int)T_out;
+    a.N = (int)N;
     a.tiles_x = (int)((W + CD_TW - 1) / CD_TW);
     a.tiles_y = (int)((H + CD_TH - 1) / CD_TH);
     a.frame = H * W * CD_C;
@@ -322,5 +384,6 @@ int gf_conv3d_direct_c96(const void* src_walk, const void* Wm, int64_t ldw, cons
     nseg = (T_out + a.tseg - 1) / a.tseg;
     const unsigned grid = (unsigned)(spatial * nseg);
     hipStream_t s = (hipStream_t)stream;
-    return epilogue == GF_EPI_BIAS_RESID ? launch_cd<GF_EPI_BIAS_RESID>(a, grid, s) : launch_cd<GF_EPI_BIAS>(a, grid, s);
+    if (N == CD_C) return epilogue == GF_EPI_BIAS_RESID ? launch_cd<GF_EPI_BIAS_RESID, 6>(a, grid, s) : launch_cd<GF_EPI_BIAS, 6>(a, grid, s);
+    return epilogue == GF_EPI_BIAS_RESID ? launch_cd<GF_EPI_BIAS_RESID, 1>(a, grid, s) : launch_cd<GF_EPI_BIAS, 1>(a, grid, s);
 }

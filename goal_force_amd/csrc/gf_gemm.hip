@@ -865,7 +865,7 @@ __global__ __launch_bounds__(A4_THREADS, 1) void gemm_a4_kernel(const GemmArgs p
     }
     // fp8: the activation scales of this lane's eight rows (one per 16-row block), requested before the K loop as well
     float rsc[FP8 ? 8 : 1];
-    if constexpr (FP8) {
+    if constexpr (FP8 && EPI != GF_EPI_VT32) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) rsc[i] = p.row_scale[min(m0 + wm * 128 + i * 16 + (lane & 15), p.M - 1)];
     }
@@ -928,6 +928,16 @@ __global__ __launch_bounds__(A4_THREADS, 1) void gemm_a4_kernel(const GemmArgs p
             }
         }
     }
+    // fp8 V^T projection: the tokens' activation scales of this lane's 8 x 4 columns (zeros past the last token)
+    f32x4 csc[(FP8 && EPI == GF_EPI_VT32) ? 8 : 1];
+    if constexpr (FP8 && EPI == GF_EPI_VT32) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int n = n0 + wn * 128 + j * 16 + fq * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) csc[j][r] = (n + r < p.wrows) ? p.row_scale[n + r] : 0.f;
+        }
+    }
     a4_static_for<0, 8>([&](auto j_c) {
         constexpr int j = decltype(j_c)::value;
         const int n = n0 + wn * 128 + j * 16 + fq * 4;
@@ -936,14 +946,19 @@ __global__ __launch_bounds__(A4_THREADS, 1) void gemm_a4_kernel(const GemmArgs p
             constexpr int i = decltype(i_c)::value;
             constexpr int A0 = (i * 8 + j) * 4;
             float y[4] = {a4_acc<A0>(), a4_acc<A0 + 1>(), a4_acc<A0 + 2>(), a4_acc<A0 + 3>()};
-            if constexpr (FP8) {   // x scale_a of the row, + bias: the same expression as the 8-wave fp8 kernel (gemm_kernel<EPI, true>)
+            if constexpr (FP8 && EPI != GF_EPI_VT32) {   // x scale_a of the row, + bias: the same expression as the 8-wave fp8 kernel (gemm_kernel<EPI, true>)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) y[r] = y[r] * rsc[i] + bv[r];
             }
             if constexpr (EPI == GF_EPI_VT32) {   // bias of the ROW (output feature); key columns that do not exist are zero
                 const float bm = bf2f(bpre[i][0]);       // requested before the K loop (0 where there is no bias / no row)
+                if constexpr (FP8) {   // operands swapped: the activation's scale_a belongs to the COLUMN (token); same x scale + bias expression
 #pragma unroll
-                for (int r = 0; r < 4; ++r) y[r] = (n + r < p.wrows) ? y[r] + bm : 0.f;
+                    for (int r = 0; r < 4; ++r) y[r] = (n + r < p.wrows) ? y[r] * csc[j][r] + bm : 0.f;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y[r] = (n + r < p.wrows) ? y[r] + bm : 0.f;
+                }
             } else if constexpr (EPI == GF_EPI_BIAS_GELU_TANH) {
                 // the Linear's output rounded to bf16 (one v_cvt_pk per pair, unpacked by a shift and a mask), then GELU on the lane's
                 // four values together — the same operations as gf_epi_act<GELU>, about half the issue slots (FFN1's epilogue cost it 6 %)
@@ -1518,6 +1533,44 @@ extern "C" GF_API int gf_linear_vt32(const void* x, int64_t ldx, const void* w, 
     return launch_gemm_a4<GF_EPI_VT32>(a, (hipStream_t)stream);
 }
 
+// gf_linear_vt32 on the fp8_linear contract (BASELINE config 5): x8 / w8 are e4m3 bytes, x_scale the tokens' activation scales
+// (gf_quant_fp8_rowscale / gf_layernorm_modulate_fp8); vt[n][pos(s)] = bf16(sum_k x8[s,k] w8[n,k] * x_scale[s] + bias[n]) —
+// bit-identical to gf_gemm_fp8(x8, w8, x_scale, bias) followed by gf_transpose_v32 (same kernel, operands swapped, K rotation by
+// row tile).
+extern "C" GF_API int gf_linear_vt32_fp8(const void* x8, int64_t ldx, const float* x_scale, const void* w8, int64_t ldw, const void* bias,
+                                         void* vt, int64_t kv_len, int64_t kv_pad, int64_t N, int64_t K, void* stream) {
+    GF_CHECK_ARG(x8 && w8 && vt && x_scale, "gf_linear_vt32_fp8: null x8/w8/vt/x_scale");
+    GF_CHECK_ARG(kv_len > 0 && kv_pad >= kv_len && kv_pad % 64 == 0 && kv_pad - kv_len < 64, "gf_linear_vt32_fp8: kv_pad = kv_len rounded up to 64");
+    GF_CHECK_ARG(N >= 512 && N % 128 == 0 && K > 0 && K % 128 == 0, "gf_linear_vt32_fp8: N=%ld (>= 512, multiple of 128), K=%ld (multiple of 128)", (long)N, (long)K);
+    GF_CHECK_ARG(ldx % 16 == 0 && ldw % 16 == 0 && ldx >= K && ldw >= K, "gf_linear_vt32_fp8: leading dimensions must be multiples of 16 covering K");
+    GF_CHECK_ARG(gf_aligned16(x8) && gf_aligned16(w8) && gf_aligned16(vt) && (!bias || ((uintptr_t)bias & 1u) == 0), "gf_linear_vt32_fp8: alignment");
+    GF_CHECK_ARG(N * kv_pad < (1LL << 31) && 256L * ldx + K < (1L << 31) && 256L * ldw + K < (1L << 31),
+                 "gf_linear_vt32_fp8: operand too large for 32-bit staging offsets");
+    GemmArgs a;
+    a.A = (const u16*)w8;
+    a.W = (const u16*)x8;
+    a.bias = (const u16*)bias;
+    a.C = (u16*)vt;
+    a.R = nullptr;
+    a.gate = nullptr;
+    a.row_scale = x_scale;
+    a.M = (int)N;
+    a.N = (int)kv_pad;
+    a.K = (int)K;
+    a.lda = ldw;
+    a.ldw = ldx;
+    a.ldc = kv_pad;
+    a.ldr = 0;
+    a.tiles_m = (int)((N + BM - 1) / BM);
+    a.tiles_n = (int)((kv_pad + BN - 1) / BN);
+    a.dbg = nullptr;
+    a.whatif = 0;
+    a.stagger = gf_options().a4_stagger.load(std::memory_order_relaxed);
+    a.wrows = (int)kv_len;
+    a.stagger_rows = 1;
+    return launch_gemm_a4<GF_EPI_VT32, true>(a, (hipStream_t)stream);
+}
+
 // Causal 3-D / 2-D convolution of the Wan VAE as ONE implicit GEMM (no patch matrix in HBM): out[(j, Y, X), n] =
 // bias[n] + sum over (dt, dy, dx, c) of in[t_off + j*t_stride - (kt-1) + dt, Y', X', c] * Wm[n, ((dt*ks + dy)*ks + dx)*C + c]
 // with the gather rules of gf_vae_im2col (mode 0 / 1 / 2), frames < 0 taken from `cache` (its 2 frames are frames -2, -1).
@@ -1599,10 +1652,10 @@ extern "C" GF_API int gf_conv3d_bf16(const void* src, const void* cache, const v
     a.cv.hist_front = (kt == 3 && !cache) ? 1 : 0;
     // the 96-channel full-resolution level (ResidualBlock convolutions with their history in front of src): direct convolution,
     // bit-identical to the implicit GEMM below (gf_conv_direct.hip; GF_CONV_DIRECT=0 switches it off)
-    if (kt == 3 && ks == 3 && mode == 0 && !cache && t_stride == 1 && C == 96 && N == 96 && ldc == 96 &&
-        (epilogue == GF_EPI_BIAS || ldr == 96) && gf_options().conv_direct.load(std::memory_order_relaxed)) {
+    if (kt == 3 && ks == 3 && mode == 0 && !cache && t_stride == 1 && C == 96 && (N == 96 || N <= 16) && ldc == N &&
+        (epilogue == GF_EPI_BIAS || ldr == N) && gf_options().conv_direct.load(std::memory_order_relaxed)) {
         const u16* walk = (const u16*)src + (long)(t_off - 2) * H * W * C;
-        const int rc = gf_conv3d_direct_c96(walk, Wm, ldw, bias, out, T_out, H, W, epilogue, resid, a.cv.zero, stream);
+        const int rc = gf_conv3d_direct_c96(walk, Wm, ldw, bias, out, T_out, H, W, N, epilogue, resid, a.cv.zero, stream);
         if (rc != GF_ERR_UNSUPPORTED) return rc;
     }
     // contiguous source frames and stride-1 taps: the pointer-per-row gather (GF_CONV_GATHER=1 forces the general one, A/B)

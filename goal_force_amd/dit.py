@@ -226,6 +226,13 @@ class SelfAttention(nn.Module):
             # inference on one GPU: nothing but the attention reads V, so the projection writes it straight in the layout the
             # attention kernel wants (gf_linear_vt32: same bits as the plain projection + the transpose, one pass over V less)
             return ops.flash_attn(q, k, None, self.num_heads, vt=ops.linear_vt32(x2, self.v.weight, self.v.bias))
+        if sp is None and keep is None and fp8 and xin.is_cuda and self.v.weight.shape[0] >= 512 and self.v.weight.shape[1] % 128 == 0 \
+                and ops.vt32_ok(xin.shape[0], self.num_heads, self.head_dim):
+            # config 5 on one GPU: the fp8 V projection writes the attention kernel's V^T operand as well (gf_linear_vt32_fp8)
+            if self.v._gf_w8_key != param_key(self.v.weight):
+                self.v._gf_w8 = ops.cast_fp8(self.v.weight.detach().contiguous())
+                self.v._gf_w8_key = param_key(self.v.weight)
+            return ops.flash_attn(q, k, None, self.num_heads, vt=ops.linear_vt32_fp8(xin.x8, xin.scale, self.v._gf_w8, self.v.bias))
         v = linear(xin, self.v)
         if sp is not None:
             return sp.attention(q, k, v, self.num_heads)

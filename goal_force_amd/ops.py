@@ -259,6 +259,29 @@ def linear_vt32(x, weight, bias):
     return vt
 
 
+def linear_vt32_fp8(x8, x_scale, w8, bias):
+    """linear_vt32 on the fp8_linear contract (config 5): x8 [S, K] float8_e4m3fn + its row scales, w8 [N, K] float8_e4m3fn ->
+    the V^T workspace (gf_linear_vt32_fp8); same bits as gemm_fp8(x8, x_scale, w8, bias) followed by the transpose."""
+    _req(x8, "linear_vt32_fp8.x8", _FP8)
+    _req(w8, "linear_vt32_fp8.w8", _FP8)
+    _req(x_scale, "linear_vt32_fp8.x_scale", torch.float32)
+    if x8.dim() != 2 or w8.dim() != 2 or x8.stride(1) != 1 or w8.stride(1) != 1 or x8.shape[1] != w8.shape[1]:
+        raise GoalForceError("linear_vt32_fp8: x8 [S,K], w8 [N,K] with contiguous rows expected")
+    skv, K = x8.shape
+    N = w8.shape[0]
+    if x_scale.numel() != skv or not x_scale.is_contiguous():
+        raise GoalForceError("linear_vt32_fp8.x_scale: contiguous [S] expected")
+    if bias is not None:
+        _req(bias, "linear_vt32_fp8.bias")
+        if bias.numel() != N or not bias.is_contiguous():
+            raise GoalForceError(f"linear_vt32_fp8.bias: expected contiguous [{N}]")
+    kv_pad = -(-skv // 64) * 64
+    vt = _vt_workspace(N * kv_pad, x8.device)
+    _lib.check(_lib.load().gf_linear_vt32_fp8(_ptr(x8), x8.stride(0), _ptr(x_scale), _ptr(w8), w8.stride(0), _ptr(bias), _ptr(vt), skv,
+                                              kv_pad, N, K, _stream(x8)), "gf_linear_vt32_fp8")
+    return vt
+
+
 def flash_attn(q, k, v, num_heads, out=None, scale=None, vt=None):
     """softmax(q k^T / sqrt(d)) v per head; q [Sq, H*128], k/v [Skv, H*128] (row-strided views OK).  `vt` (instead of v): the
     V^T operand linear_vt32 produced for these keys."""

@@ -370,6 +370,12 @@ GF_API int gf_layernorm_modulate_fp8(const void* x, void* out8, float* scale, co
                                      const void* scale1p, const void* shift, int64_t rows, int64_t dim,
                                      int64_t x_stride, int64_t out_stride, float eps, void* stream);
 
+/* gf_linear_vt32_fp8 — gf_linear_vt32 on the fp8_linear contract: the V projection of a self-attention under config 5 written
+ * directly as attention kernel 3's V^T operand.  x8 [kv_len, K] / w8 [N, K] e4m3 bytes, x_scale [kv_len] fp32 (the tokens'
+ * activation scales); bit-identical to gf_gemm_fp8 + gf_transpose_v32.  N >= 512, N % 128 == 0, K % 128 == 0. */
+GF_API int gf_linear_vt32_fp8(const void* x8, int64_t ldx, const float* x_scale, const void* w8, int64_t ldw, const void* bias,
+                              void* vt, int64_t kv_len, int64_t kv_pad, int64_t N, int64_t K, void* stream);
+
 /* gf_cast_fp8 — bf16 -> e4m3 elementwise (weight.to(float8_e4m3fn), VRAM:138); n % 8 == 0. */
 GF_API int gf_cast_fp8(const void* x, void* out8, int64_t n, void* stream);
 

@@ -275,3 +275,40 @@ def test_hip_layernorm_fp8_fusion_is_bit_identical(dim, kind):
     assert torch.equal(got8.view(torch.uint8), want8.view(torch.uint8))
     if kind == "modulate":
         assert float(wants.max()) > 1.0, "the case must exercise scale_a > 1"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("skv,n,k", [(2100, 512, 256), (4100, 1024, 384), (32760, 5120, 5120)])
+def test_hip_fp8_linear_vt32_is_projection_plus_transpose_bit_for_bit(skv, n, k):
+    """gf_linear_vt32_fp8 (config 5's V projection written as attention kernel 3's V^T operand: the 4-wave fp8 GEMM with the
+    operands swapped, the tokens' activation scales applied per COLUMN) against the path it replaces, gf_gemm_fp8 then
+    gf_transpose_v32 — the same bits, zero key columns from kv_len to kv_pad included; and SelfAttention.attend under enable_fp8
+    with it == with the plain fp8 projection + transpose (GF_VT_FROM_GEMM=0)."""
+    from goal_force_amd import _lib, ops
+    g = torch.Generator().manual_seed(skv + n)
+    x = (torch.randn((skv, k), generator=g) * 2).to(BF).cuda()
+    x[11, 3] = 1800.0                                                      # one token with scale_a > 1
+    w8 = ops.cast_fp8((torch.randn((n, k), generator=g) * 0.05).to(BF).cuda())
+    b = torch.randn((n,), generator=g).to(BF).cuda()
+    x8, s = ops.quant_fp8_rowscale(x)
+    kv_pad = -(-skv // 64) * 64
+    v = ops.gemm_fp8(x8, s, w8, b)
+    want = torch.full((n * kv_pad,), 7.0, dtype=BF, device="cuda")
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.gf_transpose_v32(v.data_ptr(), v.stride(0), want.data_ptr(), skv, kv_pad, n // 128, st) == 0
+    got = ops.linear_vt32_fp8(x8, s, w8, b)[: n * kv_pad].clone()
+    torch.cuda.synchronize()
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    if n == 512:
+        from goal_force_amd.dit import RopeTable, SelfAttention, enable_fp8, DiTBlock
+        torch.manual_seed(3)
+        blk = enable_fp8(DiTBlock(False, 512, 4, 1024).to(BF).cuda())
+        sa = blk.self_attn
+        xa = (torch.randn((skv, 512), generator=g) * 0.5).to(BF).cuda()
+        pos = torch.arange(skv, dtype=torch.float32)[:, None] * torch.arange(1, 65, dtype=torch.float32)[None, :] * 1e-3
+        rope = RopeTable(torch.polar(torch.ones_like(pos), pos), "cuda")
+        a = sa.attend(xa, rope)
+        with ops.env_options(GF_VT_FROM_GEMM="0"):
+            bb = sa.attend(xa, rope)
+        assert torch.equal(a, bb)

@@ -159,7 +159,8 @@ def test_hip_implicit_conv_bit_identical_to_im2col_gemm(case):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("T,H,W,C,N,ks", [(3, 9, 11, 96, 96, 3), (5, 18, 20, 96, 8, 3), (2, 6, 5, 32, 64, 1), (4, 13, 7, 192, 192, 3),
-                                          (1, 5, 5, 16, 24, 3), (9, 20, 70, 96, 96, 3), (22, 13, 33, 96, 96, 3), (1, 6, 32, 96, 96, 3)])
+                                          (1, 5, 5, 16, 24, 3), (9, 20, 70, 96, 96, 3), (22, 13, 33, 96, 96, 3), (1, 6, 32, 96, 96, 3),
+                                          (7, 30, 45, 96, 8, 3), (3, 9, 40, 96, 16, 3), (13, 8, 32, 96, 8, 3)])
 def test_hip_conv_history_in_front_bit_identical(T, H, W, C, N, ks):
     """The pointer-per-row gather (history frames in front of src, one buffer) == the general gather with a separate cache
     == gf_vae_im2col + gf_gemm_bf16, bit for bit, with and without a residual."""
