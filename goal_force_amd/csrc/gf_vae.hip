@@ -146,17 +146,33 @@ __global__ __launch_bounds__(VT) void rmsnorm_silu_kernel(const u16* __restrict_
 #pragma unroll
         for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
         const float nrm = fmaxf(rbf(sqrtf(s)), 1e-12f);  // x.norm(2, dim).clamp_min(eps), bf16 tensor
+        // x / norm: ONE correctly rounded reciprocal per row, then a multiply per value.  Bit-identical to the division after the
+        // bf16 rounding that follows: the quotient of two bf16 numbers (8-bit significands mx / mn) is either exactly a bf16 number
+        // or at least 2^-17 (relative) away from every bf16 rounding boundary — mx 2^9 - k mn is a non-zero integer — while x * (1/n)
+        // is within 2^-23 of it; an exact tie cannot occur (it would need a 9-bit quotient of two 8-bit integers' ratio).  The
+        // per-value IEEE division (10 instructions) and expf + division of SiLU made this kernel VALU-bound at 4.4 TB/s.
+        const float rinv = 1.0f / nrm;
         if (live) {
-            u16x8 o;
+            u32x4 o;
+            const u32x4 vv = __builtin_bit_cast(u32x4, v), gg = __builtin_bit_cast(u32x4, g8);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float y = rbf(bf2f(v[j]) / nrm);   // x / norm
-                y = rbf(y * scale);                // * dim**0.5
-                y = rbf(y * bf2f(g8[j]));          // * gamma  (+ bias 0.)
-                if (silu) y = y / (1.0f + expf(-y));
-                o[j] = f2bf(y);
+            for (int p = 0; p < 4; ++p) {                  // values in pairs: one v_cvt_pk_bf16_f32 per rounding and pair
+                float y0 = __uint_as_float(vv[p] << 16) * rinv, y1 = __uint_as_float(vv[p] & 0xffff0000u) * rinv;      // x / norm
+                unsigned r = pack2bf(y0, y1);
+                y0 = __uint_as_float(r << 16) * scale, y1 = __uint_as_float(r & 0xffff0000u) * scale;                    // * dim**0.5
+                r = pack2bf(y0, y1);
+                y0 = __uint_as_float(r << 16) * __uint_as_float(gg[p] << 16);                                            // * gamma (+ bias 0.)
+                y1 = __uint_as_float(r & 0xffff0000u) * __uint_as_float(gg[p] & 0xffff0000u);
+                r = pack2bf(y0, y1);
+                if (silu) {   // x * sigmoid(x) on the bf16 values, exp2 + rcp (a few fp32 ulp, inside the bf16 rounding that follows)
+                    y0 = __uint_as_float(r << 16), y1 = __uint_as_float(r & 0xffff0000u);
+                    const float t0 = __builtin_amdgcn_exp2f(y0 * -1.4426950408889634f), t1 = __builtin_amdgcn_exp2f(y1 * -1.4426950408889634f);
+                    y0 = y0 * __builtin_amdgcn_rcpf(1.0f + t0), y1 = y1 * __builtin_amdgcn_rcpf(1.0f + t1);
+                    r = pack2bf(y0, y1);
+                }
+                o[p] = r;
             }
-            *reinterpret_cast<u16x8*>(out + row * C + (sub << 3)) = o;
+            *reinterpret_cast<u32x4*>(out + row * C + (sub << 3)) = o;
         }
     }
 }

@@ -132,3 +132,21 @@ def test_a4_accumulator_handoff_is_clean_in_the_built_kernel():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_a4_agpr.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("ok  ") >= 13
+
+
+def test_bf16_quotient_equals_product_with_the_rounded_reciprocal():
+    """What gf_vae.hip::rmsnorm_silu_kernel relies on when it replaces x / norm (one IEEE division per value) by x * (1 / norm)
+    (one division per row): for bf16 x and norm, bf16(fp32(x / n)) == bf16(fp32(x * fp32(1 / n))).  The quotient of two 8-bit
+    significands is either exactly a bf16 number or at least 2^-17 away from every bf16 rounding boundary, so the 2^-23 error of
+    the product cannot flip the rounding.  Checked here for EVERY pair of significands over a range of exponents."""
+    import torch
+    BF = torch.bfloat16
+    mant = torch.arange(128, 256, dtype=torch.float32) / 128.0                      # all normalised 8-bit significands in [1, 2)
+    exps = 2.0 ** torch.arange(-6, 7, dtype=torch.float32)
+    x = (mant[:, None] * exps[None, :]).reshape(-1)
+    x = torch.cat([x, -x, torch.zeros(1)])
+    n = (mant[:, None] * exps[None, :]).reshape(-1)
+    assert torch.equal(x.to(BF).float(), x) and torch.equal(n.to(BF).float(), n)   # all exactly bf16
+    q = (x[:, None] / n[None, :]).to(BF)
+    p = (x[:, None] * (1.0 / n)[None, :]).to(BF)
+    assert torch.equal(q.view(torch.int16), p.view(torch.int16))
