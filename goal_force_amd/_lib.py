@@ -23,7 +23,7 @@ SYMBOLS = (
     "gf_vae_prep_latent", "gf_vae_im2col", "gf_vae_finish_latent", "gf_vae_rmsnorm_silu", "gf_softmax_rows", "gf_transpose_pad",
     "gf_vae_tile_blend", "gf_vae_tile_finalize",
     "gf_quant_fp8_rowscale", "gf_cast_fp8", "gf_gemm_fp8", "gf_layernorm_modulate_fp8", "gf_modulate", "gf_rope_apply", "gf_linear_vt32_fp8",
-    "gf_flash_attn_fwd_lse", "gf_flash_attn_bwd",
+    "gf_flash_attn_fwd_lse", "gf_flash_attn_bwd", "gf_flash_attn_bwd_workspace_bytes",
     "gf_layernorm_bwd", "gf_rmsnorm_rope_bwd", "gf_colsum", "gf_act_bwd", "gf_mse_loss", "gf_adamw_step", "gf_f32_to_bf16", "gf_sumsq",
     "gf_transpose_v", "gf_flash_attn_fwd_vt", "gf_transpose_v32", "gf_flash_attn_fwd_vt32", "gf_linear_vt32",
     "gf_conv3d_bf16",
@@ -59,6 +59,7 @@ def _declare(lib):
         "gf_flash_attn_fwd": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _vp],
         "gf_flash_attn_fwd_lse": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _vp],
         "gf_flash_attn_bwd": [_vp] * 10 + [_i64] * 12 + [_f32, _vp],
+        "gf_flash_attn_bwd_workspace_bytes": [_i64] * 3,
         "gf_layernorm_bwd": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _f32, _vp],
         "gf_rmsnorm_rope_bwd": [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _f32, _vp],
         "gf_colsum": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i64, _vp],
@@ -99,7 +100,7 @@ def _declare(lib):
     }
     for name, argtypes in sigs.items():
         fn = getattr(lib, name)
-        fn.restype = _int
+        fn.restype = _i64 if name.endswith("_bytes") else _int
         fn.argtypes = argtypes
 
 

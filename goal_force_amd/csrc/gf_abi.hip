@@ -6,7 +6,7 @@
 #include <cstring>
 #include <mutex>
 
-#define GF_ABI_VERSION 8
+#define GF_ABI_VERSION 9
 
 static thread_local char g_err[512] = "";
 
@@ -47,7 +47,8 @@ static void load_options() {
     g_options.a4_whatif.store(env_int("GF_A4_WHATIF", 0, 0, 1 << 20), std::memory_order_relaxed);
     const char* ak = getenv("GF_ATTN_KERNEL");
     g_options.attn_kernel1.store((ak && ak[0] == '1') ? 1 : 0, std::memory_order_relaxed);
-    g_options.bwd_fused_dkv.store(env_int("GF_ATTN_BWD_FUSED_DKV", 0, 0, 1), std::memory_order_relaxed);
+    const char* bw = getenv("GF_ATTN_BWD");
+    g_options.bwd_v1.store((bw && bw[0] == 'v' && bw[1] == '1') ? 1 : 0, std::memory_order_relaxed);
     g_options.conv_nb.store(env_int("GF_CONV_NB", 0, 0, 2), std::memory_order_relaxed);
     g_options.conv_gather.store(env_int("GF_CONV_GATHER", 0, 0, 1), std::memory_order_relaxed);
     g_options.conv_direct.store(env_int("GF_CONV_DIRECT", 1, 0, 1), std::memory_order_relaxed);

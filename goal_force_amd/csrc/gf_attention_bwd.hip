@@ -16,24 +16,6 @@
 #include "gf_common.h"
 #include <type_traits>
 
-// Variant switches of the tile bodies (tools/attnbwd_ab.py builds the combinations side by side; round 3, S = 32760 x 40 heads,
-// one process, profiles/r03/attnbwd_ab1.log):
-//   GF_BWD_SEED   1: the score / dP accumulator chains START from -lse / -delta and the register-resident operand is pre-scaled by
-//                    scale log2 e (p = exp2(acc), dS = p * dP': one exp2, one multiply and half a pack per score instead of fma /
-//                    exp2 / subtract / multiply / convert); 0: zero start, p = exp2(fma(S, c, -lse)), dS = p * (dP - delta).
-//                    MEASURED SLOWER (100 ms against 86): the 32 seeded accumulators are live before their chains start, which
-//                    pushes the dQ kernel over the 256 registers of two waves per SIMD (26 spilled dwords reloaded every tile).
-//   GF_BWD_HALVES 1: the tile's two 32-row halves one after the other (32 score / dP accumulators live instead of 64): 88 ms
-//                    against 86 — the compiler re-interleaves the halves anyway and the pressure stays.
-// The ragged last tile is the only one that pays for the bounds compare / select (no effect on the time either: 86.1 against
-// 85.4 ms for round 2's loop) — the kernels are not VALU-bound; what they lack is the forward's pinned tile pipeline.
-#ifndef GF_BWD_SEED
-#define GF_BWD_SEED 0
-#endif
-#ifndef GF_BWD_HALVES
-#define GF_BWD_HALVES 0
-#endif
-
 namespace {
 
 constexpr int KVB = 64, HD = 128;
@@ -134,24 +116,11 @@ __device__ __forceinline__ void zero16(f32x16& a) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) a[e] = 0.f;
 }
-__device__ __forceinline__ void splat16(f32x16& a, float v) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) a[e] = v;
-}
 // 8 fp32 -> one bf16x8 fragment, two values per v_cvt_pk_bf16_f32
 __device__ __forceinline__ bf16x8 pack8(const float (&x)[8]) {
     const u32x4 w = {pack2bf(x[0], x[1]), pack2bf(x[2], x[3]), pack2bf(x[4], x[5]), pack2bf(x[6], x[7])};
     return __builtin_bit_cast(bf16x8, w);
 }
-// operand pre-scaled by c = scale * log2(e) (one rounding to bf16, as the forward's kernel 3 does with Q): the score accumulator
-// is then directly the base-2 exponent
-__device__ __forceinline__ bf16x8 scale8(const bf16x8& v, float c) {
-    float x[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) x[j] = (float)v[j] * c;
-    return pack8(x);
-}
-
 // transposed accumulator acc[d][e] (lane = owned row, register e of block d = column 32d + (e&3) + 8(e>>2) + 4h) -> row of out
 __device__ __forceinline__ void store_rows(u16* rowp, const f32x16 (&acc)[4], float mul, int h) {
 #pragma unroll
@@ -189,15 +158,7 @@ __global__ __launch_bounds__(DQ_THREADS, 2) void attn_bwd_dq_kernel(const BwdArg
     }
     const float lse = p.lse[(long)qr * p.heads + head];
     const float dl = p.delta[(long)qr * p.heads + head];
-    // Q pre-scaled by c = scale log2 e: S' = (c Q) K^T accumulated ON TOP OF -lse (the chain's initial accumulator) is the exponent
-    // itself, and dP accumulated on top of -delta is (dP - delta): p = exp2(S'), dS = p * dP' — per score one v_exp_f32, one multiply
-    // and half a v_cvt_pk instead of fma / exp2 / subtract / multiply / compare / select / convert
-#if GF_BWD_SEED
-#pragma unroll
-    for (int kd = 0; kd < 8; ++kd) qf[kd] = scale8(qf[kd], p.scale_log2e);
-#endif
     const float c = p.scale_log2e;
-    (void)c;
     const FragOffsets fo = frag_offsets(lane);
     f32x16 dq[4];
 #pragma unroll
@@ -222,50 +183,19 @@ __global__ __launch_bounds__(DQ_THREADS, 2) void attn_bwd_dq_kernel(const BwdArg
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int e = 8 * s8 + j;
-#if GF_BWD_SEED
-                    float pr = __builtin_amdgcn_exp2f(sc[e]);
-#else
                     float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[e], c, -lse));
-#endif
                     if constexpr (MASKED) pr = (t * KVB + 32 * half + (e & 3) + 8 * (e >> 2) + 4 * h < p.kv_len) ? pr : 0.f;
-#if GF_BWD_SEED
-                    x[j] = pr * dp[e];
-#else
                     x[j] = pr * (dp[e] - dl);
-#endif
                 }
                 dsf[half][s8] = pack8(x);
             }
         };
-        auto init = [&](f32x16& sc, f32x16& dp) {
-#if GF_BWD_SEED
-            splat16(sc, -lse);
-            splat16(dp, -dl);
-#else
-            zero16(sc);
-            zero16(dp);
-#endif
-        };
-#if GF_BWD_HALVES
-        // one 32-key half at a time: only 32 score / dP accumulators are live beside dQ^T, Q and dO
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            f32x16 sc, dp;
-            init(sc, dp);
-#pragma unroll
-            for (int kd = 0; kd < 8; ++kd) {
-                const bf16x8 kk = *(GF_LDS bf16x8*)(kbuf + fo.row[kd] + half * 32 * 256);
-                const bf16x8 vv = *(GF_LDS bf16x8*)(vbuf + fo.row[kd] + half * 32 * 256);
-                mfma32(sc, kk, qf[kd]);      // S'^T[key, query] = c K Q^T - lse
-                mfma32(dp, vv, dof[kd]);     // dP'^T[key, query] = V dO^T - delta
-            }
-            softmax_half(half, sc, dp);
-        }
-#else
         {
             f32x16 sc[2], dp[2];
-            init(sc[0], dp[0]);
-            init(sc[1], dp[1]);
+            zero16(sc[0]);
+            zero16(sc[1]);
+            zero16(dp[0]);
+            zero16(dp[1]);
 #pragma unroll
             for (int kd = 0; kd < 8; ++kd) {
                 const bf16x8 k0 = *(GF_LDS bf16x8*)(kbuf + fo.row[kd]);
@@ -280,7 +210,6 @@ __global__ __launch_bounds__(DQ_THREADS, 2) void attn_bwd_dq_kernel(const BwdArg
             softmax_half(0, sc[0], dp[0]);
             softmax_half(1, sc[1], dp[1]);
         }
-#endif
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -308,7 +237,7 @@ __global__ __launch_bounds__(DQ_THREADS, 2) void attn_bwd_dq_kernel(const BwdArg
 // recomputes S once more (5 products instead of 4) and still takes less time than PART 0: a lone wave per SIMD leaves the matrix
 // pipe idle through every one of its own waits.
 template <int PART>
-__global__ __launch_bounds__(DKV_THREADS, PART == 0 ? 1 : 2) void attn_bwd_dkv_kernel(const BwdArgs p) {
+__global__ __launch_bounds__(DKV_THREADS, 2) void attn_bwd_dkv_kernel(const BwdArgs p) {
     constexpr bool DO_V = PART != 2, DO_K = PART != 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     GF_LDS char* lds = (GF_LDS char*)smem;
@@ -331,14 +260,7 @@ __global__ __launch_bounds__(DKV_THREADS, PART == 0 ? 1 : 2) void attn_bwd_dkv_k
             if constexpr (DO_K) vf[kd] = *reinterpret_cast<const bf16x8*>(vp + 16 * kd);
         }
     }
-    // K pre-scaled by c = scale log2 e (this wave's own 32 keys, once): with -lse of the tile's queries as the initial accumulator the
-    // score chain ends on the exponent itself; dP starts from -delta.  (The UNSCALED keys are not needed: dK = scale dS^T Q.)
-#if GF_BWD_SEED
-#pragma unroll
-    for (int kd = 0; kd < 8; ++kd) kf[kd] = scale8(kf[kd], p.scale_log2e);
-#endif
     const float c = p.scale_log2e;
-    (void)c;
     const FragOffsets fo = frag_offsets(lane);
     f32x16 dk[4], dv[4];
 #pragma unroll
@@ -365,34 +287,10 @@ __global__ __launch_bounds__(DKV_THREADS, PART == 0 ? 1 : 2) void attn_bwd_dkv_k
         GF_LDS float* lse_s = scal + (t & 1) * 2 * KVB;
         GF_LDS float* dl_s = lse_s + KVB;
         bf16x8 pf[2][2], dsf[2][2];
-        auto init = [&](int half, f32x16& sc, f32x16& dp, f32x16& lsev, f32x16& dlv) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int qi = 32 * half + 8 * g + 4 * h;      // 4 consecutive queries of registers 4g..4g+3
-                const f32x4 l4 = *(GF_LDS f32x4*)(lse_s + qi);
-                f32x4 d4 = {0.f, 0.f, 0.f, 0.f};
-                if constexpr (DO_K) d4 = *(GF_LDS f32x4*)(dl_s + qi);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-#if GF_BWD_SEED
-                    sc[4 * g + i] = -l4[i];
-                    dp[4 * g + i] = -d4[i];
-#else
-                    sc[4 * g + i] = 0.f;
-                    dp[4 * g + i] = 0.f;
-                    (void)l4;
-                    (void)d4;
-                    (void)lsev;
-                    (void)dlv;
-#endif
-                }
-            }
-        };
-        auto softmax_half = [&](int half, const f32x16& sc, const f32x16& dp, const f32x16& lsev, const f32x16& dlv) {
+        auto softmax_half = [&](int half, const f32x16& sc, const f32x16& dp) {
 #pragma unroll
             for (int s8 = 0; s8 < 2; ++s8) {
                 float xp[8], xs[8];
-#if !GF_BWD_SEED     // the rows' lse / delta are read where they are used (4 queries per ds_read_b128), not held across the chains
                 f32x4 l4[2], d4[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
                 for (int g2 = 0; g2 < 2; ++g2) {
@@ -400,48 +298,24 @@ __global__ __launch_bounds__(DKV_THREADS, PART == 0 ? 1 : 2) void attn_bwd_dkv_k
                     l4[g2] = *(GF_LDS f32x4*)(lse_s + qi);
                     if constexpr (DO_K) d4[g2] = *(GF_LDS f32x4*)(dl_s + qi);
                 }
-#endif
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int e = 8 * s8 + j;
-#if GF_BWD_SEED
-                    float pr = __builtin_amdgcn_exp2f(sc[e]);
-#else
                     float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[e], c, -l4[j >> 2][j & 3]));
-#endif
                     if constexpr (MASKED) pr = (t * KVB + 32 * half + 8 * (e >> 2) + 4 * h + (e & 3) < p.q_len) ? pr : 0.f;
                     xp[j] = pr;
-#if GF_BWD_SEED
-                    if constexpr (DO_K) xs[j] = pr * dp[e];
-#else
                     if constexpr (DO_K) xs[j] = pr * (dp[e] - d4[j >> 2][j & 3]);
-#endif
                 }
                 if constexpr (DO_V) pf[half][s8] = pack8(xp);
                 if constexpr (DO_K) dsf[half][s8] = pack8(xs);
             }
         };
-#if GF_BWD_HALVES
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {      // one 32-query half at a time (register pressure, as in the dQ kernel)
-            f32x16 sc, dp, lsev, dlv;
-            init(half, sc, dp, lsev, dlv);
-#pragma unroll
-            for (int kd = 0; kd < 8; ++kd) {
-                const bf16x8 qq = *(GF_LDS bf16x8*)(qbuf + fo.row[kd] + half * 32 * 256);
-                mfma32(sc, qq, kf[kd]);     // S'[query, key] = c Q K^T - lse: lane = key, registers = queries
-                if constexpr (DO_K) {
-                    const bf16x8 dd = *(GF_LDS bf16x8*)(dobuf + fo.row[kd] + half * 32 * 256);
-                    mfma32(dp, dd, vf[kd]);     // dP'[query, key] = dO V^T - delta
-                }
-            }
-            softmax_half(half, sc, dp, lsev, dlv);
-        }
-#else
         {
-            f32x16 sc[2], dp[2], lsev[2], dlv[2];
-            init(0, sc[0], dp[0], lsev[0], dlv[0]);
-            init(1, sc[1], dp[1], lsev[1], dlv[1]);
+            f32x16 sc[2], dp[2];
+            zero16(sc[0]);
+            zero16(sc[1]);
+            zero16(dp[0]);
+            zero16(dp[1]);
 #pragma unroll
             for (int kd = 0; kd < 8; ++kd) {
                 const bf16x8 q0f = *(GF_LDS bf16x8*)(qbuf + fo.row[kd]);
@@ -455,10 +329,9 @@ __global__ __launch_bounds__(DKV_THREADS, PART == 0 ? 1 : 2) void attn_bwd_dkv_k
                     mfma32(dp[1], d1f, vf[kd]);
                 }
             }
-            softmax_half(0, sc[0], dp[0], lsev[0], dlv[0]);
-            softmax_half(1, sc[1], dp[1], lsev[1], dlv[1]);
+            softmax_half(0, sc[0], dp[0]);
+            softmax_half(1, sc[1], dp[1]);
         }
-#endif
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -486,14 +359,573 @@ __global__ __launch_bounds__(DKV_THREADS, PART == 0 ? 1 : 2) void attn_bwd_dkv_k
     }
 }
 
+
+// =====================================================================================================================
+// Round 3: the backward on v_mfma_f32_16x16x32_bf16 (the forward's kernel 3 algebra: 12 % less power per FLOP than 32x32x16 on
+// random data) with 7 tile products instead of 8:
+//   * ONE LDS image per operand tile serves row fragments (ds_read_b128: A = X[16 rows x 32 d]) and transposed fragments (two
+//     ds_read_b64_tr_b16: A = X^T[16 d x 32 rows], rows in the order of a B operand built from two accumulator tiles): rows of 256
+//     bytes, 16-byte chunk c of row r at c ^ 2 (r & 7) — both read shapes touch every bank once.  What limits these kernels is the
+//     LDS-DMA fill rate (a CU takes ~25 GB/s while its MFMAs run): staging each operand once, in one layout, is what counts;
+//   * every LDS-DMA is the buffer form with a per-lane offset computed once and the tile position in the descriptor (no VALU per
+//     request; the first version spent 30 ms of 80 on address arithmetic); rows past the end of a ragged sequence arrive as zeros
+//     (num_records), which also makes masking unnecessary: a padded key / query meets a zero row in the last product;
+//   * dQ: a wave owns 32 queries (two 16-query blocks on the lane) and walks 64-key tiles — S^T = K Q^T, dP^T = V dO^T,
+//     dQ^T += K^T dS^T: 96 MFMAs per tile;
+//   * dK and dV in ONE kernel by wave PAIRS that own the same 32 keys and walk 32-query granules:
+//       wave A: S = Q K^T, P = exp2(c S - lse), P (fp32, accumulator layout) -> LDS hand-off, dV^T += dO^T P;
+//       wave B: dP = dO V^T, dS = P (dP - delta) with the P wave A left one granule earlier, dK^T += Q^T dS.
+//     Each wave keeps 64 accumulator registers + one 32-register operand, so the exp2 of one role overlaps the MFMAs of the other;
+//     S is computed once for dK and dV (the split kernels computed it twice).  B runs one granule behind A: ONE barrier per granule
+//     publishes the landed DMA pieces and the hand-off and frees the ring slots.  Q rows and dO rows in rings of 4 granules
+//     (A reads granule i, B granule i - 1, two more in flight; counted vmcnt), the hand-off double buffered.
+// Arithmetic per element as in the first kernels (p = exp2(fma(S, c, -lse)), dS = p (dP - delta), one rounding to bf16 per MFMA
+// operand); the summation ORDER over keys / queries differs (16x16x32 adds 32 products per step), so results differ in the last bits.
+constexpr int GR = 32;                         // queries per granule of the dK/dV kernel
+constexpr int GR_BYTES = GR * HD * 2;          // 8 KiB: one operand array of one granule
+constexpr int KV16_RING = 4;
+template <int NP> struct Kv16 {                // NP wave pairs = 32 NP keys per workgroup
+    static constexpr int WAVES = 2 * NP, THREADS = 64 * WAVES, ROWS = 32 * NP;
+    static constexpr int Q = 0, DO = KV16_RING * GR_BYTES, H = 2 * KV16_RING * GR_BYTES;      // Q ring | dO ring | hand-off | scalars
+    static constexpr int HBUF = NP * 4096;     // one hand-off buffer: NP pairs x (2 x 2 accumulator tiles x 1 KiB)
+    static constexpr int S = H + 2 * HBUF;     // scalars: 4 slots x (32 lse | 32 delta) floats
+    static constexpr int LDS = S + KV16_RING * 2 * GR * (int)sizeof(float);
+};
+constexpr int DQ16_STAGE = 2 * TILE_BYTES;     // K rows | V rows
+constexpr int DQ16_LDS = 2 * DQ16_STAGE;
+
+struct Bwd16Args {
+    BwdArgs b;
+    const float* sd;     // [heads][ngp][32 lse | 32 delta]
+    int ngp;             // granule records per head
+};
+
+// delta[s, h] = sum_d dO[s, h, d] O[s, h, d], stored twice: [q_len, heads] (per-lane reads of the dQ kernel) and with lse as the
+// dK/dV kernel's granule records sd[h][s / 32][32 lse | 32 delta] (zeros past q_len)
+__global__ __launch_bounds__(256) void attn_bwd_delta16_kernel(const Bwd16Args a, float* sd) {
+    const BwdArgs& p = a.b;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)a.ngp * GR * p.heads) return;
+    const int s = (int)(idx / p.heads), h = (int)(idx % p.heads);
+    float acc = 0.f, l = 0.f;
+    if (s < p.q_len) {
+        const u16* op = p.o + (long)s * p.o_stride + h * HD;
+        const u16* dp = p.dout + (long)s * p.do_stride + h * HD;
+#pragma unroll 4
+        for (int i = 0; i < HD / 8; ++i) {
+            const u16x8 x = *reinterpret_cast<const u16x8*>(op + 8 * i);
+            const u16x8 y = *reinterpret_cast<const u16x8*>(dp + 8 * i);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc += bf2f(x[e]) * bf2f(y[e]);
+        }
+        p.delta[idx] = acc;
+        l = p.lse[idx];
+    }
+    float* rec = sd + ((long)h * a.ngp + (s >> 5)) * (2 * GR) + (s & 31);
+    rec[0] = l;
+    rec[GR] = acc;
+}
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4s;
+__device__ __forceinline__ void mfma16(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+}
+// buffer descriptor over [base, base + bytes): a request (lane offset + 16 bytes) beyond it returns zeros
+__device__ __forceinline__ u32x4s make_srd(const void* base, unsigned bytes) {
+    const unsigned long b = (unsigned long)base;
+    u32x4s s;
+    s[0] = (unsigned)b;
+    s[1] = (unsigned)(b >> 32) & 0xffffu;
+    s[2] = bytes;
+    s[3] = 0x00020000u;
+    return s;
+}
+// LDS-DMA, buffer form: lane L's 16 (4) bytes at srd base + voff + soff land at l + 16 L (4 L).  M0 (the LDS destination) is a
+// reserved register hipcc sets itself before the few instructions that read it (none in these kernels): set here, not restored.
+__device__ __forceinline__ void dma16b(const u32x4s& srd, unsigned voff, unsigned soff, GF_LDS char* l) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)l);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" : : "v"(voff), "s"(srd), "s"(dst), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void dma4b(const u32x4s& srd, unsigned voff, unsigned soff, GF_LDS char* l) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)l);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %0, %1, %3 offen lds" : : "v"(voff), "s"(srd), "s"(dst), "s"(soff) : "memory");
+}
+__device__ __forceinline__ bf16x8 pack44(const f32x4& a, const f32x4& b) {
+    const u32x4 w = {pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(b[0], b[1]), pack2bf(b[2], b[3])};
+    return __builtin_bit_cast(bf16x8, w);
+}
+// XCD-aware block order (as the forward): the blocks of one head run on one XCD, whose L2 then holds that head's streamed operands
+__device__ __forceinline__ void head_block(int pid, int heads, int nblk, int& head, int& blk) {
+    if ((heads & 7) == 0) {
+        const int xcd = pid & 7, idx = pid >> 3;
+        head = xcd + 8 * (idx / nblk);
+        blk = idx % nblk;
+    } else {
+        head = pid / nblk;
+        blk = pid % nblk;
+    }
+}
+// descriptor over rows row0 .. len - 1 of a [len, stride] bf16 tensor, head column offset included: rows >= len read as zeros
+__device__ __forceinline__ u32x4s rows_srd(const u16* base, long stride, int head, int row0, int len) {
+    const int rem = len - row0;
+    return make_srd(base + (long)row0 * stride + head * HD, rem > 0 ? (unsigned)rem * (unsigned)stride * 2u : 0u);
+}
+// The tile image: 32-row blocks of 256-byte rows, chunk c of row r at c ^ 2 (r & 7).
+//   rows fragment (block, ks), lane (r = lane & 15, g = lane >> 4): X[16 blk + r][32 ks + 8 g ..]  = one b128 at row_off[ks] + 4096 blk
+//   transposed fragment (32-row group, db): X^T[16 db + r][k], k position 8 g + i <-> row 4 g + i (i < 4) / 16 + 4 g + (i - 4): two
+//   ds_read_b64_tr_b16 (a 16-lane group hands in 4 rows x 16 columns as 4-element pieces, lane i gets column i): lane i's piece is row
+//   4 g + (i >> 2) (+ 16), columns 16 db + 4 (i & 3) ..: tr_off + 32 db (the swizzle moves whole 32-byte pairs: (2 db + c) ^ 2 x)
+struct ImgOffsets {
+    int row[4];
+    int tr[2][8];
+};
+__device__ __forceinline__ ImgOffsets img_offsets(int lane) {
+    ImgOffsets f;
+    const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) f.row[ks] = 256 * r + 16 * ((4 * ks + g) ^ (2 * (r & 7)));
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        const int row = 16 * hf + 4 * g + (r >> 2);
+#pragma unroll
+        for (int db = 0; db < 8; ++db) f.tr[hf][db] = 256 * row + 16 * ((2 * db + ((r & 3) >> 1)) ^ (2 * (row & 7))) + 8 * (r & 1);
+    }
+    return f;
+}
+__device__ __forceinline__ bf16x8 tr16_frag(GF_LDS char* blk32, const ImgOffsets& f, int db) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GF_LDS s16x4*)(blk32 + f.tr[0][db]));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GF_LDS s16x4*)(blk32 + f.tr[1][db]));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 vv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, vv);
+}
+// per-lane source offset (bytes) of LDS-DMA piece `piece` (rows 4 piece .. 4 piece + 3) of a rows image: lane L fetches the chunk that
+// belongs at its physical place (row 4 piece + (L >> 4), physical chunk L & 15)
+__device__ __forceinline__ unsigned img_src_off(int piece, int lane, long stride) {
+    const int row = 4 * piece + (lane >> 4);
+    const int lch = (lane & 15) ^ (2 * (row & 7));
+    return ((unsigned)row * (unsigned)stride + lch * 8) * 2u;
+}
+
+// ---- dQ: wave owns queries q0 .. q0 + 31 (block qb: query q0 + 16 qb + (lane & 15)) ---------------------------------------
+__global__ __launch_bounds__(DQ_THREADS, 2) void attn_bwd_dq16_kernel(const Bwd16Args a) {
+    const BwdArgs& p = a.b;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    GF_LDS char* lds = (GF_LDS char*)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int nqb = (p.q_len + DQ_ROWS - 1) / DQ_ROWS;
+    int head, qblk;
+    head_block(blockIdx.x, p.heads, nqb, head, qblk);
+    const int q0 = qblk * DQ_ROWS + wave * 32;
+
+    bf16x8 qf[2][4], dof[2][4];      // B operands: Q^T / dO^T [32 d x 16 queries]: lane = query column, 8 d at 32 ks + 8 g
+    float lse[2], dl[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int qr = min(q0 + 16 * qb + r, p.q_len - 1);
+        const u16* qp = p.q + (long)qr * p.q_stride + head * HD + 8 * g;
+        const u16* dp = p.dout + (long)qr * p.do_stride + head * HD + 8 * g;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            qf[qb][ks] = *reinterpret_cast<const bf16x8*>(qp + 32 * ks);
+            dof[qb][ks] = *reinterpret_cast<const bf16x8*>(dp + 32 * ks);
+        }
+        lse[qb] = p.lse[(long)qr * p.heads + head];
+        dl[qb] = p.delta[(long)qr * p.heads + head];
+    }
+    const float c = p.scale_log2e;
+    const ImgOffsets fo = img_offsets(lane);
+    f32x4 dq[8][2];
+#pragma unroll
+    for (int db = 0; db < 8; ++db)
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) dq[db][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nt = (p.kv_len + KVB - 1) / KVB;
+    // a tile's two images are 32 pieces of 1 KiB: wave w stages pieces w and w + 8 of each (the swizzle of a row depends on row & 7:
+    // the same per-lane offset serves both, 32 rows apart)
+    const unsigned k_voff = img_src_off(wave, lane, p.k_stride), v_voff = img_src_off(wave, lane, p.v_stride);
+    auto stage = [&](int t) {
+        GF_LDS char* b = lds + (t & 1) * DQ16_STAGE + wave * 1024;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {       // a descriptor per half tile: the SGPR offset of a request is not bounds-checked
+            dma16b(rows_srd(p.k, p.k_stride, head, t * KVB + 32 * jj, p.kv_len), k_voff, 0u, b + jj * 8192);
+            dma16b(rows_srd(p.v, p.v_stride, head, t * KVB + 32 * jj, p.kv_len), v_voff, 0u, b + TILE_BYTES + jj * 8192);
+        }
+    };
+    // No masking of a ragged last tile: rows past kv_len arrive as zeros, so those keys' dS (finite: p = exp2(-lse), dP = 0) meets a
+    // zero row of K in the last product.
+    auto tile = [&](int t) {
+        GF_LDS char* kbuf = lds + (t & 1) * DQ16_STAGE;
+        GF_LDS char* vbuf = kbuf + TILE_BYTES;
+        f32x4 sc[4][2], dp[4][2];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                sc[kb][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                dp[kb][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                const bf16x8 kf = *(GF_LDS bf16x8*)(kbuf + 4096 * kb + fo.row[ks]);
+                const bf16x8 vf = *(GF_LDS bf16x8*)(vbuf + 4096 * kb + fo.row[ks]);
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    mfma16(sc[kb][qb], kf, qf[qb][ks]);      // S^T[key 16 kb + 4 g + j, query 16 qb + r]
+                    mfma16(dp[kb][qb], vf, dof[qb][ks]);     // dP^T
+                }
+            }
+        bf16x8 dsf[2][2];        // dS^T as B operand [32 keys x 16 queries]: {tile 2 kk, tile 2 kk + 1}
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                f32x4 x[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int kb = 2 * kk + i;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kb][qb][j], c, -lse[qb]));
+                        x[i][j] = pr * (dp[kb][qb][j] - dl[qb]);
+                    }
+                }
+                dsf[kk][qb] = pack44(x[0], x[1]);
+            }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int db = 0; db < 8; ++db) {
+                const bf16x8 ktf = tr16_frag(kbuf + 8192 * kk, fo, db);
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) mfma16(dq[db][qb], ktf, dsf[kk][qb]);     // dQ^T[d 16 db + 4 g + j, query] += K^T dS^T
+            }
+    };
+    stage(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll 1
+    for (int t = 0; t < nt; ++t) {
+        if (t + 1 < nt) stage(t + 1);
+        tile(t);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int qrow = q0 + 16 * qb + r;
+        if (qrow < p.q_len) {
+            u16* rowp = p.dq + (long)qrow * p.dq_stride + head * HD + 4 * g;
+#pragma unroll
+            for (int db = 0; db < 8; ++db) {
+                u32x2 pk;
+                pk[0] = pack2bf(dq[db][qb][0] * p.scale, dq[db][qb][1] * p.scale);
+                pk[1] = pack2bf(dq[db][qb][2] * p.scale, dq[db][qb][3] * p.scale);
+                *reinterpret_cast<u32x2*>(rowp + 16 * db) = pk;
+            }
+        }
+    }
+}
+
+// ---- dK, dV: wave pair (w, w + NP) owns keys k0 .. k0 + 31 (block kb: key k0 + 16 kb + (lane & 15)) ---------------------------
+#ifndef KV16_WHATIF      // timing-only builds (wrong results; tools/attnbwd_ab.py): 1 no DMA in the loop, 4 no hand-off, 8 no barrier,
+#define KV16_WHATIF 0    // 16 no counted wait, 32 every batch fetches the same granule
+#endif
+#if KV16_WHATIF & 8
+#define KV16_WAIT_BARRIER(N) asm volatile("s_waitcnt vmcnt(" #N ")\n\ts_waitcnt lgkmcnt(0)" ::: "memory")
+#elif KV16_WHATIF & 16
+#define KV16_WAIT_BARRIER(N) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#else
+#define KV16_WAIT_BARRIER(N) asm volatile("s_waitcnt vmcnt(" #N ")\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
+template <int NP>
+__global__ __launch_bounds__(Kv16<NP>::THREADS) void attn_bwd_dkv16_kernel(const Bwd16Args a) {
+    using L = Kv16<NP>;
+    const BwdArgs& p = a.b;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    GF_LDS char* lds = (GF_LDS char*)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const bool roleB = wave >= NP;
+    const int pair = roleB ? wave - NP : wave;
+    const int nkb = (p.kv_len + L::ROWS - 1) / L::ROWS;
+    int head, kblk;
+    head_block(blockIdx.x, p.heads, nkb, head, kblk);
+    const int k0 = kblk * L::ROWS + pair * 32;
+
+    // the pair's register-resident B operand: wave A K^T, wave B V^T [32 d x 16 keys]: lane = key column, 8 d at 32 ks + 8 g
+    bf16x8 own[2][4];
+    {
+        const u16* base = roleB ? p.v : p.k;
+        const long stride = roleB ? p.v_stride : p.k_stride;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const int kr = min(k0 + 16 * kb + r, p.kv_len - 1);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                own[kb][ks] = *reinterpret_cast<const bf16x8*>(base + (long)kr * stride + head * HD + 8 * g + 32 * ks);
+        }
+    }
+    // the compiler must see these loads completed HERE: it cannot count the asm LDS-DMA requests, and a vmcnt wait it placed at the first
+    // use inside the loop would wait for the newest DMA batch as well (every iteration)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(own[kb][ks]));
+    const float c = p.scale_log2e;
+    const ImgOffsets fo = img_offsets(lane);
+    f32x4 acc[8][2];                 // wave A: dV^T, wave B: dK^T — [db][kb]: key 16 kb + r, d = 16 db + 4 g + j
+#pragma unroll
+    for (int db = 0; db < 8; ++db)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) acc[db][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int ng = (p.q_len + GR - 1) / GR;
+    // DMA batch of iteration i (i >= -2): Q rows and dO rows of granule i + 2 (8 pieces each: waves 0 .. 7 take piece `wave` of both)
+    // and its scalars (wave 0).  Always the same number of instructions per wave (a granule past the end arrives as zeros): the counted
+    // wait relies on it.
+    const unsigned q_voff = img_src_off(wave & 7, lane, p.q_stride), do_voff = img_src_off(wave & 7, lane, p.do_stride);
+    const u32x4s srd_sd = make_srd(a.sd + (long)head * a.ngp * (2 * GR), 0xffffffffu);
+    auto issue = [&](int i) {
+#if KV16_WHATIF & 32
+        i = 0;
+#endif
+        const int ga = i + 2;
+        if (wave < 8) {
+            GF_LDS char* dst = lds + (ga & 3) * GR_BYTES + wave * 1024;
+            dma16b(rows_srd(p.q, p.q_stride, head, ga * GR, p.q_len), q_voff, 0u, dst + L::Q);
+            dma16b(rows_srd(p.dout, p.do_stride, head, ga * GR, p.q_len), do_voff, 0u, dst + L::DO);
+        }
+        if (wave == 0) dma4b(srd_sd, (unsigned)lane * 4u, (unsigned)min(ga, a.ngp - 1) * (2u * GR * 4u), lds + L::S + (ga & 3) * (2 * GR * 4));
+    };
+    // (no masking of a ragged last granule: its rows past q_len arrive as zeros, so the finite P and dS of those queries meet zero rows
+    // of dO / Q in the second product)
+    // Order inside a step (pinned by scheduling barriers: left alone, hipcc reads one fragment, waits for it, issues its two MFMAs and
+    // so on — the matrix pipe then idles through every LDS round trip): the first product's 8 row fragments are requested, the SECOND
+    // product of the previous granule runs from registers (transposed fragments + packed P / dS carried over the barrier), then the
+    // first product, then this granule's transposed fragments are requested and land during the exp2 / dS arithmetic.
+    bf16x8 carry_a[8], carry_b[2];
+#define KV16_SB() __builtin_amdgcn_sched_barrier(0)
+    // wave A, iteration i: dV of granule i - 1 from registers; S, P of granule i
+    auto stepA = [&](int i) {
+        const bool first = i < ng, second = i >= 1 && i <= ng;
+        GF_LDS char* qbuf = lds + L::Q + (i & 3) * GR_BYTES;
+        GF_LDS char* dobuf = lds + L::DO + (i & 3) * GR_BYTES;
+        GF_LDS float* lse_s = (GF_LDS float*)(lds + L::S + (i & 3) * (2 * GR * 4));
+        GF_LDS char* hb = lds + L::H + (i & 1) * L::HBUF + pair * 4096 + lane * 16;
+        bf16x8 qfr[2][4];
+        if (first) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+#if KV16_WHATIF & 256
+                    qfr[qb][ks] = own[qb][ks];
+#else
+                    qfr[qb][ks] = *(GF_LDS bf16x8*)(qbuf + 4096 * qb + fo.row[ks]);
+#endif
+                }
+        }
+        KV16_SB();
+        if (second) {
+#pragma unroll
+            for (int db = 0; db < 8; ++db)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) mfma16(acc[db][kb], carry_a[db], carry_b[kb]);       // dV^T[d, key] += dO^T P
+        }
+        KV16_SB();
+        if (!first) return;
+        f32x4 sc[2][2];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) sc[qb][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) mfma16(sc[qb][kb], qfr[qb][ks], own[kb][ks]);        // S[query 16 qb + 4 g + j, key 16 kb + r]
+        KV16_SB();
+#pragma unroll
+        for (int db = 0; db < 8; ++db) {
+#if !(KV16_WHATIF & 128)
+            carry_a[db] = tr16_frag(dobuf, fo, db);
+#else
+            asm volatile("" : "+v"(carry_a[db]));
+#endif
+        }
+        f32x4 l4[2];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) l4[qb] = *(GF_LDS f32x4*)(lse_s + 16 * qb + 4 * g);
+        KV16_SB();
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#if !(KV16_WHATIF & 64)
+                    sc[qb][kb][j] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[qb][kb][j], c, -l4[qb][j]));
+#endif
+                }
+#if !(KV16_WHATIF & 4)
+                *(GF_LDS f32x4*)(hb + (2 * qb + kb) * 1024) = sc[qb][kb];
+#endif
+            }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) carry_b[kb] = pack44(sc[0][kb], sc[1][kb]);
+    };
+    // wave B, iteration i: dK of granule i - 2 from registers; dP, dS of granule i - 1
+    auto stepB = [&](int i) {
+        const int gi = i - 1;
+        const bool first = gi >= 0 && gi < ng, second = i >= 2;
+        GF_LDS char* qbuf = lds + L::Q + (gi & 3) * GR_BYTES;
+        GF_LDS char* dobuf = lds + L::DO + (gi & 3) * GR_BYTES;
+        GF_LDS float* dl_s = (GF_LDS float*)(lds + L::S + (gi & 3) * (2 * GR * 4)) + GR;
+        GF_LDS char* hb = lds + L::H + (gi & 1) * L::HBUF + pair * 4096 + lane * 16;
+        bf16x8 dofr[2][4];
+        if (first) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+#if KV16_WHATIF & 256
+                    dofr[qb][ks] = own[qb][ks];
+#else
+                    dofr[qb][ks] = *(GF_LDS bf16x8*)(dobuf + 4096 * qb + fo.row[ks]);
+#endif
+                }
+        }
+        KV16_SB();
+        if (second) {
+#pragma unroll
+            for (int db = 0; db < 8; ++db)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) mfma16(acc[db][kb], carry_a[db], carry_b[kb]);       // dK^T[d, key] += Q^T dS
+        }
+        KV16_SB();
+        if (!first) return;
+        f32x4 dp[2][2];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) dp[qb][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) mfma16(dp[qb][kb], dofr[qb][ks], own[kb][ks]);       // dP[query, key] = dO V^T
+        KV16_SB();
+#pragma unroll
+        for (int db = 0; db < 8; ++db) {
+#if !(KV16_WHATIF & 128)
+            carry_a[db] = tr16_frag(qbuf, fo, db);
+#else
+            asm volatile("" : "+v"(carry_a[db]));
+#endif
+        }
+        f32x4 d4[2], pp[2][2];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            d4[qb] = *(GF_LDS f32x4*)(dl_s + 16 * qb + 4 * g);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#if KV16_WHATIF & 4
+                pp[qb][kb] = d4[qb];
+#else
+                pp[qb][kb] = *(GF_LDS f32x4*)(hb + (2 * qb + kb) * 1024);
+#endif
+            }
+        }
+        KV16_SB();
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dp[qb][kb][j] = pp[qb][kb][j] * (dp[qb][kb][j] - d4[qb][j]);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) carry_b[kb] = pack44(dp[0][kb], dp[1][kb]);
+    };
+    issue(-2);
+    issue(-1);
+    // One loop per role (the register allocator then sees each role's live ranges alone; both execute the same number of barriers).
+    // At the top of iteration i: this wave's pieces of batch i - 2 have landed (batch i - 1 stays in flight), its hand-off stores and
+    // LDS reads are done; behind the barrier that holds for every wave: granule i (A) / i - 1 (B) is readable, the slots batch i goes
+    // to (granule i - 2's, last read by B in iteration i - 1) are free.
+#if KV16_WHATIF & 1
+#define KV16_ISSUE(i) (void)issue
+#else
+#define KV16_ISSUE(i) issue(i)
+#endif
+    auto wait_barrier = [&]() {
+        if (wave == 0) KV16_WAIT_BARRIER(3);
+        else if (wave < 8) KV16_WAIT_BARRIER(2);
+        else KV16_WAIT_BARRIER(0);
+    };
+    if (!roleB) {
+#pragma unroll 1
+        for (int i = 0; i <= ng + 1; ++i) {
+            wait_barrier();
+            KV16_ISSUE(i);
+            stepA(i);
+        }
+    } else {
+#pragma unroll 1
+        for (int i = 0; i <= ng + 1; ++i) {
+            wait_barrier();
+            KV16_ISSUE(i);
+            stepB(i);
+        }
+    }
+    const float mul = roleB ? p.scale : 1.0f;
+    u16* outp = roleB ? p.dk : p.dv;
+    const long ostride = roleB ? p.dk_stride : p.dv_stride;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const int krow = k0 + 16 * kb + r;
+        if (krow < p.kv_len) {
+            u16* rowp = outp + (long)krow * ostride + head * HD + 4 * g;
+#pragma unroll
+            for (int db = 0; db < 8; ++db) {
+                u32x2 pk;
+                pk[0] = pack2bf(acc[db][kb][0] * mul, acc[db][kb][1] * mul);
+                pk[1] = pack2bf(acc[db][kb][2] * mul, acc[db][kb][3] * mul);
+                *reinterpret_cast<u32x2*>(rowp + 16 * db) = pk;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the last batches must not outlive the workgroup's LDS
+}
+
 }  // namespace
 
+static inline int64_t pad64(int64_t n) { return (n + 63) / 64 * 64; }
+static inline int64_t align256(int64_t n) { return (n + 255) / 256 * 256; }
+
+// bytes of the caller-owned workspace of gf_flash_attn_bwd: delta [q_len, heads] fp32 | granule records [heads][pad64(q_len)/32][64] fp32
+extern "C" GF_API int64_t gf_flash_attn_bwd_workspace_bytes(int64_t q_len, int64_t kv_len, int64_t heads) {
+    if (q_len <= 0 || kv_len <= 0 || heads <= 0) return 0;
+    return align256(q_len * heads * 4) + align256(heads * pad64(q_len) * 2 * 4);
+}
+
+#ifndef KV16_NP
+#define KV16_NP 4
+#endif
 extern "C" GF_API int gf_flash_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,
-                                        const float* lse, float* delta_ws, void* dq, void* dk, void* dv, int64_t q_len,
+                                        const float* lse, void* workspace, void* dq, void* dk, void* dv, int64_t q_len,
                                         int64_t kv_len, int64_t heads, int64_t head_dim, int64_t q_stride, int64_t k_stride,
                                         int64_t v_stride, int64_t o_stride, int64_t do_stride, int64_t dq_stride,
                                         int64_t dk_stride, int64_t dv_stride, float scale, void* stream) {
-    GF_CHECK_ARG(q && k && v && o && dout && lse && delta_ws && dq && dk && dv, "gf_flash_attn_bwd: null pointer");
+    GF_CHECK_ARG(q && k && v && o && dout && lse && workspace && dq && dk && dv, "gf_flash_attn_bwd: null pointer");
     if (head_dim != HD) {
         gf_set_error("gf_flash_attn_bwd: head_dim=%ld unsupported (kernels are built for 128)", (long)head_dim);
         return GF_ERR_UNSUPPORTED;
@@ -504,44 +936,55 @@ extern "C" GF_API int gf_flash_attn_bwd(const void* q, const void* k, const void
     for (int i = 0; i < 8; ++i)
         GF_CHECK_ARG(strides[i] % 8 == 0 && strides[i] >= heads * HD, "gf_flash_attn_bwd: strides must cover heads*128 and be multiples of 8");
     GF_CHECK_ARG(gf_aligned16(q) && gf_aligned16(k) && gf_aligned16(v) && gf_aligned16(o) && gf_aligned16(dout) &&
-                     gf_aligned16(dq) && gf_aligned16(dk) && gf_aligned16(dv),
+                     gf_aligned16(dq) && gf_aligned16(dk) && gf_aligned16(dv) && gf_aligned16(workspace),
                  "gf_flash_attn_bwd: 16-byte alignment required");
-    const int lds_bytes = BWD_LDS;
+    GF_CHECK_ARG((q_len + 64) * q_stride * 2 < (1LL << 32) &&
+                     (q_len + 64) * do_stride * 2 < (1LL << 32) && (kv_len + 64) * k_stride * 2 < (1LL << 32) && (kv_len + 64) * v_stride * 2 < (1LL << 32),
+                 "gf_flash_attn_bwd: a sequence (len x stride) must stay below 4 GiB");
     static GfDeviceOnce once;
     hipError_t e = gf_once_per_device(once, [] {
-        const void* fns[4] = {reinterpret_cast<const void*>(attn_bwd_dq_kernel), reinterpret_cast<const void*>(attn_bwd_dkv_kernel<0>),
-                              reinterpret_cast<const void*>(attn_bwd_dkv_kernel<1>), reinterpret_cast<const void*>(attn_bwd_dkv_kernel<2>)};
+        const void* fns[3] = {reinterpret_cast<const void*>(attn_bwd_dq_kernel), reinterpret_cast<const void*>(attn_bwd_dkv_kernel<1>),
+                              reinterpret_cast<const void*>(attn_bwd_dkv_kernel<2>)};
         for (const void* fn : fns) {
             hipError_t r = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
             if (r != hipSuccess) return r;
         }
-        return hipSuccess;
+        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DQ16_LDS);
+        if (r != hipSuccess) return r;
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv16_kernel<KV16_NP>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   Kv16<KV16_NP>::LDS);
     });
     if (e != hipSuccess) {
         gf_set_error("gf_flash_attn_bwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
         return GF_ERR_LAUNCH;
     }
-    BwdArgs a;
+    Bwd16Args b;
+    BwdArgs& a = b.b;
     a.q = (const u16*)q; a.k = (const u16*)k; a.v = (const u16*)v; a.o = (const u16*)o; a.dout = (const u16*)dout;
-    a.lse = lse; a.delta = delta_ws;
+    a.lse = lse; a.delta = (float*)workspace;
     a.dq = (u16*)dq; a.dk = (u16*)dk; a.dv = (u16*)dv;
     a.q_len = (int)q_len; a.kv_len = (int)kv_len; a.heads = (int)heads;
     a.q_stride = q_stride; a.k_stride = k_stride; a.v_stride = v_stride; a.o_stride = o_stride; a.do_stride = do_stride;
     a.dq_stride = dq_stride; a.dk_stride = dk_stride; a.dv_stride = dv_stride;
     a.scale = scale; a.scale_log2e = scale * 1.4426950408889634f;
     hipStream_t s = (hipStream_t)stream;
-    const long nd = q_len * heads;
-    hipLaunchKernelGGL(attn_bwd_delta_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, s, a);
     const unsigned nqb = (unsigned)((q_len + DQ_ROWS - 1) / DQ_ROWS), nkb = (unsigned)((kv_len + DKV_ROWS - 1) / DKV_ROWS);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(nqb * (unsigned)heads), dim3(DQ_THREADS), lds_bytes, s, a);
-    // GF_ATTN_BWD_FUSED_DKV=1: dK and dV in one pass at one wave per SIMD (the first version, A/B)
-    const int fused = gf_options().bwd_fused_dkv.load(std::memory_order_relaxed);
-    if (fused) {
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<0>, dim3(nkb * (unsigned)heads), dim3(DKV_THREADS), lds_bytes, s, a);
-    } else {
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<1>, dim3(nkb * (unsigned)heads), dim3(DKV_THREADS), lds_bytes, s, a);
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<2>, dim3(nkb * (unsigned)heads), dim3(DKV_THREADS), lds_bytes, s, a);
+    if (gf_options().bwd_v1.load(std::memory_order_relaxed)) {      // GF_ATTN_BWD=v1: the first kernels (32x32x16, 8 tile products), A/B
+        hipLaunchKernelGGL(attn_bwd_delta_kernel, dim3((unsigned)((q_len * heads + 255) / 256)), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(nqb * (unsigned)heads), dim3(DQ_THREADS), BWD_LDS, s, a);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<1>, dim3(nkb * (unsigned)heads), dim3(DKV_THREADS), BWD_LDS, s, a);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<2>, dim3(nkb * (unsigned)heads), dim3(DKV_THREADS), BWD_LDS, s, a);
+        GF_CHECK_LAUNCH("gf_flash_attn_bwd");
+        return GF_OK;
     }
+    const int64_t q_pad = pad64(q_len);
+    b.ngp = (int)(q_pad / GR);
+    float* sd = (float*)((char*)workspace + align256(q_len * heads * 4));
+    b.sd = sd;
+    hipLaunchKernelGGL(attn_bwd_delta16_kernel, dim3((unsigned)((q_pad * heads + 255) / 256)), dim3(256), 0, s, b, sd);
+    hipLaunchKernelGGL(attn_bwd_dq16_kernel, dim3(nqb * (unsigned)heads), dim3(DQ_THREADS), DQ16_LDS, s, b);
+    const unsigned nkb16 = (unsigned)((kv_len + Kv16<KV16_NP>::ROWS - 1) / Kv16<KV16_NP>::ROWS);
+    hipLaunchKernelGGL(attn_bwd_dkv16_kernel<KV16_NP>, dim3(nkb16 * (unsigned)heads), dim3(Kv16<KV16_NP>::THREADS), Kv16<KV16_NP>::LDS, s, b);
     GF_CHECK_LAUNCH("gf_flash_attn_bwd");
     return GF_OK;
 }

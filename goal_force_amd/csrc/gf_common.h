@@ -111,7 +111,7 @@ struct GfOptions {
     std::atomic<int> a4_loop_h{0};      // GF_A4_LOOP=h (-DGF_A4_HALFTILE_AB builds only)
     std::atomic<int> a4_whatif{0};      // GF_A4_WHATIF (-DGF_A4_WHATIF builds only)
     std::atomic<int> attn_kernel1{0};   // GF_ATTN_KERNEL=1: gf_flash_attn_fwd on the phase-serial kernel 1
-    std::atomic<int> bwd_fused_dkv{0};  // GF_ATTN_BWD_FUSED_DKV=1
+    std::atomic<int> bwd_v1{0};         // GF_ATTN_BWD=v1: gf_flash_attn_bwd on the first kernels (32x32x16 MFMAs, dQ / dV / dK passes)
     std::atomic<int> conv_nb{0};        // GF_CONV_NB: 0 = by Cout, 1 / 2 forced
     std::atomic<int> conv_gather{0};    // GF_CONV_GATHER=1: the general gather
     std::atomic<int> conv_direct{1};    // GF_CONV_DIRECT=0: the 96-channel 3x3x3 convolutions on the implicit GEMM instead of gf_conv_direct.hip

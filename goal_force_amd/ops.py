@@ -375,8 +375,10 @@ def flash_attn_bwd(q, k, v, o, dout, lse, num_heads, scale=None):
         raise GoalForceError("flash_attn_bwd.lse: expected contiguous fp32 [Sq, heads]")
     dq, dk, dv = torch.empty_like(q, memory_format=torch.contiguous_format), \
         torch.empty((skv, hd_all), dtype=_BF16, device=q.device), torch.empty((skv, hd_all), dtype=_BF16, device=q.device)
-    delta = torch.empty((sq, num_heads), dtype=torch.float32, device=q.device)
-    _lib.check(_lib.load().gf_flash_attn_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(dout), _ptr(lse), _ptr(delta), _ptr(dq),
+    lib = _lib.load()
+    # rowsum(dout * o) and the transposed copies of k, q, dout the kernels stream; scratch, sized by the library
+    ws = torch.empty((int(lib.gf_flash_attn_bwd_workspace_bytes(sq, skv, num_heads)),), dtype=torch.uint8, device=q.device)
+    _lib.check(lib.gf_flash_attn_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(dout), _ptr(lse), _ptr(ws), _ptr(dq),
                                              _ptr(dk), _ptr(dv), sq, skv, num_heads, head_dim, q.stride(0), k.stride(0),
                                              v.stride(0), o.stride(0), dout.stride(0), dq.stride(0), dk.stride(0),
                                              dv.stride(0), float(scale), _stream(q)), "gf_flash_attn_bwd")

@@ -13,10 +13,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, "build", "ab")
 VARIANTS = {
-    "seed0_halves0": ["-DGF_BWD_SEED=0", "-DGF_BWD_HALVES=0"],
-    "seed0_halves1": ["-DGF_BWD_SEED=0", "-DGF_BWD_HALVES=1"],
-    "seed1_halves0": ["-DGF_BWD_SEED=1", "-DGF_BWD_HALVES=0"],
-    "seed1_halves1": ["-DGF_BWD_SEED=1", "-DGF_BWD_HALVES=1"],
+    "base": [],
+    "w1_nodma": ["-DKV16_WHATIF=1"],
+    "w9_nodma_nobarrier": ["-DKV16_WHATIF=9"],
+    "w73_noexp": ["-DKV16_WHATIF=73"],
+    "w13_nohandoff": ["-DKV16_WHATIF=13"],
+    "w137_notr": ["-DKV16_WHATIF=137"],
+    "w265_norowfrag": ["-DKV16_WHATIF=265"],
+    "w461_mfmaonly": ["-DKV16_WHATIF=461"],
 }
 for spec in os.environ.get("BWD_AB_EXTRA", "").split(";"):     # name:flag,flag
     if spec:
@@ -27,6 +31,8 @@ for spec in os.environ.get("BWD_AB_EXTRA", "").split(";"):     # name:flag,flag
 def build():
     os.makedirs(OUT, exist_ok=True)
     src = [os.path.join(ROOT, "goal_force_amd", "csrc", f) for f in ("gf_attention_bwd.hip", "gf_abi.hip")]
+    for old in os.listdir(OUT):
+        os.remove(os.path.join(OUT, old))
     for name, flags in VARIANTS.items():
         subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DGF_BUILD",
                         f"-I{ROOT}/include", f"-I{ROOT}/goal_force_amd/csrc", "-o", os.path.join(OUT, f"libbwd_{name}.so")] + flags + src,
@@ -41,7 +47,8 @@ def run():
     torch.manual_seed(0)
     q, k, v, do = (torch.randn((S, D), device="cuda").to(torch.bfloat16) for _ in range(4))
     o, lse = ops.flash_attn_lse(q, k, v, H)
-    delta = torch.empty((S, H), dtype=torch.float32, device="cuda")
+    from goal_force_amd import _lib
+    ws = torch.empty((int(_lib.load().gf_flash_attn_bwd_workspace_bytes(S, S, H)),), dtype=torch.uint8, device="cuda")
     vp, i64 = ctypes.c_void_p, ctypes.c_int64
     st = torch.cuda.current_stream().cuda_stream
     libs, outs, best = {}, {}, {}
@@ -50,10 +57,19 @@ def run():
         lib = ctypes.CDLL(path)
         lib.gf_flash_attn_bwd.argtypes = [vp] * 10 + [i64] * 12 + [ctypes.c_float, vp]
         libs[os.path.basename(path)[7:-3]] = lib
+    if os.environ.get("BWD_AB_V1", "1") == "1":      # the shipped library's first kernels (GF_ATTN_BWD=v1) as the yardstick
+        for lib in libs.values():
+            lib.gf_reload_options()                 # every library reads the knobs for itself: the variants without GF_ATTN_BWD
+        os.environ["GF_ATTN_BWD"] = "v1"
+        v1 = ctypes.CDLL(os.path.join(ROOT, "goal_force_amd", "libgoalforce_hip.so"))     # the handle ops uses (the forward is not affected)
+        v1.gf_flash_attn_bwd.argtypes = [vp] * 10 + [i64] * 12 + [ctypes.c_float, vp]
+        v1.gf_reload_options()
+        del os.environ["GF_ATTN_BWD"]
+        libs = {"shipped_v1": v1, **libs}
     bufs = [torch.empty_like(q) for _ in range(3)]
 
     def call(lib):
-        rc = lib.gf_flash_attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(), delta.data_ptr(),
+        rc = lib.gf_flash_attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(), ws.data_ptr(),
                                    bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr(), S, S, H, 128, D, D, D, D, D, D, D, D,
                                    128 ** -0.5, st)
         assert rc == 0

@@ -101,8 +101,8 @@ def main():
         do = torch.randn((s, D), device="cuda").to(BF)
         o, lse = ops.flash_attn_lse(q, k, v, H)
         med, mn = timeit(lambda: ops.flash_attn_bwd(q, k, v, o, do, lse, H), a.iters)
-        fl = 10.0 * s * s * D       # the 5 necessary products (dQ / dV / dK passes compute 3 + 2 + 3 = 8; fused dK+dV: 7)
-        ex = 1.4 if os.environ.get("GF_ATTN_BWD_FUSED_DKV") == "1" else 1.6
+        fl = 10.0 * s * s * D       # the 5 necessary products (executed: dQ 3 + dK/dV 4 = 7; GF_ATTN_BWD=v1: 3 + 2 + 3 = 8)
+        ex = 1.6 if os.environ.get("GF_ATTN_BWD") == "v1" else 1.4
         print(f"flash_attn_bwd S={s} H={H}: median {med:.3f} ms ({fl / med / 1e9:.1f} TFLOP/s algorithmic, "
               f"{ex * fl / med / 1e9:.1f} executed)")
     elif a.what == "gemm":
