@@ -392,7 +392,7 @@ template <int NP> struct Kv16 {                // NP wave pairs = 32 NP keys per
     static constexpr int LDS = S + KV16_RING * 2 * GR * (int)sizeof(float);
 };
 constexpr int DQ16_STAGE = 2 * TILE_BYTES;     // K rows | V rows
-constexpr int DQ16_LDS = 2 * DQ16_STAGE;
+constexpr int DQ16_LDS = 3 * DQ16_STAGE;
 
 struct Bwd16Args {
     BwdArgs b;
@@ -477,24 +477,21 @@ __device__ __forceinline__ u32x4s rows_srd(const u16* base, long stride, int hea
 //   4 g + (i >> 2) (+ 16), columns 16 db + 4 (i & 3) ..: tr_off + 32 db (the swizzle moves whole 32-byte pairs: (2 db + c) ^ 2 x)
 struct ImgOffsets {
     int row[4];
-    int tr[2][8];
+    int tr[8];       // first read (rows 4 g + ..); the second (rows 16 + 4 g + ..) is 4096 bytes on: same row & 7, same swizzle
 };
 __device__ __forceinline__ ImgOffsets img_offsets(int lane) {
     ImgOffsets f;
     const int r = lane & 15, g = lane >> 4;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) f.row[ks] = 256 * r + 16 * ((4 * ks + g) ^ (2 * (r & 7)));
+    const int row = 4 * g + (r >> 2);
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-        const int row = 16 * hf + 4 * g + (r >> 2);
-#pragma unroll
-        for (int db = 0; db < 8; ++db) f.tr[hf][db] = 256 * row + 16 * ((2 * db + ((r & 3) >> 1)) ^ (2 * (row & 7))) + 8 * (r & 1);
-    }
+    for (int db = 0; db < 8; ++db) f.tr[db] = 256 * row + 16 * ((2 * db + ((r & 3) >> 1)) ^ (2 * (row & 7))) + 8 * (r & 1);
     return f;
 }
 __device__ __forceinline__ bf16x8 tr16_frag(GF_LDS char* blk32, const ImgOffsets& f, int db) {
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GF_LDS s16x4*)(blk32 + f.tr[0][db]));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GF_LDS s16x4*)(blk32 + f.tr[1][db]));
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GF_LDS s16x4*)(blk32 + f.tr[db]));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GF_LDS s16x4*)(blk32 + f.tr[db] + 4096));
     typedef __attribute__((ext_vector_type(8))) short s16x8;
     const s16x8 vv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(bf16x8, vv);
@@ -535,6 +532,17 @@ __global__ __launch_bounds__(DQ_THREADS, 2) void attn_bwd_dq16_kernel(const Bwd1
         lse[qb] = p.lse[(long)qr * p.heads + head];
         dl[qb] = p.delta[(long)qr * p.heads + head];
     }
+    // the compiler must see these loads completed HERE (it cannot count the asm LDS-DMA requests: a vmcnt wait it placed at the first use
+    // inside the loop would wait for the newest DMA batch as well)
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            asm volatile("" : "+v"(qf[qb][ks]));
+            asm volatile("" : "+v"(dof[qb][ks]));
+        }
+        asm volatile("" : "+v"(lse[qb]), "+v"(dl[qb]));
+    }
     const float c = p.scale_log2e;
     const ImgOffsets fo = img_offsets(lane);
     f32x4 dq[8][2];
@@ -545,10 +553,10 @@ __global__ __launch_bounds__(DQ_THREADS, 2) void attn_bwd_dq16_kernel(const Bwd1
 
     const int nt = (p.kv_len + KVB - 1) / KVB;
     // a tile's two images are 32 pieces of 1 KiB: wave w stages pieces w and w + 8 of each (the swizzle of a row depends on row & 7:
-    // the same per-lane offset serves both, 32 rows apart)
+    // the same per-lane offset serves both, 32 rows apart).  Three stages, requested two tiles ahead, counted waits.
     const unsigned k_voff = img_src_off(wave, lane, p.k_stride), v_voff = img_src_off(wave, lane, p.v_stride);
     auto stage = [&](int t) {
-        GF_LDS char* b = lds + (t & 1) * DQ16_STAGE + wave * 1024;
+        GF_LDS char* b = lds + (t % 3) * DQ16_STAGE + wave * 1024;
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {       // a descriptor per half tile: the SGPR offset of a request is not bounds-checked
             dma16b(rows_srd(p.k, p.k_stride, head, t * KVB + 32 * jj, p.kv_len), k_voff, 0u, b + jj * 8192);
@@ -557,65 +565,120 @@ __global__ __launch_bounds__(DQ_THREADS, 2) void attn_bwd_dq16_kernel(const Bwd1
     };
     // No masking of a ragged last tile: rows past kv_len arrive as zeros, so those keys' dS (finite: p = exp2(-lse), dP = 0) meets a
     // zero row of K in the last product.
-    auto tile = [&](int t) {
-        GF_LDS char* kbuf = lds + (t & 1) * DQ16_STAGE;
-        GF_LDS char* vbuf = kbuf + TILE_BYTES;
-        f32x4 sc[4][2], dp[4][2];
+    // One 32-key half of a tile; the order is pinned by scheduling barriers (left alone, hipcc reads a fragment, waits for it, issues its
+    // two MFMAs, and so on — the matrix pipe idles through every LDS round trip).  F = 8 fragment registers, refilled in halves as soon as
+    // the MFMAs that read them have been issued; the exp2 / dS arithmetic of key block 2 h is INTERLEAVED with the MFMAs of block 2 h + 1
+    // (both waves of a SIMD leave the tile barrier together: phases of pure arithmetic would coincide and leave the matrix pipe idle):
+    //   F = K, V row fragments of block 2 h (F[2 ks] = K, F[2 ks + 1] = V; requested inside the previous half's last product)
+    //   8 MFMAs (ks 0, 1); F[0..3] <- block 2 h + 1;  8 MFMAs (ks 2, 3); F[4..7] <- block 2 h + 1
+    //   8 MFMAs of block 2 h + 1 with the arithmetic of block 2 h between them; F[0..3] <- K^T fragments d blocks 0..3 (transposed reads)
+    //   8 MFMAs; F[4..7] <- d blocks 4..7;  arithmetic of block 2 h + 1 (covers the reads);
+    //   dQ^T: 8 MFMAs, F[0..3] <- next half's first fragments, 8 MFMAs, F[4..7] <- the rest.
+    bf16x8 F[8];
+#ifndef DQ16_NO_INTERLEAVE
+#define DQ16_NO_INTERLEAVE 0
+#endif
+#define DQ16_SB() __builtin_amdgcn_sched_barrier(0)
+    auto load_kb = [&](GF_LDS char* kbuf, int kb, int lo, int hi) __attribute__((always_inline)) {      // F[2 ks] = K, F[2 ks + 1] = V fragment (kb, ks)
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
+        for (int ks = lo; ks < hi; ++ks) {
+            F[2 * ks] = *(GF_LDS bf16x8*)(kbuf + 4096 * kb + fo.row[ks]);
+            F[2 * ks + 1] = *(GF_LDS bf16x8*)(kbuf + TILE_BYTES + 4096 * kb + fo.row[ks]);
+        }
+    };
+    auto half = [&](GF_LDS char* kbuf, int h, bool has_next) __attribute__((always_inline)) {
+        u32x4 dsw[2];            // dS^T as B operand [32 keys x 16 queries] per query block: words 0, 1 = key block 2 h, words 2, 3 = 2 h + 1
+        f32x4 sc[2][2], dp[2][2];
+#pragma unroll
+        for (int kbb = 0; kbb < 2; ++kbb)
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) {
-                sc[kb][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
-                dp[kb][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                sc[kbb][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                dp[kbb][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
+        auto first = [&](int kbb, int lo, int hi) __attribute__((always_inline)) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) {
-                const bf16x8 kf = *(GF_LDS bf16x8*)(kbuf + 4096 * kb + fo.row[ks]);
-                const bf16x8 vf = *(GF_LDS bf16x8*)(vbuf + 4096 * kb + fo.row[ks]);
+            for (int ks = lo; ks < hi; ++ks)
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb) {
-                    mfma16(sc[kb][qb], kf, qf[qb][ks]);      // S^T[key 16 kb + 4 g + j, query 16 qb + r]
-                    mfma16(dp[kb][qb], vf, dof[qb][ks]);     // dP^T
+                    mfma16(sc[kbb][qb], F[2 * ks], qf[qb][ks]);          // S^T[key 32 h + 16 kbb + 4 g + j, query 16 qb + r]
+                    mfma16(dp[kbb][qb], F[2 * ks + 1], dof[qb][ks]);     // dP^T
                 }
-            }
-        bf16x8 dsf[2][2];        // dS^T as B operand [32 keys x 16 queries]: {tile 2 kk, tile 2 kk + 1}
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
+        };
+        auto softmax = [&](int kbb) __attribute__((always_inline)) {
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) {
-                f32x4 x[2];
+                float x[4];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int kb = 2 * kk + i;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kb][qb][j], c, -lse[qb]));
-                        x[i][j] = pr * (dp[kb][qb][j] - dl[qb]);
-                    }
+                for (int j = 0; j < 4; ++j) {
+                    const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kbb][qb][j], c, -lse[qb]));
+                    x[j] = pr * (dp[kbb][qb][j] - dl[qb]);
                 }
-                dsf[kk][qb] = pack44(x[0], x[1]);
+                dsw[qb][2 * kbb] = pack2bf(x[0], x[1]);
+                dsw[qb][2 * kbb + 1] = pack2bf(x[2], x[3]);
             }
+        };
+        DQ16_SB();
+        first(0, 0, 2);
+        DQ16_SB();
+        load_kb(kbuf, 2 * h + 1, 0, 2);
+        DQ16_SB();
+        first(0, 2, 4);
+        DQ16_SB();
+        load_kb(kbuf, 2 * h + 1, 2, 4);
+        DQ16_SB();
+        softmax(0);
+        first(1, 0, 2);
+#if !DQ16_NO_INTERLEAVE
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
+        for (int i = 0; i < 8; ++i) {        // one MFMA, then its share of the 8 exp2 and ~30 other arithmetic instructions
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        }
+#endif
+        DQ16_SB();
 #pragma unroll
-            for (int db = 0; db < 8; ++db) {
-                const bf16x8 ktf = tr16_frag(kbuf + 8192 * kk, fo, db);
+        for (int db = 0; db < 4; ++db) F[db] = tr16_frag(kbuf + 8192 * h, fo, db);
+        DQ16_SB();
+        first(1, 2, 4);
+        DQ16_SB();
 #pragma unroll
-                for (int qb = 0; qb < 2; ++qb) mfma16(dq[db][qb], ktf, dsf[kk][qb]);     // dQ^T[d 16 db + 4 g + j, query] += K^T dS^T
-            }
+        for (int db = 4; db < 8; ++db) F[db] = tr16_frag(kbuf + 8192 * h, fo, db);
+        DQ16_SB();
+        softmax(1);
+        DQ16_SB();
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) mfma16(dq[db][qb], F[db], __builtin_bit_cast(bf16x8, dsw[qb]));     // dQ^T[d 16 db + 4 g + j, query] += K^T dS^T
+        DQ16_SB();
+        if (has_next) load_kb(kbuf, 2 * h + 2, 0, 2);
+        DQ16_SB();
+#pragma unroll
+        for (int db = 4; db < 8; ++db)
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) mfma16(dq[db][qb], F[db], __builtin_bit_cast(bf16x8, dsw[qb]));
+        DQ16_SB();
+        if (has_next) load_kb(kbuf, 2 * h + 2, 2, 4);
+        DQ16_SB();
     };
+#define DQ16_WAIT_BARRIER(N) asm volatile("s_waitcnt vmcnt(" #N ")\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
     stage(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (nt > 1) stage(1);
+    else { stage(0); }           // (keeps the request count per wave uniform; re-fetches tile 0 into its own slot)
 #pragma unroll 1
     for (int t = 0; t < nt; ++t) {
-        if (t + 1 < nt) stage(t + 1);
-        tile(t);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        // this wave's pieces of tile t have landed (tile t + 1's stay in flight) and, behind the barrier, everybody's; the slot tile t + 2
+        // goes to (tile t - 1's) is free
+        DQ16_WAIT_BARRIER(4);
+        stage(t + 2 < nt ? t + 2 : t);          // past the end: a re-fetch of the tile being read into its own slot (same bytes)
+        GF_LDS char* kbuf = lds + (t % 3) * DQ16_STAGE;
+        load_kb(kbuf, 0, 0, 4);
+        half(kbuf, 0, true);
+        half(kbuf, 1, false);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the last requests must not outlive the workgroup's LDS
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
         const int qrow = q0 + 16 * qb + r;
@@ -724,13 +787,7 @@ __global__ __launch_bounds__(Kv16<NP>::THREADS) void attn_bwd_dkv16_kernel(const
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-                for (int qb = 0; qb < 2; ++qb) {
-#if KV16_WHATIF & 256
-                    qfr[qb][ks] = own[qb][ks];
-#else
-                    qfr[qb][ks] = *(GF_LDS bf16x8*)(qbuf + 4096 * qb + fo.row[ks]);
-#endif
-                }
+                for (int qb = 0; qb < 2; ++qb) qfr[qb][ks] = *(GF_LDS bf16x8*)(qbuf + 4096 * qb + fo.row[ks]);
         }
         KV16_SB();
         if (second) {
@@ -754,13 +811,7 @@ __global__ __launch_bounds__(Kv16<NP>::THREADS) void attn_bwd_dkv16_kernel(const
                 for (int kb = 0; kb < 2; ++kb) mfma16(sc[qb][kb], qfr[qb][ks], own[kb][ks]);        // S[query 16 qb + 4 g + j, key 16 kb + r]
         KV16_SB();
 #pragma unroll
-        for (int db = 0; db < 8; ++db) {
-#if !(KV16_WHATIF & 128)
-            carry_a[db] = tr16_frag(dobuf, fo, db);
-#else
-            asm volatile("" : "+v"(carry_a[db]));
-#endif
-        }
+        for (int db = 0; db < 8; ++db) carry_a[db] = tr16_frag(dobuf, fo, db);
         f32x4 l4[2];
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) l4[qb] = *(GF_LDS f32x4*)(lse_s + 16 * qb + 4 * g);
@@ -770,11 +821,7 @@ __global__ __launch_bounds__(Kv16<NP>::THREADS) void attn_bwd_dkv16_kernel(const
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-#if !(KV16_WHATIF & 64)
-                    sc[qb][kb][j] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[qb][kb][j], c, -l4[qb][j]));
-#endif
-                }
+                for (int j = 0; j < 4; ++j) sc[qb][kb][j] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[qb][kb][j], c, -l4[qb][j]));
 #if !(KV16_WHATIF & 4)
                 *(GF_LDS f32x4*)(hb + (2 * qb + kb) * 1024) = sc[qb][kb];
 #endif
@@ -782,29 +829,50 @@ __global__ __launch_bounds__(Kv16<NP>::THREADS) void attn_bwd_dkv16_kernel(const
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) carry_b[kb] = pack44(sc[0][kb], sc[1][kb]);
     };
-    // wave B, iteration i: dK of granule i - 2 from registers; dP, dS of granule i - 1
+    // wave B, iteration i: dS of granule i - 1 (its dP is in registers since the last iteration, its P in the hand-off buffer), dK of
+    // granule i - 1 (Q^T fragments in registers), then dP of granule i.  B starts an iteration with arithmetic and ends with its MFMAs,
+    // A the other way round: after the barrier the two waves of a SIMD are in opposite phases.
+    f32x4 dpc[2][2];                 // dP of the granule whose dS comes next
     auto stepB = [&](int i) {
-        const int gi = i - 1;
-        const bool first = gi >= 0 && gi < ng, second = i >= 2;
-        GF_LDS char* qbuf = lds + L::Q + (gi & 3) * GR_BYTES;
-        GF_LDS char* dobuf = lds + L::DO + (gi & 3) * GR_BYTES;
-        GF_LDS float* dl_s = (GF_LDS float*)(lds + L::S + (gi & 3) * (2 * GR * 4)) + GR;
-        GF_LDS char* hb = lds + L::H + (gi & 1) * L::HBUF + pair * 4096 + lane * 16;
+        const int gd = i - 1;        // granule of the dS / dK part
+        const bool second = gd >= 0 && gd < ng, first = i < ng;
+        GF_LDS char* qbuf = lds + L::Q + (i & 3) * GR_BYTES;
+        GF_LDS char* dobuf = lds + L::DO + (i & 3) * GR_BYTES;
+        GF_LDS float* dl_s = (GF_LDS float*)(lds + L::S + (gd & 3) * (2 * GR * 4)) + GR;
+        GF_LDS char* hb = lds + L::H + (gd & 1) * L::HBUF + pair * 4096 + lane * 16;
+        f32x4 d4[2], pp[2][2];
         bf16x8 dofr[2][4];
+        if (second) {
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                d4[qb] = *(GF_LDS f32x4*)(dl_s + 16 * qb + 4 * g);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+#if KV16_WHATIF & 4
+                    pp[qb][kb] = d4[qb];
+#else
+                    pp[qb][kb] = *(GF_LDS f32x4*)(hb + (2 * qb + kb) * 1024);
+#endif
+                }
+            }
+        }
         if (first) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-                for (int qb = 0; qb < 2; ++qb) {
-#if KV16_WHATIF & 256
-                    dofr[qb][ks] = own[qb][ks];
-#else
-                    dofr[qb][ks] = *(GF_LDS bf16x8*)(dobuf + 4096 * qb + fo.row[ks]);
-#endif
-                }
+                for (int qb = 0; qb < 2; ++qb) dofr[qb][ks] = *(GF_LDS bf16x8*)(dobuf + 4096 * qb + fo.row[ks]);
         }
         KV16_SB();
         if (second) {
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) dpc[qb][kb][j] = pp[qb][kb][j] * (dpc[qb][kb][j] - d4[qb][j]);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) carry_b[kb] = pack44(dpc[0][kb], dpc[1][kb]);
+            KV16_SB();
 #pragma unroll
             for (int db = 0; db < 8; ++db)
 #pragma unroll
@@ -812,48 +880,20 @@ __global__ __launch_bounds__(Kv16<NP>::THREADS) void attn_bwd_dkv16_kernel(const
         }
         KV16_SB();
         if (!first) return;
-        f32x4 dp[2][2];
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) dp[qb][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int kb = 0; kb < 2; ++kb) dpc[qb][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb) mfma16(dp[qb][kb], dofr[qb][ks], own[kb][ks]);       // dP[query, key] = dO V^T
+                for (int kb = 0; kb < 2; ++kb) mfma16(dpc[qb][kb], dofr[qb][ks], own[kb][ks]);      // dP[query, key] = dO V^T
         KV16_SB();
 #pragma unroll
-        for (int db = 0; db < 8; ++db) {
-#if !(KV16_WHATIF & 128)
-            carry_a[db] = tr16_frag(qbuf, fo, db);
-#else
-            asm volatile("" : "+v"(carry_a[db]));
-#endif
-        }
-        f32x4 d4[2], pp[2][2];
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-            d4[qb] = *(GF_LDS f32x4*)(dl_s + 16 * qb + 4 * g);
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-#if KV16_WHATIF & 4
-                pp[qb][kb] = d4[qb];
-#else
-                pp[qb][kb] = *(GF_LDS f32x4*)(hb + (2 * qb + kb) * 1024);
-#endif
-            }
-        }
+        for (int db = 0; db < 8; ++db) carry_a[db] = tr16_frag(qbuf, fo, db);
         KV16_SB();
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) dp[qb][kb][j] = pp[qb][kb][j] * (dp[qb][kb][j] - d4[qb][j]);
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) carry_b[kb] = pack44(dp[0][kb], dp[1][kb]);
     };
     issue(-2);
     issue(-1);
@@ -873,14 +913,14 @@ __global__ __launch_bounds__(Kv16<NP>::THREADS) void attn_bwd_dkv16_kernel(const
     };
     if (!roleB) {
 #pragma unroll 1
-        for (int i = 0; i <= ng + 1; ++i) {
+        for (int i = 0; i <= ng; ++i) {
             wait_barrier();
             KV16_ISSUE(i);
             stepA(i);
         }
     } else {
 #pragma unroll 1
-        for (int i = 0; i <= ng + 1; ++i) {
+        for (int i = 0; i <= ng; ++i) {
             wait_barrier();
             KV16_ISSUE(i);
             stepB(i);

@@ -53,6 +53,26 @@ def test_flash_attn_backward(sq, skv, heads):
         assert got.dtype == BF and got.shape == want.shape
 
 
+@pytest.mark.parametrize("sq,skv,heads", [(1000, 777, 8), (2085, 1999, 8), (96, 4000, 3)])
+def test_flash_attn_backward_kernels_agree_with_the_first_kernels(sq, skv, heads):
+    """The 16x16x32 kernels (dQ + paired dK/dV, 7 tile products) against the first kernels (GF_ATTN_BWD=v1: 32x32x16, dQ / dV / dK
+    passes): the same per-element arithmetic, another summation order — ragged lengths, the XCD-ordered grid (heads % 8 == 0)."""
+    from goal_force_amd import ops
+    g = torch.Generator().manual_seed(sq + skv)
+    q = torch.randn((sq, heads * HD), generator=g).to(BF).cuda()
+    k = torch.randn((skv, heads * HD), generator=g).to(BF).cuda()
+    v = torch.randn((skv, heads * HD), generator=g).to(BF).cuda()
+    dout = torch.randn((sq, heads * HD), generator=g).to(BF).cuda()
+    o, lse = ops.flash_attn_lse(q, k, v, heads)
+    got = ops.flash_attn_bwd(q, k, v, o, dout, lse, heads)
+    with ops.env_options(GF_ATTN_BWD="v1"):
+        want = ops.flash_attn_bwd(q, k, v, o, dout, lse, heads)
+    for name, a, b in zip(("dq", "dk", "dv"), got, want):
+        assert torch.isfinite(a.float()).all(), name
+        e = rel_l2(a.float().cpu(), b.float().cpu())
+        assert e < 3e-3, f"{name}: rel_l2={e:.3e}"
+
+
 def test_flash_attn_backward_strided_inputs():
     """q, k, v as column slices of one fused [S, 3D] buffer (row stride 3D), as the fused QKV projection produces them."""
     from goal_force_amd import ops
