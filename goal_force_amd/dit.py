@@ -215,10 +215,14 @@ class SelfAttention(nn.Module):
         """x2 [S,D] -> attention output BEFORE the o projection, [S,D].  With a sequence_parallel.SequenceParallel
         group `sp`, x2 and rope are this rank's token chunk and the heads are exchanged over xGMI (usp_attn_forward,
         diffsynth/distributed/xdit_context_parallel.py:109-131).  `keep` (a dict, training): the attention output and the
-        rows' log-sum-exp are stored under "attn" / "lse" so that the backward does not run the attention again."""
+        rows' log-sum-exp are stored under "attn" / "lse" so that the backward does not run the attention again; with
+        keep["wide"] also the three projections ("qp", "kp" before their norm, "v")."""
         fp8 = getattr(self.q, "_gf_w8", None) is not None
         xin = (x2 if isinstance(x2, QuantizedInput) else QuantizedInput(x2)) if fp8 else x2
         q, k = linear(xin, self.q), linear(xin, self.k)
+        if keep is not None and keep.get("wide"):      # training with room to spare: the pre-norm projections stay for the backward
+            keep["qp"], keep["kp"] = q, k
+            q, k = q.clone(), k.clone()
         ops.rmsnorm_rope(q, self.norm_q.weight, rope.cos, rope.sin, self.head_dim, self.norm_q.eps)
         ops.rmsnorm_rope(k, self.norm_k.weight, rope.cos, rope.sin, self.head_dim, self.norm_k.eps)
         if sp is None and keep is None and not fp8 and x2.is_cuda and self.v.weight.shape[0] >= 512 \
@@ -238,6 +242,8 @@ class SelfAttention(nn.Module):
             return sp.attention(q, k, v, self.num_heads)
         if keep is not None:
             keep["attn"], keep["lse"] = ops.flash_attn_lse(q, k, v, self.num_heads)
+            if keep.get("wide"):
+                keep["v"] = v
             return keep["attn"]
         return ops.flash_attn(q, k, v, self.num_heads)
 
@@ -326,6 +332,8 @@ class DiTBlock(nn.Module):
             a = self.self_attn.attend(h, rope, sp, keep)
             x_new = out if out is not None else torch.empty_like(x2)
             linear(a, self.self_attn.o, epilogue=ops.EPI_BIAS_GATE_RESID, resid=x2, gate=mod[2], out=x_new)   # DIT:226
+            if keep is not None and keep.get("wide"):
+                keep["x1"] = x_new.clone()               # (the rest of the block updates x_new in place)
             if self_attn_memo is not None:
                 self_attn_memo["x"] = x_new.clone()      # the rest of the block updates x_new in place
         if fp8:
@@ -336,6 +344,8 @@ class DiTBlock(nn.Module):
             context_kv = self.cross_attn.context_kv(_tokens2d(context))
         a = self.cross_attn.attend(h, context_kv)
         linear(a, self.cross_attn.o, epilogue=ops.EPI_BIAS_RESID, resid=x_new, out=x_new)               # DIT:227
+        if keep is not None and keep.get("wide"):
+            keep["x2b"] = x_new.clone()
         if fp8:
             h = QuantizedInput.layernorm(x_new, scale1p=mod[4], shift=mod[3], eps=self.eps)
         else:

@@ -200,9 +200,21 @@ _PARAM_NAMES = (
 )
 
 
-# Keep every block's self-attention output + log-sum-exp from the forward (GF_TRAIN_KEEP_ATTN=0: recompute them in the backward,
-# 17 GB less at A14B size, 0.9 s more per step).
-KEEP_ATTENTION = os.environ.get("GF_TRAIN_KEEP_ATTN", "1") != "0"
+# What a block's forward keeps for its backward besides its inputs (GF_TRAIN_KEEP):
+#   "none": nothing — the backward recomputes the whole block (GF_TRAIN_KEEP_ATTN=0 is the same switch under its first name);
+#   "attn": the self-attention output + log-sum-exp (0.34 GB per block at 32760 tokens; 17 GB at A14B size, 0.9 s less per step);
+#   "wide" (default): also the three self-attention projections (pre-norm q, k; v) and the block's state after the self- and the
+#           cross-attention branch: 2.0 GB per block, 100 GB at A14B size — a training step then peaks near 190 GB of the 288 GB and
+#           its backward skips 4.6 (trainable block) to 9.5 ms (frozen block: also o, GELU and FFN2, which only feed parameter
+#           gradients) of recomputed GEMMs per block.  Kept tensors are the forward's own values: same kernels, same inputs.
+_KEEP = os.environ.get("GF_TRAIN_KEEP", "wide")
+if os.environ.get("GF_TRAIN_KEEP_ATTN", "1") == "0":
+    _KEEP = "none"
+if _KEEP not in ("none", "attn", "wide"):
+    raise GoalForceError(f"GF_TRAIN_KEEP={_KEEP!r}: expected none, attn or wide")
+KEEP_ATTENTION = _KEEP != "none"
+KEEP_WIDE = _KEEP == "wide"
+_WIDE_NAMES = ("qp", "kp", "v", "x1", "x2b")
 
 
 def _block_params(block: DiTBlock):
@@ -220,12 +232,15 @@ class DiTBlockFn(torch.autograd.Function):
             # the backward recomputes the block on the bf16 kernels: an fp8 forward would not be the function differentiated
             raise GoalForceError("training through an enable_fp8 block is refused: call enable_fp8(module, False) first")
         ctx.param_needs = [p.requires_grad for p in params]
-        keep = {} if KEEP_ATTENTION else None
+        keep = ({"wide": True} if KEEP_WIDE else {}) if KEEP_ATTENTION else None
         with torch.no_grad():
             out = block(x2, ctx2, t_mod, rope, keep=keep)
         # kept for the backward besides the block's inputs: the self-attention output (S x D bf16) and its log-sum-exp
         # (S x heads fp32) — 0.34 GB per block at 32760 tokens against 18.6 ms of attention per block not run again
-        if keep:
+        ctx.wide = bool(keep) and all(n in keep for n in _WIDE_NAMES)
+        if ctx.wide:
+            ctx.save_for_backward(x2, ctx2, t_mod, keep["attn"], keep["lse"], *(keep[n] for n in _WIDE_NAMES))
+        elif keep:
             ctx.save_for_backward(x2, ctx2, t_mod, keep["attn"], keep["lse"])
         else:
             ctx.save_for_backward(x2, ctx2, t_mod)
@@ -235,7 +250,8 @@ class DiTBlockFn(torch.autograd.Function):
     def backward(ctx, dout):
         block, rope = ctx.block, ctx.rope
         x, c2, t_mod = ctx.saved_tensors[:3]
-        kept = ctx.saved_tensors[3:]
+        kept = ctx.saved_tensors[3:5]
+        wide = dict(zip(_WIDE_NAMES, ctx.saved_tensors[5:])) if ctx.wide else None
         need = dict(zip(_PARAM_NAMES, ctx.param_needs))
         any_param = any(ctx.param_needs)
         eps, dev, d = block.eps, x.device, block.dim
@@ -253,27 +269,33 @@ class DiTBlockFn(torch.autograd.Function):
                 g[prefix + ".bias"] = bias_grad(dy)
             return linear_dx(dy, layer.weight) if want_dx else None
 
-        # ---- recompute the forward, un-fused, keeping the intermediates (DIT:218-229)
+        # ---- recompute the forward, un-fused, keeping the intermediates (DIT:218-229); what the forward kept (`wide`) is taken as it
+        # is, and what would only feed a parameter gradient nobody asked for (a frozen block) is not computed
         mod = ops.modulation(block.modulation, t_mod.contiguous(), onep_mask=0b010010)
-        h1 = ops.layernorm_modulate(x, scale1p=mod[1], shift=mod[0], eps=eps)
-        qp, kp, vv = lin(h1, sa.q), lin(h1, sa.k), lin(h1, sa.v)
+        need_h1 = wide is None or any(need[f"self_attn.{n}.weight"] for n in "qkv")
+        h1 = ops.layernorm_modulate(x, scale1p=mod[1], shift=mod[0], eps=eps) if need_h1 else None
+        if wide is not None:
+            qp, kp, vv = wide["qp"], wide["kp"], wide["v"]
+        else:
+            qp, kp, vv = lin(h1, sa.q), lin(h1, sa.k), lin(h1, sa.v)
         qn, kn = qp.clone(), kp.clone()
         ops.rmsnorm_rope(qn, sa.norm_q.weight, rope.cos, rope.sin, hd, sa.norm_q.eps)
         ops.rmsnorm_rope(kn, sa.norm_k.weight, rope.cos, rope.sin, hd, sa.norm_k.eps)
-        a, lse = kept if kept else ops.flash_attn_lse(qn, kn, vv, heads)
-        o = lin(a, sa.o)
-        x1 = ops.add(x, ops.colsum(o, gate=mod[2]))                                  # x + gate_msa * o
+        a, lse = kept if len(kept) else ops.flash_attn_lse(qn, kn, vv, heads)
+        o = lin(a, sa.o) if (wide is None or need["modulation"]) else None            # o: x1 (unless kept) and the gate's gradient
+        x1 = wide["x1"] if wide is not None else ops.add(x, ops.colsum(o, gate=mod[2]))   # x + gate_msa * o
         h2 = ops.layernorm_modulate(x1, weight=block.norm3.weight, bias=block.norm3.bias, eps=eps)
         q2p, k2p, v2 = lin(h2, ca.q), lin(c2, ca.k), lin(c2, ca.v)
         q2n, k2n = q2p.clone(), k2p.clone()
         ops.rmsnorm_rope(q2n, ca.norm_q.weight, None, None, hd, ca.norm_q.eps)
         ops.rmsnorm_rope(k2n, ca.norm_k.weight, None, None, hd, ca.norm_k.eps)
         a2, lse2 = ops.flash_attn_lse(q2n, k2n, v2, heads)
-        x2b = ops.gemm(a2, ca.o.weight, ca.o.bias, epilogue=ops.EPI_BIAS_RESID, resid=x1)
+        x2b = wide["x2b"] if wide is not None else ops.gemm(a2, ca.o.weight, ca.o.bias, epilogue=ops.EPI_BIAS_RESID, resid=x1)
         h3 = ops.layernorm_modulate(x2b, scale1p=mod[4], shift=mod[3], eps=eps)
         u = lin(h3, block.ffn[0])
-        f = ops.act(u, "gelu_tanh")
-        y = lin(f, block.ffn[2])
+        need_y = need["modulation"]                                                      # y: only the gate's gradient reads it
+        f = ops.act(u, "gelu_tanh") if (need_y or need["ffn.2.weight"]) else None
+        y = lin(f, block.ffn[2]) if need_y else None
 
         def acc():
             return _zeros_f32(d, dev) if need["modulation"] else None

@@ -268,6 +268,45 @@ def test_dit_block_backward_mid_size_vs_oracle():
         assert e < (8e-2 if n.endswith("attn.k.bias") else 2.5e-2), f"{n}: rel_l2={e:.3e}"
 
 
+def test_dit_block_backward_is_the_same_whatever_the_forward_kept(monkeypatch):
+    """GF_TRAIN_KEEP = none / attn / wide: kept tensors are the forward's own values, so the gradients agree to rounding (the fused
+    forward rounds x1 / x2b once where the un-fused recompute rounds per op), for a trainable and for a frozen block."""
+    import gen_inputs as gi
+    from goal_force_amd import training
+    from goal_force_amd.dit import DiTBlock, RopeTable, precompute_freqs_cis_3d
+    cfg = gi.MID
+    sd = gi.block_sd(torch.Generator().manual_seed(31), cfg["dim"], cfg["ffn_dim"], "", BF)
+    x, ctx, t_mod = gi.block_inputs(cfg["dim"], 960, 512, seed=32)
+    dout = torch.randn(x.shape, generator=torch.Generator().manual_seed(33)).to(BF)
+    blk = DiTBlock(False, cfg["dim"], cfg["num_heads"], cfg["ffn_dim"], cfg["eps"])
+    blk.load_state_dict(sd, strict=True)
+    blk = blk.to(BF).cuda()
+    rope = RopeTable.from_grid(precompute_freqs_cis_3d(cfg["dim"] // cfg["num_heads"]), 5, 12, 16, "cuda")
+    res = {}
+    for frozen in (False, True):
+        for p_ in blk.parameters():
+            p_.requires_grad_(not frozen)
+        for level in ("none", "attn", "wide"):
+            monkeypatch.setattr(training, "KEEP_ATTENTION", level != "none")
+            monkeypatch.setattr(training, "KEEP_WIDE", level == "wide")
+            for p_ in blk.parameters():
+                p_.grad = None
+            xc = x[0].cuda().requires_grad_(True)
+            with torch.enable_grad():
+                training.block_forward(blk, xc, ctx[0].cuda(), t_mod.cuda(), rope).backward(dout[0].cuda())
+            res[(frozen, level)] = (xc.grad.float().cpu(), {n: p_.grad.float().cpu() for n, p_ in blk.named_parameters() if p_.grad is not None})
+    for frozen in (False, True):
+        dx0, g0 = res[(frozen, "none")]
+        assert frozen == (len(g0) == 0)
+        for level in ("attn", "wide"):
+            dx, g = res[(frozen, level)]
+            assert rel_l2(dx, dx0) < 6e-3, (frozen, level)
+            assert g.keys() == g0.keys()
+            for n in g:
+                assert rel_l2(g[n], g0[n]) < (6e-2 if n.endswith("attn.k.bias") else 1e-2), (frozen, level, n)
+        assert torch.equal(res[(frozen, "attn")][0], dx0), "keeping only the attention output changes no bit"
+
+
 def _tiny_train_models():
     import gen_inputs as gi
     from goal_force_amd.controlnet import ControlNet
