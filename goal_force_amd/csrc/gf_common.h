@@ -119,6 +119,8 @@ struct GfOptions {
 // gf_conv_direct.hip: direct convolution of the 96-channel level; GF_ERR_UNSUPPORTED = shape not covered (caller falls back)
 int gf_conv3d_direct_c96(const void* src_walk, const void* Wm, int64_t ldw, const void* bias, void* out, int64_t T_out, int64_t H,
                          int64_t W, int64_t N, int epilogue, const void* resid, const void* zero_page, void* stream);
+int gf_conv2d_up_direct_c192(const void* src0, const void* Wm, int64_t ldw, const void* bias, void* out, int64_t T_out, int64_t Hs,
+                             int64_t Ws, const void* zero_page, void* stream);
 const GfOptions& gf_options();          // gf_abi.hip
 extern "C" GF_API void gf_reload_options(void);
 

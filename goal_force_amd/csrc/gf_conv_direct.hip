@@ -333,6 +333,206 @@ __global__ __launch_bounds__(CD_THREADS, 2) void conv3d_c96_kernel(const CdArgs 
     epilogue(j1 - 1, []() {});                             // the segment's last output frame finished with input j1 + 1 (set 2)
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The decoder's last spatial upsample (Resample "upsample2d", VAE:91-99: nearest-exact 2x + Conv2d 3x3, 192 -> 96 channels at full
+// resolution): as an implicit GEMM it ran at 0.37 PFLOP/s (7.2 ms for 2.65 TFLOP per launch: every source pixel gathered 9 x 4 times
+// through L2, the N tile three quarters full).  Direct form on the same skeleton as above:
+//   * a workgroup owns an 8 x 32 patch of OUTPUT pixels x 96 channels of one frame after the other; the patch's source is a
+//     (4 + 2) x (16 + 2) halo of the HALF-resolution frame (108 pixels x 192 channels, 416-byte pitch = 384 + 32: conflict-free
+//     fragment reads; two output pixels share a source pixel: the same address, a broadcast), double buffered — the next frame's
+//     halo is requested late in the current frame so that the counted weight waits stay simple;
+//   * the K loop is 9 taps x 2 channel halves = 18 stages of a [96 x 96] weight block — the weight ring, the B fragments, the
+//     barrier per stage and the epilogue are the 96-channel kernel's; the tap (dy, dx) of output pixel (y, x) reads source pixel
+//     ((y + dy - 1) >> 1, (x + dx - 1) >> 1): the row part is wave-uniform, the column part three per-lane offsets per 16-pixel block;
+//   * one accumulator set (48 registers); a frame's result leaves at the start of the next frame, under its first weight waits.
+// Same summation order as the implicit GEMM (taps in sequence, 32 channels per MFMA): bit-identical (tests/test_vae.py).
+constexpr int UP_C = 192, UP_PITCH = 416, UP_SLOTS = 26;                             // 24 data + 2 pad slots of 16 bytes per source pixel
+constexpr int UP_HH = CD_TH / 2 + 2, UP_HW = CD_TW / 2 + 2;                         // 6 x 18 source pixels
+constexpr int UP_HALO_INSTR = (UP_HH * UP_HW * UP_SLOTS + 63) / 64;                  // 44
+constexpr int UP_HALO_BYTES = UP_HALO_INSTR * 1024;                                  // 45056
+constexpr int UP_HK = (UP_HALO_INSTR + CD_WAVES - 1) / CD_WAVES;                     // 6
+constexpr int UP_STAGES = 18;
+constexpr int UP_LDS = 2 * UP_HALO_BYTES + CD_STAGES * CdShape<6>::W_BYTES;          // 154624
+
+struct UpArgs {
+    const u16* src;     // [T, H/2, W/2, 192]: frame 0 = the frame output 0 reads
+    const u16* w;       // [96, ldw], K order (dy, dx, cin)
+    const u16* bias;
+    u16* out;           // [T_out, H, W, 96]
+    const u16* zero;
+    int H, W, T_out, tseg, tiles_x, tiles_y;     // H, W: OUTPUT resolution
+    long sframe;        // (H/2) * (W/2) * 192
+    long ldw;
+};
+
+__global__ __launch_bounds__(CD_THREADS, 1) void conv2d_up_c192_kernel(const UpArgs p) {
+    using SH = CdShape<6>;
+    constexpr int PB = 4, CB = 3, W_INSTR = SH::W_INSTR, W_BYTES = SH::W_BYTES, WK = SH::WK;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    GF_LDS char* lds = (GF_LDS char*)smem;
+    GF_LDS char* wbuf = lds + 2 * UP_HALO_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = wave >> 1, wc = wave & 1;
+    const int l15 = lane & 15, kc = lane >> 4;
+    const int spatial = p.tiles_x * p.tiles_y;
+    const int seg = blockIdx.x / spatial, sp = blockIdx.x - seg * spatial;
+    const int y0 = (sp / p.tiles_x) * CD_TH, x0 = (sp % p.tiles_x) * CD_TW;
+    const int j0 = seg * p.tseg, j1 = min(p.T_out, j0 + p.tseg);
+    const int Hs = p.H >> 1, Ws = p.W >> 1, sy0 = (y0 >> 1) - 1, sx0 = (x0 >> 1) - 1;
+
+    int woff[WK];
+#pragma unroll
+    for (int k = 0; k < WK; ++k) {
+        const int slot = (wave + CD_WAVES * k) * 64 + lane;
+        const int n = slot / CD_SLOTS, sl = min(slot % CD_SLOTS, 11);
+        woff[k] = (int)(n * p.ldw * 2) + sl * 16;
+    }
+    auto issue_w = [&](int stage, int stage_off) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < WK; ++k) {
+            const int i = wave + CD_WAVES * k;
+            if (i < W_INSTR) cd_glds16((const char*)p.w + woff[k] + stage * (CD_C * 2), wbuf + stage_off + i * 1024);
+        }
+    };
+    const bool more = wave + CD_WAVES * (WK - 1) < W_INSTR;          // 3 weight requests per stage (else 2)
+    const bool hmore = wave + CD_WAVES * (UP_HK - 1) < UP_HALO_INSTR; // 6 halo requests per frame (else 5)
+    auto issue_halo = [&](int g, int lane_v, GF_LDS char* hbuf) __attribute__((always_inline)) {
+        const char* base = (const char*)(p.src + (long)g * p.sframe);
+#pragma unroll
+        for (int k = 0; k < UP_HK; ++k) {
+            const int i = wave + CD_WAVES * k;
+            if (i < UP_HALO_INSTR) {
+                const int slot = i * 64 + lane_v;
+                const int px = slot / UP_SLOTS, sl = slot - px * UP_SLOTS;
+                const int hy = px / UP_HW, hx = px - hy * UP_HW;
+                const int y = sy0 + hy, x = sx0 + hx;
+                const bool ok = px < UP_HH * UP_HW && sl < 24 && y >= 0 && y < Hs && x >= 0 && x < Ws;
+                cd_glds16(ok ? base + (long)((y * Ws + x) * (UP_C * 2) + sl * 16) : (const char*)p.zero, hbuf + i * 1024);
+            }
+        }
+    };
+    // A fragment of pixel block b (row 2 wp + (b >> 1), columns 16 (b & 1) + l15) at tap (dy, dx): halo pixel
+    // (((row + dy - 1) >> 1) + 1, ((col + dx - 1) >> 1) + 1); per lane: the column part for (dx, b & 1)
+    int colo[3][2];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int xb = 0; xb < 2; ++xb) colo[dx][xb] = (((16 * xb + l15 + dx - 1) >> 1) + 1) * UP_PITCH + kc * 16;
+    GF_LDS char* const b_base = wbuf + l15 * CD_PITCH + kc * 16 + CB * wc * 16 * CD_PITCH;
+
+    f32x4 acc[PB][CB];
+    u16x4 bias4[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+        const int n = (CB * wc + cb) * 16 + kc * 4;
+        bias4[cb] = p.bias ? *reinterpret_cast<const u16x4*>(p.bias + n) : u16x4{0, 0, 0, 0};
+    }
+    int st_cur = 0, st_nxt = W_BYTES, st_free = 2 * W_BYTES;
+    int stage_next2 = 2;
+    // frame j's accumulators -> out (bias), staged as in the kernel above — in the halo buffer that is idle at a frame's start (the
+    // weight ring is requested into again right behind the epilogue, with no barrier in between)
+    auto epilogue = [&](int j, GF_LDS char* idle) __attribute__((always_inline)) {
+        GF_LDS char* ep = idle + wave * CD_EP_BYTES;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int y = y0 + 2 * wp + (b >> 1), xb = x0 + (b & 1) * 16;
+            const long blkbase = (((long)j * p.H + y) * p.W + xb) * CD_C + wc * 48;
+#pragma unroll
+            for (int cb = 0; cb < 3; ++cb) {
+                const f32x4 a = acc[b][cb];
+                u32x2 pk;
+                pk[0] = pack2bf(a[0] + bf2f(bias4[cb][0]), a[1] + bf2f(bias4[cb][1]));
+                pk[1] = pack2bf(a[2] + bf2f(bias4[cb][2]), a[3] + bf2f(bias4[cb][3]));
+                *(GF_LDS u32x2*)(ep + l15 * 96 + cb * 32 + kc * 8) = pk;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int s = i * 64 + lane;
+                const int px = s / 6, sl = s - px * 6;
+                if (s < 96 && y < p.H && xb + px < p.W)
+                    *reinterpret_cast<u16x8*>(p.out + blkbase + (long)px * CD_C + sl * 8) = *(GF_LDS u16x8*)(ep + s * 16);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    };
+    issue_w(0, 0);
+    issue_w(1, W_BYTES);
+    {
+        int lane_v = lane;
+        asm volatile("" : "+v"(lane_v));
+        issue_halo(j0, lane_v, lds);
+    }
+#pragma unroll 1
+    for (int g = j0; g < j1; ++g) {
+        GF_LDS char* const hbuf = lds + ((g - j0) & 1) * UP_HALO_BYTES;
+        GF_LDS char* const hnext = lds + (((g - j0) & 1) ^ 1) * UP_HALO_BYTES;
+        CD_WAIT_BARRIER(0);                                // halo g and the first two stages' weights landed; the other halo buffer is free
+        if (g > j0) epilogue(g - 1, hnext);
+#pragma unroll
+        for (int b = 0; b < PB; ++b)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) acc[b][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int s = 0; s < UP_STAGES; ++s) {
+            if (s > 0) {
+                // this stage's weights landed; in flight stay the newest weight request (3 or 2) and, from stage 15 on, the next halo
+                if (s <= 15) {
+                    if (more) CD_WAIT_BARRIER(3);
+                    else CD_WAIT_BARRIER(2);
+                } else if (hmore) {
+                    if (more) CD_WAIT_BARRIER(9);
+                    else CD_WAIT_BARRIER(8);
+                } else {
+                    if (more) CD_WAIT_BARRIER(8);
+                    else CD_WAIT_BARRIER(7);
+                }
+            }
+            issue_w(stage_next2, st_free);
+            stage_next2 = stage_next2 == UP_STAGES - 1 ? 0 : stage_next2 + 1;
+            if (s == 15) {
+                int lane_v = lane;
+                asm volatile("" : "+v"(lane_v));
+                issue_halo(g + 1 < j1 ? g + 1 : g, lane_v, hnext);     // (last frame: a re-fetch nobody reads keeps the counts uniform)
+            }
+            const int tap = s >> 1, hf = s & 1;
+            const int dy = (tap * 11) >> 5, dx = tap - 3 * dy;
+            GF_LDS char* const baddr = b_base + st_cur;
+            GF_LDS char* arow[2];
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) arow[rr] = hbuf + (((2 * wp + rr + dy - 1) >> 1) + 1) * (UP_HW * UP_PITCH) + hf * (CD_C * 2);
+            const int c0 = dx == 0 ? colo[0][0] : (dx == 1 ? colo[1][0] : colo[2][0]);
+            const int c1 = dx == 0 ? colo[0][1] : (dx == 1 ? colo[1][1] : colo[2][1]);
+            bf16x8 af[2][PB], bfr[2][CB];
+            auto load = [&](int ks, int set) __attribute__((always_inline)) {
+#pragma unroll
+                for (int b = 0; b < PB; ++b) af[set][b] = *(GF_LDS bf16x8*)(arow[b >> 1] + ((b & 1) ? c1 : c0) + ks * 64);
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) bfr[set][cb] = *(GF_LDS bf16x8*)(baddr + cb * 16 * CD_PITCH + ks * 64);
+            };
+            load(0, 0);
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) {
+                if (ks < 2) load(ks + 1, (ks + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int b = 0; b < PB; ++b)
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb)
+                        acc[b][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks & 1][cb], af[ks & 1][b], acc[b][cb], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const int t = st_cur;
+            st_cur = st_nxt;
+            st_nxt = st_free;
+            st_free = t;
+        }
+    }
+    CD_WAIT_BARRIER(0);                                    // the ring's last prefetches and the spare halo must not outlive the workgroup's LDS
+    epilogue(j1 - 1, lds + (((j1 - j0) & 1)) * UP_HALO_BYTES);       // either buffer is idle now
+}
+
 template <int EPI, int NCB>
 int launch_cd(const CdArgs& a, unsigned grid, hipStream_t stream) {
     static GfDeviceOnce once;
@@ -386,4 +586,42 @@ int gf_conv3d_direct_c96(const void* src_walk, const void* Wm, int64_t ldw, cons
     hipStream_t s = (hipStream_t)stream;
     if (N == CD_C) return epilogue == GF_EPI_BIAS_RESID ? launch_cd<GF_EPI_BIAS_RESID, 6>(a, grid, s) : launch_cd<GF_EPI_BIAS, 6>(a, grid, s);
     return epilogue == GF_EPI_BIAS_RESID ? launch_cd<GF_EPI_BIAS_RESID, 1>(a, grid, s) : launch_cd<GF_EPI_BIAS, 1>(a, grid, s);
+}
+
+// Called by gf_conv3d_bf16 for: kt = 1, ks = 3, mode 1 (nearest-exact 2x upsample folded in), C = 192, N = 96, bias epilogue, contiguous
+// out rows.  `src0` = the source frame output 0 reads; Hs, Ws = SOURCE resolution.
+int gf_conv2d_up_direct_c192(const void* src0, const void* Wm, int64_t ldw, const void* bias, void* out, int64_t T_out, int64_t Hs,
+                             int64_t Ws, const void* zero_page, void* stream) {
+    const int64_t H = 2 * Hs, W = 2 * Ws;
+    if (Hs * Ws * UP_C * 2 >= (1LL << 31) || ldw * 2 * CD_C >= (1LL << 31) || T_out <= 0) return GF_ERR_UNSUPPORTED;
+    UpArgs a;
+    a.src = (const u16*)src0;
+    a.w = (const u16*)Wm;
+    a.bias = (const u16*)bias;
+    a.out = (u16*)out;
+    a.zero = (const u16*)zero_page;
+    a.H = (int)H;
+    a.W = (int)W;
+    a.T_out = (int)T_out;
+    a.tiles_x = (int)((W + CD_TW - 1) / CD_TW);
+    a.tiles_y = (int)((H + CD_TH - 1) / CD_TH);
+    a.sframe = Hs * Ws * UP_C;
+    a.ldw = ldw;
+    const long spatial = (long)a.tiles_x * a.tiles_y;
+    long nseg = (3 * 256 + spatial - 1) / spatial;       // one workgroup per CU at a time: a few rounds over the chip
+    if (nseg > T_out) nseg = T_out;
+    if (nseg < 1) nseg = 1;
+    a.tseg = (int)((T_out + nseg - 1) / nseg);
+    nseg = (T_out + a.tseg - 1) / a.tseg;
+    static GfDeviceOnce once;
+    hipError_t e = gf_once_per_device(once, [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(conv2d_up_c192_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, UP_LDS);
+    });
+    if (e != hipSuccess) {
+        gf_set_error("gf_conv3d_bf16 (direct upsample): hipFuncSetAttribute(%d B LDS) failed: %s", UP_LDS, hipGetErrorString(e));
+        return GF_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(conv2d_up_c192_kernel, dim3((unsigned)(spatial * nseg)), dim3(CD_THREADS), UP_LDS, (hipStream_t)stream, a);
+    GF_CHECK_LAUNCH("gf_conv3d_bf16 (direct upsample)");
+    return GF_OK;
 }

@@ -1658,6 +1658,13 @@ extern "C" GF_API int gf_conv3d_bf16(const void* src, const void* cache, const v
         const int rc = gf_conv3d_direct_c96(walk, Wm, ldw, bias, out, T_out, H, W, N, epilogue, resid, a.cv.zero, stream);
         if (rc != GF_ERR_UNSUPPORTED) return rc;
     }
+    // the decoder's full-resolution upsample convolution (nearest 2x + 3x3, 192 -> 96): direct form, bit-identical as well
+    if (kt == 1 && ks == 3 && mode == 1 && t_stride == 1 && C == 192 && N == 96 && ldc == N && epilogue == GF_EPI_BIAS && (H % 4) == 0 &&
+        (W % 16) == 0 && gf_options().conv_direct.load(std::memory_order_relaxed)) {
+        const u16* src0 = (const u16*)src + (long)t_off * H * W * C;
+        const int rc = gf_conv2d_up_direct_c192(src0, Wm, ldw, bias, out, T_out, H, W, a.cv.zero, stream);
+        if (rc != GF_ERR_UNSUPPORTED) return rc;
+    }
     // contiguous source frames and stride-1 taps: the pointer-per-row gather (GF_CONV_GATHER=1 forces the general one, A/B)
     const int force_g = gf_options().conv_gather.load(std::memory_order_relaxed);
     const bool fast = force_g != 1 && mode == 0 && (kt == 1 || !cache);

@@ -213,6 +213,30 @@ def test_hip_direct_conv_c96_equals_implicit_gemm_at_tile_size():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("T,Hs,Ws,t_off", [(3, 12, 16, 0), (5, 8, 48, 1), (2, 120, 208, 0), (9, 20, 32, 2)])
+def test_hip_direct_upsample_conv_equals_implicit_gemm(T, Hs, Ws, t_off):
+    """The decoder's full-resolution upsample convolution (nearest 2x + 3x3, 192 -> 96 channels): the direct kernel (8 x 32 output
+    patches, half-resolution halo, 18 weight stages per frame) against the implicit GEMM (GF_CONV_DIRECT=0) and, at the small sizes,
+    the patch matrix + GEMM — bit for bit, with a frame offset and over several frame segments."""
+    from goal_force_amd import ops
+    g = torch.Generator().manual_seed(T * 1000 + Hs)
+    C, N = 192, 96
+    k = 9 * C
+    x = (torch.randn((T, Hs, Ws, C), generator=g) * 0.7).to(BF).cuda()
+    w = (torch.randn((N, k), generator=g) / k ** 0.5).to(BF).cuda()
+    b = torch.randn((N,), generator=g).to(BF).cuda()
+    kw = dict(upsample2x=True, t_off=t_off, t_out=T - t_off)
+    with ops.env_options(GF_CONV_DIRECT="0"):
+        ref = ops.vae_conv3d(x, None, w, b, 1, 3, **kw)
+    got = ops.vae_conv3d(x, None, w, b, 1, 3, **kw)
+    assert got.shape == ref.shape == ((T - t_off) * 4 * Hs * Ws, N)
+    assert torch.equal(got, ref), f"{int((got != ref).sum())} of {ref.numel()} differ"
+    if Hs * Ws < 2000:
+        assert torch.equal(ops.gemm(ops.vae_im2col(x, None, 1, 3, k, **kw), w, b), ref)
+    assert float(ref.float().abs().max()) > 0.5
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(24))
 def test_hip_implicit_conv_random_shapes(seed):
     """Randomised geometry (frames, image size, channels, output width, kernel, gather mode, temporal stride / offset, history in

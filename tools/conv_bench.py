@@ -40,6 +40,25 @@ def main():
                     best[key] = min(best.get(key, 1e9), e0.elapsed_time(e1) / 3)
     for key, ms in best.items():
         print(f"{key:16s} {ms:7.3f} ms  {fl / ms / 1e9:7.1f} TFLOP/s", flush=True)
+    # the decoder's upsample convolution of the same tile (nearest 2x + 3x3, 192 -> 96 channels, source 120 x 208): 2.65 TFLOP
+    xs = (torch.randn((T, H // 2, W // 2, 192), device="cuda") * 0.7).to(BF)
+    ku = 9 * 192
+    wu = (torch.randn((96, ku), device="cuda") / ku ** 0.5).to(BF)
+    flu = 2.0 * T * H * W * ku * 96
+    bestu = {}
+    for rnd in range(3):
+        for name, env in (("implicit", "0"), ("direct", "1")):
+            with ops.env_options(GF_CONV_DIRECT=env):
+                ops.vae_conv3d(xs, None, wu, b, 1, 3, upsample2x=True)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(3):
+                    ops.vae_conv3d(xs, None, wu, b, 1, 3, upsample2x=True)
+                e1.record()
+                torch.cuda.synchronize()
+                bestu[name] = min(bestu.get(name, 1e9), e0.elapsed_time(e1) / 3)
+    for key, ms in bestu.items():
+        print(f"upsample {key:8s} {ms:7.3f} ms  {flu / ms / 1e9:7.1f} TFLOP/s", flush=True)
     # timing-only what-if builds of the direct kernel (-DCD_WHATIF=n: 1 no counted wait, 2 no barrier, 4 no weight requests; wrong
     # results): build/whatif/libcd_w<n>.so = gf_conv_direct.hip + gf_gemm.hip + gf_abi.hip
     import ctypes
