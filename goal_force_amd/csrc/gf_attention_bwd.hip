@@ -401,7 +401,7 @@ struct Bwd16Args {
 };
 
 // delta[s, h] = sum_d dO[s, h, d] O[s, h, d], stored twice: [q_len, heads] (per-lane reads of the dQ kernel) and with lse as the
-// dK/dV kernel's granule records sd[h][s / 32][32 lse | 32 delta] (zeros past q_len)
+// dK/dV kernel's granule records sd[h][s / 32][32 x -lse | 32 x -delta] (zeros past q_len)
 __global__ __launch_bounds__(256) void attn_bwd_delta16_kernel(const Bwd16Args a, float* sd) {
     const BwdArgs& p = a.b;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -422,8 +422,8 @@ __global__ __launch_bounds__(256) void attn_bwd_delta16_kernel(const Bwd16Args a
         l = p.lse[idx];
     }
     float* rec = sd + ((long)h * a.ngp + (s >> 5)) * (2 * GR) + (s & 31);
-    rec[0] = l;
-    rec[GR] = acc;
+    rec[0] = -l;            // negated: the records are the INITIAL accumulators of the dK/dV kernel's S and dP chains
+    rec[GR] = -acc;
 }
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4s;
@@ -543,6 +543,9 @@ __global__ __launch_bounds__(DQ_THREADS, 2) void attn_bwd_dq16_kernel(const Bwd1
         }
         asm volatile("" : "+v"(lse[qb]), "+v"(dl[qb]));
     }
+    f32x4 ndl[2];                    // -delta of this lane's query: the dP chains start from it (dS = P * chain result, one multiply per score)
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) ndl[qb] = f32x4{-dl[qb], -dl[qb], -dl[qb], -dl[qb]};
     const float c = p.scale_log2e;
     const ImgOffsets fo = img_offsets(lane);
     f32x4 dq[8][2];
@@ -594,7 +597,7 @@ __global__ __launch_bounds__(DQ_THREADS, 2) void attn_bwd_dq16_kernel(const Bwd1
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) {
                 sc[kbb][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
-                dp[kbb][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                dp[kbb][qb] = ndl[qb];
             }
         auto first = [&](int kbb, int lo, int hi) __attribute__((always_inline)) {
 #pragma unroll
@@ -612,7 +615,7 @@ __global__ __launch_bounds__(DQ_THREADS, 2) void attn_bwd_dq16_kernel(const Bwd1
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kbb][qb][j], c, -lse[qb]));
-                    x[j] = pr * (dp[kbb][qb][j] - dl[qb]);
+                    x[j] = pr * dp[kbb][qb][j];
                 }
                 dsw[qb][2 * kbb] = pack2bf(x[0], x[1]);
                 dsw[qb][2 * kbb + 1] = pack2bf(x[2], x[3]);
@@ -741,6 +744,11 @@ __global__ __launch_bounds__(Kv16<NP>::THREADS) void attn_bwd_dkv16_kernel(const
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(own[kb][ks]));
+    // Row constants as initial accumulators where that is exact: wave B's dP chains START from -delta (the records hold -delta), so
+    // dS = P * chain result.  Wave A keeps p = exp2(fma(S, c, -lse)): starting its chains from -lse needs K (or Q) pre-multiplied by
+    // c = scale log2 e and rounded to bf16 again, which measured +25 % error on dK / dV against an fp64 reference (2.9e-3 instead of
+    // 2.35e-3) for 0.6 ms.  The vector issue port, which an MFMA holds for 8 of its 16 cycles, is the limit of this kernel: MFMAs +
+    // arithmetic + LDS address adds came to ~1150 issue cycles per 1024-cycle iteration before the address adds and B's subtracts went.
     const float c = p.scale_log2e;
     const ImgOffsets fo = img_offsets(lane);
     f32x4 acc[8][2];                 // wave A: dV^T, wave B: dK^T — [db][kb]: key 16 kb + r, d = 16 db + 4 g + j
@@ -752,20 +760,21 @@ __global__ __launch_bounds__(Kv16<NP>::THREADS) void attn_bwd_dkv16_kernel(const
     const int ng = (p.q_len + GR - 1) / GR;
     // DMA batch of iteration i (i >= -2): Q rows and dO rows of granule i + 2 (8 pieces each: waves 0 .. 7 take piece `wave` of both)
     // and its scalars (wave 0).  Always the same number of instructions per wave (a granule past the end arrives as zeros): the counted
-    // wait relies on it.
+    // wait relies on it.  The loop is unrolled four times so that every ring slot is a compile-time constant: each LDS address is a
+    // per-lane offset computed once + an immediate.
     const unsigned q_voff = img_src_off(wave & 7, lane, p.q_stride), do_voff = img_src_off(wave & 7, lane, p.do_stride);
     const u32x4s srd_sd = make_srd(a.sd + (long)head * a.ngp * (2 * GR), 0xffffffffu);
-    auto issue = [&](int i) {
+    auto issue = [&](int i, int slot2) __attribute__((always_inline)) {        // slot2 = (i + 2) & 3
 #if KV16_WHATIF & 32
         i = 0;
 #endif
         const int ga = i + 2;
         if (wave < 8) {
-            GF_LDS char* dst = lds + (ga & 3) * GR_BYTES + wave * 1024;
+            GF_LDS char* dst = lds + slot2 * GR_BYTES + wave * 1024;
             dma16b(rows_srd(p.q, p.q_stride, head, ga * GR, p.q_len), q_voff, 0u, dst + L::Q);
             dma16b(rows_srd(p.dout, p.do_stride, head, ga * GR, p.q_len), do_voff, 0u, dst + L::DO);
         }
-        if (wave == 0) dma4b(srd_sd, (unsigned)lane * 4u, (unsigned)min(ga, a.ngp - 1) * (2u * GR * 4u), lds + L::S + (ga & 3) * (2 * GR * 4));
+        if (wave == 0) dma4b(srd_sd, (unsigned)lane * 4u, (unsigned)min(ga, a.ngp - 1) * (2u * GR * 4u), lds + L::S + slot2 * (2 * GR * 4));
     };
     // (no masking of a ragged last granule: its rows past q_len arrive as zeros, so the finite P and dS of those queries meet zero rows
     // of dO / Q in the second product)
@@ -775,19 +784,22 @@ __global__ __launch_bounds__(Kv16<NP>::THREADS) void attn_bwd_dkv16_kernel(const
     // first product, then this granule's transposed fragments are requested and land during the exp2 / dS arithmetic.
     bf16x8 carry_a[8], carry_b[2];
 #define KV16_SB() __builtin_amdgcn_sched_barrier(0)
-    // wave A, iteration i: dV of granule i - 1 from registers; S, P of granule i
-    auto stepA = [&](int i) {
+    GF_LDS char* const img = lds;                                                    // + slot * GR_BYTES (+ L::DO) + fragment offset
+    GF_LDS char* const hbase = lds + L::H + pair * 4096 + lane * 16;                 // + (granule & 1) * HBUF + 1024 * tile
+    GF_LDS char* const sbase = lds + L::S + 16 * g;                                  // + slot * 256 + 64 qb (+ 128: delta)
+    // wave A, iteration i (slot = i & 3): dV of granule i - 1 from registers; S, P of granule i
+    auto stepA = [&](int i, auto slot_c) __attribute__((always_inline)) {
+        constexpr int SLOT = decltype(slot_c)::value;
         const bool first = i < ng, second = i >= 1 && i <= ng;
-        GF_LDS char* qbuf = lds + L::Q + (i & 3) * GR_BYTES;
-        GF_LDS char* dobuf = lds + L::DO + (i & 3) * GR_BYTES;
-        GF_LDS float* lse_s = (GF_LDS float*)(lds + L::S + (i & 3) * (2 * GR * 4));
-        GF_LDS char* hb = lds + L::H + (i & 1) * L::HBUF + pair * 4096 + lane * 16;
         bf16x8 qfr[2][4];
+        f32x4 l4[2];
         if (first) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-                for (int qb = 0; qb < 2; ++qb) qfr[qb][ks] = *(GF_LDS bf16x8*)(qbuf + 4096 * qb + fo.row[ks]);
+                for (int qb = 0; qb < 2; ++qb) qfr[qb][ks] = *(GF_LDS bf16x8*)(img + (L::Q + SLOT * GR_BYTES + 4096 * qb) + fo.row[ks]);
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) l4[qb] = *(GF_LDS f32x4*)(sbase + (SLOT * 256 + 64 * qb));
         }
         KV16_SB();
         if (second) {
@@ -811,56 +823,54 @@ __global__ __launch_bounds__(Kv16<NP>::THREADS) void attn_bwd_dkv16_kernel(const
                 for (int kb = 0; kb < 2; ++kb) mfma16(sc[qb][kb], qfr[qb][ks], own[kb][ks]);        // S[query 16 qb + 4 g + j, key 16 kb + r]
         KV16_SB();
 #pragma unroll
-        for (int db = 0; db < 8; ++db) carry_a[db] = tr16_frag(dobuf, fo, db);
-        f32x4 l4[2];
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb) l4[qb] = *(GF_LDS f32x4*)(lse_s + 16 * qb + 4 * g);
+        for (int db = 0; db < 8; ++db) {
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GF_LDS s16x4*)(img + (L::DO + SLOT * GR_BYTES) + fo.tr[db]));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GF_LDS s16x4*)(img + (L::DO + SLOT * GR_BYTES + 4096) + fo.tr[db]));
+            carry_a[db] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
         KV16_SB();
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) sc[qb][kb][j] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[qb][kb][j], c, -l4[qb][j]));
+                for (int j = 0; j < 4; ++j) sc[qb][kb][j] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[qb][kb][j], c, l4[qb][j]));   // l4 = -lse
 #if !(KV16_WHATIF & 4)
-                *(GF_LDS f32x4*)(hb + (2 * qb + kb) * 1024) = sc[qb][kb];
+                *(GF_LDS f32x4*)(hbase + ((SLOT & 1) * L::HBUF + (2 * qb + kb) * 1024)) = sc[qb][kb];
 #endif
             }
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) carry_b[kb] = pack44(sc[0][kb], sc[1][kb]);
     };
-    // wave B, iteration i: dS of granule i - 1 (its dP is in registers since the last iteration, its P in the hand-off buffer), dK of
-    // granule i - 1 (Q^T fragments in registers), then dP of granule i.  B starts an iteration with arithmetic and ends with its MFMAs,
-    // A the other way round: after the barrier the two waves of a SIMD are in opposite phases.
-    f32x4 dpc[2][2];                 // dP of the granule whose dS comes next
-    auto stepB = [&](int i) {
+    // wave B, iteration i (slot = i & 3): dS of granule i - 1 (its dP - delta is in registers since the last iteration, its P in the
+    // hand-off buffer), dK of granule i - 1 (Q^T fragments in registers), then dP of granule i.  B starts an iteration with arithmetic
+    // and ends with its MFMAs, A the other way round: after the barrier the two waves of a SIMD are in opposite phases.
+    f32x4 dpc[2][2];                 // dP - delta of the granule whose dS comes next
+    auto stepB = [&](int i, auto slot_c) __attribute__((always_inline)) {
+        constexpr int SLOT = decltype(slot_c)::value, PREV = (SLOT + 3) & 3;
         const int gd = i - 1;        // granule of the dS / dK part
         const bool second = gd >= 0 && gd < ng, first = i < ng;
-        GF_LDS char* qbuf = lds + L::Q + (i & 3) * GR_BYTES;
-        GF_LDS char* dobuf = lds + L::DO + (i & 3) * GR_BYTES;
-        GF_LDS float* dl_s = (GF_LDS float*)(lds + L::S + (gd & 3) * (2 * GR * 4)) + GR;
-        GF_LDS char* hb = lds + L::H + (gd & 1) * L::HBUF + pair * 4096 + lane * 16;
         f32x4 d4[2], pp[2][2];
         bf16x8 dofr[2][4];
         if (second) {
 #pragma unroll
-            for (int qb = 0; qb < 2; ++qb) {
-                d4[qb] = *(GF_LDS f32x4*)(dl_s + 16 * qb + 4 * g);
+            for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) {
 #if KV16_WHATIF & 4
-                    pp[qb][kb] = d4[qb];
+                    pp[qb][kb] = dpc[qb][kb];
 #else
-                    pp[qb][kb] = *(GF_LDS f32x4*)(hb + (2 * qb + kb) * 1024);
+                    pp[qb][kb] = *(GF_LDS f32x4*)(hbase + ((PREV & 1) * L::HBUF + (2 * qb + kb) * 1024));
 #endif
                 }
-            }
         }
         if (first) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-                for (int qb = 0; qb < 2; ++qb) dofr[qb][ks] = *(GF_LDS bf16x8*)(dobuf + 4096 * qb + fo.row[ks]);
+                for (int qb = 0; qb < 2; ++qb) dofr[qb][ks] = *(GF_LDS bf16x8*)(img + (L::DO + SLOT * GR_BYTES + 4096 * qb) + fo.row[ks]);
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) d4[qb] = *(GF_LDS f32x4*)(sbase + (SLOT * 256 + 128 + 64 * qb));
         }
         KV16_SB();
         if (second) {
@@ -869,7 +879,7 @@ __global__ __launch_bounds__(Kv16<NP>::THREADS) void attn_bwd_dkv16_kernel(const
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) dpc[qb][kb][j] = pp[qb][kb][j] * (dpc[qb][kb][j] - d4[qb][j]);
+                    for (int j = 0; j < 4; ++j) dpc[qb][kb][j] *= pp[qb][kb][j];
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) carry_b[kb] = pack44(dpc[0][kb], dpc[1][kb]);
             KV16_SB();
@@ -883,47 +893,63 @@ __global__ __launch_bounds__(Kv16<NP>::THREADS) void attn_bwd_dkv16_kernel(const
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) dpc[qb][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int kb = 0; kb < 2; ++kb) dpc[qb][kb] = d4[qb];                                     // -delta of queries 16 qb + 4 g + j
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb) mfma16(dpc[qb][kb], dofr[qb][ks], own[kb][ks]);      // dP[query, key] = dO V^T
+                for (int kb = 0; kb < 2; ++kb) mfma16(dpc[qb][kb], dofr[qb][ks], own[kb][ks]);      // dP - delta [query, key] = dO V^T - delta
         KV16_SB();
 #pragma unroll
-        for (int db = 0; db < 8; ++db) carry_a[db] = tr16_frag(qbuf, fo, db);
+        for (int db = 0; db < 8; ++db) {
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GF_LDS s16x4*)(img + (L::Q + SLOT * GR_BYTES) + fo.tr[db]));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GF_LDS s16x4*)(img + (L::Q + SLOT * GR_BYTES + 4096) + fo.tr[db]));
+            carry_a[db] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
         KV16_SB();
     };
-    issue(-2);
-    issue(-1);
+    issue(-2, 0);
+    issue(-1, 1);
     // One loop per role (the register allocator then sees each role's live ranges alone; both execute the same number of barriers).
     // At the top of iteration i: this wave's pieces of batch i - 2 have landed (batch i - 1 stays in flight), its hand-off stores and
-    // LDS reads are done; behind the barrier that holds for every wave: granule i (A) / i - 1 (B) is readable, the slots batch i goes
-    // to (granule i - 2's, last read by B in iteration i - 1) are free.
+    // LDS reads are done; behind the barrier that holds for every wave: granule i is readable, the slot batch i goes to (granule
+    // i - 2's) is free.
 #if KV16_WHATIF & 1
-#define KV16_ISSUE(i) (void)issue
+#define KV16_ISSUE(i, s) (void)issue
 #else
-#define KV16_ISSUE(i) issue(i)
+#define KV16_ISSUE(i, s) issue(i, s)
 #endif
-    auto wait_barrier = [&]() {
+    auto wait_barrier = [&]() __attribute__((always_inline)) {
         if (wave == 0) KV16_WAIT_BARRIER(3);
         else if (wave < 8) KV16_WAIT_BARRIER(2);
         else KV16_WAIT_BARRIER(0);
     };
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, 1> S1;
+    typedef std::integral_constant<int, 2> S2;
+    typedef std::integral_constant<int, 3> S3;
+#define KV16_ITER(STEP, k, SC)                                   \
+    if (i + k <= ng) {                                           \
+        wait_barrier();                                          \
+        KV16_ISSUE(i + k, (k + 2) & 3);                          \
+        STEP(i + k, SC{});                                       \
+    }
     if (!roleB) {
 #pragma unroll 1
-        for (int i = 0; i <= ng; ++i) {
-            wait_barrier();
-            KV16_ISSUE(i);
-            stepA(i);
+        for (int i = 0; i <= ng; i += 4) {
+            KV16_ITER(stepA, 0, S0)
+            KV16_ITER(stepA, 1, S1)
+            KV16_ITER(stepA, 2, S2)
+            KV16_ITER(stepA, 3, S3)
         }
     } else {
 #pragma unroll 1
-        for (int i = 0; i <= ng; ++i) {
-            wait_barrier();
-            KV16_ISSUE(i);
-            stepB(i);
+        for (int i = 0; i <= ng; i += 4) {
+            KV16_ITER(stepB, 0, S0)
+            KV16_ITER(stepB, 1, S1)
+            KV16_ITER(stepB, 2, S2)
+            KV16_ITER(stepB, 3, S3)
         }
     }
     const float mul = roleB ? p.scale : 1.0f;
