@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""Flash-attention backward against an fp64 autograd reference and against the first kernels (GF_ATTN_BWD=v1) at two mid sizes:
+rel-L2 of dq / dk / dv (what a change of the P arithmetic costs in accuracy; run on the GPU)."""
 import math, os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from goal_force_amd import ops
 BF = torch.bfloat16; HD = 128
 def rel(a, b): return float((a - b).norm() / b.norm())
