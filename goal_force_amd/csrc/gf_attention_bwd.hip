@@ -392,7 +392,7 @@ template <int NP> struct Kv16 {                // NP wave pairs = 32 NP keys per
     static constexpr int LDS = S + KV16_RING * 2 * GR * (int)sizeof(float);
 };
 constexpr int DQ16_STAGE = 2 * TILE_BYTES;     // K rows | V rows
-constexpr int DQ16_LDS = 3 * DQ16_STAGE;
+constexpr int DQ16_LDS = 2 * DQ16_STAGE;
 
 struct Bwd16Args {
     BwdArgs b;
@@ -556,16 +556,30 @@ __global__ __launch_bounds__(DQ_THREADS, 2) void attn_bwd_dq16_kernel(const Bwd1
 
     const int nt = (p.kv_len + KVB - 1) / KVB;
     // a tile's two images are 32 pieces of 1 KiB: wave w stages pieces w and w + 8 of each (the swizzle of a row depends on row & 7:
-    // the same per-lane offset serves both, 32 rows apart).  Three stages, requested two tiles ahead, counted waits.
+    // the same per-lane offset serves both, 32 rows apart).  Two stages (a tile is ~2.4 us of MFMAs: one tile ahead is enough), 64 KiB:
+    // with the loop unrolled by two every LDS address is a pinned per-lane pointer + an immediate (the dynamic LDS base is a link-time
+    // symbol: `lds + offset` inside the loop cost a v_add per read, 72 per tile).
     const unsigned k_voff = img_src_off(wave, lane, p.k_stride), v_voff = img_src_off(wave, lane, p.v_stride);
-    auto stage = [&](int t) {
-        GF_LDS char* b = lds + (t % 3) * DQ16_STAGE + wave * 1024;
+    auto stage = [&](int t, int st) {
+        GF_LDS char* b = lds + st * DQ16_STAGE + wave * 1024;
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {       // a descriptor per half tile: the SGPR offset of a request is not bounds-checked
             dma16b(rows_srd(p.k, p.k_stride, head, t * KVB + 32 * jj, p.kv_len), k_voff, 0u, b + jj * 8192);
             dma16b(rows_srd(p.v, p.v_stride, head, t * KVB + 32 * jj, p.kv_len), v_voff, 0u, b + TILE_BYTES + jj * 8192);
         }
     };
+    GF_LDS char* prow[4];            // + stage * DQ16_STAGE (+ TILE_BYTES: V) + 4096 * key block
+    GF_LDS char* ptr[8];             // + stage * DQ16_STAGE + 8192 * half (+ 4096: second read)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        prow[ks] = lds + fo.row[ks];
+        asm volatile("" : "+v"(prow[ks]));
+    }
+#pragma unroll
+    for (int db = 0; db < 8; ++db) {
+        ptr[db] = lds + fo.tr[db];
+        asm volatile("" : "+v"(ptr[db]));
+    }
     // No masking of a ragged last tile: rows past kv_len arrive as zeros, so those keys' dS (finite: p = exp2(-lse), dP = 0) meets a
     // zero row of K in the last product.
     // One 32-key half of a tile; the order is pinned by scheduling barriers (left alone, hipcc reads a fragment, waits for it, issues its
@@ -582,30 +596,29 @@ __global__ __launch_bounds__(DQ_THREADS, 2) void attn_bwd_dq16_kernel(const Bwd1
 #define DQ16_NO_INTERLEAVE 0
 #endif
 #define DQ16_SB() __builtin_amdgcn_sched_barrier(0)
-    auto load_kb = [&](GF_LDS char* kbuf, int kb, int lo, int hi) __attribute__((always_inline)) {      // F[2 ks] = K, F[2 ks + 1] = V fragment (kb, ks)
+    auto load_kb = [&](int sto, int kb, int lo, int hi) __attribute__((always_inline)) {      // F[2 ks] = K, F[2 ks + 1] = V fragment (kb, ks); sto = stage offset
 #pragma unroll
         for (int ks = lo; ks < hi; ++ks) {
-            F[2 * ks] = *(GF_LDS bf16x8*)(kbuf + 4096 * kb + fo.row[ks]);
-            F[2 * ks + 1] = *(GF_LDS bf16x8*)(kbuf + TILE_BYTES + 4096 * kb + fo.row[ks]);
+            F[2 * ks] = *(GF_LDS bf16x8*)(prow[ks] + (sto + 4096 * kb));
+            F[2 * ks + 1] = *(GF_LDS bf16x8*)(prow[ks] + (sto + TILE_BYTES + 4096 * kb));
         }
     };
-    auto half = [&](GF_LDS char* kbuf, int h, bool has_next) __attribute__((always_inline)) {
+    auto load_tr = [&](int sto, int h, int db) __attribute__((always_inline)) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GF_LDS s16x4*)(ptr[db] + (sto + 8192 * h)));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GF_LDS s16x4*)(ptr[db] + (sto + 8192 * h + 4096)));
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    auto half = [&](int sto, int h, bool has_next) __attribute__((always_inline)) {
         u32x4 dsw[2];            // dS^T as B operand [32 keys x 16 queries] per query block: words 0, 1 = key block 2 h, words 2, 3 = 2 h + 1
         f32x4 sc[2][2], dp[2][2];
-#pragma unroll
-        for (int kbb = 0; kbb < 2; ++kbb)
-#pragma unroll
-            for (int qb = 0; qb < 2; ++qb) {
-                sc[kbb][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
-                dp[kbb][qb] = ndl[qb];
-            }
-        auto first = [&](int kbb, int lo, int hi) __attribute__((always_inline)) {
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        auto first = [&](int kbb, int lo, int hi) __attribute__((always_inline)) {     // (the chains start from 0 / -delta through the first MFMA's C operand)
 #pragma unroll
             for (int ks = lo; ks < hi; ++ks)
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb) {
-                    mfma16(sc[kbb][qb], F[2 * ks], qf[qb][ks]);          // S^T[key 32 h + 16 kbb + 4 g + j, query 16 qb + r]
-                    mfma16(dp[kbb][qb], F[2 * ks + 1], dof[qb][ks]);     // dP^T
+                    sc[kbb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F[2 * ks], qf[qb][ks], ks == 0 ? zero4 : sc[kbb][qb], 0, 0, 0);      // S^T[key 32 h + 16 kbb + 4 g + j, query 16 qb + r]
+                    dp[kbb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F[2 * ks + 1], dof[qb][ks], ks == 0 ? ndl[qb] : dp[kbb][qb], 0, 0, 0);   // dP^T - delta
                 }
         };
         auto softmax = [&](int kbb) __attribute__((always_inline)) {
@@ -624,11 +637,11 @@ __global__ __launch_bounds__(DQ_THREADS, 2) void attn_bwd_dq16_kernel(const Bwd1
         DQ16_SB();
         first(0, 0, 2);
         DQ16_SB();
-        load_kb(kbuf, 2 * h + 1, 0, 2);
+        load_kb(sto, 2 * h + 1, 0, 2);
         DQ16_SB();
         first(0, 2, 4);
         DQ16_SB();
-        load_kb(kbuf, 2 * h + 1, 2, 4);
+        load_kb(sto, 2 * h + 1, 2, 4);
         DQ16_SB();
         softmax(0);
         first(1, 0, 2);
@@ -642,12 +655,12 @@ __global__ __launch_bounds__(DQ_THREADS, 2) void attn_bwd_dq16_kernel(const Bwd1
 #endif
         DQ16_SB();
 #pragma unroll
-        for (int db = 0; db < 4; ++db) F[db] = tr16_frag(kbuf + 8192 * h, fo, db);
+        for (int db = 0; db < 4; ++db) F[db] = load_tr(sto, h, db);
         DQ16_SB();
         first(1, 2, 4);
         DQ16_SB();
 #pragma unroll
-        for (int db = 4; db < 8; ++db) F[db] = tr16_frag(kbuf + 8192 * h, fo, db);
+        for (int db = 4; db < 8; ++db) F[db] = load_tr(sto, h, db);
         DQ16_SB();
         softmax(1);
         DQ16_SB();
@@ -656,30 +669,30 @@ __global__ __launch_bounds__(DQ_THREADS, 2) void attn_bwd_dq16_kernel(const Bwd1
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) mfma16(dq[db][qb], F[db], __builtin_bit_cast(bf16x8, dsw[qb]));     // dQ^T[d 16 db + 4 g + j, query] += K^T dS^T
         DQ16_SB();
-        if (has_next) load_kb(kbuf, 2 * h + 2, 0, 2);
+        if (has_next) load_kb(sto, 2 * h + 2, 0, 2);
         DQ16_SB();
 #pragma unroll
         for (int db = 4; db < 8; ++db)
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) mfma16(dq[db][qb], F[db], __builtin_bit_cast(bf16x8, dsw[qb]));
         DQ16_SB();
-        if (has_next) load_kb(kbuf, 2 * h + 2, 2, 4);
+        if (has_next) load_kb(sto, 2 * h + 2, 2, 4);
         DQ16_SB();
     };
 #define DQ16_WAIT_BARRIER(N) asm volatile("s_waitcnt vmcnt(" #N ")\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-    stage(0);
-    if (nt > 1) stage(1);
-    else { stage(0); }           // (keeps the request count per wave uniform; re-fetches tile 0 into its own slot)
+    stage(0, 0);
+#define DQ16_TILE(t, ST)                                                                                              \
+    {   /* tile t landed (this wave's pieces: vmcnt(0); everybody's behind the barrier); the other stage is free */   \
+        DQ16_WAIT_BARRIER(0);                                                                                         \
+        if ((t) + 1 < nt) stage((t) + 1, 1 - (ST));                                                                   \
+        load_kb((ST) * DQ16_STAGE, 0, 0, 4);                                                                          \
+        half((ST) * DQ16_STAGE, 0, true);                                                                             \
+        half((ST) * DQ16_STAGE, 1, false);                                                                            \
+    }
 #pragma unroll 1
-    for (int t = 0; t < nt; ++t) {
-        // this wave's pieces of tile t have landed (tile t + 1's stay in flight) and, behind the barrier, everybody's; the slot tile t + 2
-        // goes to (tile t - 1's) is free
-        DQ16_WAIT_BARRIER(4);
-        stage(t + 2 < nt ? t + 2 : t);          // past the end: a re-fetch of the tile being read into its own slot (same bytes)
-        GF_LDS char* kbuf = lds + (t % 3) * DQ16_STAGE;
-        load_kb(kbuf, 0, 0, 4);
-        half(kbuf, 0, true);
-        half(kbuf, 1, false);
+    for (int t = 0; t < nt; t += 2) {
+        DQ16_TILE(t, 0)
+        if (t + 1 < nt) DQ16_TILE(t + 1, 1)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the last requests must not outlive the workgroup's LDS
 #pragma unroll
@@ -784,23 +797,35 @@ __global__ __launch_bounds__(Kv16<NP>::THREADS) void attn_bwd_dkv16_kernel(const
     // first product, then this granule's transposed fragments are requested and land during the exp2 / dS arithmetic.
     bf16x8 carry_a[8], carry_b[2];
 #define KV16_SB() __builtin_amdgcn_sched_barrier(0)
-    GF_LDS char* const img = lds;                                                    // + slot * GR_BYTES (+ L::DO) + fragment offset
-    GF_LDS char* const hbase = lds + L::H + pair * 4096 + lane * 16;                 // + (granule & 1) * HBUF + 1024 * tile
-    GF_LDS char* const sbase = lds + L::S + 16 * g;                                  // + slot * 256 + 64 qb (+ 128: delta)
+    // Per-lane LDS POINTERS, made once and pinned in registers: the dynamic LDS base is a link-time symbol, so `lds + offset` inside
+    // the loop costs a v_add_u32 per read (110 of them per four iterations before this) — with these every address is register + immediate.
+    GF_LDS char* prow[4];                                                            // + slot * GR_BYTES (+ L::DO) + 4096 * block
+    GF_LDS char* ptr[8];                                                             // + slot * GR_BYTES (+ L::DO) (+ 4096: second read)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        prow[ks] = lds + fo.row[ks];
+        asm volatile("" : "+v"(prow[ks]));
+    }
+#pragma unroll
+    for (int db = 0; db < 8; ++db) {
+        ptr[db] = lds + fo.tr[db];
+        asm volatile("" : "+v"(ptr[db]));
+    }
+    GF_LDS char* hbase = lds + L::H + pair * 4096 + lane * 16;                       // + (granule & 1) * HBUF + 1024 * tile
+    GF_LDS char* sbase = lds + L::S + 16 * g;                                        // + slot * 256 + 64 qb (+ 128: delta)
+    asm volatile("" : "+v"(hbase), "+v"(sbase));
     // wave A, iteration i (slot = i & 3): dV of granule i - 1 from registers; S, P of granule i
     auto stepA = [&](int i, auto slot_c) __attribute__((always_inline)) {
         constexpr int SLOT = decltype(slot_c)::value;
         const bool first = i < ng, second = i >= 1 && i <= ng;
-        bf16x8 qfr[2][4];
+        bf16x8 qfr[2][4];            // (read whether or not the granule exists: the slot is valid LDS, the values go unused)
         f32x4 l4[2];
-        if (first) {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
+        for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-                for (int qb = 0; qb < 2; ++qb) qfr[qb][ks] = *(GF_LDS bf16x8*)(img + (L::Q + SLOT * GR_BYTES + 4096 * qb) + fo.row[ks]);
+            for (int qb = 0; qb < 2; ++qb) qfr[qb][ks] = *(GF_LDS bf16x8*)(prow[ks] + (L::Q + SLOT * GR_BYTES + 4096 * qb));
 #pragma unroll
-            for (int qb = 0; qb < 2; ++qb) l4[qb] = *(GF_LDS f32x4*)(sbase + (SLOT * 256 + 64 * qb));
-        }
+        for (int qb = 0; qb < 2; ++qb) l4[qb] = *(GF_LDS f32x4*)(sbase + (SLOT * 256 + 64 * qb));
         KV16_SB();
         if (second) {
 #pragma unroll
@@ -824,8 +849,8 @@ __global__ __launch_bounds__(Kv16<NP>::THREADS) void attn_bwd_dkv16_kernel(const
         KV16_SB();
 #pragma unroll
         for (int db = 0; db < 8; ++db) {
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GF_LDS s16x4*)(img + (L::DO + SLOT * GR_BYTES) + fo.tr[db]));
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GF_LDS s16x4*)(img + (L::DO + SLOT * GR_BYTES + 4096) + fo.tr[db]));
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GF_LDS s16x4*)(ptr[db] + (L::DO + SLOT * GR_BYTES)));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GF_LDS s16x4*)(ptr[db] + (L::DO + SLOT * GR_BYTES + 4096)));
             carry_a[db] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
         }
         KV16_SB();
@@ -852,26 +877,22 @@ __global__ __launch_bounds__(Kv16<NP>::THREADS) void attn_bwd_dkv16_kernel(const
         const bool second = gd >= 0 && gd < ng, first = i < ng;
         f32x4 d4[2], pp[2][2];
         bf16x8 dofr[2][4];
-        if (second) {
 #pragma unroll
-            for (int qb = 0; qb < 2; ++qb)
+        for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb) {
+            for (int kb = 0; kb < 2; ++kb) {
 #if KV16_WHATIF & 4
-                    pp[qb][kb] = dpc[qb][kb];
+                pp[qb][kb] = dpc[qb][kb];
 #else
-                    pp[qb][kb] = *(GF_LDS f32x4*)(hbase + ((PREV & 1) * L::HBUF + (2 * qb + kb) * 1024));
+                pp[qb][kb] = *(GF_LDS f32x4*)(hbase + ((PREV & 1) * L::HBUF + (2 * qb + kb) * 1024));
 #endif
-                }
-        }
-        if (first) {
+            }
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
+        for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-                for (int qb = 0; qb < 2; ++qb) dofr[qb][ks] = *(GF_LDS bf16x8*)(img + (L::DO + SLOT * GR_BYTES + 4096 * qb) + fo.row[ks]);
+            for (int qb = 0; qb < 2; ++qb) dofr[qb][ks] = *(GF_LDS bf16x8*)(prow[ks] + (L::DO + SLOT * GR_BYTES + 4096 * qb));
 #pragma unroll
-            for (int qb = 0; qb < 2; ++qb) d4[qb] = *(GF_LDS f32x4*)(sbase + (SLOT * 256 + 128 + 64 * qb));
-        }
+        for (int qb = 0; qb < 2; ++qb) d4[qb] = *(GF_LDS f32x4*)(sbase + (SLOT * 256 + 128 + 64 * qb));
         KV16_SB();
         if (second) {
 #pragma unroll
@@ -891,20 +912,17 @@ __global__ __launch_bounds__(Kv16<NP>::THREADS) void attn_bwd_dkv16_kernel(const
         KV16_SB();
         if (!first) return;
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) dpc[qb][kb] = d4[qb];                                     // -delta of queries 16 qb + 4 g + j
-#pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb) mfma16(dpc[qb][kb], dofr[qb][ks], own[kb][ks]);      // dP - delta [query, key] = dO V^T - delta
+                for (int kb = 0; kb < 2; ++kb)                                                       // dP - delta [query, key] = dO V^T - delta:
+                    dpc[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dofr[qb][ks], own[kb][ks], ks == 0 ? d4[qb] : dpc[qb][kb], 0, 0, 0);   // the chain starts from -delta (no copy)
         KV16_SB();
 #pragma unroll
         for (int db = 0; db < 8; ++db) {
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GF_LDS s16x4*)(img + (L::Q + SLOT * GR_BYTES) + fo.tr[db]));
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GF_LDS s16x4*)(img + (L::Q + SLOT * GR_BYTES + 4096) + fo.tr[db]));
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GF_LDS s16x4*)(ptr[db] + (L::Q + SLOT * GR_BYTES)));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GF_LDS s16x4*)(ptr[db] + (L::Q + SLOT * GR_BYTES + 4096)));
             carry_a[db] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
         }
         KV16_SB();

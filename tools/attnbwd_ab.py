@@ -31,7 +31,7 @@ def build():
     for old in os.listdir(OUT):
         os.remove(os.path.join(OUT, old))
     for name, flags in VARIANTS.items():
-        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DGF_BUILD",
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DGF_BUILD", "-fno-slp-vectorize",
                         f"-I{ROOT}/include", f"-I{ROOT}/goal_force_amd/csrc", "-o", os.path.join(OUT, f"libbwd_{name}.so")] + flags + src,
                        check=True)
         print("built", name, flags, flush=True)
