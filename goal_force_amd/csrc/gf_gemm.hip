@@ -67,6 +67,7 @@ struct ConvGeom {
     const u16* zero;    // >= 16 zero bytes
     int H, W, C, Ho, Wo, kt, ks, mode, t_stride, t_off, taps;
     int hist_front;     // kt == 3 without `cache`: frames -2, -1 lie directly in front of src (one [2 + T, H, W, C] buffer)
+    int c64;            // C % 64 == 0 and no K padding: a 64-channel K tile lies inside ONE tap (the tap arithmetic is then scalar)
     long frame;         // H*W*C
     float inv_c, inv_ks2;
 };
@@ -325,14 +326,20 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmArgs p)
 // NB = number of 128-column halves of the tile: 2 = the 256 x 256 tile described above; 1 = a 256 x 128 tile (convolutions with
 // Cout <= 128: the decoder's 96-channel level and its RGB head would otherwise multiply 160 / 248 padding columns) — two phases
 // per K-tile, (A0, B0) and (A1, B0), half-tile stream A0 B0 A1 with three stage calls (6 DMA instructions) in flight.
+// NB = 3: a 256 x 192 tile (Cout = 192, 384: the 256-wide tile multiplied 64 / 128 padding columns, a quarter of the MFMAs): the B1
+// half-tile holds 64 weight rows (one DMA instruction per wave, so 7 instead of 8 stay in flight), wave (wr, wc) owns ONE 16-column
+// block of it (columns 128 + 16 wc): quadrants (a, 1) are 64 x 16 — 48 MFMAs per wave and K tile instead of 64.
 // CONV: 0 = dense A operand; 1 = the general gather (all modes, history from `cache`); 2 = stride-1 gather whose source frames
 // are one contiguous run (mode 0 with the causal history in front of src, or no temporal taps): each A row keeps a 64-bit
 // pointer to its pixel in its first source frame plus 4 border flags, and a piece's address is that pointer + one per-tap offset.
 template <int EPI, bool FP8, int CONV = 0, int NB = 2>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs p) {
     static_assert(!(CONV && FP8), "the implicit-GEMM convolution is bf16 only");
-    static_assert(NB == 2 || (NB == 1 && !FP8), "NB = 1 is built for bf16");
-    constexpr int BNT = NB * 128;   // tile width
+    static_assert(NB == 2 || ((NB == 1 || NB == 3) && !FP8), "NB = 1 and 3 are built for bf16");
+    constexpr bool WIDE = NB >= 2;                      // two B half-tiles per K tile
+    constexpr int NBH = WIDE ? 2 : 1;                   // B half-tiles
+    constexpr int J1 = NB == 3 ? 1 : 2;                 // 16-column blocks a wave owns in B1
+    constexpr int BNT = NB == 3 ? 192 : NB * 128;       // tile width
     constexpr int ESZ = FP8 ? 1 : 2;
     constexpr int BKE = 128 / ESZ;
     constexpr int HALF_BYTES = 128 * 128;  // 16 KiB
@@ -373,6 +380,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs
         srcp[1][i] = (const char*)p.W + (b0 * p.ldw) * ESZ + schunk * 16;
         srcp[2][i] = (const char*)p.W + (b1 * p.ldw) * ESZ + schunk * 16;
     }
+    const char* srcp_b1h = (const char*)p.W + (min((long)(n0 + 128 + wave * 8 + srow), (long)p.N - 1) * p.ldw) * ESZ + schunk * 16;   // NB = 3
     // CONV: this lane's four A rows as output pixels: (Y << 16 | X) and the first source frame of the causal window
     int cyx[2][2], cf[2][2];
     const u16* rowp[2][2];   // CONV == 2: the row's pixel in its first source frame
@@ -395,6 +403,20 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs
                 }
             }
     }
+    // CONV == 2 with C % 64 == 0 (the 192- and 384-channel VAE levels): a K tile = 64 channels of ONE tap, so the tap of the tile an A
+    // kind stages next is wave-uniform state advanced by scalar instructions (tiles are staged in order, once per kind); per lane and
+    // piece only the border test and one 64-bit add are left.  The general form below derives the tap per lane from the K index
+    // (two float multiplies, a 64-bit multiply-add, ...): ~45 vector instructions per staged half-tile, which made these convolutions
+    // vector-issue-bound (48 MFMAs x 8 issue cycles + ~90 x 4 per K tile against 768 MFMA cycles).
+    int s_c0[2] = {0, 0}, s_dt[2] = {0, 0}, s_dy[2] = {0, 0}, s_dx[2] = {0, 0};
+    if constexpr (CONV == 2) {
+        if (p.cv.c64) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) rowp[a][i] += schunk * 8;        // the lane's 8 channels inside the tile
+        }
+    }
     const int nk = p.K / BKE;
     // region byte offsets inside one double-buffer, indexed by kind
     auto region = [](int kind) { return kind == 0 ? 0 : (kind == 3 ? HALF_BYTES : (kind == 1 ? 2 * HALF_BYTES : 3 * HALF_BYTES)); };
@@ -412,6 +434,28 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs
                 return;
                 }
 #endif
+                if constexpr (CONV == 2) {
+                    if (g.c64) {
+                        const int hf = g.ks >> 1;
+                        const long toff = (long)s_dt[a] * g.frame + (long)(((s_dy[a] - hf) * g.W + (s_dx[a] - hf)) * g.C + s_c0[a]);
+                        int need = 0;
+                        if (g.ks == 3) need = (s_dy[a] == 0 ? 1 : 0) | (s_dy[a] == 2 ? 2 : 0) | (s_dx[a] == 0 ? 4 : 0) | (s_dx[a] == 2 ? 8 : 0);
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) glds16((need & rmask[a][i]) ? g.zero : rowp[a][i] + toff, dst + i * 1024);
+                        s_c0[a] += 64;                                       // the next tile of this kind
+                        if (s_c0[a] == g.C) {
+                            s_c0[a] = 0;
+                            if (++s_dx[a] == g.ks) {
+                                s_dx[a] = 0;
+                                if (++s_dy[a] == g.ks) {
+                                    s_dy[a] = 0;
+                                    ++s_dt[a];
+                                }
+                            }
+                        }
+                        return;
+                    }
+                }
                 const int ke = tile * 64 + schunk * 8;                       // first of this lane's 8 channels along K
                 const int tap = (int)(((float)ke + 0.5f) * g.inv_c);         // exact: ke < 2^16, C <= 512
                 const int c = ke - tap * g.C;
@@ -457,6 +501,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs
             }
         }
         const long koff = (long)tile * 128;
+        if constexpr (NB == 3) {
+            if (kind == 2) {                               // 64 rows: one instruction per wave (rows 8 wave .. 8 wave + 7)
+                glds16(srcp_b1h + koff, lds + (tile & 1) * STAGE_BYTES + region(2) + wave * 1024);
+                return;
+            }
+        }
         glds16(srcp[kind][0] + koff, dst);
         glds16(srcp[kind][1] + koff, dst + 1024);
     };
@@ -465,6 +515,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs
     const int frow = lane & 15, fq = lane >> 4, sw = frow & 7;
     const int a_off = (wr * 64 + frow) * 128;   // + i*2048, i < 4
     const int b_off = (wc * 32 + frow) * 128;   // + j*2048, j < 2
+    const int b_off1 = NB == 3 ? (wc * 16 + frow) * 128 : b_off;   // B1 of the 192-wide tile: one block per wave
     int chb[4];                                 // swizzled 16-byte chunk offsets of this lane
     if constexpr (!FP8) {
         chb[0] = ((0 + fq) ^ sw) << 4;          // k-substep 0
@@ -487,16 +538,17 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs
     auto read_b = [&](GF_LDS char* buf, int b) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            bfr[b][j][0] = *(GF_LDS u32x4*)(buf + region(b ? 2 : 1) + b_off + j * 2048 + chb[0]);
-            bfr[b][j][1] = *(GF_LDS u32x4*)(buf + region(b ? 2 : 1) + b_off + j * 2048 + chb[1]);
+            if (b && j >= J1) continue;
+            bfr[b][j][0] = *(GF_LDS u32x4*)(buf + region(b ? 2 : 1) + (b ? b_off1 : b_off) + j * 2048 + chb[0]);
+            bfr[b][j][1] = *(GF_LDS u32x4*)(buf + region(b ? 2 : 1) + (b ? b_off1 : b_off) + j * 2048 + chb[1]);
         }
     };
 
-    f32x4 acc[2][NB][4][2];  // [a][b][i][j]
+    f32x4 acc[2][NBH][4][2];  // [a][b][i][j]
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
+        for (int b = 0; b < NBH; ++b)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -511,6 +563,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
+                if (b && j >= J1) continue;
                 if constexpr (!FP8) {
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks)
@@ -530,8 +583,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs
     };
 
     // ---- prologue: half-tiles seq 0..5 = (t0: A0 B0 B1 A1) (t1: A0 B0) ------------------------------------------------
-    const int total = (NB == 2 ? 4 : 3) * nk;  // half-tiles in the stream
-    if constexpr (NB == 2) {
+    const int total = (WIDE ? 4 : 3) * nk;  // half-tiles in the stream
+    if constexpr (WIDE) {
         stage(0, 0);
         stage(0, 1);
         stage(0, 2);
@@ -539,7 +592,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs
         if (nk > 1) {
             stage(1, 0);
             stage(1, 1);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // seq 0,1 landed
+            if constexpr (NB == 3) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // seq 0,1 landed
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -562,6 +616,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs
 #define GF_PHASE_END(SEQ_ISSUED)                                                  \
     GSTAMP(1)                                                                    \
     if ((SEQ_ISSUED) >= total) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  \
+    else if constexpr (NB == 3) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); \
     else if constexpr (NB == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); \
     else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                        \
     GSTAMP(2)                                                                    \
@@ -645,10 +700,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs
     // ---- epilogue: bf16 quadrants -> swizzled 256 x 256 LDS image (512-byte rows) -> full-row stores ---------------------
     // acc[a][b][i][j][r] = C[m0 + a*128 + wr*64 + i*16 + frow][n0 + b*128 + wc*32 + j*16 + fq*4 + r]
 #pragma unroll
-    for (int b = 0; b < NB; ++b)
+    for (int b = 0; b < NBH; ++b)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int ncol = b * 128 + wc * 32 + j * 16 + fq * 4;  // column inside the tile
+            if (b && j >= J1) continue;
+            const int ncol = (NB == 3 && b) ? 128 + wc * 16 + fq * 4 : b * 128 + wc * 32 + j * 16 + fq * 4;  // column inside the tile
             float bv[4] = {0.f, 0.f, 0.f, 0.f};
             if (p.bias && n0 + ncol < p.N) {
                 const u16x4 b4 = *reinterpret_cast<const u16x4*>(p.bias + n0 + ncol);
@@ -1620,8 +1676,10 @@ extern "C" GF_API int gf_conv3d_bf16(const void* src, const void* cache, const v
     // Cout <= 128 (the 96-channel level, the RGB head): the 256 x 128 tile; GF_CONV_NB=2 forces the 256 x 256 tile (A/B timing)
     const int force_nb = gf_options().conv_nb.load(std::memory_order_relaxed);
     const bool narrow = force_nb ? force_nb == 1 : N <= 128;
+    // 192-wide tiles where they cover N with fewer padded columns than 256-wide ones (Cout = 192, 384: none instead of a quarter)
+    const bool w192 = !narrow && !force_nb && ((N + 191) / 192) * 192 < ((N + BN - 1) / BN) * BN;
     a.tiles_m = (int)((M + BM - 1) / BM);
-    a.tiles_n = narrow ? (int)((N + 127) / 128) : (int)((N + BN - 1) / BN);
+    a.tiles_n = narrow ? (int)((N + 127) / 128) : (w192 ? (int)((N + 191) / 192) : (int)((N + BN - 1) / BN));
     a.dbg = nullptr;
     a.whatif = 0;
     a.stagger = 0;
@@ -1650,6 +1708,7 @@ extern "C" GF_API int gf_conv3d_bf16(const void* src, const void* cache, const v
     a.cv.inv_ks2 = 1.0f / (float)(ks * ks);
     hipStream_t s = (hipStream_t)stream;
     a.cv.hist_front = (kt == 3 && !cache) ? 1 : 0;
+    a.cv.c64 = (C % 64 == 0 && K == taps * C && (ks == 1 || ks == 3)) ? 1 : 0;
     // the 96-channel full-resolution level (ResidualBlock convolutions with their history in front of src): direct convolution,
     // bit-identical to the implicit GEMM below (gf_conv_direct.hip; GF_CONV_DIRECT=0 switches it off)
     if (kt == 3 && ks == 3 && mode == 0 && !cache && t_stride == 1 && C == 96 && (N == 96 || N <= 16) && ldc == N &&
@@ -1671,9 +1730,11 @@ extern "C" GF_API int gf_conv3d_bf16(const void* src, const void* cache, const v
 #define GF_CONV_CASE(E, NBV, CV) return launch_conv<E, NBV, CV>(a, s)
     if (fast) {
         if (narrow) { if (epilogue == GF_EPI_BIAS) GF_CONV_CASE(GF_EPI_BIAS, 1, 2); else GF_CONV_CASE(GF_EPI_BIAS_RESID, 1, 2); }
+        if (w192) { if (epilogue == GF_EPI_BIAS) GF_CONV_CASE(GF_EPI_BIAS, 3, 2); else GF_CONV_CASE(GF_EPI_BIAS_RESID, 3, 2); }
         if (epilogue == GF_EPI_BIAS) GF_CONV_CASE(GF_EPI_BIAS, 2, 2); else GF_CONV_CASE(GF_EPI_BIAS_RESID, 2, 2);
     }
     if (narrow) { if (epilogue == GF_EPI_BIAS) GF_CONV_CASE(GF_EPI_BIAS, 1, 1); else GF_CONV_CASE(GF_EPI_BIAS_RESID, 1, 1); }
+    if (w192) { if (epilogue == GF_EPI_BIAS) GF_CONV_CASE(GF_EPI_BIAS, 3, 1); else GF_CONV_CASE(GF_EPI_BIAS_RESID, 3, 1); }
     if (epilogue == GF_EPI_BIAS) GF_CONV_CASE(GF_EPI_BIAS, 2, 1); else GF_CONV_CASE(GF_EPI_BIAS_RESID, 2, 1);
 #undef GF_CONV_CASE
 }

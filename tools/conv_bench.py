@@ -40,6 +40,24 @@ def main():
                     best[key] = min(best.get(key, 1e9), e0.elapsed_time(e1) / 3)
     for key, ms in best.items():
         print(f"{key:16s} {ms:7.3f} ms  {fl / ms / 1e9:7.1f} TFLOP/s", flush=True)
+    # the 192-channel level of the same tile (half resolution, 3x3x3, 192 -> 192: 3.97 TFLOP): the implicit GEMM
+    T2 = T
+    b192 = (torch.randn((T2 + 2, H // 2, W // 2, 192), device="cuda") * 0.7).to(BF)
+    k192 = 27 * 192
+    w192 = (torch.randn((192, k192), device="cuda") / k192 ** 0.5).to(BF)
+    bb = torch.randn((192,), device="cuda").to(BF)
+    r192 = torch.randn((T2 * (H // 2) * (W // 2), 192), device="cuda").to(BF)
+    fl192 = 2.0 * T2 * (H // 2) * (W // 2) * k192 * 192
+    for kind, kw in (("bias", {}), ("resid", dict(resid=r192))):
+        ops.vae_conv3d(b192[2:], None, w192, bb, 3, 3, history_in_front=True, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            ops.vae_conv3d(b192[2:], None, w192, bb, 3, 3, history_in_front=True, **kw)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 3
+        print(f"C=192 implicit {kind:6s} {ms:7.3f} ms  {fl192 / ms / 1e9:7.1f} TFLOP/s", flush=True)
     # the decoder's upsample convolution of the same tile (nearest 2x + 3x3, 192 -> 96 channels, source 120 x 208): 2.65 TFLOP
     xs = (torch.randn((T, H // 2, W // 2, 192), device="cuda") * 0.7).to(BF)
     ku = 9 * 192
