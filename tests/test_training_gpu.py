@@ -33,7 +33,8 @@ def _ref_attention_grads(q, k, v, dout, heads):
     return o.detach(), lse2.detach(), qf.grad, kf.grad, vf.grad
 
 
-@pytest.mark.parametrize("sq,skv,heads", [(72, 72, 2), (300, 200, 3), (1000, 512, 4), (128, 64, 1), (257, 130, 2)])
+@pytest.mark.parametrize("sq,skv,heads", [(72, 72, 2), (300, 200, 3), (1000, 512, 4), (128, 64, 1), (257, 130, 2), (5, 3, 1), (33, 129, 8),
+                                          (31, 2000, 2)])
 def test_flash_attn_backward(sq, skv, heads):
     from goal_force_amd import ops
     g = torch.Generator().manual_seed(sq * 7 + skv)
