@@ -12,11 +12,10 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, "build", "ab")
-VARIANTS = {      # KV16_WHATIF bits (timing only, wrong results): 1 no DMA in the loop, 4 no P hand-off, 8 no barrier, 16 no counted wait, 32 L2-hot DMA
+VARIANTS = {      # KV16_WHATIF bits (32-key kernel only; timing only, wrong results): 1 no DMA in the loop, 4 no P hand-off, 8 no barrier, 16 no counted wait, 32 L2-hot DMA
     "base": [],
-    "w1_nodma": ["-DKV16_WHATIF=1"],
-    "w4_nohandoff": ["-DKV16_WHATIF=4"],
-    "w8_nobarrier": ["-DKV16_WHATIF=8"],
+    "kv32": ["-DKV_USE_48=0"],
+    "kv32_w8_nobarrier": ["-DKV_USE_48=0", "-DKV16_WHATIF=8"],
     "dq_nointerleave": ["-DDQ16_NO_INTERLEAVE=1"],
 }
 for spec in os.environ.get("BWD_AB_EXTRA", "").split(";"):     # name:flag,flag
