@@ -372,13 +372,17 @@ __global__ __launch_bounds__(DKV_THREADS, 2) void attn_bwd_dkv_kernel(const BwdA
 //     (num_records), which also makes masking unnecessary: a padded key / query meets a zero row in the last product;
 //   * dQ: a wave owns 32 queries (two 16-query blocks on the lane) and walks 64-key tiles — S^T = K Q^T, dP^T = V dO^T,
 //     dQ^T += K^T dS^T: 96 MFMAs per tile;
-//   * dK and dV in ONE kernel by wave PAIRS that own the same 32 keys and walk 32-query granules:
+//   * dK and dV in ONE kernel by wave PAIRS that own the same keys (48 per pair in the shipped attn_bwd_dkv48_kernel, 32 in
+//     attn_bwd_dkv16_kernel, its A/B partner) and walk 32-query granules:
 //       wave A: S = Q K^T, P = exp2(c S - lse), P (fp32, accumulator layout) -> LDS hand-off, dV^T += dO^T P;
 //       wave B: dP = dO V^T, dS = P (dP - delta) with the P wave A left one granule earlier, dK^T += Q^T dS.
-//     Each wave keeps 64 accumulator registers + one 32-register operand, so the exp2 of one role overlaps the MFMAs of the other;
-//     S is computed once for dK and dV (the split kernels computed it twice).  B runs one granule behind A: ONE barrier per granule
-//     publishes the landed DMA pieces and the hand-off and frees the ring slots.  Q rows and dO rows in rings of 4 granules
-//     (A reads granule i, B granule i - 1, two more in flight; counted vmcnt), the hand-off double buffered.
+//     A SIMD holds one A and one B wave, so the exp2 of one role overlaps the MFMAs of the other; S is computed once for dK and dV
+//     (the split kernels computed it twice).  ONE barrier per granule publishes the landed DMA pieces and the hand-off and frees the
+//     ring slots.  Q rows and dO rows in rings of 4 granules requested two ahead (counted vmcnt), the hand-off double buffered;
+//   * the vector issue port is the scarce resource once the MFMAs flow (an MFMA holds it for 8 of its 16 cycles): per-lane LDS
+//     pointers are pinned in registers and the loops unrolled over their ring slots (address = register + immediate; `lds + offset`
+//     costs a v_add_u32 per read because the dynamic LDS base is a link-time symbol), accumulation chains start from 0 / -delta through
+//     the first MFMA's C operand, and the file is built with -fno-slp-vectorize (v_pk_mul_f32 costs more beside MFMAs than two v_mul).
 // Arithmetic per element as in the first kernels (p = exp2(fma(S, c, -lse)), dS = p (dP - delta), one rounding to bf16 per MFMA
 // operand); the summation ORDER over keys / queries differs (16x16x32 adds 32 products per step), so results differ in the last bits.
 constexpr int GR = 32;                         // queries per granule of the dK/dV kernel
