@@ -1238,7 +1238,9 @@ extern "C" GF_API int gf_flash_attn_bwd(const void* q, const void* k, const void
                                         int64_t kv_len, int64_t heads, int64_t head_dim, int64_t q_stride, int64_t k_stride,
                                         int64_t v_stride, int64_t o_stride, int64_t do_stride, int64_t dq_stride,
                                         int64_t dk_stride, int64_t dv_stride, float scale, void* stream) {
-    GF_CHECK_ARG(q && k && v && o && dout && lse && workspace && dq && dk && dv, "gf_flash_attn_bwd: null pointer");
+    GF_CHECK_ARG(q && k && v && o && dout && lse && workspace && dq && ((dk && dv) || (!dk && !dv)),
+                 "gf_flash_attn_bwd: null pointer (dk and dv may be NULL together: only dq is computed)");
+    const bool want_dkv = dk != nullptr;
     if (head_dim != HD) {
         gf_set_error("gf_flash_attn_bwd: head_dim=%ld unsupported (kernels are built for 128)", (long)head_dim);
         return GF_ERR_UNSUPPORTED;
@@ -1249,7 +1251,7 @@ extern "C" GF_API int gf_flash_attn_bwd(const void* q, const void* k, const void
     for (int i = 0; i < 8; ++i)
         GF_CHECK_ARG(strides[i] % 8 == 0 && strides[i] >= heads * HD, "gf_flash_attn_bwd: strides must cover heads*128 and be multiples of 8");
     GF_CHECK_ARG(gf_aligned16(q) && gf_aligned16(k) && gf_aligned16(v) && gf_aligned16(o) && gf_aligned16(dout) &&
-                     gf_aligned16(dq) && gf_aligned16(dk) && gf_aligned16(dv) && gf_aligned16(workspace),
+                     gf_aligned16(dq) && (!want_dkv || (gf_aligned16(dk) && gf_aligned16(dv))) && gf_aligned16(workspace),
                  "gf_flash_attn_bwd: 16-byte alignment required");
     GF_CHECK_ARG((q_len + 64) * q_stride * 2 < (1LL << 32) &&
                      (q_len + 64) * do_stride * 2 < (1LL << 32) && (kv_len + 64) * k_stride * 2 < (1LL << 32) && (kv_len + 64) * v_stride * 2 < (1LL << 32),
@@ -1287,8 +1289,10 @@ extern "C" GF_API int gf_flash_attn_bwd(const void* q, const void* k, const void
     if (gf_options().bwd_v1.load(std::memory_order_relaxed)) {      // GF_ATTN_BWD=v1: the first kernels (32x32x16, 8 tile products), A/B
         hipLaunchKernelGGL(attn_bwd_delta_kernel, dim3((unsigned)((q_len * heads + 255) / 256)), dim3(256), 0, s, a);
         hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(nqb * (unsigned)heads), dim3(DQ_THREADS), BWD_LDS, s, a);
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<1>, dim3(nkb * (unsigned)heads), dim3(DKV_THREADS), BWD_LDS, s, a);
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<2>, dim3(nkb * (unsigned)heads), dim3(DKV_THREADS), BWD_LDS, s, a);
+        if (want_dkv) {
+            hipLaunchKernelGGL(attn_bwd_dkv_kernel<1>, dim3(nkb * (unsigned)heads), dim3(DKV_THREADS), BWD_LDS, s, a);
+            hipLaunchKernelGGL(attn_bwd_dkv_kernel<2>, dim3(nkb * (unsigned)heads), dim3(DKV_THREADS), BWD_LDS, s, a);
+        }
         GF_CHECK_LAUNCH("gf_flash_attn_bwd");
         return GF_OK;
     }
@@ -1298,6 +1302,10 @@ extern "C" GF_API int gf_flash_attn_bwd(const void* q, const void* k, const void
     b.sd = sd;
     hipLaunchKernelGGL(attn_bwd_delta16_kernel, dim3((unsigned)((q_pad * heads + 255) / 256)), dim3(256), 0, s, b, sd);
     hipLaunchKernelGGL(attn_bwd_dq16_kernel, dim3(nqb * (unsigned)heads), dim3(DQ_THREADS), DQ16_LDS, s, b);
+    if (!want_dkv) {
+        GF_CHECK_LAUNCH("gf_flash_attn_bwd");
+        return GF_OK;
+    }
 #if KV_USE_48
     const unsigned nkb48 = (unsigned)((kv_len + Kv48::ROWS - 1) / Kv48::ROWS);
     hipLaunchKernelGGL(attn_bwd_dkv48_kernel, dim3(nkb48 * (unsigned)heads), dim3(Kv48::THREADS), Kv48::LDS, s, b);

@@ -118,6 +118,167 @@ __global__ __launch_bounds__(ROW_THREADS) void layernorm_bwd_kernel(const u16* _
     }
 }
 
+// Wave-per-row forms of the two row backward kernels (round 3): a row of up to 5120 elements sits in the registers of ONE wave
+// (10 chunks of 16 bytes per lane), the four row sums are wave shuffles — no LDS, no barrier.  The block-per-16-rows kernels above /
+// below take 8 barriers per row at two waves per workgroup and ran at a quarter of the HBM rate (0.69 / 0.53 ms per [32760, 5120]
+// call against ~0.17 for the bytes).  They serve the calls that want NO column sums (a frozen block: 4 of 5 calls of a training step):
+// 0.37 ms.  With column sums the block kernels stay: keeping 160 partial sums per lane in registers (1.3 ms) or adding them into LDS
+// with ds_add_f32 (1.9 ms) both lost to them.  (A frozen block's dx therefore differs from a trainable one's in the last bit of some
+// elements: the row sums are added in another order.)
+constexpr int WROW_NCH = 10, WROW_WAVES = 4, WROW_DIM = WROW_NCH * 64 * 8;
+constexpr int WROW_ROWS = 2;      // rows per wave
+__global__ __launch_bounds__(64 * WROW_WAVES) void layernorm_bwd_wave_kernel(const u16* __restrict__ x, const u16* __restrict__ dy,
+                                                                             const u16* __restrict__ g, u16* __restrict__ dx,
+                                                                             int rows, int dim, long x_stride, long dy_stride,
+                                                                             long dx_stride, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nchunks = dim >> 3;
+    u16x8 g8[WROW_NCH];
+#pragma unroll
+    for (int i = 0; i < WROW_NCH; ++i) {
+        const int c = lane + 64 * i;
+        g8[i] = (g && c < nchunks) ? *reinterpret_cast<const u16x8*>(g + (c << 3)) : u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    const long row0 = ((long)blockIdx.x * WROW_WAVES + wave) * WROW_ROWS;
+    const float inv_dim = 1.0f / (float)dim;
+    for (int rr = 0; rr < WROW_ROWS && row0 + rr < rows; ++rr) {
+        const long row = row0 + rr;
+        const u16* xr = x + row * x_stride;
+        const u16* dr = dy + row * dy_stride;
+        u16x8 v[WROW_NCH], d[WROW_NCH];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < WROW_NCH; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunks) {
+                v[i] = *reinterpret_cast<const u16x8*>(xr + (c << 3));
+                d[i] = *reinterpret_cast<const u16x8*>(dr + (c << 3));
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s += bf2f(v[i][j]);
+            }
+        }
+        const float mean = wave_sum(s) * inv_dim;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < WROW_NCH; ++i)
+            if (lane + 64 * i < nchunks) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float t = bf2f(v[i][j]) - mean;
+                    q += t * t;
+                }
+            }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) * inv_dim + eps);
+        float a1 = 0.f, a2 = 0.f;      // m1 = mean(dxhat), m2 = mean(dxhat * xhat)
+#pragma unroll
+        for (int i = 0; i < WROW_NCH; ++i)
+            if (lane + 64 * i < nchunks) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xh = (bf2f(v[i][j]) - mean) * rstd;
+                    const float dyv = bf2f(d[i][j]);
+                    const float dxh = g ? dyv * bf2f(g8[i][j]) : dyv;
+                    a1 += dxh;
+                    a2 += dxh * xh;
+                }
+            }
+        const float m1 = wave_sum(a1) * inv_dim, m2 = wave_sum(a2) * inv_dim;
+        u16* orow = dx + row * dx_stride;
+#pragma unroll
+        for (int i = 0; i < WROW_NCH; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunks) {
+                u16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xh = (bf2f(v[i][j]) - mean) * rstd;
+                    const float dxh = g ? bf2f(d[i][j]) * bf2f(g8[i][j]) : bf2f(d[i][j]);
+                    o[j] = f2bf(rstd * (dxh - m1 - xh * m2));
+                }
+                *reinterpret_cast<u16x8*>(orow + (c << 3)) = o;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(64 * WROW_WAVES) void rmsnorm_rope_bwd_wave_kernel(const u16* __restrict__ x, const u16* __restrict__ dy,
+                                                                                const u16* __restrict__ weight,
+                                                                                const float* __restrict__ cos_tab,
+                                                                                const float* __restrict__ sin_tab, u16* __restrict__ dx,
+                                                                                int rows, int dim, int head_dim, long x_stride,
+                                                                                long dy_stride, long dx_stride, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nchunks = dim >> 3, half = head_dim >> 1;
+    u16x8 w8[WROW_NCH];
+#pragma unroll
+    for (int i = 0; i < WROW_NCH; ++i) {
+        const int c = lane + 64 * i;
+        w8[i] = c < nchunks ? *reinterpret_cast<const u16x8*>(weight + (c << 3)) : u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    const long row0 = ((long)blockIdx.x * WROW_WAVES + wave) * WROW_ROWS;
+    const float inv_dim = 1.0f / (float)dim;
+    for (int rr = 0; rr < WROW_ROWS && row0 + rr < rows; ++rr) {
+        const long row = row0 + rr;
+        const u16* xr = x + row * x_stride;
+        const u16* dr = dy + row * dy_stride;
+        u16x8 v[WROW_NCH];
+        float dz[WROW_NCH][8];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < WROW_NCH; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunks) {
+                v[i] = *reinterpret_cast<const u16x8*>(xr + (c << 3));
+                const u16x8 d8 = *reinterpret_cast<const u16x8*>(dr + (c << 3));
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float f = bf2f(v[i][j]);
+                    s += f * f;
+                    dz[i][j] = bf2f(d8[j]);
+                }
+                if (cos_tab) {
+                    const int p0 = ((c << 3) % head_dim) >> 1;
+                    const f32x4 cs = *reinterpret_cast<const f32x4*>(cos_tab + row * half + p0);
+                    const f32x4 sn = *reinterpret_cast<const f32x4*>(sin_tab + row * half + p0);
+#pragma unroll
+                    for (int pp = 0; pp < 4; ++pp) {   // transpose of [[c,-s],[s,c]]
+                        const float aa = dz[i][2 * pp], bb = dz[i][2 * pp + 1];
+                        dz[i][2 * pp] = aa * cs[pp] + bb * sn[pp];
+                        dz[i][2 * pp + 1] = -aa * sn[pp] + bb * cs[pp];
+                    }
+                }
+            }
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(s) * inv_dim + eps);
+        float a2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < WROW_NCH; ++i)
+            if (lane + 64 * i < nchunks) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xn = bf2f(v[i][j]) * rstd;
+                    dz[i][j] *= bf2f(w8[i][j]);          // dxn
+                    a2 += dz[i][j] * xn;
+                }
+            }
+        const float m2 = wave_sum(a2) * inv_dim;
+        u16* orow = dx + row * dx_stride;
+#pragma unroll
+        for (int i = 0; i < WROW_NCH; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunks) {
+                u16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xn = bf2f(v[i][j]) * rstd;
+                    o[j] = f2bf(rstd * (dz[i][j] - xn * m2));
+                }
+                *reinterpret_cast<u16x8*>(orow + (c << 3)) = o;
+            }
+        }
+    }
+}
+
 // RMSNorm(+RoPE) backward.  x = the PRE-norm tensor, dy = gradient of the rotated output.
 //   dz = rope^-1(dy) (rotation by -theta);  xn = x*rinv;  dw += dz*xn;  dxn = dz*w;  dx = rinv (dxn - xn mean(dxn xn))
 __global__ __launch_bounds__(ROW_THREADS) void rmsnorm_rope_bwd_kernel(const u16* __restrict__ x, const u16* __restrict__ dy,
@@ -335,6 +496,11 @@ extern "C" GF_API int gf_layernorm_bwd(const void* x, int64_t x_stride, const vo
                      gf_aligned16(dx) && (!g || gf_aligned16(g)),
                  "gf_layernorm_bwd: 16-byte alignment required");
     if (rows == 0) return GF_OK;
+    if (dim <= WROW_DIM && !dg_acc && !db_acc) {      // no column sums wanted and a row fits one wave's registers
+        const unsigned grid = (unsigned)((rows + WROW_WAVES * WROW_ROWS - 1) / (WROW_WAVES * WROW_ROWS));
+        hipLaunchKernelGGL(layernorm_bwd_wave_kernel, dim3(grid), dim3(64 * WROW_WAVES), 0, (hipStream_t)stream, (const u16*)x, (const u16*)dy,
+                           (const u16*)g, (u16*)dx, (int)rows, (int)dim, (long)x_stride, (long)dy_stride, (long)dx_stride, eps);
+    } else
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)((rows + ROWS_PER_WG - 1) / ROWS_PER_WG)), dim3(ROW_THREADS), 0,
                        (hipStream_t)stream, (const u16*)x, (const u16*)dy, (const u16*)g, (u16*)dx, dg_acc, db_acc, (int)rows,
                        (int)dim, (long)x_stride, (long)dy_stride, (long)dx_stride, eps);
@@ -354,6 +520,12 @@ extern "C" GF_API int gf_rmsnorm_rope_bwd(const void* x, int64_t x_stride, const
                      gf_aligned16(dx) && gf_aligned16(weight) && (!cos_tab || (gf_aligned16(cos_tab) && gf_aligned16(sin_tab))),
                  "gf_rmsnorm_rope_bwd: 16-byte alignment required");
     if (rows == 0) return GF_OK;
+    if (dim <= WROW_DIM && !dw_acc) {
+        const unsigned grid = (unsigned)((rows + WROW_WAVES * WROW_ROWS - 1) / (WROW_WAVES * WROW_ROWS));
+        hipLaunchKernelGGL(rmsnorm_rope_bwd_wave_kernel, dim3(grid), dim3(64 * WROW_WAVES), 0, (hipStream_t)stream, (const u16*)x, (const u16*)dy,
+                           (const u16*)weight, cos_tab, sin_tab, (u16*)dx, (int)rows, (int)dim, (int)head_dim, (long)x_stride,
+                           (long)dy_stride, (long)dx_stride, eps);
+    } else
     hipLaunchKernelGGL(rmsnorm_rope_bwd_kernel, dim3((unsigned)((rows + ROWS_PER_WG - 1) / ROWS_PER_WG)), dim3(ROW_THREADS), 0,
                        (hipStream_t)stream, (const u16*)x, (const u16*)dy, (const u16*)weight, cos_tab, sin_tab, (u16*)dx, dw_acc,
                        (int)rows, (int)dim, (int)head_dim, (long)x_stride, (long)dy_stride, (long)dx_stride, eps);

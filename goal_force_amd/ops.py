@@ -360,8 +360,9 @@ def flash_attn_lse(q, k, v, num_heads, scale=None):
     return out, lse
 
 
-def flash_attn_bwd(q, k, v, o, dout, lse, num_heads, scale=None):
-    """Gradients of flash_attn: (dq [Sq, H*128], dk, dv [Skv, H*128]) bf16."""
+def flash_attn_bwd(q, k, v, o, dout, lse, num_heads, scale=None, need_dkv=True):
+    """Gradients of flash_attn: (dq [Sq, H*128], dk, dv [Skv, H*128]) bf16; need_dkv=False: (dq, None, None) — the dK/dV kernel is
+    not launched (a frozen block's cross-attention: nobody reads the gradients of the text context)."""
     for n, t in (("q", q), ("k", k), ("v", v), ("o", o), ("dout", dout)):
         _req(t, f"flash_attn_bwd.{n}")
         if t.dim() != 2 or t.stride(1) != 1:
@@ -373,15 +374,17 @@ def flash_attn_bwd(q, k, v, o, dout, lse, num_heads, scale=None):
         scale = 1.0 / math.sqrt(head_dim)
     if lse.dtype != torch.float32 or tuple(lse.shape) != (sq, num_heads) or not lse.is_contiguous():
         raise GoalForceError("flash_attn_bwd.lse: expected contiguous fp32 [Sq, heads]")
-    dq, dk, dv = torch.empty_like(q, memory_format=torch.contiguous_format), \
-        torch.empty((skv, hd_all), dtype=_BF16, device=q.device), torch.empty((skv, hd_all), dtype=_BF16, device=q.device)
+    dq = torch.empty_like(q, memory_format=torch.contiguous_format)
+    dk = torch.empty((skv, hd_all), dtype=_BF16, device=q.device) if need_dkv else None
+    dv = torch.empty((skv, hd_all), dtype=_BF16, device=q.device) if need_dkv else None
     lib = _lib.load()
     # rowsum(dout * o) and the transposed copies of k, q, dout the kernels stream; scratch, sized by the library
     ws = torch.empty((int(lib.gf_flash_attn_bwd_workspace_bytes(sq, skv, num_heads)),), dtype=torch.uint8, device=q.device)
     _lib.check(lib.gf_flash_attn_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(dout), _ptr(lse), _ptr(ws), _ptr(dq),
-                                             _ptr(dk), _ptr(dv), sq, skv, num_heads, head_dim, q.stride(0), k.stride(0),
-                                             v.stride(0), o.stride(0), dout.stride(0), dq.stride(0), dk.stride(0),
-                                             dv.stride(0), float(scale), _stream(q)), "gf_flash_attn_bwd")
+                                             _ptr(dk) if need_dkv else None, _ptr(dv) if need_dkv else None, sq, skv, num_heads, head_dim,
+                                             q.stride(0), k.stride(0), v.stride(0), o.stride(0), dout.stride(0), dq.stride(0),
+                                             dk.stride(0) if need_dkv else hd_all, dv.stride(0) if need_dkv else hd_all, float(scale),
+                                             _stream(q)), "gf_flash_attn_bwd")
     return dq, dk, dv
 
 

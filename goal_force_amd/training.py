@@ -311,7 +311,7 @@ class DiTBlockFn(torch.autograd.Function):
         del dy, df, du, dh3, u, f, y, h3
         # ---- cross-attention branch: x2b = x1 + o2
         da2 = lin_bwd(d_x2b, a2, ca.o, "cross_attn.o")
-        dq2n, dk2n, dv2 = ops.flash_attn_bwd(q2n, k2n, v2, a2, da2, lse2, heads)
+        dq2n, dk2n, dv2 = ops.flash_attn_bwd(q2n, k2n, v2, a2, da2, lse2, heads, need_dkv=any_param)   # the context side only feeds parameter gradients
         wq_acc = _zeros_f32(d, dev) if need["cross_attn.norm_q.weight"] else None
         wk_acc = _zeros_f32(d, dev) if need["cross_attn.norm_k.weight"] else None
         dq2p = ops.rmsnorm_rope_bwd(q2p, dq2n, ca.norm_q.weight, None, None, hd, ca.norm_q.eps, dw_acc=wq_acc)

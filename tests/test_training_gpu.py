@@ -86,6 +86,8 @@ def test_flash_attn_backward_strided_inputs():
     dq, dk, dv = ops.flash_attn_bwd(q, k, v, o, dout, lse, heads)
     dq2, dk2, dv2 = ops.flash_attn_bwd(q.contiguous(), k.contiguous(), v.contiguous(), o, dout, lse, heads)
     assert torch.equal(dq, dq2) and torch.equal(dk, dk2) and torch.equal(dv, dv2)
+    dq3, dk3, dv3 = ops.flash_attn_bwd(q, k, v, o, dout, lse, heads, need_dkv=False)      # dq alone: the dK/dV kernel is not launched
+    assert torch.equal(dq3, dq) and dk3 is None and dv3 is None
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -238,7 +240,8 @@ def test_dit_block_backward_vs_oracle():
     xc2 = x[0].cuda().requires_grad_(True)
     with torch.enable_grad():
         block_forward(blk, xc2, ctx[0].cuda(), t_mod.cuda(), rope).backward(dout[0].cuda())
-    assert torch.equal(xc2.grad, xc.grad) and all(p_.grad is None for p_ in blk.parameters())
+    # (not bit for bit: without column sums the row-norm backward kernels are the wave-per-row forms, which add a row in another order)
+    assert rel_l2(xc2.grad.float().cpu(), xc.grad.float().cpu()) < 2e-3 and all(p_.grad is None for p_ in blk.parameters())
 
 
 def test_dit_block_backward_mid_size_vs_oracle():
