@@ -115,6 +115,10 @@ def test_hip_vae_im2col_and_norm_kernels_exact():
     assert rel_l2(p[:, :24].float(), torch.softmax(s.float() * 0.3, -1)) < 3e-3 and float(p[:, 24:].abs().sum()) == 0
     tp = ops.transpose_pad(s.cuda(), 64).cpu()
     assert torch.equal(tp[:, :20], s.t()) and float(tp[:, 20:].abs().sum()) == 0
+    for R, C, rpad, ld in ((333, 136, 384, 200), (64, 64, 64, 64), (1000, 5120, 1024, 5120), (7, 12, 8, 12)):   # 64 x 64 vector tiles / the 2-byte kernel
+        big = torch.randn((R, ld), generator=g).to(BF).cuda()
+        tq = ops.transpose_pad(big[:, :C], rpad).cpu()
+        assert torch.equal(tq[:, :R], big[:, :C].cpu().t()) and float(tq[:, R:].abs().sum()) == 0, (R, C, rpad)
 
 
 @pytest.mark.gpu
