@@ -150,3 +150,30 @@ def test_bf16_quotient_equals_product_with_the_rounded_reciprocal():
     q = (x[:, None] / n[None, :]).to(BF)
     p = (x[:, None] * (1.0 / n)[None, :]).to(BF)
     assert torch.equal(q.view(torch.int16), p.view(torch.int16))
+
+
+def test_attention_backward_workspace_size_is_host_arithmetic():
+    """gf_flash_attn_bwd_workspace_bytes touches no device: rowsum(dO.O) [q, heads] fp32 + one (-lse | -delta) record of 64 floats per
+    32-query granule and head, each part rounded up to 256 bytes; zero for empty problems."""
+    from goal_force_amd import _lib
+    lib = _lib.load()
+    f = lib.gf_flash_attn_bwd_workspace_bytes
+    assert f(0, 5, 1) == 0 and f(5, 0, 1) == 0 and f(5, 5, 0) == 0
+    for q, kv, h in ((1, 1, 1), (32, 7, 2), (33, 4000, 8), (32760, 32760, 40)):
+        n = f(q, kv, h)
+        pad64 = -(-q // 64) * 64
+        want = -(-(q * h * 4) // 256) * 256 + -(-(h * pad64 * 2 * 4) // 256) * 256
+        assert n == want and n % 256 == 0, (q, kv, h, n, want)
+
+
+def test_training_keep_level_is_validated(monkeypatch):
+    import importlib
+    import goal_force_amd.training as tr
+    from goal_force_amd._lib import GoalForceError
+    monkeypatch.setenv("GF_TRAIN_KEEP", "everything")
+    with pytest.raises(GoalForceError):
+        importlib.reload(tr)
+    monkeypatch.setenv("GF_TRAIN_KEEP", "attn")
+    assert importlib.reload(tr).KEEP_ATTENTION and not tr.KEEP_WIDE
+    monkeypatch.delenv("GF_TRAIN_KEEP")
+    assert importlib.reload(tr).KEEP_WIDE
