@@ -52,6 +52,7 @@ static void load_options() {
     g_options.conv_nb.store(env_int("GF_CONV_NB", 0, 0, 2), std::memory_order_relaxed);
     g_options.conv_gather.store(env_int("GF_CONV_GATHER", 0, 0, 1), std::memory_order_relaxed);
     g_options.conv_direct.store(env_int("GF_CONV_DIRECT", 1, 0, 1), std::memory_order_relaxed);
+    g_options.vae_rms3.store(env_int("GF_VAE_RMS3", 1, 0, 1), std::memory_order_relaxed);
 }
 
 const GfOptions& gf_options() {

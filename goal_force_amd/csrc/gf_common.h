@@ -114,6 +114,7 @@ struct GfOptions {
     std::atomic<int> bwd_v1{0};         // GF_ATTN_BWD=v1: gf_flash_attn_bwd on the first kernels (32x32x16 MFMAs, dQ / dV / dK passes)
     std::atomic<int> conv_nb{0};        // GF_CONV_NB: 0 = by Cout, 1 / 2 forced
     std::atomic<int> conv_gather{0};    // GF_CONV_GATHER=1: the general gather
+    std::atomic<int> vae_rms3{1};       // GF_VAE_RMS3=0: RMS_norm+SiLU at C = 96 / 192 / 384 on the power-of-two kernel (a quarter of its lanes idle), A/B
     std::atomic<int> conv_direct{1};    // GF_CONV_DIRECT=0: the 96-channel 3x3x3 convolutions on the implicit GEMM instead of gf_conv_direct.hip
 };
 // gf_conv_direct.hip: direct convolution of the 96-channel level; GF_ERR_UNSUPPORTED = shape not covered (caller falls back)

@@ -129,50 +129,137 @@ __global__ __launch_bounds__(VT) void rmsnorm_silu_kernel(const u16* __restrict_
     const int nch = C >> 3;
     u16x8 g8 = {0, 0, 0, 0, 0, 0, 0, 0};
     if (sub < nch) g8 = *reinterpret_cast<const u16x8*>(gamma + (sub << 3));
-    // the loop bound is wave-uniform (the shuffles below need every lane): rows past the end are computed on zeros, not stored
-    for (long rb = row0 - lane / LPR; rb < rows; rb += rstride) {
-        const long row = rb + lane / LPR;
-        const bool live = sub < nch && row < rows;
-        u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        float s = 0.f;
-        if (live) {
-            v = *reinterpret_cast<const u16x8*>(x + row * C + (sub << 3));
+    // the loop bound is wave-uniform (the shuffles below need every lane): rows past the end are computed on zeros, not stored.
+    // UNR row groups per iteration: their loads are all in flight before the first is used (one 16-byte load per lane and iteration
+    // left ~32 KB in flight per CU: 4 TB/s at HBM latency, whatever the arithmetic cost).
+    constexpr int UNR = 4;
+    for (long rb = row0 - lane / LPR; rb < rows; rb += UNR * rstride) {
+        u16x8 v[UNR];
+        bool live[UNR];
+        long rowi[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            rowi[u] = rb + u * rstride + lane / LPR;
+            live[u] = sub < nch && rowi[u] < rows;
+            v[u] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (live[u]) v[u] = *reinterpret_cast<const u16x8*>(x + rowi[u] * C + (sub << 3));
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            if (rb + u * rstride >= rows) break;          // wave-uniform
+            float s = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float f = bf2f(v[j]);
+                const float f = bf2f(v[u][j]);
                 s += f * f;
+            }
+#pragma unroll
+            for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            const float nrm = fmaxf(rbf(sqrtf(s)), 1e-12f);  // x.norm(2, dim).clamp_min(eps), bf16 tensor
+            // x / norm: ONE correctly rounded reciprocal per row, then a multiply per value.  Bit-identical to the division after the
+            // bf16 rounding that follows: the quotient of two bf16 numbers (8-bit significands mx / mn) is either exactly a bf16 number
+            // or at least 2^-17 (relative) away from every bf16 rounding boundary — mx 2^9 - k mn is a non-zero integer — while x * (1/n)
+            // is within 2^-23 of it; an exact tie cannot occur (it would need a 9-bit quotient of two 8-bit integers' ratio).  The
+            // per-value IEEE division (10 instructions) and expf + division of SiLU made this kernel VALU-bound at 4.4 TB/s.
+            const float rinv = 1.0f / nrm;
+            if (live[u]) {
+                u32x4 o;
+                const u32x4 vv = __builtin_bit_cast(u32x4, v[u]), gg = __builtin_bit_cast(u32x4, g8);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {                  // values in pairs: one v_cvt_pk_bf16_f32 per rounding and pair
+                    float y0 = __uint_as_float(vv[p] << 16) * rinv, y1 = __uint_as_float(vv[p] & 0xffff0000u) * rinv;      // x / norm
+                    unsigned r = pack2bf(y0, y1);
+                    y0 = __uint_as_float(r << 16) * scale, y1 = __uint_as_float(r & 0xffff0000u) * scale;                    // * dim**0.5
+                    r = pack2bf(y0, y1);
+                    y0 = __uint_as_float(r << 16) * __uint_as_float(gg[p] << 16);                                            // * gamma (+ bias 0.)
+                    y1 = __uint_as_float(r & 0xffff0000u) * __uint_as_float(gg[p] & 0xffff0000u);
+                    r = pack2bf(y0, y1);
+                    if (silu) {   // x * sigmoid(x) on the bf16 values, exp2 + rcp (a few fp32 ulp, inside the bf16 rounding that follows)
+                        y0 = __uint_as_float(r << 16), y1 = __uint_as_float(r & 0xffff0000u);
+                        const float t0 = __builtin_amdgcn_exp2f(y0 * -1.4426950408889634f), t1 = __builtin_amdgcn_exp2f(y1 * -1.4426950408889634f);
+                        y0 = y0 * __builtin_amdgcn_rcpf(1.0f + t0), y1 = y1 * __builtin_amdgcn_rcpf(1.0f + t1);
+                        r = pack2bf(y0, y1);
+                    }
+                    o[p] = r;
+                }
+                *reinterpret_cast<u32x4*>(out + rowi[u] * C + (sub << 3)) = o;
+            }
+        }
+    }
+}
+
+// The same for C = 96, 192, 384 (three quarters of a power of two: a quarter of the lanes above load nothing, which caps the kernel at
+// ~4.9 TB/s): LP lanes per pixel with THREE 16-byte chunks each (sub, sub + LP, sub + 2 LP), every lane live.  The row sum is the same
+// tree as above — its two top butterfly stages pair chunk c with c ^ 2 LP and c ^ LP, which are now additions inside the lane
+// ((p[sub] + p[sub + 2 LP]) + (p[sub + LP] + 0)) — so the results are bit-identical to rmsnorm_silu_kernel<4 LP>.
+template <int LP>
+__global__ __launch_bounds__(VT) void rmsnorm_silu3_kernel(const u16* __restrict__ x, const u16* __restrict__ gamma,
+                                                           u16* __restrict__ out, long rows, float scale, int silu) {
+    constexpr int RPW = 64 / LP, C = 24 * LP;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane & (LP - 1);
+    const long row0 = ((long)blockIdx.x * (VT / 64) + (threadIdx.x >> 6)) * RPW;
+    const long rstride = (long)gridDim.x * (VT / 64) * RPW;
+    u32x4 gg[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) gg[k] = *reinterpret_cast<const u32x4*>(gamma + ((sub + k * LP) << 3));
+    constexpr int UNR = 2;
+    for (long rb = row0; rb < rows; rb += UNR * rstride) {        // wave-uniform bound
+        u16x8 v[UNR][3];
+        long rowi[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            rowi[u] = rb + u * rstride + lane / LP;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                v[u][k] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                if (rowi[u] < rows) v[u][k] = *reinterpret_cast<const u16x8*>(x + rowi[u] * C + ((sub + k * LP) << 3));
             }
         }
 #pragma unroll
-        for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        const float nrm = fmaxf(rbf(sqrtf(s)), 1e-12f);  // x.norm(2, dim).clamp_min(eps), bf16 tensor
-        // x / norm: ONE correctly rounded reciprocal per row, then a multiply per value.  Bit-identical to the division after the
-        // bf16 rounding that follows: the quotient of two bf16 numbers (8-bit significands mx / mn) is either exactly a bf16 number
-        // or at least 2^-17 (relative) away from every bf16 rounding boundary — mx 2^9 - k mn is a non-zero integer — while x * (1/n)
-        // is within 2^-23 of it; an exact tie cannot occur (it would need a 9-bit quotient of two 8-bit integers' ratio).  The
-        // per-value IEEE division (10 instructions) and expf + division of SiLU made this kernel VALU-bound at 4.4 TB/s.
-        const float rinv = 1.0f / nrm;
-        if (live) {
-            u32x4 o;
-            const u32x4 vv = __builtin_bit_cast(u32x4, v), gg = __builtin_bit_cast(u32x4, g8);
+        for (int u = 0; u < UNR; ++u) {
+            if (rb + u * rstride >= rows) break;
+            float ps[3];
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {                  // values in pairs: one v_cvt_pk_bf16_f32 per rounding and pair
-                float y0 = __uint_as_float(vv[p] << 16) * rinv, y1 = __uint_as_float(vv[p] & 0xffff0000u) * rinv;      // x / norm
-                unsigned r = pack2bf(y0, y1);
-                y0 = __uint_as_float(r << 16) * scale, y1 = __uint_as_float(r & 0xffff0000u) * scale;                    // * dim**0.5
-                r = pack2bf(y0, y1);
-                y0 = __uint_as_float(r << 16) * __uint_as_float(gg[p] << 16);                                            // * gamma (+ bias 0.)
-                y1 = __uint_as_float(r & 0xffff0000u) * __uint_as_float(gg[p] & 0xffff0000u);
-                r = pack2bf(y0, y1);
-                if (silu) {   // x * sigmoid(x) on the bf16 values, exp2 + rcp (a few fp32 ulp, inside the bf16 rounding that follows)
-                    y0 = __uint_as_float(r << 16), y1 = __uint_as_float(r & 0xffff0000u);
-                    const float t0 = __builtin_amdgcn_exp2f(y0 * -1.4426950408889634f), t1 = __builtin_amdgcn_exp2f(y1 * -1.4426950408889634f);
-                    y0 = y0 * __builtin_amdgcn_rcpf(1.0f + t0), y1 = y1 * __builtin_amdgcn_rcpf(1.0f + t1);
-                    r = pack2bf(y0, y1);
+            for (int k = 0; k < 3; ++k) {
+                float t = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float f = bf2f(v[u][k][j]);
+                    t += f * f;
                 }
-                o[p] = r;
+                ps[k] = t;
             }
-            *reinterpret_cast<u32x4*>(out + row * C + (sub << 3)) = o;
+            float s = (ps[0] + ps[2]) + (ps[1] + 0.f);
+#pragma unroll
+            for (int o = LP / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            const float nrm = fmaxf(rbf(sqrtf(s)), 1e-12f);
+            const float rinv = 1.0f / nrm;
+            if (rowi[u] < rows) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    u32x4 o;
+                    const u32x4 vv = __builtin_bit_cast(u32x4, v[u][k]);
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        float y0 = __uint_as_float(vv[p] << 16) * rinv, y1 = __uint_as_float(vv[p] & 0xffff0000u) * rinv;
+                        unsigned r = pack2bf(y0, y1);
+                        y0 = __uint_as_float(r << 16) * scale, y1 = __uint_as_float(r & 0xffff0000u) * scale;
+                        r = pack2bf(y0, y1);
+                        y0 = __uint_as_float(r << 16) * __uint_as_float(gg[k][p] << 16);
+                        y1 = __uint_as_float(r & 0xffff0000u) * __uint_as_float(gg[k][p] & 0xffff0000u);
+                        r = pack2bf(y0, y1);
+                        if (silu) {
+                            y0 = __uint_as_float(r << 16), y1 = __uint_as_float(r & 0xffff0000u);
+                            const float t0 = __builtin_amdgcn_exp2f(y0 * -1.4426950408889634f), t1 = __builtin_amdgcn_exp2f(y1 * -1.4426950408889634f);
+                            y0 = y0 * __builtin_amdgcn_rcpf(1.0f + t0), y1 = y1 * __builtin_amdgcn_rcpf(1.0f + t1);
+                            r = pack2bf(y0, y1);
+                        }
+                        o[p] = r;
+                    }
+                    *reinterpret_cast<u32x4*>(out + rowi[u] * C + ((sub + k * LP) << 3)) = o;
+                }
+            }
         }
     }
 }
@@ -349,11 +436,19 @@ extern "C" GF_API int gf_vae_rmsnorm_silu(const void* x, const void* gamma, void
 #define GF_RMS_LAUNCH(LPR)                                                                                                  \
     hipLaunchKernelGGL(rmsnorm_silu_kernel<LPR>, dim3(vgrid(rows * LPR)), dim3(VT), 0, (hipStream_t)stream, (const u16*)x,  \
                        (const u16*)gamma, (u16*)out, (long)rows, (int)C, sqrtf((float)C), silu ? 1 : 0)
-    if (C <= 64) GF_RMS_LAUNCH(8);
+#define GF_RMS3_LAUNCH(LP)                                                                                                   \
+    hipLaunchKernelGGL(rmsnorm_silu3_kernel<LP>, dim3(vgrid(rows * LP)), dim3(VT), 0, (hipStream_t)stream, (const u16*)x,       \
+                       (const u16*)gamma, (u16*)out, (long)rows, sqrtf((float)C), silu ? 1 : 0)
+    const bool rms3 = gf_options().vae_rms3.load(std::memory_order_relaxed) != 0;
+    if (rms3 && C == 96) GF_RMS3_LAUNCH(4);
+    else if (rms3 && C == 192) GF_RMS3_LAUNCH(8);
+    else if (rms3 && C == 384) GF_RMS3_LAUNCH(16);
+    else if (C <= 64) GF_RMS_LAUNCH(8);
     else if (C <= 128) GF_RMS_LAUNCH(16);
     else if (C <= 256) GF_RMS_LAUNCH(32);
     else GF_RMS_LAUNCH(64);
 #undef GF_RMS_LAUNCH
+#undef GF_RMS3_LAUNCH
     GF_CHECK_LAUNCH("gf_vae_rmsnorm_silu");
     return GF_OK;
 }

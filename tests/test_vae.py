@@ -217,6 +217,23 @@ def test_hip_direct_conv_c96_equals_implicit_gemm_at_tile_size():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("C", [96, 192, 384])
+def test_hip_rmsnorm_silu_three_chunk_kernel_is_bit_identical(C):
+    """RMS_norm (+SiLU) at C = 96 / 192 / 384: the all-lanes-live kernel (three chunks per lane, the row sum's two top butterfly stages
+    as in-lane additions) against the power-of-two kernel (GF_VAE_RMS3=0) — bit for bit, ragged row counts included."""
+    from goal_force_amd import ops
+    g = torch.Generator().manual_seed(C)
+    for rows in (1, 37, 4099, 120 * 208):
+        x = (torch.randn((rows, C), generator=g) * 2.5).to(BF).cuda()
+        gam = (1 + 0.1 * torch.randn(C, generator=g)).to(BF).cuda()
+        for silu in (True, False):
+            with ops.env_options(GF_VAE_RMS3="0"):
+                ref = ops.vae_rmsnorm_silu(x, gam, silu=silu)
+            got = ops.vae_rmsnorm_silu(x, gam, silu=silu)
+            assert torch.equal(got, ref), (C, rows, silu, int((got != ref).sum()))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("T,Hs,Ws,t_off", [(3, 12, 16, 0), (5, 8, 48, 1), (2, 120, 208, 0), (9, 20, 32, 2)])
 def test_hip_direct_upsample_conv_equals_implicit_gemm(T, Hs, Ws, t_off):
     """The decoder's full-resolution upsample convolution (nearest 2x + 3x3, 192 -> 96 channels): the direct kernel (8 x 32 output
