@@ -229,6 +229,8 @@ class WanVideoVAE(nn.Module):
         # latent frames per decoder call / 4-frame chunks per encoder call after the first frame (1 = the reference's streaming
         # granularity; any value gives the same bits).  20 = the whole 81-frame clip of a tile: ~10 GB of activations.
         self.frames_per_chunk = int(os.environ.get("GF_VAE_FRAMES_PER_CHUNK", "20"))
+        # the clip's first frame in one chunk with the first group of frames (0: a chunk of its own, as the reference streams it; A/B)
+        self.merge_first = os.environ.get("GF_VAE_MERGE_FIRST", "1") != "0"
 
     # ---------------------------------------------------------------- state dict
     def load_state_dict(self, state_dict, strict=True, **kw):
@@ -344,18 +346,28 @@ class WanVideoVAE(nn.Module):
         return out
 
     def _upsample(self, P, name, x, C, temporal, first):
-        """Resample upsample2d / upsample3d (VAE:82-174)."""
+        """Resample upsample2d / upsample3d (VAE:82-174).  `first`: x starts with the clip's FIRST frame, which skips the temporal
+        doubling (VAE:139-147); frames behind it in the same chunk go through time_conv with zero history ('Rep'), exactly as they
+        would in a chunk of their own."""
         T, H, W, _ = x.shape
-        if temporal and not first:
-            tc = P[name + ".time_conv"]
-            cache = self._cache.get(name + ".time_conv")
-            if cache is None:  # 'Rep': the first executed time_conv sees zero history (VAE:139-147)
-                cache = torch.zeros((CACHE_T, H, W, C), dtype=x.dtype, device=x.device)
-            self._cache[name + ".time_conv"] = _roll_cache(cache, x)
-            y2 = _conv(x, cache, tc)                                  # [T*hw, 2C]
-            # channels [jC,(j+1)C) of frame t become frame 2t+j (VAE:155-158)
-            x = y2.view(T, H * W, 2, C).transpose(1, 2).contiguous().view(2 * T, H, W, C)
-            T = 2 * T
+        if temporal:
+            x0, xr = (x[:1], x[1:]) if first else (None, x)
+            Tr = xr.shape[0]
+            if Tr > 0:
+                tc = P[name + ".time_conv"]
+                cache = self._cache.get(name + ".time_conv")
+                if cache is None:  # 'Rep': the first executed time_conv sees zero history (VAE:139-147)
+                    cache = torch.zeros((CACHE_T, H, W, C), dtype=x.dtype, device=x.device)
+                self._cache[name + ".time_conv"] = _roll_cache(cache, xr)
+                y2 = _conv(xr, cache, tc)                                 # [Tr*hw, 2C]
+                # channels [jC,(j+1)C) of frame t become frame 2t+j (VAE:155-158); the first frame, if here, in front
+                n0 = 0 if x0 is None else 1
+                out = torch.empty((n0 + 2 * Tr, H, W, C), dtype=x.dtype, device=x.device)
+                if n0:
+                    out[0].copy_(x0[0])
+                out[n0:].view(Tr, 2, H * W, C).copy_(y2.view(Tr, H * W, 2, C).transpose(1, 2))
+                x = out
+                T = n0 + 2 * Tr
         return _conv(x, None, P[name + ".resample.1"], upsample2x=True).view(T, 2 * H, 2 * W, -1)
 
     def _decode_chunk(self, P, x, first):
@@ -385,11 +397,13 @@ class WanVideoVAE(nn.Module):
         c2 = P["conv2"]
         x = ops.gemm(zc.reshape(T * h * w, 64), c2["w"], c2["b"]).view(T, h, w, -1)  # conv2, 1x1x1
         # The reference streams one latent frame per call through the feature caches (VAE:1021-1033).  A causal conv over a
-        # GROUP of frames with the same 2-frame cache in front computes exactly the same sums, so after the first frame (which
-        # skips the temporal upsampling) the frames go through in groups: launches that fill the chip, bit-identical output.
-        frames = [self._decode_chunk(P, x[:1].contiguous(), first=True)]
+        # GROUP of frames with the same 2-frame cache in front computes exactly the same sums, so the frames go through in groups:
+        # launches that fill the chip, bit-identical output.  The first frame skips the temporal upsampling; it travels in front of
+        # the first group (merge_first) — alone it costs ~60 ms of launches that each fill a twentieth of the chip.
         g = max(1, int(self.frames_per_chunk))
-        for i in range(1, T, g):
+        n0 = 1 + (g if self.merge_first else 0)
+        frames = [self._decode_chunk(P, x[:n0].contiguous(), first=True)]
+        for i in range(n0, T, g):
             frames.append(self._decode_chunk(P, x[i:i + g].contiguous(), first=False))
         self._cache = {}
         return torch.cat(frames, dim=0)
@@ -402,11 +416,19 @@ class WanVideoVAE(nn.Module):
         if temporal:
             key = name + ".time_conv"
             prev = self._cache.get(key)
-            if prev is None:   # first chunk: remember the frame, no temporal conv (VAE:162-164)
-                self._cache[key] = torch.cat([torch.zeros_like(x[-1:]), x[-1:]], dim=0).contiguous()
-            else:              # conv over [prev_last, x_0..x_{T-1}], kernel 3, stride 2, no padding (VAE:166-170)
+            x0 = None
+            if prev is None:   # the clip's first frame: remembered, no temporal conv (VAE:162-164); frames behind it in this chunk follow below
+                prev = torch.cat([torch.zeros_like(x[:1]), x[:1]], dim=0).contiguous()
+                x0, x = x[:1], x[1:]
+                T -= 1
+            if T > 0:          # conv over [prev_last, x_0..x_{T-1}], kernel 3, stride 2, no padding (VAE:166-170)
                 self._cache[key] = _roll_cache(prev, x)
                 x = _conv(x, prev, P[key], t_stride=2, t_off=1, t_out=T // 2).view(T // 2, H // 2, W // 2, -1)
+                if x0 is not None:
+                    x = torch.cat([x0, x], dim=0)
+            else:
+                self._cache[key] = prev
+                x = x0
         return x
 
     def _encode_chunk(self, P, x):
@@ -434,10 +456,12 @@ class WanVideoVAE(nn.Module):
         T = video_slice.shape[1]
         xin = ops.vae_prep_latent(video_slice, P["zero3"], P["one3"], cpad=8)    # channels-last, RGB padded to 8
         # frame 0 alone, then the 4-frame chunks of VAE:994-1001 in groups (same sums as one chunk at a time, see decode)
-        outs = [self._encode_chunk(P, xin[:1].contiguous())]
+        # (the first frame travels in front of the first group, see decode_tile_channels_last)
         n4 = 4 * ((T - 1) // 4)
         g = 4 * max(1, int(self.frames_per_chunk))
-        for i in range(1, 1 + n4, g):
+        n0 = 1 + (min(g, n4) if self.merge_first else 0)
+        outs = [self._encode_chunk(P, xin[:n0].contiguous())]
+        for i in range(n0, 1 + n4, g):
             outs.append(self._encode_chunk(P, xin[i:min(i + g, 1 + n4)].contiguous()))
         self._cache = {}
         h = torch.cat(outs, dim=0)                                               # [T', h, w, 64]

@@ -351,13 +351,21 @@ def test_hip_vae_frame_grouping_is_bit_identical_to_streaming():
     z = torch.randn((1, 16, 6, 8, 8), generator=gen).to(BF).cuda()
     video = (torch.rand((3, 21, 64, 64), generator=gen) * 2 - 1).to(BF).cuda()
     outs, encs = [], []
-    for fpc in (1, 2, 20):
-        vae.frames_per_chunk = fpc
+    for fpc, merge in ((1, False), (2, False), (20, False), (1, True), (3, True), (20, True)):
+        # merge_first: the clip's first frame (which skips the temporal resampling) in one chunk with the first group, the shipped
+        # default, against a chunk of its own (how the reference streams it)
+        vae.frames_per_chunk, vae.merge_first = fpc, merge
         outs.append(vae.decode(z, tiled=False))
         encs.append(vae.encode([video], tiled=False))
     assert outs[0].shape == (1, 3, 21, 64, 64) and encs[0].shape == (1, 16, 6, 8, 8)
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
-    assert torch.equal(encs[0], encs[1]) and torch.equal(encs[0], encs[2])
+    for o, e in zip(outs[1:], encs[1:]):
+        assert torch.equal(outs[0], o) and torch.equal(encs[0], e)
+    # a single frame (image): the merged chunk degenerates to the first frame alone
+    vae.frames_per_chunk, vae.merge_first = 20, True
+    one_m = (vae.decode(z[:, :, :1], tiled=False), vae.encode([video[:, :1]], tiled=False))
+    vae.merge_first = False
+    one_s = (vae.decode(z[:, :, :1], tiled=False), vae.encode([video[:, :1]], tiled=False))
+    assert torch.equal(one_m[0], one_s[0]) and torch.equal(one_m[1], one_s[1]) and one_m[0].shape == (1, 3, 1, 64, 64)
 
 
 @pytest.mark.gpu
