@@ -334,16 +334,17 @@ class WanVideoVAE(nn.Module):
         kp = _pad_to(hw, 64)
         xn = ops.vae_rmsnorm_silu(x, P[name + ".norm.gamma"], silu=False)
         qkv_c, proj_c = P[name + ".to_qkv"], P[name + ".proj"]
-        out = torch.empty_like(x)
+        # the two 1x1 convolutions (to_qkv, proj + residual) for all frames of the chunk in one GEMM each; the attention itself per frame
+        qkv_all = ops.gemm(xn.reshape(T * hw, C), qkv_c["w"], qkv_c["b"]).view(T, hw, 3 * C)
+        o_all = torch.empty((T, hw, C), dtype=x.dtype, device=x.device)
         for t in range(T):
-            qkv = ops.gemm(xn[t].reshape(hw, C), qkv_c["w"], qkv_c["b"])                  # [hw, 3C]
+            qkv = qkv_all[t]                                                               # [hw, 3C]
             scores = ops.gemm(qkv[:, :C], qkv[:, C:2 * C])                                 # q k^T  [hw, hw]
             p = ops.softmax_rows(scores, 1.0 / math.sqrt(C), kp)                           # [hw, kp]
             vt = ops.transpose_pad(qkv[:, 2 * C:], kp)                                     # [C, kp]
-            o = ops.gemm(p, vt)                                                            # [hw, C]
-            ops.gemm(o, proj_c["w"], proj_c["b"], epilogue=ops.EPI_BIAS_RESID, resid=x[t].reshape(hw, C),
-                     out=out[t].reshape(hw, C))
-        return out
+            ops.gemm(p, vt, out=o_all[t])                                                  # [hw, C]
+        out = ops.gemm(o_all.view(T * hw, C), proj_c["w"], proj_c["b"], epilogue=ops.EPI_BIAS_RESID, resid=x.reshape(T * hw, C))
+        return out.view(T, H, W, C)
 
     def _upsample(self, P, name, x, C, temporal, first):
         """Resample upsample2d / upsample3d (VAE:82-174).  `first`: x starts with the clip's FIRST frame, which skips the temporal
