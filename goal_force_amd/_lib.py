@@ -26,7 +26,7 @@ SYMBOLS = (
     "gf_flash_attn_fwd_lse", "gf_flash_attn_bwd", "gf_flash_attn_bwd_workspace_bytes",
     "gf_layernorm_bwd", "gf_rmsnorm_rope_bwd", "gf_colsum", "gf_act_bwd", "gf_mse_loss", "gf_adamw_step", "gf_f32_to_bf16", "gf_sumsq",
     "gf_transpose_v", "gf_flash_attn_fwd_vt", "gf_transpose_v32", "gf_flash_attn_fwd_vt32", "gf_linear_vt32",
-    "gf_conv3d_bf16",
+    "gf_conv3d_bf16", "gf_gemm_bf16_batched", "gf_transpose_pad_batched",
 )
 
 EPI_BIAS, EPI_BIAS_GELU_TANH, EPI_BIAS_GATE_RESID, EPI_BIAS_RESID, EPI_BIAS_SILU, EPI_BIAS_MUL = range(6)
@@ -86,6 +86,8 @@ def _declare(lib):
         "gf_vae_rmsnorm_silu": [_vp, _vp, _vp, _i64, _i64, _int, _vp],
         "gf_softmax_rows": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _f32, _vp],
         "gf_transpose_pad": [_vp, _i64, _vp, _i64, _i64, _i64, _vp],
+        "gf_transpose_pad_batched": [_vp, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _vp],
+        "gf_gemm_bf16_batched": [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp],
         "gf_vae_tile_blend": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _int, _int, _int, _int,
                               _i64, _i64, _vp],
         "gf_vae_tile_finalize": [_vp, _vp, _i64, _i64, _int, _vp],

@@ -82,6 +82,7 @@ struct GemmArgs {
     const float* row_scale;  // FP8 only: per-row dequant scale of A (gf_quant_fp8_rowscale)
     int M, N, K;
     long lda, ldw, ldc, ldr;
+    long sA = 0, sW = 0, sC = 0;   // gf_gemm_bf16_batched (gemm_ph_kernel, blockIdx.y = batch index): element strides between the problems
     int tiles_m, tiles_n;
     unsigned long long* dbg;
     ConvGeom cv;
@@ -346,6 +347,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs
     extern __shared__ __attribute__((aligned(16))) char smem[];
     GF_LDS char* lds = (GF_LDS char*)smem;
 
+    // batched launches (gf_gemm_bf16_batched): problem blockIdx.y; strides 0 and gridDim.y = 1 otherwise
+    const u16* const pA = p.A + (long)blockIdx.y * p.sA;
+    const u16* const pW = p.W + (long)blockIdx.y * p.sW;
+    u16* const pC = p.C + (long)blockIdx.y * p.sC;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -375,12 +380,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs
         const int row = (wave * 2 + i) * 8 + srow;  // 0..127 inside the half-tile
         const long a0 = min(m0 + row, p.M - 1), a1 = min(m0 + 128 + row, p.M - 1);
         const long b0 = min(n0 + row, p.N - 1), b1 = min(n0 + 128 + row, p.N - 1);
-        srcp[0][i] = (const char*)p.A + (a0 * p.lda) * ESZ + schunk * 16;
-        srcp[3][i] = (const char*)p.A + (a1 * p.lda) * ESZ + schunk * 16;
-        srcp[1][i] = (const char*)p.W + (b0 * p.ldw) * ESZ + schunk * 16;
-        srcp[2][i] = (const char*)p.W + (b1 * p.ldw) * ESZ + schunk * 16;
+        srcp[0][i] = (const char*)pA + (a0 * p.lda) * ESZ + schunk * 16;
+        srcp[3][i] = (const char*)pA + (a1 * p.lda) * ESZ + schunk * 16;
+        srcp[1][i] = (const char*)pW + (b0 * p.ldw) * ESZ + schunk * 16;
+        srcp[2][i] = (const char*)pW + (b1 * p.ldw) * ESZ + schunk * 16;
     }
-    const char* srcp_b1h = (const char*)p.W + (min((long)(n0 + 128 + wave * 8 + srow), (long)p.N - 1) * p.ldw) * ESZ + schunk * 16;   // NB = 3
+    const char* srcp_b1h = (const char*)pW + (min((long)(n0 + 128 + wave * 8 + srow), (long)p.N - 1) * p.ldw) * ESZ + schunk * 16;   // NB = 3
     // CONV: this lane's four A rows as output pixels: (Y << 16 | X) and the first source frame of the causal window
     int cyx[2][2], cf[2][2];
     const u16* rowp[2][2];   // CONV == 2: the row's pixel in its first source frame
@@ -770,7 +775,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs
                                                         : f2bf(bf2f(r8[e]) + t);      // x + ...
                     }
                 }
-                *reinterpret_cast<u16x8*>(p.C + (long)m * p.ldc + n) = o;
+                *reinterpret_cast<u16x8*>(pC + (long)m * p.ldc + n) = o;
             }
         }
     }
@@ -1444,7 +1449,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
 }
 
 template <int EPI, int NB, int CONV>
-int launch_conv(const GemmArgs& a, hipStream_t stream) {
+int launch_conv(const GemmArgs& a, hipStream_t stream, int batch = 1) {
     static GfDeviceOnce once;
     hipError_t e = gf_once_per_device(once, [] {
         return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ph_kernel<EPI, false, CONV, NB>),
@@ -1454,7 +1459,7 @@ int launch_conv(const GemmArgs& a, hipStream_t stream) {
         gf_set_error("gf_conv3d: hipFuncSetAttribute(%d B LDS) failed: %s", GEMM_LDS, hipGetErrorString(e));
         return GF_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL((gemm_ph_kernel<EPI, false, CONV, NB>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(GEMM_THREADS),
+    hipLaunchKernelGGL((gemm_ph_kernel<EPI, false, CONV, NB>), dim3((unsigned)(a.tiles_m * a.tiles_n), (unsigned)batch), dim3(GEMM_THREADS),
                        GEMM_LDS, stream, a);
     GF_CHECK_LAUNCH("gf_conv3d_bf16");
     return GF_OK;
@@ -1641,6 +1646,55 @@ extern "C" GF_API int gf_linear_vt32_fp8(const void* x8, int64_t ldx, const floa
     a.wrows = (int)kv_len;
     a.stagger_rows = 1;
     return launch_gemm_a4<GF_EPI_VT32, true>(a, (hipStream_t)stream);
+}
+
+// `batch` independent products C_b = A_b W_b^T (no bias, no epilogue) in ONE launch: problem b reads A + b strideA, W + b strideW and
+// writes C + b strideC (element strides; a stride may be smaller than a matrix: heads side by side in one [L, H d] tensor have
+// strideA = d, lda = H d).  For the small per-head / per-frame products of the umT5 and VAE attention (q k^T, p v: M, N of a few
+// hundred rows), which as separate launches fill a sixtieth of the chip each.  The 8-wave kernel (256 x 256 tile, 256 x 128 for
+// N <= 128); every element sums its K products in K order, like gf_gemm_bf16 on this kernel: bit-identical to `batch` separate calls
+// there (the 4-wave kernel that gf_gemm_bf16 takes for M >= 512 starts its K loop at a rotated tile per column tile: another order).
+extern "C" GF_API int gf_gemm_bf16_batched(const void* A, int64_t lda, int64_t strideA, const void* W, int64_t ldw, int64_t strideW,
+                                           void* C, int64_t ldc, int64_t strideC, int64_t M, int64_t N, int64_t K, int64_t batch,
+                                           void* stream) {
+    GF_CHECK_ARG(A && W && C, "gf_gemm_bf16_batched: null A/W/C");
+    GF_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch > 0 && batch < 65536, "gf_gemm_bf16_batched: bad sizes");
+    GF_CHECK_ARG(K % 64 == 0 && N % 8 == 0, "gf_gemm_bf16_batched: K=%ld must be a multiple of 64 and N=%ld of 8", (long)K, (long)N);
+    GF_CHECK_ARG(lda >= K && ldw >= K && ldc >= N && lda % 8 == 0 && ldw % 8 == 0 && ldc % 8 == 0 && strideA % 8 == 0 && strideW % 8 == 0 &&
+                     strideC % 8 == 0 && strideA >= 0 && strideW >= 0 && strideC >= 0,
+                 "gf_gemm_bf16_batched: leading dimensions / strides must be multiples of 8 elements covering K / N");
+    GF_CHECK_ARG(gf_aligned16(A) && gf_aligned16(W) && gf_aligned16(C), "gf_gemm_bf16_batched: 16-byte alignment required");
+    GF_CHECK_ARG(M < (1L << 30) && N < (1L << 30), "gf_gemm_bf16_batched: M / N too large");
+    GemmArgs a;
+    a.A = (const u16*)A;
+    a.W = (const u16*)W;
+    a.bias = nullptr;
+    a.C = (u16*)C;
+    a.R = nullptr;
+    a.gate = nullptr;
+    a.row_scale = nullptr;
+    a.M = (int)M;
+    a.N = (int)N;
+    a.K = (int)K;
+    a.lda = lda;
+    a.ldw = ldw;
+    a.ldc = ldc;
+    a.ldr = 0;
+    a.sA = strideA;
+    a.sW = strideW;
+    a.sC = strideC;
+    const bool narrow = N <= 128;
+    a.tiles_m = (int)((M + BM - 1) / BM);
+    a.tiles_n = narrow ? (int)((N + 127) / 128) : (int)((N + BN - 1) / BN);
+    a.dbg = nullptr;
+    a.whatif = 0;
+    a.stagger = 0;
+    a.wrows = (int)N;
+    a.stagger_rows = 0;
+    a.group_m = 0;
+    a.halftile = 0;
+    a.cv = ConvGeom{};
+    return narrow ? launch_conv<GF_EPI_BIAS, 1, 0>(a, (hipStream_t)stream, (int)batch) : launch_conv<GF_EPI_BIAS, 2, 0>(a, (hipStream_t)stream, (int)batch);
 }
 
 // Causal 3-D / 2-D convolution of the Wan VAE as ONE implicit GEMM (no patch matrix in HBM): out[(j, Y, X), n] =

@@ -298,7 +298,9 @@ __global__ __launch_bounds__(VT) void softmax_rows_kernel(const u16* __restrict_
 
 // dst[c, r] = src[r, c] for r < R (zero for R <= r < rpad); 32x32 tiles through LDS.
 __global__ __launch_bounds__(VT) void transpose_pad_kernel(const u16* __restrict__ src, long lds_, u16* __restrict__ dst,
-                                                           int R, int C, int rpad) {
+                                                           int R, int C, int rpad, long bsrc, long bdst) {
+    src += (long)blockIdx.z * bsrc;              // gf_transpose_pad_batched: matrix blockIdx.z
+    dst += (long)blockIdx.z * bdst;
     __shared__ u16 tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
     const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
@@ -317,7 +319,9 @@ __global__ __launch_bounds__(VT) void transpose_pad_kernel(const u16* __restrict
 // for the [32760, 5120] operands of the training step's weight-gradient GEMMs against 0.11 ms for the bytes).  Needs C % 8 == 0,
 // rpad % 8 == 0 and 16-byte aligned rows on both sides.
 __global__ __launch_bounds__(VT) void transpose_pad64_kernel(const u16* __restrict__ src, long lds_, u16* __restrict__ dst, int R, int C,
-                                                             int rpad) {
+                                                             int rpad, long bsrc, long bdst) {
+    src += (long)blockIdx.z * bsrc;
+    dst += (long)blockIdx.z * bdst;
     __shared__ u16 tile[64][64 + 2];             // 33-dword rows: the column reads below walk banks
     const int t = threadIdx.x;
     const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
@@ -464,17 +468,34 @@ extern "C" GF_API int gf_softmax_rows(const void* x, int64_t ldx, const void* bi
     return GF_OK;
 }
 
+static int transpose_pad_launch(const char* fn, const void* src, int64_t ld_src, int64_t stride_src, void* dst, int64_t stride_dst, int64_t R,
+                                int64_t C, int64_t rpad, int64_t batch, void* stream) {
+    if (C % 8 == 0 && rpad % 8 == 0 && ld_src % 8 == 0 && stride_src % 8 == 0 && stride_dst % 8 == 0 && gf_aligned16(src) && gf_aligned16(dst) &&
+        VT == 256)
+        hipLaunchKernelGGL(transpose_pad64_kernel, dim3((unsigned)((rpad + 63) / 64), (unsigned)((C + 63) / 64), (unsigned)batch), dim3(VT), 0,
+                           (hipStream_t)stream, (const u16*)src, (long)ld_src, (u16*)dst, (int)R, (int)C, (int)rpad, (long)stride_src,
+                           (long)stride_dst);
+    else
+        hipLaunchKernelGGL(transpose_pad_kernel, dim3((unsigned)((rpad + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)batch), dim3(VT), 0,
+                           (hipStream_t)stream, (const u16*)src, (long)ld_src, (u16*)dst, (int)R, (int)C, (int)rpad, (long)stride_src,
+                           (long)stride_dst);
+    GF_CHECK_LAUNCH(fn);
+    return GF_OK;
+}
+
 extern "C" GF_API int gf_transpose_pad(const void* src, int64_t ld_src, void* dst, int64_t R, int64_t C, int64_t rpad,
                                        void* stream) {
     GF_CHECK_ARG(src && dst && R > 0 && C > 0 && rpad >= R && ld_src >= C, "gf_transpose_pad: bad arguments");
-    if (C % 8 == 0 && rpad % 8 == 0 && ld_src % 8 == 0 && gf_aligned16(src) && gf_aligned16(dst) && VT == 256)
-        hipLaunchKernelGGL(transpose_pad64_kernel, dim3((unsigned)((rpad + 63) / 64), (unsigned)((C + 63) / 64)), dim3(VT), 0,
-                           (hipStream_t)stream, (const u16*)src, (long)ld_src, (u16*)dst, (int)R, (int)C, (int)rpad);
-    else
-    hipLaunchKernelGGL(transpose_pad_kernel, dim3((unsigned)((rpad + 31) / 32), (unsigned)((C + 31) / 32)), dim3(VT), 0,
-                       (hipStream_t)stream, (const u16*)src, (long)ld_src, (u16*)dst, (int)R, (int)C, (int)rpad);
-    GF_CHECK_LAUNCH("gf_transpose_pad");
-    return GF_OK;
+    return transpose_pad_launch("gf_transpose_pad", src, ld_src, 0, dst, 0, R, C, rpad, 1, stream);
+}
+
+// `batch` matrices in one launch: matrix b is src + b stride_src ([R, C] with row pitch ld_src: heads side by side in one [R, H C] tensor
+// have stride_src = C) -> dst + b stride_dst ([C, rpad]); element strides.
+extern "C" GF_API int gf_transpose_pad_batched(const void* src, int64_t ld_src, int64_t stride_src, void* dst, int64_t stride_dst, int64_t R,
+                                               int64_t C, int64_t rpad, int64_t batch, void* stream) {
+    GF_CHECK_ARG(src && dst && R > 0 && C > 0 && rpad >= R && ld_src >= C && batch > 0 && batch < 65536 && stride_src >= 0 &&
+                     stride_dst >= C * rpad, "gf_transpose_pad_batched: bad arguments");
+    return transpose_pad_launch("gf_transpose_pad_batched", src, ld_src, stride_src, dst, stride_dst, R, C, rpad, batch, stream);
 }
 
 extern "C" GF_API int gf_vae_tile_blend(void* values, void* weight, const void* tile, int64_t nch, int64_t T, int64_t th,

@@ -611,6 +611,40 @@ def transpose_pad(x, rpad):
     return out
 
 
+def transpose_pad_batched(x, rpad):
+    """x [B, R, C] (any batch / row strides, contiguous last dim) -> [B, C, rpad] (zero columns past R) in one launch."""
+    _req(x, "transpose_pad_batched.x")
+    if x.dim() != 3 or x.stride(2) != 1:
+        raise GoalForceError("transpose_pad_batched.x must be 3-D with a contiguous last dim")
+    B, R, C = x.shape
+    out = torch.empty((B, C, rpad), dtype=_BF16, device=x.device)
+    _lib.check(_lib.load().gf_transpose_pad_batched(_ptr(x), x.stride(1), x.stride(0), _ptr(out), C * rpad, R, C, rpad, B, _stream(x)),
+               "gf_transpose_pad_batched")
+    return out
+
+
+def gemm_batched(a, w, out=None):
+    """out[b] = a[b] @ w[b]^T for b < B in ONE launch (gf_gemm_bf16_batched): a [B, M, K], w [B, N, K], out [B, M, N] — views with any
+    batch / row strides and a contiguous last dim (heads of a [L, H*d] tensor: t.view(L, H, d).permute(1, 0, 2)).  No bias / epilogue.
+    The 8-wave kernel: bit-identical to B calls of gemm() under GF_GEMM_KERNEL=ph (for M >= 512 gemm() takes the 4-wave kernel, which sums the
+    same products from a rotated K tile on: equal up to fp32 summation order)."""
+    _req(a, "gemm_batched.a")
+    _req(w, "gemm_batched.w")
+    if a.dim() != 3 or w.dim() != 3 or a.stride(2) != 1 or w.stride(2) != 1 or a.shape[0] != w.shape[0] or a.shape[2] != w.shape[2]:
+        raise GoalForceError("gemm_batched: a [B, M, K] and w [B, N, K] with contiguous last dims")
+    B, M, K = a.shape
+    N = w.shape[1]
+    if out is None:
+        out = torch.empty((B, M, N), dtype=_BF16, device=a.device)
+    else:
+        _req(out, "gemm_batched.out")
+        if tuple(out.shape) != (B, M, N) or out.stride(2) != 1:
+            raise GoalForceError(f"gemm_batched.out: expected [{B}, {M}, {N}] with a contiguous last dim")
+    _lib.check(_lib.load().gf_gemm_bf16_batched(_ptr(a), a.stride(1), a.stride(0), _ptr(w), w.stride(1), w.stride(0), _ptr(out),
+                                                out.stride(1), out.stride(0), M, N, K, B, _stream(a)), "gf_gemm_bf16_batched")
+    return out
+
+
 def vae_tile_blend(values, weight, tile, y0, x0, bounds, border):
     """values [nch,T,H,W], weight [H,W], tile [T,th,tw,tc>=nch] channels-last; bounds=(top,bottom,left,right)."""
     for n, t in (("values", values), ("weight", weight), ("tile", tile)):

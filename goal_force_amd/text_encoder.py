@@ -85,12 +85,14 @@ class T5Attention(nn.Module):
         v = ops.gemm(x2, self.v.weight)
         kp = -(-L // 64) * 64
         ctx = torch.empty((L, n * c), dtype=x2.dtype, device=x2.device)
-        for h in range(n):
-            sl = slice(h * c, (h + 1) * c)
-            scores = ops.gemm(q[:, sl], k[:, sl])                                             # q k^T, no scaling
-            p = ops.softmax_rows(scores, 1.0, kp, bias=None if pos_bias is None else pos_bias[h], nvalid=nvalid)
-            vt = ops.transpose_pad(v[:, sl], kp)                                              # [c, kp]
-            ops.gemm(p, vt, out=ctx[:, sl])
+        heads = lambda t: t.view(L, n, c).permute(1, 0, 2)                                    # [n, L, c] views: head h = columns h c ..
+        # all heads per launch (one launch per head and product was 256 launches per layer, each filling 1/64 of the chip: 72 -> 23 ms per
+        # prompt); the 8-wave GEMM kernel, bit-identical to per-head calls on it (tests/test_text_encoder.py)
+        scores = ops.gemm_batched(heads(q), heads(k))                                         # q k^T, no scaling  [n, L, L]
+        bias = None if pos_bias is None else pos_bias.reshape(n * L, L)
+        p = ops.softmax_rows(scores.view(n * L, L), 1.0, kp, bias=bias, nvalid=nvalid)        # [n L, kp]
+        vt = ops.transpose_pad_batched(heads(v), kp)                                          # [n, c, kp]
+        ops.gemm_batched(p.view(n, L, kp), vt, out=heads(ctx))
         return ops.gemm(ctx, self.o.weight, epilogue=ops.EPI_BIAS_RESID, resid=resid)
 
 

@@ -337,12 +337,15 @@ class WanVideoVAE(nn.Module):
         # the two 1x1 convolutions (to_qkv, proj + residual) for all frames of the chunk in one GEMM each; the attention itself per frame
         qkv_all = ops.gemm(xn.reshape(T * hw, C), qkv_c["w"], qkv_c["b"]).view(T, hw, 3 * C)
         o_all = torch.empty((T, hw, C), dtype=x.dtype, device=x.device)
-        for t in range(T):
-            qkv = qkv_all[t]                                                               # [hw, 3C]
-            scores = ops.gemm(qkv[:, :C], qkv[:, C:2 * C])                                 # q k^T  [hw, hw]
-            p = ops.softmax_rows(scores, 1.0 / math.sqrt(C), kp)                           # [hw, kp]
-            vt = ops.transpose_pad(qkv[:, 2 * C:], kp)                                     # [C, kp]
-            ops.gemm(p, vt, out=o_all[t])                                                  # [hw, C]
+        # the frames' attention in groups (one launch per product and group; a group's scores stay below ~1 GB)
+        gsz = max(1, min(T, (1 << 29) // (hw * hw)))
+        for t0 in range(0, T, gsz):
+            qkv = qkv_all[t0:t0 + gsz]                                                     # [g, hw, 3C]
+            g = qkv.shape[0]
+            scores = ops.gemm_batched(qkv[:, :, :C], qkv[:, :, C:2 * C])                   # q k^T  [g, hw, hw]
+            p = ops.softmax_rows(scores.view(g * hw, hw), 1.0 / math.sqrt(C), kp)          # [g hw, kp]
+            vt = ops.transpose_pad_batched(qkv[:, :, 2 * C:], kp)                          # [g, C, kp]
+            ops.gemm_batched(p.view(g, hw, kp), vt, out=o_all[t0:t0 + gsz])                # [g, hw, C]
         out = ops.gemm(o_all.view(T * hw, C), proj_c["w"], proj_c["b"], epilogue=ops.EPI_BIAS_RESID, resid=x.reshape(T * hw, C))
         return out.view(T, H, W, C)
 

@@ -121,6 +121,16 @@ GF_API int gf_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, 
                  int epilogue, const void* resid, int64_t ldr, const void* gate,
                  void* stream);
 
+/* gf_gemm_bf16_batched — `batch` independent products C_b = A_b W_b^T (no bias, no epilogue) in ONE launch: problem b reads
+ * A + b*strideA ([M, K], row pitch lda), W + b*strideW ([N, K], row pitch ldw) and writes C + b*strideC ([M, N], row pitch ldc); strides in
+ * elements, and a stride may be smaller than a matrix (heads side by side in one [L, H*d] tensor: strideA = d, lda = H*d).  The small
+ * per-head / per-frame products of the umT5 encoder's attention (wan_video_text_encoder.py:61-93: q k^T and attn v per head) and of the
+ * VAE AttentionBlock (VAE:304-342, per frame).  K a multiple of 64, N of 8.  Runs on the 8-wave kernel: bit-identical to `batch`
+ * gf_gemm_bf16 calls on that kernel (M < 512, or GF_GEMM_KERNEL=ph); the 4-wave kernel gf_gemm_bf16 takes for M >= 512 rotates the K
+ * loop's start per column tile, i.e. sums the same products in another order. */
+GF_API int gf_gemm_bf16_batched(const void* A, int64_t lda, int64_t strideA, const void* W, int64_t ldw, int64_t strideW, void* C,
+                                int64_t ldc, int64_t strideC, int64_t M, int64_t N, int64_t K, int64_t batch, void* stream);
+
 /* ------------------------------------------------------------------------
  * gf_flash_attn_fwd — softmax(Q K^T * scale) V per head, non-causal, no mask,
  * no dropout, head_dim 128.  Replaces flash_attention() (DIT:28-61) /
@@ -330,6 +340,11 @@ GF_API int gf_softmax_rows(const void* x, int64_t ldx, const void* bias, int64_t
  * of the AttentionBlock's P·V GEMM).                                                   */
 GF_API int gf_transpose_pad(const void* src, int64_t ld_src, void* dst, int64_t R, int64_t C, int64_t rpad,
                             void* stream);
+
+/* gf_transpose_pad_batched — `batch` transposes in one launch: matrix b = src + b*stride_src ([R, C], row pitch ld_src; heads lying side by
+ * side in one [R, H*C] tensor have stride_src = C) -> dst + b*stride_dst ([C, rpad], zero columns past R); strides in elements. */
+GF_API int gf_transpose_pad_batched(const void* src, int64_t ld_src, int64_t stride_src, void* dst, int64_t stride_dst, int64_t R,
+                                    int64_t C, int64_t rpad, int64_t batch, void* stream);
 
 /* gf_vae_tile_blend / gf_vae_tile_finalize — WanVideoVAE.tiled_decode's weighted tile
  * accumulation (VAE:1128-1150, build_mask VAE:1081-1100) with bf16 accumulators:

@@ -85,3 +85,42 @@ def test_gemm_mul_epilogue_and_biased_softmax():
     p = ops.softmax_rows(s.cuda(), 1.0, 64, bias=b.cuda(), nvalid=33).cpu()
     refp = torch.softmax((s + b)[:, :33].float(), -1)
     assert rel_l2(p[:, :33].float(), refp) < 3e-3 and float(p[:, 33:].abs().sum()) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,M,N,K,heads_layout", [(64, 512, 512, 64, True), (5, 300, 520, 128, False), (3, 40, 64, 448, False),
+                                                  (21, 1560, 1560, 384, False), (7, 512, 64, 512, True), (1, 17, 8, 64, False)])
+def test_batched_gemm_and_transpose_equal_the_per_problem_loop(B, M, N, K, heads_layout):
+    """gf_gemm_bf16_batched / gf_transpose_pad_batched (one launch for all heads of the umT5 attention, all frames of the VAE attention)
+    against one gf_gemm_bf16 / gf_transpose_pad call per problem: bit for bit, with the operands as strided head views of one
+    [rows, B*d] tensor or as separate matrices, ragged M / N included; argument errors.  The per-problem calls are pinned to the 8-wave
+    kernel (GF_GEMM_KERNEL=ph), which the batched launch uses: for M >= 512 gf_gemm_bf16 would take the 4-wave kernel, whose column tiles
+    start their K loops at rotated K tiles — the same products summed in another order."""
+    from goal_force_amd import ops
+    from goal_force_amd._lib import GoalForceError
+    g = torch.Generator().manual_seed(B * 1000 + M)
+    if heads_layout:      # heads side by side: a [M, B*K] tensor viewed as [B, M, K]
+        a = torch.randn((M, B * K), generator=g).to(BF).cuda().view(M, B, K).permute(1, 0, 2)
+        w = torch.randn((N, B * K), generator=g).to(BF).cuda().view(N, B, K).permute(1, 0, 2)
+        out = torch.zeros((M, B * N), dtype=BF).cuda().view(M, B, N).permute(1, 0, 2)
+    else:
+        a = torch.randn((B, M, K), generator=g).to(BF).cuda()
+        w = torch.randn((B, N, K), generator=g).to(BF).cuda()
+        out = None
+    got = ops.gemm_batched(a, w, out=out)
+    assert tuple(got.shape) == (B, M, N)
+    with ops.env_options(GF_GEMM_KERNEL="ph"):
+        for b in range(B):
+            ref = ops.gemm(a[b], w[b])
+            assert torch.equal(got[b], ref), (b, int((got[b] != ref).sum()))
+    ref4 = ops.gemm(a[B - 1], w[B - 1])                          # whatever kernel the single call takes: the same numbers up to fp32 summation order
+    assert rel_l2(got[B - 1].float(), ref4.float()) < 1e-3
+    assert float(got.float().abs().max()) > 1
+    rpad = -(-M // 64) * 64
+    tb = ops.transpose_pad_batched(a, rpad)
+    for b in range(B):
+        assert torch.equal(tb[b], ops.transpose_pad(a[b], rpad))
+    with pytest.raises(GoalForceError):
+        ops.gemm_batched(a, w[:, :, : K - 8])                     # K mismatch
+    with pytest.raises(GoalForceError):
+        ops.gemm_batched(a[:, :, :32], w[:, :, :32])              # K not a multiple of 64
