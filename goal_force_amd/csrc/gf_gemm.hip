@@ -461,34 +461,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs
                         return;
                     }
                 }
-                int tap, c, dt, dy = 0, dx = 0;
-                if (CONV == 1 && g.c64) {
-                    // the general gather with C % 64 == 0 (the resampling convolutions, the time convolutions with a separate cache): the
-                    // tile's tap is the wave-uniform state of the CONV == 2 path; per lane and piece the source pixel is left
-                    dt = s_dt[a], dy = s_dy[a], dx = s_dx[a];
-                    c = s_c0[a] + schunk * 8;
-                    tap = 0;                                                 // (< g.taps: a c64 K has no padding columns)
-                    s_c0[a] += 64;
-                    if (s_c0[a] == g.C) {
-                        s_c0[a] = 0;
-                        if (++s_dx[a] == g.ks) {
-                            s_dx[a] = 0;
-                            if (++s_dy[a] == g.ks) {
-                                s_dy[a] = 0;
-                                ++s_dt[a];
-                            }
-                        }
-                    }
-                } else {
-                    const int ke = tile * 64 + schunk * 8;                   // first of this lane's 8 channels along K
-                    tap = (int)(((float)ke + 0.5f) * g.inv_c);               // exact: ke < 2^16, C <= 512
-                    c = ke - tap * g.C;
-                    dt = (int)(((float)tap + 0.5f) * g.inv_ks2);
-                    const int rem = tap - dt * g.ks * g.ks;
-                    if (g.ks == 3) {
-                        dy = (rem * 11) >> 5;                                // rem / 3 for rem < 9
-                        dx = rem - 3 * dy;
-                    }
+                const int ke = tile * 64 + schunk * 8;                       // first of this lane's 8 channels along K
+                const int tap = (int)(((float)ke + 0.5f) * g.inv_c);         // exact: ke < 2^16, C <= 512
+                const int c = ke - tap * g.C;
+                const int dt = (int)(((float)tap + 0.5f) * g.inv_ks2);
+                const int rem = tap - dt * g.ks * g.ks;
+                int dy = 0, dx = 0;
+                if (g.ks == 3) {
+                    dy = (rem * 11) >> 5;                                    // rem / 3 for rem < 9
+                    dx = rem - 3 * dy;
                 }
                 const int half = g.ks >> 1;
                 if constexpr (CONV == 2) {
