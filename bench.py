@@ -6,6 +6,12 @@ Wan2.2-I2V-A14B 832x480x81f, 50 steps).
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
+Both forms work for N > 1.  Started WITHOUT a launcher (no WORLD_SIZE in the environment) `--gpus N` starts its own N ranks:
+the parent — before it imports torch or touches a GPU — spawns N fresh child processes of this file with
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set, relays rank 0's single JSON line on its stdout
+(the other ranks' stdout goes to stderr) and exits non-zero if any child fails (the reference's scripts shard the same way,
+one plain process per device: scripts/inference/utils.py:25-57).
+
 A "step" is one full denoising iteration of the reference loop (src/goal_force/wan_video_new.py:697-723):
 cond + uncond model_fn forwards (40 DiT blocks each, + 10 ControlNet blocks and 10 zero-conv GEMMs on
 high-noise steps), CFG combine and the flow-match Euler update, at the full 832x480x81f size
@@ -103,6 +109,40 @@ def tensor_digest(torch, t):
             "absmax": float(f.abs().max())}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` with no launcher: N child processes of this file, one per GPU, torch.distributed.run's
+    environment.  Runs in a parent that has imported neither torch nor anything else that initialises HIP (a process that has
+    touched the GPU must not be replaced or forked on this pool); children are started fresh, never exec'd over the parent."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if port is None:
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+        sk.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc, alive = 0, list(procs)
+    while alive:
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:          # one rank failed: the others would wait in a collective forever
+                rc = code
+                print(f"bench.py: rank {procs.index(p)} exited with {code}; stopping the other ranks", file=sys.stderr)
+                for q in alive:
+                    q.terminate()
+        time.sleep(0.2)
+    sys.exit(rc if rc >= 0 else 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,6 +164,8 @@ def main():
     ap.add_argument("--layers", type=int, default=40, help=argparse.SUPPRESS)  # debugging only; 40 = the real model
     ap.add_argument("--sample-offset", type=int, default=0, help=argparse.SUPPRESS)  # tests: the N=1 run of video #k (seeds follow the sample id)
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)                  # never returns
 
     import torch
     import torch.distributed as dist
@@ -135,7 +177,7 @@ def main():
     torch.set_grad_enabled(False)
     rank, local, world = init_from_env()
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node and --gpus must agree")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if args.sp > 1 and world % (2 * args.sp):

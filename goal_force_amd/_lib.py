@@ -22,12 +22,17 @@ SYMBOLS = (
     "gf_force_map",
     "gf_vae_prep_latent", "gf_vae_im2col", "gf_vae_finish_latent", "gf_vae_rmsnorm_silu", "gf_softmax_rows", "gf_transpose_pad",
     "gf_vae_tile_blend", "gf_vae_tile_finalize",
-    "gf_quant_fp8_rowscale", "gf_cast_fp8", "gf_gemm_fp8", "gf_layernorm_modulate_fp8", "gf_modulate", "gf_rope_apply", "gf_linear_vt32_fp8",
+    "gf_quant_fp8_rowscale", "gf_cast_fp8", "gf_gemm_fp8", "gf_layernorm_modulate_fp8", "gf_modulate", "gf_gate_residual", "gf_rope_apply", "gf_linear_vt32_fp8",
     "gf_flash_attn_fwd_lse", "gf_flash_attn_bwd", "gf_flash_attn_bwd_workspace_bytes",
     "gf_layernorm_bwd", "gf_rmsnorm_rope_bwd", "gf_colsum", "gf_act_bwd", "gf_mse_loss", "gf_adamw_step", "gf_f32_to_bf16", "gf_sumsq",
     "gf_transpose_v", "gf_flash_attn_fwd_vt", "gf_transpose_v32", "gf_flash_attn_fwd_vt32", "gf_linear_vt32",
     "gf_conv3d_bf16", "gf_gemm_bf16_batched", "gf_transpose_pad_batched",
 )
+
+# the C ABI revision these bindings were written against (csrc/gf_abi.hip: GF_ABI_VERSION).  A stale or foreign .so whose entry
+# points take differently sized buffers (gf_flash_attn_bwd's workspace grew 3x between revisions 7 and 10 under an unchanged
+# signature) is refused at load time instead of overrunning memory.
+ABI_VERSION = 11
 
 EPI_BIAS, EPI_BIAS_GELU_TANH, EPI_BIAS_GATE_RESID, EPI_BIAS_RESID, EPI_BIAS_SILU, EPI_BIAS_MUL = range(6)
 
@@ -93,6 +98,7 @@ def _declare(lib):
         "gf_vae_tile_finalize": [_vp, _vp, _i64, _i64, _int, _vp],
         "gf_quant_fp8_rowscale": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp],
         "gf_modulate": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp],
+        "gf_gate_residual": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp],
         "gf_linear_vt32_fp8": [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _vp],
         "gf_rope_apply": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp],
         "gf_layernorm_modulate_fp8": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _vp],
@@ -125,6 +131,10 @@ def load():
             except OSError as e:  # pragma: no cover
                 raise GoalForceError(f"cannot load {LIB_PATH}: {e}") from e
             _declare(lib)
+            have = int(lib.gf_abi_version())
+            if have != ABI_VERSION:
+                raise GoalForceError(f"{LIB_PATH} speaks C ABI revision {have}, these bindings revision {ABI_VERSION}: rebuild the "
+                                     "library (`make -C goal_force_amd/csrc`) — mixing revisions can overrun caller-owned workspaces")
             _lib = lib
     return _lib
 

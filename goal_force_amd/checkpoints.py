@@ -14,6 +14,7 @@ from the tensor shapes, so the A14B files and small synthetic checkpoints go thr
 from __future__ import annotations
 
 import contextlib
+import threading
 import glob
 import os
 from typing import Optional
@@ -85,19 +86,38 @@ def params_on_meta():
     The checkpoint's tensors are then ADOPTED with `load_state_dict(assign=True)` instead of being copied into a second,
     randomly initialised fp32 copy of the model — for an A14B expert that copy would be 57 GB of host memory and minutes of
     CPU random-number generation."""
-    old = torch.nn.Module.register_parameter
+    # The patch replaces a class attribute of torch.nn.Module, i.e. it is process-wide while installed.  It is therefore
+    # (1) installed under a module-level lock by the OUTERMOST context only (nested contexts just count), restored by that same
+    # context — never in the wrong order —, and (2) inert for every other thread: a module another thread builds meanwhile
+    # registers real parameters as usual.  Two loaders in two threads serialise on the lock.
+    me = threading.get_ident()
+    with _META_LOCK:
+        if _META_STATE["depth"] and _META_STATE["owner"] == me:        # nested use by the owner: nothing to install
+            _META_STATE["depth"] += 1
+            try:
+                yield
+            finally:
+                _META_STATE["depth"] -= 1
+            return
+        old = torch.nn.Module.register_parameter
 
-    def register(module, name, param):
-        old(module, name, param)
-        if param is not None:
-            p = module._parameters[name]
-            module._parameters[name] = torch.nn.Parameter(p.detach().to("meta"), requires_grad=p.requires_grad)
+        def register(module, name, param):
+            old(module, name, param)
+            if param is not None and threading.get_ident() == me:
+                p = module._parameters[name]
+                module._parameters[name] = torch.nn.Parameter(p.detach().to("meta"), requires_grad=p.requires_grad)
 
-    torch.nn.Module.register_parameter = register
-    try:
-        yield
-    finally:
-        torch.nn.Module.register_parameter = old
+        _META_STATE.update(depth=1, owner=me)
+        torch.nn.Module.register_parameter = register
+        try:
+            yield
+        finally:
+            torch.nn.Module.register_parameter = old
+            _META_STATE.update(depth=0, owner=None)
+
+
+_META_LOCK = threading.RLock()
+_META_STATE = {"depth": 0, "owner": None}
 
 
 def _adopt(module, sd, what):

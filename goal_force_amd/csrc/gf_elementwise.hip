@@ -96,6 +96,28 @@ __global__ __launch_bounds__(EW_THREADS) void modulate_kernel(const u16* __restr
     }
 }
 
+// GateModule.forward (DIT:189-194): x + gate * residual in the reference's eager bf16 order — bf16(gate * residual) first, then the
+// add rounds again.  gate [dim] is the block's modulation row (batch 1).  The hot path fuses this into the GEMM epilogue
+// (GF_EPI_BIAS_GATE_RESID); this kernel backs the module's own forward (B3).
+__global__ __launch_bounds__(EW_THREADS) void gate_residual_kernel(const u16* __restrict__ x, const u16* __restrict__ gate,
+                                                                   const u16* __restrict__ residual, u16* __restrict__ out, long rows,
+                                                                   int dim, long x_stride, long r_stride, long out_stride) {
+    const int cpr = dim >> 3;
+    const long total = rows * cpr;
+    const long stride = (long)gridDim.x * EW_THREADS;
+    for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += stride) {
+        const long r = i / cpr;
+        const int c = (int)(i - r * cpr) << 3;
+        const u16x8 xv = *reinterpret_cast<const u16x8*>(x + r * x_stride + c);
+        const u16x8 rv = *reinterpret_cast<const u16x8*>(residual + r * r_stride + c);
+        const u16x8 gv = *reinterpret_cast<const u16x8*>(gate + c);
+        u16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(xv[j]) + rbf(bf2f(gv[j]) * bf2f(rv[j])));
+        *reinterpret_cast<u16x8*>(out + r * out_stride + c) = o;
+    }
+}
+
 // rope_apply (DIT:92-97) alone: adjacent pairs of every head rotated by the token's phases (fp32 cos / sin tables [rows, head_dim/2];
 // the reference multiplies in complex128 and rounds once to bf16).  The fused form on the hot path is gf_rmsnorm_rope.
 __global__ __launch_bounds__(EW_THREADS) void rope_apply_kernel(const u16* __restrict__ x, u16* __restrict__ out,
@@ -267,6 +289,20 @@ extern "C" GF_API int gf_modulate(const void* x, void* out, const void* scale, c
     hipLaunchKernelGGL(modulate_kernel, dim3(ew_grid(rows * (dim >> 3))), dim3(EW_THREADS), 0, (hipStream_t)stream, (const u16*)x,
                        (u16*)out, (const u16*)scale, (const u16*)shift, (long)rows, (int)dim, (long)x_stride, (long)out_stride);
     GF_CHECK_LAUNCH("gf_modulate");
+    return GF_OK;
+}
+
+extern "C" GF_API int gf_gate_residual(const void* x, const void* gate, const void* residual, void* out, int64_t rows, int64_t dim,
+                                       int64_t x_stride, int64_t r_stride, int64_t out_stride, void* stream) {
+    GF_CHECK_ARG(x && gate && residual && out && rows >= 0, "gf_gate_residual: null pointer");
+    GF_CHECK_ARG(dim > 0 && dim % 8 == 0 && x_stride % 8 == 0 && r_stride % 8 == 0 && out_stride % 8 == 0 && gf_aligned16(x) &&
+                     gf_aligned16(gate) && gf_aligned16(residual) && gf_aligned16(out),
+                 "gf_gate_residual: dim %% 8 == 0 and 16-byte aligned rows / vectors required");
+    if (rows == 0) return GF_OK;
+    hipLaunchKernelGGL(gate_residual_kernel, dim3(ew_grid(rows * (dim >> 3))), dim3(EW_THREADS), 0, (hipStream_t)stream, (const u16*)x,
+                       (const u16*)gate, (const u16*)residual, (u16*)out, (long)rows, (int)dim, (long)x_stride, (long)r_stride,
+                       (long)out_stride);
+    GF_CHECK_LAUNCH("gf_gate_residual");
     return GF_OK;
 }
 

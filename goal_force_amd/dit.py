@@ -284,10 +284,20 @@ class CrossAttention(nn.Module):
 
 
 class GateModule(nn.Module):
-    """DIT:189-194 — kept for interface parity; the gated residual is fused into the GEMM epilogue."""
+    """DIT:189-194 — `x + gate * residual`.  DiTBlock.forward fuses this into the epilogue of the GEMM that produces `residual`
+    (GF_EPI_BIAS_GATE_RESID); the module's own forward is the stand-alone kernel gf_gate_residual with the same bf16 rounding
+    order (the product first, then the sum), for callers that use the module directly."""
 
     def forward(self, x, gate, residual):
-        raise NotImplementedError("gate*residual is fused into gf_gemm_bf16(GF_EPI_BIAS_GATE_RESID)")
+        if x.shape != residual.shape:
+            raise GoalForceError("GateModule: x and residual must have the same shape")
+        d = x.shape[-1]
+        g = gate.reshape(-1, d)
+        if x.dim() == 3 and g.shape[0] == x.shape[0] and x.shape[0] > 1:        # one gate row per batch element ([B,1,D])
+            return torch.stack([ops.gate_residual(x[b], g[b].contiguous(), residual[b]) for b in range(x.shape[0])])
+        if g.shape[0] != 1:
+            raise GoalForceError("GateModule: gate must be [B or 1, 1, D] (per-token gates are outside the Goal-Force path)")
+        return ops.gate_residual(x, g[0].contiguous(), residual)
 
 
 class DiTBlock(nn.Module):

@@ -16,7 +16,7 @@ from ._lib import (EPI_BIAS, EPI_BIAS_GATE_RESID, EPI_BIAS_GELU_TANH, EPI_BIAS_M
                    GoalForceError)
 
 __all__ = [
-    "modulation", "layernorm_modulate", "rmsnorm_rope", "gemm", "flash_attn", "patchify_im2col", "unpatchify",
+    "modulation", "layernorm_modulate", "rmsnorm_rope", "gate_residual", "gemm", "flash_attn", "patchify_im2col", "unpatchify",
     "cfg_euler_step", "act", "add", "force_map",
     "EPI_BIAS", "EPI_BIAS_GELU_TANH", "EPI_BIAS_GATE_RESID", "EPI_BIAS_RESID", "EPI_BIAS_SILU", "EPI_BIAS_MUL",
 ]
@@ -125,6 +125,22 @@ def modulate(x, shift, scale):
     out = torch.empty(x.shape, dtype=_BF16, device=x.device)
     ov, _, _, os_ = _rows2d(out, "modulate.out")
     _lib.check(_lib.load().gf_modulate(_ptr(xv), _ptr(ov), _ptr(scale), _ptr(shift), rows, dim, xs, os_, _stream(x)), "gf_modulate")
+    return out
+
+
+def gate_residual(x, gate, residual):
+    """x + gate * residual in the reference's eager bf16 rounding order (DIT:189-194) — gf_gate_residual; gate [dim]."""
+    _req(x, "gate_residual.x")
+    _req(residual, "gate_residual.residual")
+    _req(gate, "gate_residual.gate")
+    xv, rows, dim, xs = _rows2d(x, "gate_residual.x")
+    rv, rrows, rdim, rs = _rows2d(residual, "gate_residual.residual")
+    if (rrows, rdim) != (rows, dim) or gate.numel() != dim or not gate.is_contiguous():
+        raise GoalForceError(f"gate_residual: residual must match x [{rows}, {dim}] and gate be contiguous [{dim}] (batch 1)")
+    out = torch.empty(x.shape, dtype=_BF16, device=x.device)
+    ov, _, _, os_ = _rows2d(out, "gate_residual.out")
+    _lib.check(_lib.load().gf_gate_residual(_ptr(xv), _ptr(gate), _ptr(rv), _ptr(ov), rows, dim, xs, rs, os_, _stream(x)),
+               "gf_gate_residual")
     return out
 
 

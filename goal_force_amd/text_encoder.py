@@ -180,11 +180,26 @@ class WanPrompter:
     def fetch_models(self, text_encoder: WanTextEncoder = None):
         self.text_encoder = text_encoder
 
+    ftfy_missing_warned = False
+
     @staticmethod
     def clean(text):
-        """'whitespace' cleaning of PR:9-21, 78 without ftfy (absent here): html-unescape twice, collapse spaces."""
+        """'whitespace' cleaning of PR:9-21, 78: `ftfy.fix_text` (mojibake, curly quotes, full-width forms ... -> canonical
+        text), html-unescape twice, collapse spaces.  ftfy is used whenever it is importable; where it is not (this image) the
+        first call says so once on stderr — prompts that ftfy would have changed then tokenise differently from the reference
+        (plain ASCII prompts, like the 13 examples of the reference, are unaffected: ftfy leaves them as they are)."""
         import html
         import re
+        try:
+            import ftfy
+            text = ftfy.fix_text(text)
+        except ImportError:
+            if not WanPrompter.ftfy_missing_warned:
+                import sys
+                WanPrompter.ftfy_missing_warned = True
+                print("goal_force_amd.WanPrompter: `ftfy` is not installed — prompts are cleaned without ftfy.fix_text "
+                      "(wan_prompter.py:11-14); text with mojibake / typographic quotes tokenises differently from the reference",
+                      file=sys.stderr)
         text = html.unescape(html.unescape(text)).strip()
         return re.sub(r"\s+", " ", text).strip()
 

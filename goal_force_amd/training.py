@@ -203,17 +203,35 @@ _PARAM_NAMES = (
 # What a block's forward keeps for its backward besides its inputs (GF_TRAIN_KEEP):
 #   "none": nothing — the backward recomputes the whole block (GF_TRAIN_KEEP_ATTN=0 is the same switch under its first name);
 #   "attn": the self-attention output + log-sum-exp (0.34 GB per block at 32760 tokens; 17 GB at A14B size, 0.9 s less per step);
-#   "wide" (default): also the three self-attention projections (pre-norm q, k; v) and the block's state after the self- and the
+#   "wide": also the three self-attention projections (pre-norm q, k; v) and the block's state after the self- and the
 #           cross-attention branch: 2.0 GB per block, 100 GB at A14B size — a training step then peaks near 190 GB of the 288 GB and
 #           its backward skips 4.6 (trainable block) to 9.5 ms (frozen block: also o, GELU and FFN2, which only feed parameter
 #           gradients) of recomputed GEMMs per block.  Kept tensors are the forward's own values: same kernels, same inputs.
-_KEEP = os.environ.get("GF_TRAIN_KEEP", "wide")
+#   "auto" (default): "wide" for a block whose forward finds the device with room for it (free memory, torch's cached blocks
+#           included, >= WIDE_HEADROOM x the five tensors it would keep), else "attn" — a process that also holds the second
+#           expert, a longer sequence or a smaller part degrades to the 17 GB setting instead of running out of memory.
+_KEEP = os.environ.get("GF_TRAIN_KEEP", "auto")
 if os.environ.get("GF_TRAIN_KEEP_ATTN", "1") == "0":
     _KEEP = "none"
-if _KEEP not in ("none", "attn", "wide"):
-    raise GoalForceError(f"GF_TRAIN_KEEP={_KEEP!r}: expected none, attn or wide")
+if _KEEP not in ("none", "attn", "wide", "auto"):
+    raise GoalForceError(f"GF_TRAIN_KEEP={_KEEP!r}: expected none, attn, wide or auto")
 KEEP_ATTENTION = _KEEP != "none"
 KEEP_WIDE = _KEEP == "wide"
+KEEP_AUTO = _KEEP == "auto"
+WIDE_HEADROOM = 24      # blocks' worth of wide tensors that must still fit (the blocks ahead of this one + the backward's ~6 GB working set)
+
+
+def _wide_fits(x2):
+    """auto mode: is there room to keep this block's five wide tensors (5 x S x D bf16) — and WIDE_HEADROOM more like it?"""
+    if KEEP_WIDE:
+        return True
+    if not KEEP_AUTO or not x2.is_cuda:
+        return False
+    free, _ = torch.cuda.mem_get_info(x2.device)
+    free += torch.cuda.memory_reserved(x2.device) - torch.cuda.memory_allocated(x2.device)     # cached blocks torch can reuse
+    return free >= WIDE_HEADROOM * 5 * x2.numel() * x2.element_size()
+
+
 _WIDE_NAMES = ("qp", "kp", "v", "x1", "x2b")
 
 
@@ -232,15 +250,19 @@ class DiTBlockFn(torch.autograd.Function):
             # the backward recomputes the block on the bf16 kernels: an fp8 forward would not be the function differentiated
             raise GoalForceError("training through an enable_fp8 block is refused: call enable_fp8(module, False) first")
         ctx.param_needs = [p.requires_grad for p in params]
-        keep = ({"wide": True} if KEEP_WIDE else {}) if KEEP_ATTENTION else None
+        keep = ({"wide": True} if _wide_fits(x2) else {}) if KEEP_ATTENTION else None
         with torch.no_grad():
             out = block(x2, ctx2, t_mod, rope, keep=keep)
         # kept for the backward besides the block's inputs: the self-attention output (S x D bf16) and its log-sum-exp
-        # (S x heads fp32) — 0.34 GB per block at 32760 tokens against 18.6 ms of attention per block not run again
-        ctx.wide = bool(keep) and all(n in keep for n in _WIDE_NAMES)
+        # (S x heads fp32) — 0.34 GB per block at 32760 tokens against 18.6 ms of attention per block not run again.
+        # What the forward actually stored decides the level (a forward that took a memo / sharded path stores less):
+        # all five wide names -> wide; attn + lse -> attn; anything else -> recompute everything.
+        has_attn = keep is not None and "attn" in keep and "lse" in keep
+        ctx.wide = has_attn and all(n in keep for n in _WIDE_NAMES)
+        ctx.kept_attn = has_attn
         if ctx.wide:
             ctx.save_for_backward(x2, ctx2, t_mod, keep["attn"], keep["lse"], *(keep[n] for n in _WIDE_NAMES))
-        elif keep:
+        elif has_attn:
             ctx.save_for_backward(x2, ctx2, t_mod, keep["attn"], keep["lse"])
         else:
             ctx.save_for_backward(x2, ctx2, t_mod)

@@ -364,6 +364,11 @@ GF_API int gf_vae_tile_finalize(void* values, const void* weight, int64_t planes
 GF_API int gf_modulate(const void* x, void* out, const void* scale, const void* shift, int64_t rows, int64_t dim,
                        int64_t x_stride, int64_t out_stride, void* stream);
 
+/* gf_gate_residual — `GateModule.forward(x, gate, residual)` (DIT:189-194): out = bf16(x + bf16(gate * residual)), gate [dim]
+ * bf16 (batch 1), x / residual / out [rows, dim] bf16 with row strides.  (Hot path: the GEMM epilogue GF_EPI_BIAS_GATE_RESID.) */
+GF_API int gf_gate_residual(const void* x, const void* gate, const void* residual, void* out, int64_t rows, int64_t dim,
+                            int64_t x_stride, int64_t r_stride, int64_t out_stride, void* stream);
+
 /* gf_rope_apply — the reference's module-level `rope_apply(x, freqs, num_heads)` (DIT:92-97) alone: adjacent pairs of every
  * head rotated by cos / sin [rows, head_dim/2] fp32.  (Hot path: fused into gf_rmsnorm_rope.) */
 GF_API int gf_rope_apply(const void* x, void* out, const float* cos_tab, const float* sin_tab, int64_t rows, int64_t dim,

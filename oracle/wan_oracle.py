@@ -30,7 +30,7 @@ import torch.nn.functional as F
 def sinusoidal_embedding_1d(dim: int, position: torch.Tensor) -> torch.Tensor:
     """DIT:68-72 — cat(cos, sin)(t * 10000^(-i/(dim/2))) in fp64, cast back to position.dtype."""
     half = dim // 2
-    inv = torch.pow(10000.0, -torch.arange(half, dtype=torch.float64) / half)
+    inv = torch.pow(10000.0, -torch.arange(half, dtype=torch.float64) / half).to(position.device)   # table built on the host as DIT:69
     ang = position.to(torch.float64)[:, None] * inv[None, :]
     return torch.cat([ang.cos(), ang.sin()], dim=1).to(position.dtype)
 
@@ -86,10 +86,31 @@ def modulate(x, shift, scale):
 
 
 # ------------------------------------------------------------------ attention
+ATTENTION_Q_CHUNK = None   # full-size fp32 runs (tests/fullsize_parity.py): query rows per chunk of attention_chunked
+
+
+def attention_chunked(q, k, v, num_heads: int, chunk: int) -> torch.Tensor:
+    """The formula of DIT:28-61 evaluated in query-row chunks with plain matmul + softmax in the tensors' own dtype: a row's
+    softmax sees all keys at once, so nothing changes mathematically, but the [heads, S, S] score tensor (171 GB in fp32 at
+    S = 32760) is never materialised.  Used for the fp32-math oracle at production size only."""
+    b, sq, hd = q.shape
+    d = hd // num_heads
+    kh = k.reshape(b, k.shape[1], num_heads, d).permute(0, 2, 3, 1)          # [b, h, d, Skv]
+    vh = v.reshape(b, v.shape[1], num_heads, d).transpose(1, 2)               # [b, h, Skv, d]
+    out = torch.empty_like(q)
+    for s0 in range(0, sq, chunk):
+        qh = q[:, s0:s0 + chunk].reshape(b, -1, num_heads, d).transpose(1, 2)  # [b, h, c, d]
+        p = torch.softmax((qh @ kh) * (1.0 / math.sqrt(d)), dim=-1)
+        out[:, s0:s0 + chunk] = (p @ vh).transpose(1, 2).reshape(b, -1, hd)
+    return out
+
+
 def attention(q, k, v, num_heads: int) -> torch.Tensor:
     """DIT:28-61 (SDPA branch) — softmax(q k^T / sqrt(d)) v, no mask; [B,S,H*d] layout."""
     b, sq, hd = q.shape
     d = hd // num_heads
+    if ATTENTION_Q_CHUNK and q.dtype in (torch.float32, torch.float64) and sq > ATTENTION_Q_CHUNK:
+        return attention_chunked(q, k, v, num_heads, ATTENTION_Q_CHUNK)
 
     def split(t):
         return t.reshape(b, t.shape[1], num_heads, d).transpose(1, 2)
@@ -187,16 +208,17 @@ def text_embed(context, sd):
 
 
 def model_fn(dit_sd, cfg, latents, timestep, context, y=None, controlnet_sd=None, control_latents=None,
-             num_controlnet_layers=0):
+             num_controlnet_layers=0, tap=None):
     """GF:1349-1591 for the Goal-Force inference configuration: no clip/vace/usp/teacache; ControlNet
     = patch-embed of the control latents, N DiT blocks on control tokens, zero-conv(state_i) added to
-    x after DiT block i (non-strided path GF:1563-1570)."""
+    x after DiT block i (non-strided path GF:1563-1570).  `tap(i, x)` (tests): called with the residual stream right after
+    DiT block i, before the ControlNet injection."""
     dim, nh, eps = cfg["dim"], cfg["num_heads"], cfg["eps"]
     t, t_mod = time_embed(timestep, dit_sd, cfg["freq_dim"], dim)
     ctx = text_embed(context, dit_sd)
     x = latents if y is None else torch.cat([latents, y], dim=1)
     x, (f, h, w) = patch_embed(x, dit_sd["patch_embedding.weight"], dit_sd["patch_embedding.bias"])
-    freqs = rope_freqs_3d(dim // nh, f, h, w)
+    freqs = rope_freqs_3d(dim // nh, f, h, w).to(latents.device)
     states = []
     if controlnet_sd is not None:
         c, _ = patch_embed(control_latents,
@@ -207,6 +229,8 @@ def model_fn(dit_sd, cfg, latents, timestep, context, y=None, controlnet_sd=None
             states.append(c)
     for i in range(cfg["num_layers"]):
         x = dit_block(x, ctx, t_mod, freqs, dit_sd, f"blocks.{i}.", nh, eps)
+        if tap is not None:
+            tap(i, x)
         if controlnet_sd is not None and i < num_controlnet_layers:
             zw = controlnet_sd[f"controlnet_zero_convs_after.{i}.weight"]
             zb = controlnet_sd[f"controlnet_zero_convs_after.{i}.bias"]

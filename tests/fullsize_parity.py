@@ -1,0 +1,293 @@
+#!/usr/bin/env python3
+"""Full-depth parity of the HIP sampling path against the fp32-math oracle ON THE GPU — test infrastructure.
+
+    python tests/fullsize_parity.py [--layers 40 --cn-layers 10 --grid 21 30 52 --steps 4] [--fp8] [--out gpurun_out/x.json]
+
+What the reference computes per video is 100 x `model_fn_wan_video` (40 DiT + 10 ControlNet blocks,
+src/goal_force/wan_video_new.py:1503-1570) inside the CFG / Euler loop (wan_video_new.py:697-723).  The goldens under
+tests/golden compare at most 2 + 1 blocks at 72 tokens; this harness runs the WHOLE stack at the production size:
+
+  (a) one high-noise forward (step 0, cond branch): rel-L2 of the residual stream after chosen DiT blocks and of the noise
+      prediction — HIP vs fp32 math, next to the reference's own bf16 arithmetic vs fp32 math (the "noise floor": what two
+      correct bf16 implementations may differ by);
+  (b) a K-step CFG loop (K-step shift-5 schedule => the expert switch is inside for K >= 2): latents per step for the same
+      three trajectories, and the PSNR of the tiled-decoded uint8 frames of the final latents;
+  (c) with --fp8 the same for BASELINE config 5: HIP fp8 kernels vs the oracle graph with every block Linear replaced by a
+      LIVE torch._scaled_mm through the call sequence of diffsynth/vram_management/layers.py:115-151.
+
+The three arithmetic modes share weights (random-init bf16, bench.py's seeds), inputs and the bf16-rounded timestep
+(wan_video_new.py:707):
+  fp32  = oracle.wan_oracle graph, fp32 tensors, attention in query chunks (never materialises S x S x heads);
+  bf16  = the same oracle graph on bf16 tensors through torch's own ROCm kernels (F.linear, F.scaled_dot_product_attention,
+          ...) — the arithmetic the reference itself runs on this stack;
+  hip   = goal_force_amd (the product).
+The oracle is the checker here, never the thing measured; nothing under goal_force_amd/ imports this file.
+tests/test_fulldepth_gpu.py runs a reduced configuration of the same code as a gated test.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from collections.abc import Mapping
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests", "golden")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+
+class LazySD(Mapping):
+    """State dict view of a module that converts a tensor to `dtype` when it is read (a 14 B-parameter expert never exists
+    twice in fp32).  2-D weights of the DiT / ControlNet blocks carry `_gf_block_linear = True` so that the config-5 chain can
+    route exactly those Linears through torch._scaled_mm (VRAM:113: only the wrapped block Linears compute in fp8)."""
+
+    def __init__(self, module, dtype):
+        self.sd, self.dtype = dict(module.state_dict()), dtype
+
+    def __getitem__(self, k):
+        p = self.sd[k]
+        t = p.to(self.dtype)
+        if "blocks." in k and k.endswith(".weight") and p.dim() == 2 and "norm" not in k:
+            t = t.clone() if t is p else t
+            t._gf_block_linear = True
+        return t
+
+    def __iter__(self):
+        return iter(self.sd)
+
+    def __len__(self):
+        return len(self.sd)
+
+
+def rel_l2(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def psnr_u8(a, b):
+    mse = float((a.float() - b.float()).pow(2).mean())
+    return float("inf") if mse == 0 else 10.0 * torch.log10(torch.tensor(255.0 ** 2 / mse)).item()
+
+
+def build(layers, cn_layers, dev, need_low=True):
+    from goal_force_amd.dit import A14B_CONFIG
+    from goal_force_amd.pipeline import WanVideoPipeline, build_random_controlnet, build_random_expert
+    from goal_force_amd.vae import WanVideoVAE
+    cfg = dict(A14B_CONFIG)
+    cfg["num_layers"] = layers
+    dit = build_random_expert(cfg, seed=100, device=dev)
+    cn = build_random_controlnet(cn_layers, cfg, seed=300, device=dev)
+    dit2 = build_random_expert(cfg, seed=200, device=dev) if need_low else None
+    cn2 = build_random_controlnet(cn_layers, cfg, seed=400, device=dev, zero_convs_zero=True) if need_low else None
+    torch.manual_seed(7)
+    vae = WanVideoVAE().to(torch.bfloat16).to(dev)
+    return cfg, WanVideoPipeline.from_modules(dit, dit2, cn, cn2, vae=vae, device=dev)
+
+
+def inputs(pipe, grid, dev, sample=0):
+    """bench.py's synthetic conditioning at the given latent grid (f, 2h, 2w)."""
+    f, hh, ww = grid
+    g = torch.Generator().manual_seed(1000 + sample)
+    lat = pipe.generate_noise((1, 16, f, hh, ww), seed=sample)
+    y = torch.randn((1, 20, f, hh, ww), generator=g)
+    y[:, :4] = 0
+    y[:, :4, 0] = 1
+    control = torch.randn((1, 16, f, hh, ww), generator=g)
+    ctx_p, ctx_n = torch.randn((1, 512, 4096), generator=g), torch.randn((1, 512, 4096), generator=g)
+    ctx_p[:, 40:] = 0
+    ctx_n[:, 40:] = 0
+    bf = torch.bfloat16
+    return dict(latents=lat, y=y.to(bf).to(dev), control=control.to(bf).to(dev), ctx_p=ctx_p.to(bf).to(dev), ctx_n=ctx_n.to(bf).to(dev))
+
+
+class OracleRunner:
+    """The oracle's model_fn / CFG / Euler (oracle.wan_oracle: GF:1349-1591, 716, FM:72-82) on device tensors in one dtype."""
+
+    def __init__(self, pipe, cfg, dtype, q_chunk=2048, fp8_chain=False):
+        from oracle import wan_oracle as wo
+        self.wo, self.cfg, self.dtype, self.q_chunk, self.fp8_chain = wo, cfg, dtype, q_chunk, fp8_chain
+        self.experts = [(LazySD(pipe.dit, dtype), LazySD(pipe.controlnet, dtype), pipe.controlnet.num_layers)]
+        if pipe.dit2 is not None:
+            # the never-trained ControlNet2 (zero-convs exactly zero, GF:565): conv1d with zero weight and bias adds exact zeros,
+            # x + 0 == x bitwise in every dtype, so the oracle skips its 10 blocks as the product does (saves GPU minutes only)
+            z = pipe.controlnet2.all_zero()
+            self.experts.append((LazySD(pipe.dit2, dtype), None if z else LazySD(pipe.controlnet2, dtype),
+                                 0 if z else pipe.controlnet2.num_layers))
+
+    def _linear(self):
+        if not self.fp8_chain:
+            return F.linear
+        from make_fp8_golden_gpu import scaled_mm_linear      # VRAM:115-151 restated around the live torch._scaled_mm
+
+        def lin(x, w, b=None):
+            if getattr(w, "_gf_block_linear", False):
+                return scaled_mm_linear(x, w, b)[0]
+            return F.linear(x, w, b)
+        return lin
+
+    def forward(self, which, latents, ts_bf16, ctx, inp, tap=None):
+        wo = self.wo
+        dsd, csd, ncn = self.experts[which]
+        old = (wo.LINEAR, wo.ATTENTION_Q_CHUNK)
+        wo.LINEAR, wo.ATTENTION_Q_CHUNK = self._linear(), self.q_chunk
+        try:
+            dt = self.dtype
+            return wo.model_fn(dsd, self.cfg, latents.to(dt), ts_bf16.to(dt), ctx.to(dt), inp["y"].to(dt), csd,
+                               None if csd is None else inp["control"].to(dt), ncn, tap=tap)
+        finally:
+            wo.LINEAR, wo.ATTENTION_Q_CHUNK = old
+
+    def loop(self, inp, n_steps, cfg_scale=5.0, boundary=0.875, tap0=None, log=None):
+        """GF:697-723 — returns the latents after every step (list of n_steps tensors, dtype of the run) and the first
+        forward's noise prediction."""
+        wo = self.wo
+        sigmas, timesteps = wo.flow_match_sigmas(n_steps, 5.0)
+        lat = inp["latents"].to(self.dtype)
+        out, first, cur = [], None, 0
+        for i, ts in enumerate(timesteps):
+            if ts.item() < boundary * 1000 and cur == 0 and len(self.experts) > 1:
+                cur = 1
+            tsb = ts.unsqueeze(0).to(torch.bfloat16).to(lat.device)          # GF:707: the timestep reaches model_fn bf16-rounded
+            t0 = time.time()
+            posi = self.forward(cur, lat, tsb, inp["ctx_p"], inp, tap=tap0 if i == 0 else None)
+            if first is None:
+                first = posi
+            nega = self.forward(cur, lat, tsb, inp["ctx_n"], inp)
+            lat = wo.euler_step(wo.cfg_combine(posi, nega, cfg_scale), i, lat, sigmas)
+            torch.cuda.synchronize()
+            if log:
+                log(f"    oracle[{self.name()}] step {i} (expert {cur}): {time.time() - t0:.1f} s")
+            out.append(lat)
+        return out, first
+
+    def name(self):
+        return ("fp8-chain" if self.fp8_chain else "bf16") if self.dtype == torch.bfloat16 else "fp32"
+
+
+def hip_loop(pipe, inp, n_steps, taps=None):
+    """The product's denoise() one step at a time (public API: step_ids) so that every step's latents can be kept; the first
+    step's cond forward is additionally run on its own with forward hooks on the chosen DiT blocks (same kernels, same inputs)."""
+    lat = inp["latents"]
+    first, tapped = None, {}
+    if taps is not None:
+        pipe.scheduler.set_timesteps(n_steps, shift=5.0)
+        ts = pipe.scheduler.timesteps[0].unsqueeze(0).to(dtype=torch.bfloat16, device=lat.device)
+        hooks = [pipe.dit.blocks[i].register_forward_hook(lambda m, a, o, i=i: tapped.__setitem__(i, o.detach().clone().reshape(1, -1, o.shape[-1])))
+                 for i in taps if i < len(pipe.dit.blocks)]
+        first = pipe.model_fn(dit=pipe.dit, controlnet=pipe.controlnet, latents=lat, timestep=ts, context=inp["ctx_p"], y=inp["y"],
+                              control_signal_video_latents=inp["control"])
+        for h in hooks:
+            h.remove()
+    out = []
+    for i in range(n_steps):
+        lat = pipe.denoise(lat, inp["ctx_p"], inp["ctx_n"], inp["y"], inp["control"], num_inference_steps=n_steps, cfg_scale=5.0,
+                           controlnet=True, step_ids=[i])
+        out.append(lat)
+    torch.cuda.synchronize()
+    return out, first, tapped
+
+
+def decode_u8(pipe, lat):
+    frames = pipe.vae.decode(lat.to(torch.bfloat16), tiled=True, tile_size=(30, 52), tile_stride=(15, 26))
+    return pipe.frames_uint8(frames)
+
+
+def run(layers=40, cn_layers=10, grid=(21, 60, 104), steps=4, fp8=False, taps=(0, 9, 19, 39), q_chunk=2048, decode=True, log=print):
+    """Returns the report dict (see the module docstring).  grid = latent (f, H/8, W/8)."""
+    from goal_force_amd.dit import enable_fp8
+    torch.set_grad_enabled(False)
+    torch.backends.cuda.matmul.allow_tf32 = False
+    dev = torch.device("cuda", torch.cuda.current_device())
+    taps = tuple(t for t in taps if t < layers)
+    cfg, pipe = build(layers, cn_layers, dev, need_low=steps >= 2)
+    inp = inputs(pipe, grid, dev)
+    tokens = grid[0] * (grid[1] // 2) * (grid[2] // 2)
+    rep = {"config": {"layers": layers, "controlnet_layers": cn_layers, "latent": [1, 16, *grid], "tokens": tokens, "steps": steps,
+                      "taps_after_dit_block": [t + 1 for t in taps], "weights": "random-init bf16 (bench.py seeds 100/200/300/400)",
+                      "device": torch.cuda.get_device_name(0), "fp32_attention_q_chunk": q_chunk}}
+
+    # ---- the product
+    t0 = time.time()
+    hip_lat, hip_first, hip_tap = hip_loop(pipe, inp, steps, taps)
+    log(f"  hip: {steps} steps + tapped forward in {time.time() - t0:.1f} s")
+    # ---- fp32 math (the yardstick)
+    f32_tap = {}
+    o32 = OracleRunner(pipe, cfg, torch.float32, q_chunk)
+    f32_lat, f32_first = o32.loop(inp, steps, tap0=lambda i, x: f32_tap.__setitem__(i, x.clone()) if i in taps else None, log=log)
+    # ---- the reference's own bf16 arithmetic
+    b16_tap = {}
+    o16 = OracleRunner(pipe, cfg, torch.bfloat16, q_chunk)
+    b16_lat, b16_first = o16.loop(inp, steps, tap0=lambda i, x: b16_tap.__setitem__(i, x.clone()) if i in taps else None, log=log)
+
+    def rows(name, tap, first, lats):
+        r = {"after_block": {str(i + 1): rel_l2(tap[i].float(), f32_tap[i]) for i in taps if i in tap},
+             "noise_pred_step0_cond": rel_l2(first.float(), f32_first),
+             "latents_after_step": [rel_l2(a.float(), b) for a, b in zip(lats, f32_lat)]}
+        log(f"  {name} vs fp32: blocks {r['after_block']}  noise_pred {r['noise_pred_step0_cond']:.3e}  "
+            f"latents/step {[f'{e:.3e}' for e in r['latents_after_step']]}")
+        return r
+
+    rep["hip_bf16_vs_fp32"] = rows("hip-bf16", hip_tap, hip_first, hip_lat)
+    rep["ref_bf16_vs_fp32"] = rows("ref-bf16", b16_tap, b16_first, b16_lat)
+    rep["hip_bf16_vs_ref_bf16"] = {"noise_pred_step0_cond": rel_l2(hip_first.float(), b16_first.float()),
+                                   "latents_after_step": [rel_l2(a.float(), b.float()) for a, b in zip(hip_lat, b16_lat)]}
+    u8 = {}
+    if decode:
+        u8 = {"fp32": decode_u8(pipe, f32_lat[-1]), "hip": decode_u8(pipe, hip_lat[-1]), "ref": decode_u8(pipe, b16_lat[-1])}
+        rep["psnr_db_decoded_uint8_frames"] = {"hip_bf16_vs_fp32": psnr_u8(u8["hip"], u8["fp32"]), "ref_bf16_vs_fp32": psnr_u8(u8["ref"], u8["fp32"]),
+                                               "hip_bf16_vs_ref_bf16": psnr_u8(u8["hip"], u8["ref"]),
+                                               "note": "all three final latents through the SAME tiled HIP VAE decode (random-init VAE) -> uint8 as UTIL:76-91"}
+        log(f"  PSNR of decoded frames: {rep['psnr_db_decoded_uint8_frames']}")
+    if fp8:
+        del b16_tap, o16
+        for m in (pipe.dit, pipe.dit2, pipe.controlnet, pipe.controlnet2):
+            if m is not None:
+                enable_fp8(m)
+        h8_lat, h8_first, h8_tap = hip_loop(pipe, inp, steps, taps)
+        for m in (pipe.dit, pipe.dit2, pipe.controlnet, pipe.controlnet2):
+            if m is not None:
+                enable_fp8(m, False)
+        c8_tap = {}
+        o8 = OracleRunner(pipe, cfg, torch.bfloat16, q_chunk, fp8_chain=True)
+        c8_lat, c8_first = o8.loop(inp, steps, tap0=lambda i, x: c8_tap.__setitem__(i, x.clone()) if i in taps else None, log=log)
+        rep["hip_fp8_vs_fp32"] = rows("hip-fp8", h8_tap, h8_first, h8_lat)
+        rep["scaled_mm_chain_vs_fp32"] = rows("scaled_mm-chain", c8_tap, c8_first, c8_lat)
+        rep["hip_fp8_vs_scaled_mm_chain"] = {"noise_pred_step0_cond": rel_l2(h8_first.float(), c8_first.float()),
+                                             "latents_after_step": [rel_l2(a.float(), b.float()) for a, b in zip(h8_lat, c8_lat)]}
+        if decode:
+            a, b = decode_u8(pipe, h8_lat[-1]), decode_u8(pipe, c8_lat[-1])
+            rep["psnr_db_decoded_uint8_frames"].update({"hip_fp8_vs_fp32": psnr_u8(a, u8["fp32"]), "scaled_mm_chain_vs_fp32": psnr_u8(b, u8["fp32"]),
+                                                        "hip_fp8_vs_scaled_mm_chain": psnr_u8(a, b)})
+            log(f"  PSNR (fp8): {rep['psnr_db_decoded_uint8_frames']}")
+    return rep
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--layers", type=int, default=40)
+    ap.add_argument("--cn-layers", type=int, default=10)
+    ap.add_argument("--grid", type=int, nargs=3, default=[21, 60, 104], help="latent f, H/8, W/8 (default 832x480x81f)")
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--fp8", action="store_true")
+    ap.add_argument("--q-chunk", type=int, default=2048)
+    ap.add_argument("--no-decode", action="store_true")
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+    t0 = time.time()
+    rep = run(a.layers, a.cn_layers, tuple(a.grid), a.steps, a.fp8, q_chunk=a.q_chunk, decode=not a.no_decode)
+    rep["wall_s"] = time.time() - t0
+    print(json.dumps(rep))
+    if a.out:
+        os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
+        with open(a.out, "w") as f:
+            json.dump(rep, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

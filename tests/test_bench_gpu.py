@@ -76,3 +76,48 @@ def test_bench_four_ranks_two_videos_bit_identical_to_single_runs():
         assert d["sample"] == k
         assert per[k]["latents_sha256"] == d["latents_sha256"], f"video {k}: latents of the 4-rank run differ from its N=1 run"
         assert per[k]["frames_uint8_sha256"] == d["frames_uint8_sha256"], f"video {k}: gathered frames differ from its N=1 run"
+
+
+def _one_json(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def _clean_env(**kv):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(GF_DIST_BACKEND="gloo", **kv)
+    return env
+
+
+def test_bench_self_launch_and_torchrun_agree():
+    """`python bench.py --gpus 2` with NO launcher (the parent spawns its own two ranks) and the same run through
+    `python -m torch.distributed.run` — the form the driver uses — print one JSON line each with identical latents / frames."""
+    cmd = [os.path.join(ROOT, "bench.py"), "--gpus", "2"] + ARGS
+    r = subprocess.run([sys.executable] + cmd, env=_clean_env(), capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    own = _one_json(r.stdout)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port())] + cmd, env=_clean_env(), capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    tr = _one_json(r.stdout)
+    for j in (own, tr):
+        assert j["n_gpus"] == 2 and j["distributed"]["world"] == 2 and j["distributed"]["backend"] == "gloo"
+    assert own["self_check"]["latents"]["sha256"] == tr["self_check"]["latents"]["sha256"]
+    assert own["self_check"]["frames_uint8"]["sha256"] == tr["self_check"]["frames_uint8"]["sha256"]
+
+
+def test_bench_self_launch_eight_ranks_and_failure_exit_code():
+    """BASELINE config 3's layout (4 videos x CFG pair = 8 ranks) through bench.py itself, self-launched, one block deep over
+    gloo on the one GPU of the box: four different videos gathered on rank 0.  And a rank that fails makes the parent exit
+    non-zero instead of hanging the others (--sp 3 is refused by every rank)."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--layers", "1", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=_clean_env(), capture_output=True, text=True, timeout=2400)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    j = _one_json(r.stdout)
+    assert j["n_gpus"] == 8 and j["samples_gathered"] == 4 and j["distributed"]["world"] == 8
+    per = j["self_check"]["per_sample"]
+    assert [d["sample"] for d in per] == [0, 1, 2, 3] and len({d["frames_uint8_sha256"] for d in per}) == 4
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--sp", "3"] + ARGS, env=_clean_env(),
+                         capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0 and not any(l.startswith("{") for l in bad.stdout.splitlines())

@@ -193,3 +193,24 @@ def test_load_model_adopts_checkpoint_tensors_without_a_second_copy(tmp_path):
     save_file(sd, path)
     with pytest.raises(RuntimeError, match="blocks.1.ffn.2.bias"):
         ck.load_model(ck.ModelConfig(path=path), torch_dtype=BF, device="cpu")
+
+
+def test_params_on_meta_is_nested_safe_and_inert_for_other_threads():
+    """the meta-device construction patches torch.nn.Module.register_parameter process-wide while active — nested
+    use must restore the original exactly once, and a module another thread builds meanwhile must get REAL parameters."""
+    import threading
+    import torch
+    from goal_force_amd.checkpoints import params_on_meta
+    orig = torch.nn.Module.register_parameter
+    other = {}
+    with params_on_meta():
+        with params_on_meta():
+            inner = torch.nn.Linear(4, 4)
+        mid = torch.nn.Linear(4, 4)                 # still inside the outer context: still meta
+        t = threading.Thread(target=lambda: other.setdefault("m", torch.nn.Linear(4, 4)))
+        t.start()
+        t.join()
+    after = torch.nn.Linear(4, 4)
+    assert inner.weight.is_meta and mid.weight.is_meta
+    assert not other["m"].weight.is_meta and not after.weight.is_meta
+    assert torch.nn.Module.register_parameter is orig

@@ -1,0 +1,39 @@
+"""Depth parity: the HIP path against the fp32-math oracle through a STACK of A14B-width blocks inside the
+CFG / Euler loop, next to the reference's own bf16 arithmetic (tests/fullsize_parity.py holds the machinery; the full
+40 + 10-block, S = 32760 run of the same code is reported in DESIGN.md §8 / profiles/r04/fullsize_parity*.json)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_stacked_blocks_cfg_loop_within_reference_bf16_drift():
+    """8 DiT + 2 ControlNet blocks at A14B width, S = 9x30x52 = 14040 tokens (BASELINE config 1's grid), 2 CFG steps of the
+    2-step shift-5 schedule (step 0 on the high-noise expert + ControlNet, step 1 on the low-noise expert: the switch of
+    GF:699-704 is inside).  Bar: at every tap — residual stream after DiT blocks 1 / 4 / 8 of the first forward,
+    its noise prediction, the latents after each step — HIP-vs-fp32 <= 1.25 x (reference-bf16-arithmetic vs fp32), and the
+    decoded frames no further (in PSNR) from the fp32 trajectory's than the reference arithmetic's, within 1 dB."""
+    import fullsize_parity as fp
+    rep = fp.run(layers=8, cn_layers=2, grid=(9, 60, 104), steps=2, fp8=False, taps=(0, 3, 7), log=lambda s: print(s, flush=True))
+    hip, ref = rep["hip_bf16_vs_fp32"], rep["ref_bf16_vs_fp32"]
+    assert set(hip["after_block"]) == {"1", "4", "8"}
+    for k in hip["after_block"]:
+        assert hip["after_block"][k] <= 1.25 * ref["after_block"][k], (k, hip["after_block"], ref["after_block"])
+    assert hip["noise_pred_step0_cond"] <= 1.25 * ref["noise_pred_step0_cond"], (hip, ref)
+    for a, b in zip(hip["latents_after_step"], ref["latents_after_step"]):
+        assert a <= 1.25 * b, (hip["latents_after_step"], ref["latents_after_step"])
+    ps = rep["psnr_db_decoded_uint8_frames"]
+    assert ps["hip_bf16_vs_fp32"] >= ps["ref_bf16_vs_fp32"] - 1.0, ps
+
+
+def test_stacked_blocks_fp8_within_scaled_mm_chain_drift():
+    """The same stack on the fp8_linear contract (BASELINE config 5): HIP fp8 kernels vs the oracle graph with a LIVE
+    torch._scaled_mm behind every block Linear (VRAM:115-151).  The contract's own quantisation noise dominates, so the bar is
+    relative to it: HIP-fp8-vs-fp32 <= 1.25 x (scaled_mm chain vs fp32) at the noise prediction and after each step."""
+    import fullsize_parity as fp
+    rep = fp.run(layers=4, cn_layers=1, grid=(9, 60, 104), steps=2, fp8=True, taps=(0, 3), decode=False, log=lambda s: print(s, flush=True))
+    hip, ref = rep["hip_fp8_vs_fp32"], rep["scaled_mm_chain_vs_fp32"]
+    assert ref["noise_pred_step0_cond"] > 2 * rep["ref_bf16_vs_fp32"]["noise_pred_step0_cond"], "the fp8 contract must be in force in the chain"
+    assert hip["noise_pred_step0_cond"] <= 1.25 * ref["noise_pred_step0_cond"], (hip, ref)
+    for a, b in zip(hip["latents_after_step"], ref["latents_after_step"]):
+        assert a <= 1.25 * b, (hip["latents_after_step"], ref["latents_after_step"])

@@ -175,5 +175,52 @@ def test_training_keep_level_is_validated(monkeypatch):
         importlib.reload(tr)
     monkeypatch.setenv("GF_TRAIN_KEEP", "attn")
     assert importlib.reload(tr).KEEP_ATTENTION and not tr.KEEP_WIDE
+    monkeypatch.setenv("GF_TRAIN_KEEP", "wide")
+    assert importlib.reload(tr).KEEP_WIDE and tr._wide_fits(torch.zeros(4, 8))
     monkeypatch.delenv("GF_TRAIN_KEEP")
-    assert importlib.reload(tr).KEEP_WIDE
+    tr = importlib.reload(tr)                      # default: wide only where the device has room for it
+    assert tr.KEEP_AUTO and tr.KEEP_ATTENTION and not tr.KEEP_WIDE
+    assert not tr._wide_fits(torch.zeros(4, 8))    # host tensor: no device to ask -> the 17 GB setting
+
+
+def test_bindings_refuse_a_library_of_another_abi_revision(monkeypatch):
+    """_lib.load() compares gf_abi_version() with the revision the bindings were written for (a stale .so would be
+    overrun through gf_flash_attn_bwd's caller-owned workspace, whose size changed under an unchanged signature)."""
+    from goal_force_amd import _lib
+    assert _lib.load().gf_abi_version() == _lib.ABI_VERSION
+    src = open(os.path.join(ROOT, "goal_force_amd", "csrc", "gf_abi.hip")).read()
+    assert int(re.search(r"#define GF_ABI_VERSION (\d+)", src).group(1)) == _lib.ABI_VERSION
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "ABI_VERSION", _lib.ABI_VERSION + 1)
+    with pytest.raises(_lib.GoalForceError, match="ABI revision"):
+        _lib.load()
+
+
+def test_prompt_cleaner_uses_ftfy_when_importable(monkeypatch, capsys):
+    """wan_prompter.py:11-14: ftfy.fix_text, html-unescape twice, strip, collapse whitespace.  With ftfy importable it is
+    called first; without it the first call says so once on stderr."""
+    import sys
+    import types
+    from goal_force_amd.text_encoder import WanPrompter
+    fake = types.ModuleType("ftfy")
+    fake.fix_text = lambda t: t.replace("\u201c", '"').replace("\u201d", '"')
+    monkeypatch.setitem(sys.modules, "ftfy", fake)
+    assert WanPrompter.clean("  a \u201cball\u201d  &amp;amp;  a\n cube ") == 'a "ball" & a cube'
+    monkeypatch.setitem(sys.modules, "ftfy", None)            # import ftfy -> ImportError
+    monkeypatch.setattr(WanPrompter, "ftfy_missing_warned", False)
+    assert WanPrompter.clean("  a  &lt;ball&gt; ") == "a <ball>"
+    WanPrompter.clean("again")
+    assert capsys.readouterr().err.count("ftfy") >= 1 and WanPrompter.ftfy_missing_warned
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="with a GPU the two ranks would really run (tests/test_bench_gpu.py covers that)")
+def test_bench_self_launch_reports_a_failed_rank():
+    """`python bench.py --gpus 2` with no launcher starts its own ranks; here (no GPU) both fail at torch.cuda.set_device and the
+    parent must exit non-zero promptly, print no JSON line and leave no rank waiting in a rendezvous."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--layers", "1", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "stopping the other ranks" in r.stderr
+    assert not any(l.startswith("{") for l in r.stdout.splitlines())

@@ -400,6 +400,21 @@ def test_cfg_euler_step_bit_exact(ops):
     assert torch.equal(ops.cfg_euler_step(dev(a).clone(), dev(b), dev(c), 5.0, -0.25).cpu(), ref)
 
 
+def test_gate_module_forward_bit_exact(ops):
+    """GateModule.forward (DIT:189-194) on gf_gate_residual: `x + gate * residual` with the reference's eager bf16 roundings —
+    bit-identical to torch's bf16 arithmetic for [1,S,D] x [1,1,D] (the shapes DIT:226-229 use), a row-strided view, batch 2."""
+    from goal_force_amd.dit import GateModule
+    g = torch.Generator().manual_seed(12)
+    x, r = torch.randn(1, 77, 256, generator=g).to(BF), torch.randn(1, 77, 256, generator=g).to(BF)
+    gate = torch.randn(1, 1, 256, generator=g).to(BF)
+    gm = GateModule()
+    assert torch.equal(gm(dev(x), dev(gate), dev(r)).cpu(), x + gate * r)
+    wide = torch.randn(77, 512, generator=g).to(BF)
+    assert torch.equal(ops.gate_residual(dev(wide)[:, :256], dev(gate).reshape(-1), dev(r)[0]).cpu(), wide[:, :256] + gate[0] * r[0])
+    x2, r2, g2 = torch.randn(2, 9, 256, generator=g).to(BF), torch.randn(2, 9, 256, generator=g).to(BF), torch.randn(2, 1, 256, generator=g).to(BF)
+    assert torch.equal(gm(dev(x2), dev(g2), dev(r2)).cpu(), x2 + g2 * r2)
+
+
 def test_add_act(ops):
     g = torch.Generator().manual_seed(6)
     a, b = torch.randn(4099, generator=g).to(BF), torch.randn(4099, generator=g).to(BF)
