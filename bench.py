@@ -37,12 +37,42 @@ sys.path.insert(0, ROOT)
 # the variable when the process first touches the GPU, so it is set before torch is imported.  setdefault: the launcher's choice wins.
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-# HBM bytes per self-attention launch (flash_attn_fwd_kernel3<2>; its V^T operand comes from the projection GEMM) from rocprofv3 --pmc, separate
-# FETCH_SIZE / WRITE_SIZE passes over tools/microbench.py attn (tools/profile_r03.sh): (2 x FETCH_SIZE [gfx950 reports half of a
-# 16-B/lane stream] + WRITE_SIZE) KiB -> bytes, this round's build.  PMC needs the profiler, so this is a STATIC figure from
-# the named files, not measured by the run that prints it ("traffic_static": true in the JSON line).
-ATTN_TRAFFIC_BYTES = (2 * 1490380 + 501680) * 1024
-ATTN_TRAFFIC_SOURCE = "profiles/r03/pmc/attn_FETCH_SIZE.md + attn_WRITE_SIZE.md (tools/profile_r03.sh, this round's build)"
+# HBM-side bytes per launch of the dominant kernels come from rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes over
+# tools/microbench.py; (2 x FETCH_SIZE [gfx950 reports half of a 16-B/lane stream] + WRITE_SIZE) KiB -> bytes).  PMC needs the
+# profiler, so the bench line carries STATIC figures ("traffic_static": true) read from profiles/pmc_static.json — which records
+# the sha256 of the kernel sources the passes were taken on (tools/pmc_static.py).  A figure whose kernel source has changed since
+# is NOT printed: traffic becomes null and the line says why, loudly, instead of describing a kernel that no longer exists.
+PMC_STATIC = os.path.join(ROOT, "profiles", "pmc_static.json")
+
+
+def source_sha256(files):
+    import hashlib
+    h = hashlib.sha256()
+    for f in files:
+        with open(os.path.join(ROOT, "goal_force_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def static_traffic(key):
+    """(bytes or None, source note) for `key` of profiles/pmc_static.json ("attn_self", "gemm_ffn1", "gemm_ffn2", "gemm_dd",
+    "gemm_fp8_*"): None with the reason when the file is absent, the entry missing, or the kernel sources differ from the ones
+    the counters were collected on."""
+    try:
+        with open(PMC_STATIC) as f:
+            tab = json.load(f)
+        e = tab["entries"][key]
+    except (OSError, KeyError, ValueError) as ex:
+        return None, f"no static PMC figure for {key} ({type(ex).__name__})"
+    now = source_sha256(e["sources"])
+    if now != e["sources_sha256"]:
+        msg = (f"STALE: {', '.join(e['sources'])} changed since the PMC pass {e['from']} (sha256 {e['sources_sha256'][:12]} -> "
+               f"{now[:12]}): re-run tools/profile_r04.sh + tools/pmc_static.py")
+        print(f"bench.py: roofline traffic for {key} withheld — {msg}", file=sys.stderr)
+        return None, msg
+    return int(e["bytes_per_launch"]), f"{e['from']} (kernel sources sha256 {now[:12]}, library {tab.get('gf_version', '?')})"
+
+
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md (Chip-level parameters)
 PEAK_FP8_TFLOPS = 5000.0   # dense fp8 MFMA peak (same table): the denominator of the GEMM entries under --fp8 (config 5)
 S_TOK, DIM, HEADS, FFN, LTXT = 32760, 5120, 40, 13824, 512
@@ -57,6 +87,31 @@ def forward_flops(with_controlnet):
     if with_controlnet:
         fl += 10 * block_flops(S_TOK) + 10 * 2 * S_TOK * DIM * DIM + 2 * S_TOK * 64 * DIM
     return fl
+
+
+def gemm_entries(gprof, m_rows, fp8):
+    """roofline entries of the three block GEMM shapes from the per-launch events (ops.PROFILE_GEMM): achieved = 2 M N K /
+    mean launch time against the dense MFMA peak of the operand type; traffic = the static PMC figure of that shape (fabric-side
+    bytes per launch) beside the algorithmic bytes A + W + C (+ residual) the launch must move at least."""
+    peak = PEAK_FP8_TFLOPS if fp8 else PEAK_BF16_TFLOPS
+    eb = 1 if fp8 else 2                                   # bytes per operand element
+    out = []
+    for key, n, kk, name, extra_c in (
+            ("ffn1", FFN, DIM, "gemm_a4_kernel<GELU> FFN1 [S,5120]x[13824,5120]^T", 0),
+            ("ffn2", DIM, FFN, "gemm_a4_kernel<gate*+resid> FFN2 [S,13824]x[5120,13824]^T", 1),
+            ("dd", DIM, DIM, "gemm_a4_kernel D->D projections (q,k,v,o, zero-conv)", 0)):
+        ms = [a.elapsed_time(b) for a, b, M, N, K, _ in gprof if (M, N, K) == (m_rows, n, kk)]
+        if not ms:
+            continue
+        avg = sum(ms) / len(ms)
+        fl = 2.0 * m_rows * n * kk
+        traffic, src = static_traffic(("gemm_fp8_" if fp8 else "gemm_") + key)
+        out.append({"bound": "mfma", "kernel": name + (" — e4m3 operands, v_mfma_f32_16x16x128_f8f6f4" if fp8 else ""),
+                    "achieved": fl / (avg * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": fl / (avg * 1e-3) / 1e12 / peak,
+                    "traffic": traffic, "traffic_static": True, "traffic_source": src,
+                    "algorithmic_bytes_per_launch": m_rows * kk * eb + n * kk * eb + (1 + extra_c) * m_rows * n * 2,
+                    "launches": len(ms), "avg_launch_ms": avg, "algorithmic_flops_per_launch": fl})
+    return out
 
 
 def cpu_model_name():
@@ -158,6 +213,9 @@ def main():
                          "encodings of the real first frame and of the rendered goal-force map (the kernels' speed depends on the data)")
     ap.add_argument("--peaky", type=float, default=1.0, help="multiply every self-attention norm_q weight by this factor (8: attention "
                     "logits x 8, near-one-hot softmax rows) — data-sensitivity runs only")
+    ap.add_argument("--config5-steps", type=int, default=4, help="N = 1, bf16 run: after the bf16 timed region, switch the SAME modules to "
+                    "the fp8_linear contract (BASELINE config 5) and time this many steps (1 warm-up first); reported as `config5` in the "
+                    "JSON line; 0 = skip")
     ap.add_argument("--no-launch-events", action="store_true", help="do not record the per-launch HIP events behind `roofline` / "
                     "`roofline_gemm` in the timed region (they are then null): measures what those ~900 event pairs per forward cost "
                     "(profiles/r03/README.md: below 0.1 %)")
@@ -269,6 +327,7 @@ def main():
     elapsed = time.perf_counter() - t0
     prof, ops.PROFILE_ATTN = ops.PROFILE_ATTN or [], None
     gprof, ops.PROFILE_GEMM = ops.PROFILE_GEMM or [], None
+    step_ms = list(pipe.last_step_ms)           # (ms, is_low_noise) of the timed steps (the config-5 leg below records its own)
     # ---- self-check of what the timed steps produced: a forward that overflowed would time the same
     if not bool(torch.isfinite(final.float()).all()):
         raise SystemExit(f"rank {rank}: non-finite latents after the timed steps")
@@ -319,13 +378,52 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, vae_s, gather_s = (float(v) for v in t.tolist())
 
+    # ---- BASELINE config 5 on the same modules (N = 1, bf16 run only): every block Linear on the fp8_linear contract
+    # (VRAM:115-151), 1 warm-up + --config5-steps timed steps spread over the schedule like the bf16 ones
+    config5 = None
+    if world == 1 and not args.fp8 and args.config5_steps > 0:
+        from goal_force_amd.dit import enable_fp8
+        for m in (dit, dit2, cn, cn2):
+            enable_fp8(m)
+        k5 = args.config5_steps
+        ids5 = sorted({min(n_sched - 1, ((2 * i + 1) * n_sched) // (2 * k5)) for i in range(k5)}) if k5 > 1 else [0]
+        run([ids5[0]])
+        torch.cuda.synchronize()
+        ops.PROFILE_ATTN, ops.PROFILE_GEMM = (None, None) if args.no_launch_events else ([], [])
+        t5 = time.perf_counter()
+        final5 = run(ids5, record=True)
+        torch.cuda.synchronize()
+        el5 = time.perf_counter() - t5
+        prof5, ops.PROFILE_ATTN = ops.PROFILE_ATTN or [], None
+        gprof5, ops.PROFILE_GEMM = ops.PROFILE_GEMM or [], None
+        if not bool(torch.isfinite(final5.float()).all()):
+            raise SystemExit("config 5: non-finite latents after the timed fp8 steps")
+        hi5 = [ms for ms, low in pipe.last_step_ms if not low]
+        lo5 = [ms for ms, low in pipe.last_step_ms if low]
+        att5 = [a.elapsed_time(b) for a, b, sq, skv, _ in prof5 if sq == skv == S_TOK]
+        sps5 = el5 / len(ids5)
+        config5 = {"what": "BASELINE config 5: the same run with every nn.Linear of the DiT / ControlNet blocks on the fp8_linear contract "
+                           "(per-row dynamic activation scale, unit weight scale, OCP e4m3; diffsynth/vram_management/layers.py:115-151)",
+                   "dtype": "fp8-e4m3 block Linears (bf16 elsewhere, fp32 accumulate)", "steps": len(ids5), "warmup": 1, "step_ids": ids5,
+                   "ms_per_step": sps5 * 1e3, "denoise_step_ms_high_noise": sum(hi5) / len(hi5) if hi5 else None,
+                   "denoise_step_ms_low_noise": sum(lo5) / len(lo5) if lo5 else None,
+                   "frames_per_sec": 81.0 / (n_sched * sps5 + vae_s),
+                   "frames_per_sec_schedule_weighted": (81.0 / ((21 * sum(hi5) / len(hi5) + 29 * sum(lo5) / len(lo5)) / 1e3 + vae_s)
+                                                        if hi5 and lo5 else None),
+                   "self_attention_avg_launch_ms": sum(att5) / len(att5) if att5 else None,
+                   "latents": tensor_digest(torch, final5),
+                   "roofline_gemm": gemm_entries(gprof5, S_TOK, True)}
+        for m in (dit, dit2, cn, cn2):
+            enable_fp8(m, False)
+
     if rank == 0:
+        attn_traffic, attn_traffic_src = static_traffic("attn_self")
         sec_per_step = elapsed / k
         videos = 1 if world == 1 else world // (2 * args.sp)
         loop_s = n_sched * sec_per_step
         value = videos * 81.0 / (loop_s + vae_s + gather_s)
-        hi = [ms for ms, low in pipe.last_step_ms if not low]
-        lo = [ms for ms, low in pipe.last_step_ms if low]
+        hi = [ms for ms, low in step_ms if not low]
+        lo = [ms for ms, low in step_ms if low]
         # dominant kernel: self-attention flash-attention launches (q_len == kv_len == S)
         self_att = [(a.elapsed_time(b)) for a, b, sq, skv, _ in prof if sq == skv == S_TOK]
         att_ms = sum(self_att) / max(1, len(self_att))
@@ -384,27 +482,17 @@ def main():
                          # tools/microbench.py attn, profiles/r01/pmc/): (2 x FETCH_SIZE [gfx950 reports half of a 16-B/lane
                          # stream] + WRITE_SIZE) KiB -> bytes.  Not collected live: PMC needs the profiler.
                          # The launch = flash_attn_fwd_kernel3<2> alone (V^T is written by the V projection, gf_linear_vt32).
-                         "traffic": ATTN_TRAFFIC_BYTES, "traffic_static": True,
-                         "traffic_source": ATTN_TRAFFIC_SOURCE,
+                         "traffic": attn_traffic, "traffic_static": True,
+                         "traffic_source": attn_traffic_src,
+                         "algorithmic_bytes_per_launch": 4 * S_TOK * DIM * 2 // args.sp,      # Q + K + V read, O written
                          "launches": len(self_att), "avg_launch_ms": att_ms if self_att else None,
                          "algorithmic_flops_per_launch": att_flops},
         }
         # second entry: the FFN GEMMs (D->F with the GELU epilogue, F->D with gate*+residual) — with the four D->D
         # projections the GEMMs are the other ~45 % of a step
-        def gemm_entry(n, kk, name):
-            ms = [a.elapsed_time(b) for a, b, M, N, K, _ in gprof if (M, N, K) == (S_TOK // args.sp, n, kk)]
-            if not ms:
-                return None
-            avg = sum(ms) / len(ms)
-            fl = 2.0 * (S_TOK // args.sp) * n * kk
-            peak = PEAK_FP8_TFLOPS if args.fp8 else PEAK_BF16_TFLOPS
-            return {"bound": "mfma", "kernel": name + (" — e4m3 operands, v_mfma_f32_16x16x128_f8f6f4" if args.fp8 else ""),
-                    "achieved": fl / (avg * 1e-3) / 1e12, "peak": peak,
-                    "unit": "TFLOP/s", "frac": fl / (avg * 1e-3) / 1e12 / peak, "traffic": None,
-                    "launches": len(ms), "avg_launch_ms": avg, "algorithmic_flops_per_launch": fl}
-        out["roofline_gemm"] = [e for e in (gemm_entry(FFN, DIM, "gemm_a4_kernel<GELU> FFN1 [S,5120]x[13824,5120]^T"),
-                                            gemm_entry(DIM, FFN, "gemm_a4_kernel<gate*+resid> FFN2 [S,13824]x[5120,13824]^T"),
-                                            gemm_entry(DIM, DIM, "gemm_a4_kernel D->D projections (q,k,v,o, zero-conv)")) if e]
+        out["roofline_gemm"] = gemm_entries(gprof, S_TOK // args.sp, args.fp8)
+        if config5 is not None:
+            out["config5"] = config5
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(torch)
         print(json.dumps(out))

@@ -48,6 +48,9 @@
 #ifndef GF_K3_WHATIF
 #define GF_K3_WHATIF 0   // timing-only variants of kernel 3's steady phase (tools/attn_ab.py); 0 in the shipped library
 #endif
+#ifndef GF_K3_ORMAX
+#define GF_K3_ORMAX 0    // kernel 3: the steady phase's running-maximum watch on the packed P instead of the fp32 scores (see `phase`)
+#endif
 #ifndef GF_ATTN_BUFFER_DMA
 #define GF_ATTN_BUFFER_DMA 1   // 1: K/V staging by buffer_load ... lds with scalar tile offsets; 0: global_load_lds (A/B builds)
 #endif
@@ -60,9 +63,18 @@
 #ifndef GF_ATTN_STAMP
 #define GF_ATTN_STAMP 0
 #endif
-#if GF_ATTN_STAMP
+// GF_K3_CLOCK: diagnostic build only (tools/attn_clock.py) — kernel 3 reads s_memtime (shader cycles) and s_memrealtime
+// (100 MHz) once before and once after its steady loop and writes the two differences per workgroup to a debug buffer of its
+// own: the clock the chip holds INSIDE the loop = d(memtime) / d(memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS item 6).
+// No output value depends on the stamps; the shipped library is built without them.
+#ifndef GF_K3_CLOCK
+#define GF_K3_CLOCK 0
+#endif
+#if GF_ATTN_STAMP || GF_K3_CLOCK
 static unsigned long long* g_attn_dbg = nullptr;
 extern "C" GF_API void gf_debug_set_attn_buffer(void* p) { g_attn_dbg = (unsigned long long*)p; }
+#endif
+#if GF_ATTN_STAMP
 #define STAMP(i)                                                                            \
     {                                                                                       \
         unsigned long long t_;                                                              \
@@ -873,6 +885,10 @@ __global__ __launch_bounds__(AT2_THREADS, 2) void flash_attn_fwd_kernel2(const A
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // ---- steady phases 1 .. nt-2
+#if GF_K3_CLOCK
+    unsigned long long clk_t0, clk_r0;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk_t0), "=s"(clk_r0)::"memory");
+#endif
     int pi = 1;
     for (; pi + 1 <= nt - 2; pi += 2) {
         phase(C1{}, pi);
@@ -882,6 +898,16 @@ __global__ __launch_bounds__(AT2_THREADS, 2) void flash_attn_fwd_kernel2(const A
         phase(C1{}, pi);
         ++pi;
     }
+#if GF_K3_CLOCK
+    {
+        unsigned long long clk_t1, clk_r1;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk_t1), "=s"(clk_r1)::"memory");
+        if (p.dbg && tid == 0) {
+            p.dbg[2 * (long)blockIdx.x] = clk_t1 - clk_t0;
+            p.dbg[2 * (long)blockIdx.x + 1] = clk_r1 - clk_r0;
+        }
+    }
+#endif
     // ---- last phase p = nt-1 (nt >= 2): V(nt-1) in flight; PV(nt-2); softmax(nt-1)
     if (nt >= 2) {
         const int par = (nt - 1) & 1;
@@ -1314,7 +1340,7 @@ __global__ __launch_bounds__(At3<NQ>::THREADS, (NQ == 2 ? 2 : 1)) void flash_att
             mfma_op(s_c, par_c);
             if constexpr (S % NQ == 0) frag_load(std::integral_constant<int, S / NQ + RING - 1>{}, par_c);
             // partial maxima: slot S takes key block S / NQ of query block S % NQ (4 scores: two v_max3)
-            if constexpr ((GF_K3_WHATIF & 16) == 0) {
+            if constexpr ((GF_K3_WHATIF & 16) == 0 && !GF_K3_ORMAX) {
                 constexpr int kb = S / NQ, qb = S % NQ;
                 const f32x4& v = sc[PAR][kb][qb];
                 mx[qb] = fmaxf(fmaxf(mx[qb], v[0]), v[1]);
@@ -1322,8 +1348,18 @@ __global__ __launch_bounds__(At3<NQ>::THREADS, (NQ == 2 ? 2 : 1)) void flash_att
             }
             __builtin_amdgcn_sched_barrier(0);
         });
-        if constexpr ((GF_K3_WHATIF & 16) == 0) new_max(par_c, mx, false);
+        if constexpr ((GF_K3_WHATIF & 16) == 0 && !GF_K3_ORMAX) new_max(par_c, mx, false);
         float mc[NQ], pe[2];
+        // GF_K3_ORMAX: no maximum is taken before the exponentials.  P = exp2(S' - m) is >= 2 exactly when a score exceeds the
+        // running maximum by >= 1, and a bf16 >= 2 (Inf included) has bit 14 set while every bf16 in [0, 2) has it clear: the
+        // bitwise OR of the tile's packed P words (v_or3_b32: two words per instruction, 8 per wave and phase instead of 16
+        // v_max3 on the fp32 scores) tells whether ANY score did.  Only then (a few per cent of the phases on random data, never
+        // on the common path) are the true maxima taken from S(p) — still intact in its registers — and, if one is more than 6
+        // above the running maximum, the rescale of `new_max` runs and the tile's P is recomputed; an overflow to Inf cannot
+        // escape, it sets bit 14 as well.
+        unsigned orp[NQ];
+#pragma unroll
+        for (int qb = 0; qb < NQ; ++qb) orp[qb] = 0u;
 #pragma unroll
         for (int qb = 0; qb < NQ; ++qb) mc[qb] = CINIT ? 0.f : m_run[qb] * c;
         static_for<4 * NQ, NS>([&](auto s_c) {
@@ -1356,11 +1392,56 @@ __global__ __launch_bounds__(At3<NQ>::THREADS, (NQ == 2 ? 2 : 1)) void flash_att
                     unsigned w;
                     asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(pe[0]), "v"(pe[1]));
                     pfw[kk][qb][(kb & 1) * 2 + (j >> 1)] = w;
+                    if constexpr (GF_K3_ORMAX != 0) {      // every second pack folds its word and the one before it into the watch
+                        constexpr int widx = (kb & 1) * 2 + (j >> 1);
+                        if constexpr (widx & 1)
+                            asm volatile("v_or3_b32 %0, %0, %1, %2" : "+v"(orp[qb]) : "v"(pfw[kk][qb][widx - 1]), "v"(w));
+                    }
                     if constexpr (!SUMMFMA) asm volatile("v_add_f32 %0, %0, %1" : "+v"(l_run[qb]) : "v"(pe[1]));
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
         });
+        if constexpr (GF_K3_ORMAX != 0 && (GF_K3_WHATIF & 16) == 0) {
+            unsigned any = orp[0];
+#pragma unroll
+            for (int qb = 1; qb < NQ; ++qb) any |= orp[qb];
+            if (__builtin_expect(!__all((any & 0x40004000u) == 0u), 0)) {
+                // rare: some P >= 2.  True partial maxima of S(p) (relative to the running maximum) ...
+                float mxr[NQ];
+#pragma unroll
+                for (int qb = 0; qb < NQ; ++qb) {
+                    mxr[qb] = sc[PAR][0][qb][0];
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) mxr[qb] = fmaxf(mxr[qb], sc[PAR][kb][qb][j]);
+                }
+                f32x4 negm_old[NQ];
+#pragma unroll
+                for (int qb = 0; qb < NQ; ++qb) negm_old[qb] = negm[qb];
+                const bool pend_old = pend;
+                new_max(par_c, mxr, false);        // ... moves the running maximum (and corrects S(p)) only if one is > 6 above it
+#pragma unroll
+                for (int qb = 0; qb < NQ; ++qb) {
+                    const float d = negm_old[qb][0] - negm[qb][0];      // how far this query block's maximum moved (0: untouched)
+                    if (__builtin_expect(!__all(d == 0.f), 0)) {
+                        // S(p+1) was started from the OLD maximum during this phase: move it along, and redo the tile's P
+#pragma unroll
+                        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) sc[1 - PAR][kb][qb][e] -= d;
+#pragma unroll
+                        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                            for (int j = 0; j < 4; j += 2)
+                                pfw[kb >> 1][qb][(kb & 1) * 2 + (j >> 1)] =
+                                    pack2bf(__builtin_amdgcn_exp2f(sc[PAR][kb][qb][j]), __builtin_amdgcn_exp2f(sc[PAR][kb][qb][j + 1]));
+                    }
+                }
+                (void)pend_old;
+            }
+        }
         if constexpr ((GF_K3_WHATIF & 1) == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -1395,6 +1476,10 @@ __global__ __launch_bounds__(At3<NQ>::THREADS, (NQ == 2 ? 2 : 1)) void flash_att
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // ---- steady phases 1 .. nt-2
+#if GF_K3_CLOCK
+    unsigned long long clk_t0, clk_r0;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk_t0), "=s"(clk_r0)::"memory");
+#endif
     int pi = 1;
     for (; pi + 1 <= nt - 2; pi += 2) {
         phase(C1{}, pi);
@@ -1404,6 +1489,16 @@ __global__ __launch_bounds__(At3<NQ>::THREADS, (NQ == 2 ? 2 : 1)) void flash_att
         phase(C1{}, pi);
         ++pi;
     }
+#if GF_K3_CLOCK
+    {
+        unsigned long long clk_t1, clk_r1;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk_t1), "=s"(clk_r1)::"memory");
+        if (p.dbg && tid == 0) {
+            p.dbg[2 * (long)blockIdx.x] = clk_t1 - clk_t0;
+            p.dbg[2 * (long)blockIdx.x + 1] = clk_r1 - clk_r0;
+        }
+    }
+#endif
     // ---- last phase p = nt-1 (nt >= 2): V(nt-1) in flight; PV(nt-2); softmax(nt-1)
     if (nt >= 2) {
         const int par = (nt - 1) & 1;
@@ -1698,7 +1793,11 @@ extern "C" GF_API int gf_flash_attn_fwd_vt32(const void* q, const void* k, const
     a.lse = lse;
     a.vt = (const u16*)vt;
     a.kv_pad = kv_pad;
+#if GF_K3_CLOCK
+    a.dbg = g_attn_dbg;
+#else
     a.dbg = nullptr;
+#endif
     hipLaunchKernelGGL(flash_attn_fwd_kernel3<GF_K3_NQ>, dim3((unsigned)(a.n_qblocks * a.heads)), dim3(At3<GF_K3_NQ>::THREADS), AT3_LDS,
                        (hipStream_t)stream, a);
     GF_CHECK_LAUNCH("gf_flash_attn_fwd_vt32");

@@ -364,6 +364,26 @@ GF_API int gf_vae_tile_finalize(void* values, const void* weight, int64_t planes
 GF_API int gf_modulate(const void* x, void* out, const void* scale, const void* shift, int64_t rows, int64_t dim,
                        int64_t x_stride, int64_t out_stride, void* stream);
 
+/* ---- Canny-edge control signal (ControlSignalDataset_CannyEdge._generate_control_video, src/goal_force/unified_dataset.py:559-578;
+ * the reference calls cv2 / controlnet_aux per frame on the host — absent here: OpenCV's published algorithm restated, "parity unpinned").
+ * All images are uint8 [frames, H, W, 3] (HWC), all tables device arrays built by goal_force_amd/canny.py.
+ * gf_resize_lanczos4_u8 — cv2.resize(INTER_LANCZOS4) on 8-bit pixels: xofs/yofs = floor source coordinate per destination column / row,
+ *   xcoef/ycoef [n][8] = the 8 tap weights in 11-bit fixed point; replicated border; one rounding shift by 22. */
+GF_API int gf_resize_lanczos4_u8(const void* src, void* dst, const int* xofs, const short* xcoef, const int* yofs, const short* ycoef,
+                                 int64_t frames, int64_t H, int64_t W, int64_t Hd, int64_t Wd, void* stream);
+/* gf_resize_area_u8 — cv2.resize(INTER_AREA), shrinking by a non-integer ratio: CSR tables (start [n+1], source index, fp32 weight) per
+ *   axis.  mode 0: uint8 [frames,H,W,3] -> uint8 [frames,Hd,Wd,3].  mode 1: src is gf_canny_u8's state map [frames,H,W] (2 = edge -> 255,
+ *   else 0) and dst the dataset's control video: bf16 [frames,Hd,Wd,3], three equal channels of x / 127.5 - 1. */
+GF_API int gf_resize_area_u8(const void* src, void* dst, const int* xstart, const int* xsrc, const float* xalpha, const int* ystart,
+                             const int* ysrc, const float* yalpha, int64_t frames, int64_t H, int64_t W, int64_t Hd, int64_t Wd, int mode,
+                             void* stream);
+/* gf_canny_u8 — cv2.Canny(img, low, high), aperture 3, L1 gradient, on uint8 [frames,H,W,3]: Sobel (replicated border), strongest
+ *   channel per pixel, non-maximum suppression, double threshold, hysteresis to the fixpoint -> state uint8 [frames,H,W]
+ *   (2 = edge).  mag_ws / dxy_ws: int32 [frames*H*W] scratch each; changed: one device int.  Synchronises the stream once per
+ *   hysteresis pass (a dataset loader, not the sampling loop); fails if max_passes are not enough. */
+GF_API int gf_canny_u8(const void* img, void* state, void* mag_ws, void* dxy_ws, int* changed, int64_t frames, int64_t H, int64_t W,
+                       int low, int high, int max_passes, void* stream);
+
 /* gf_gate_residual — `GateModule.forward(x, gate, residual)` (DIT:189-194): out = bf16(x + bf16(gate * residual)), gate [dim]
  * bf16 (batch 1), x / residual / out [rows, dim] bf16 with row strides.  (Hot path: the GEMM epilogue GF_EPI_BIAS_GATE_RESID.) */
 GF_API int gf_gate_residual(const void* x, const void* gate, const void* residual, void* out, int64_t rows, int64_t dim,

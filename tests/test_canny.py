@@ -1,0 +1,172 @@
+"""Canny-edge control signal (SURVEY §8 f4 remainder: ControlSignalDataset_CannyEdge, src/goal_force/unified_dataset.py:406-613).
+cv2 / controlnet_aux are absent from this image: **parity unpinned** — the oracle (oracle/canny_oracle.py) restates OpenCV's
+published algorithm and is pinned here by hand-computed known-answer cases only; the HIP kernels must equal it bit for bit."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import canny_oracle as co
+
+
+def _rgb(g):
+    return np.stack([g, g, g], axis=2).astype(np.uint8)
+
+
+# ------------------------------------------------------------------ the oracle against hand-computed answers (CPU)
+def test_oracle_step_edge_known_answer():
+    """A vertical 0 -> 255 step between columns 7 and 8: Sobel dx = 4 * 255 = 1020 at x = 7 and x = 8, dy = 0 -> horizontal
+    direction; non-maximum suppression keeps a pixel when m > left AND m >= right: x = 7 stays (0 < 1020 >= 1020), x = 8 goes
+    (1020 > 1020 is false).  One edge column, every row (the border is replicated)."""
+    g = np.zeros((16, 16), np.uint8)
+    g[:, 8:] = 255
+    e = co.canny_u8(_rgb(g))
+    want = np.zeros((16, 16), np.uint8)
+    want[:, 7] = 255
+    assert np.array_equal(e, want)
+    e = co.canny_u8(_rgb(g.T.copy()))                    # horizontal step: keep when m > above AND m >= below -> row 7
+    assert np.array_equal(e, want.T)
+
+
+def test_oracle_thresholds_and_hysteresis_known_answer():
+    """Step heights h give magnitude 4 h: h = 20 -> 80 (below low = 100: nothing), h = 40 -> 160 (between the thresholds: an edge
+    only where connected to a strong one), h = 60 -> 240 (above high = 200: an edge).  Rows 0-7 carry a strong step at column 7
+    whose height drops to the weak 40 in rows 8-15: the weak part continues the strong edge and survives; the same weak step alone
+    (second image) disappears."""
+    a = np.zeros((16, 16), np.uint8)
+    a[:8, 8:] = 60
+    a[8:, 8:] = 40
+    e = co.canny_u8(_rgb(a))
+    # (around rows 7 / 8 the change of height adds a vertical gradient and the ridge steps over to column 8: left out)
+    assert (e[:6, 7] == 255).all() and (e[10:, 7] == 255).all(), "the weak rows 10-15 survive only through the hysteresis"
+    assert e[:6].sum() == 255 * 6 and e[10:].sum() == 255 * 6 and 14 <= e.sum() // 255 <= 20
+    b = np.zeros((16, 16), np.uint8)
+    b[:, 8:] = 40
+    assert co.canny_u8(_rgb(b)).sum() == 0
+    c = np.zeros((16, 16), np.uint8)
+    c[:, 8:] = 20
+    assert co.canny_u8(_rgb(c)).sum() == 0
+
+
+def test_oracle_strongest_channel_and_diagonal_direction():
+    """Only the red channel carries the step: the pixel takes the strongest channel's gradient (the first one on ties).  A 45-degree
+    step (dx = dy) is compared along the main diagonal (up-left / down-right), with strict inequality on both sides."""
+    g = np.zeros((16, 16, 3), np.uint8)
+    g[:, 8:, 0] = 255
+    want = np.zeros((16, 16), np.uint8)
+    want[:, 7] = 255
+    assert np.array_equal(co.canny_u8(g), want)
+    d = np.fromfunction(lambda y, x: (x + y >= 16) * 255, (16, 16)).astype(np.uint8)
+    e = co.canny_u8(_rgb(d))
+    ys, xs = np.nonzero(e)
+    assert len(ys) > 8 and set((xs + ys).tolist()) <= {14, 15, 16}, "edge pixels lie on the anti-diagonal x + y ~ 15"
+
+
+def test_oracle_resize_rules():
+    """resize_image: 480 x 832 -> k = 512/480 -> (512, 896), enlarging (Lanczos); 720 x 1280 -> (512, 896) shrinking (area);
+    area weights of a destination cell sum to one, so a constant image stays constant; fixed-point Lanczos maps 0 -> 0."""
+    assert co.resize_target(480, 832)[:2] == (512, 896) and co.resize_target(480, 832)[2] > 1
+    assert co.resize_target(720, 1280)[:2] == (512, 896) and co.resize_target(720, 1280)[2] < 1
+    img = np.full((60, 104, 3), 77, np.uint8)
+    assert (co.resize_area_u8(img, 48, 96) == 77).all()
+    assert (co.resize_lanczos4_u8(np.zeros((30, 52, 3), np.uint8), 64, 128) == 0).all()
+    up = co.resize_lanczos4_u8(np.full((30, 52, 3), 200, np.uint8), 64, 128)
+    assert up.min() >= 199 and up.max() <= 201          # the 11-bit taps sum to 2046 .. 2050, not exactly 2048
+
+
+def test_product_tables_equal_the_oracles_independent_restatement():
+    from goal_force_amd import canny as cn
+    for s, d in ((832, 896), (480, 512), (100, 128)):
+        ofs, coef = cn.lanczos4_tables(s, d)
+        idx, oc = co._lanczos_axis(s, d)
+        assert np.array_equal(np.clip(ofs[:, None] + np.arange(-3, 5)[None], 0, s - 1), idx) and np.array_equal(coef, oc)
+    for s, d in ((896, 832), (512, 480), (1000, 832)):
+        st, src, al = cn.area_tables(s, d)
+        flat = [e for r in co._area_axis(s, d) for e in r]
+        assert [e[0] for e in flat] == src.tolist() and np.array([e[1] for e in flat], np.float32).tobytes() == al.tobytes()
+        assert st[0] == 0 and st[-1] == len(src)
+    assert cn.resized_shape(480, 832) == co.resize_target(480, 832)
+    with pytest.raises(NotImplementedError):
+        cn._area_or_identity(1024, 512)
+
+
+def test_dataset_host_logic(tmp_path, monkeypatch):
+    """Constructor arguments, metadata formats, __len__ / __getitem__ contract of DS:406-613 (the pixel work mocked out)."""
+    from goal_force_amd.canny import ControlSignalDataset_CannyEdge as DS
+    meta = tmp_path / "m.jsonl"
+    meta.write_text("\n".join(json.dumps({"video": f"v{i}.mp4", "caption": f"c{i}"}) for i in range(3)))
+    ds = DS(base_path=str(tmp_path), metadata_path=str(meta), repeat=2, data_file_keys=("video",),
+            main_data_operator=lambda p: None if p.endswith("v1.mp4") else [p], device="cpu")
+    monkeypatch.setattr(ds, "_generate_control_video", lambda v: ("ctrl", v))
+    assert len(ds) == 6 and not ds.load_from_cache
+    item = ds[0]
+    assert item["prompt"] == "c0" and "caption" not in item and item["video"] == ["v0.mp4"] and item["control_video"] == ("ctrl", ["v0.mp4"])
+    assert ds[1] is None                                   # a clip that failed to load invalidates the sample (DS:594-596)
+    assert ds[5]["prompt"] == "c2"
+    out = ds.process_for_validation("v2.mp4", "a prompt")
+    assert out == {"prompt": "a prompt", "control_signal_video": ("ctrl", ["v2.mp4"])}
+    (tmp_path / "clip.csv").write_text("video,caption\nhere.mp4,x\nmissing.mp4,y\n")
+    (tmp_path / "here.mp4").write_bytes(b"")
+    ds2 = DS(base_path=str(tmp_path), metadata_path=str(tmp_path / "clip.csv"), device="cpu")
+    assert [d["video"] for d in ds2.data] == ["here.mp4"]
+
+
+# ------------------------------------------------------------------ HIP kernels == oracle, bit for bit (GPU)
+def _frames(seed, t, h, w):
+    """Structured content (blocks, a disc, a gradient) + noise: real edges of every direction, weak and strong."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    out = []
+    for i in range(t):
+        f = np.zeros((h, w, 3), np.float32)
+        f[..., 0] = (xx * 255.0 / w)
+        f[..., 1] = 40 + 30 * np.sin(yy / 17.0 + i)
+        f[..., 2] = 90
+        f[h // 5: h // 2, w // 6: w // 3] = (220, 30, 60)
+        f[((yy - h * 0.6) ** 2 + (xx - w * 0.6 - 9 * i) ** 2) < (h * 0.18) ** 2] = (20, 200, 240)
+        f[int(h * 0.8):, : w // 2] += 45                                  # a weak step
+        f += rng.normal(0, 4 + 3 * i, f.shape)
+        out.append(np.clip(np.rint(f), 0, 255).astype(np.uint8))
+    return np.stack(out, 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 480, 832), (1, 600, 1000), (1, 512, 896), (2, 123, 211)])
+def test_hip_control_video_equals_oracle(shape):
+    """The whole `_generate_control_video` (resize -> Canny -> area resize back -> x / 127.5 - 1 -> bf16) on the HIP kernels against
+    the numpy oracle, all frames of the clip in one batch: the production size (Lanczos enlarging), a larger frame (area shrinking),
+    a frame already at the detector's size (no resize either way) and a ragged small one."""
+    from goal_force_amd.canny import CannyDetector, ControlSignalDataset_CannyEdge as DS
+    fr = _frames(sum(shape), *shape)
+    ds = DS(device="cuda")
+    got = ds._generate_control_video(fr)
+    assert got.dtype == torch.bfloat16 and tuple(got.shape) == fr.shape
+    want = co.control_video(fr)
+    assert torch.equal(got.cpu(), want), f"{int((got.cpu() != want).sum())} of {want.numel()} values differ"
+    assert 0.002 < float((want.float() > 0).float().mean()) < 0.5, "the case must contain edges"
+    det = CannyDetector("cuda")(fr[:1])
+    assert torch.equal(det.cpu(), torch.from_numpy(co.canny_detector(fr[0]))[None])
+
+
+@pytest.mark.gpu
+def test_hip_hysteresis_long_chain_and_inputs():
+    """A one-pixel-wide weak spiral tied to one strong pixel crosses hundreds of 32 x 32 tiles: the hysteresis must run to its
+    fixpoint (many passes).  PIL frames and grey frames are accepted like the reference's np.array(processed_video)."""
+    from PIL import Image
+    from goal_force_amd.canny import CannyDetector
+    h, w = 512, 896
+    g = np.zeros((h, w), np.uint8)
+    for k in range(0, 200, 8):                           # nested rectangles joined into one long weak ridge
+        g[k:h - k, k] = 30
+        g[k:h - k, w - 1 - k] = 30
+        g[k, k:w - k] = 30
+        g[h - 1 - k, k + 8:w - k] = 30
+        g[h - 1 - k:h - 1 - k + 1, k:k + 9] = 30
+    g[0:3, 0:3] = 255                                    # the only strong spot
+    fr = _rgb(g)[None]
+    det = CannyDetector("cuda")
+    got = det(fr)
+    want = co.canny_detector(fr[0])
+    assert torch.equal(got.cpu()[0], torch.from_numpy(want))
+    assert torch.equal(det([Image.fromarray(fr[0])]).cpu(), got.cpu()) and torch.equal(det(torch.from_numpy(g)[None]).cpu(), got.cpu())

@@ -41,6 +41,9 @@ def main():
     ap.add_argument("--zeros", action="store_true", help="attn: all-zero q/k/v as well (same instruction stream, no data toggling: "
                     "how much of the time is the clock the chip grants an MFMA stream on REAL data)")
     ap.add_argument("--ab", action="store_true", help="gemm: interleaved A/B of GF_GEMM_KERNEL=a4 (4 waves, shipped) and ph (8 waves)")
+    ap.add_argument("--only", choices=["dd", "ffn1", "ffn2"], default=None, help="gemm: ONE block shape with the epilogue the block runs it "
+                    "with (dd: bias; ffn1: GELU; ffn2: gate*+resid), bf16 — or e4m3 with --fp8: the target of the per-shape PMC passes "
+                    "(tools/profile_r04.sh), so that a counter table holds one shape per kernel instantiation")
     ap.add_argument("--ref", action="store_true", help="also time torch F.linear (hipBLASLt) on the same shapes: a yardstick, not a product path")
     a = ap.parse_args()
     torch.manual_seed(0)
@@ -105,6 +108,25 @@ def main():
         ex = 1.6 if os.environ.get("GF_ATTN_BWD") == "v1" else 1.4
         print(f"flash_attn_bwd S={s} H={H}: median {med:.3f} ms ({fl / med / 1e9:.1f} TFLOP/s algorithmic, "
               f"{ex * fl / med / 1e9:.1f} executed)")
+    elif a.what == "gemm" and a.only:
+        n, k = {"dd": (D, D), "ffn1": (F, D), "ffn2": (D, F)}[a.only]
+        inp = torch.randn((s, k), device="cuda").to(BF)
+        w = (torch.randn((n, k), device="cuda") / k ** 0.5).to(BF)
+        b = torch.randn((n,), device="cuda").to(BF)
+        out = torch.empty((s, n), device="cuda", dtype=BF)
+        kw = {}
+        if a.only == "ffn1":
+            kw = dict(epilogue=ops.EPI_BIAS_GELU_TANH)
+        if a.only == "ffn2":
+            kw = dict(epilogue=ops.EPI_BIAS_GATE_RESID, resid=torch.randn((s, n), device="cuda").to(BF), gate=torch.randn((n,), device="cuda").to(BF))
+        fl = 2.0 * s * n * k
+        if a.fp8:
+            w8 = ops.cast_fp8(w)
+            x8, sc = ops.quant_fp8_rowscale(inp)
+            med, mn = timeit(lambda: ops.gemm_fp8(x8, sc, w8, b, out=out, **kw), a.iters)
+        else:
+            med, mn = timeit(lambda: ops.gemm(inp, w, b, out=out, **kw), a.iters)
+        print(f"gemm {'fp8' if a.fp8 else 'bf16'} {a.only} [{s},{k}]x[{n},{k}]^T: median {med:.3f} ms ({fl / med / 1e9:.1f} TFLOP/s), min {mn:.3f} ms")
     elif a.what == "gemm":
         x = torch.randn((s, D), device="cuda").to(BF)
         xf = torch.randn((s, F), device="cuda").to(BF)
