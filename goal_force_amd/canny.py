@@ -12,7 +12,7 @@ then `stack -> float32 / 127.5 - 1.0 -> bf16` [frames, H, W, 3].
 
 cv2 and controlnet_aux are NOT in this image: the class cannot be imported here and nothing it computes can be pinned against
 it.  What is built is OpenCV's published algorithm (imgproc resize.cpp / canny.cpp) restated integer for integer — "parity
-unpinned (cv2 absent)"; the HIP kernels are tested bit-exact against the numpy restatement oracle/canny_oracle.py.
+unpinned (cv2 absent)"; the HIP kernels are tested bit-exact against an independent numpy restatement (tests/test_canny.py).
 Video decoding (`LoadVideo`, imageio) is host I/O outside the path: `main_data_operator` is injectable exactly as in the
 reference (default: identity — pass already decoded frames).
 """
