@@ -6,7 +6,7 @@
 #include <cstring>
 #include <mutex>
 
-#define GF_ABI_VERSION 12
+#define GF_ABI_VERSION 13
 
 static thread_local char g_err[512] = "";
 

@@ -402,7 +402,32 @@ struct Bwd16Args {
     BwdArgs b;
     const float* sd;     // [heads][ngp][32 lse | 32 delta]
     int ngp;             // granule records per head
+    const u16* qs;       // GF_BWD_QSCALE: Q' = bf16(Q * scale * log2 e) [q_len, heads * 128] — the forward's own operand (below)
 };
+
+// GF_BWD_QSCALE (round 4): the forward kernel multiplies Q by scale * log2(e) ONCE, rounds to bf16, and takes its scores S' = Q' K^T
+// straight in the exp2 domain; the log-sum-exp it returns belongs to THOSE scores.  The backward kernels used to rebuild
+// P = exp2(c * (Q K^T) - lse) from the unscaled Q — one fma per score, and a P that differs from the forward's by the rounding of Q'.
+// With the same Q' (a 0.67 GB pass, 0.13 ms at S = 32760; a copy in the workspace, because the dK/dV kernel streams Q through LDS)
+// the S chains START from -lse (the MFMA's C operand) and leave the matrix pipe as the exponent: no fma per score, and P is the
+// forward's P bit for bit.  dK = scale * dS^T Q = dS^T Q' / log2(e): the dK/dV epilogue multiplies by ln 2 instead of by scale.
+#ifndef GF_BWD_QSCALE
+#define GF_BWD_QSCALE 1
+#endif
+__global__ __launch_bounds__(256) void attn_bwd_qscale_kernel(const u16* __restrict__ q, u16* __restrict__ qs, long rows, int hd_all,
+                                                              long q_stride, float c) {
+    const int cpr = hd_all >> 3;
+    const long total = rows * cpr;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long r = i / cpr;
+        const int col = (int)(i - r * cpr) << 3;
+        const u16x8 x = *reinterpret_cast<const u16x8*>(q + r * q_stride + col);
+        u16x8 y;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] = f2bf(bf2f(x[e]) * c);         // exactly the forward's `(__bf16)((float)q * scale_log2e)`
+        *reinterpret_cast<u16x8*>(qs + r * hd_all + col) = y;
+    }
+}
 
 // delta[s, h] = sum_d dO[s, h, d] O[s, h, d], stored twice: [q_len, heads] (per-lane reads of the dQ kernel) and with lse as the
 // dK/dV kernel's granule records sd[h][s / 32][32 x -lse | 32 x -delta] (zeros past q_len)
@@ -526,7 +551,11 @@ __global__ __launch_bounds__(DQ_THREADS, 2) void attn_bwd_dq16_kernel(const Bwd1
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
         const int qr = min(q0 + 16 * qb + r, p.q_len - 1);
+#if GF_BWD_QSCALE
+        const u16* qp = a.qs + (long)qr * (p.heads * HD) + head * HD + 8 * g;     // Q' = bf16(c Q): the forward's operand
+#else
         const u16* qp = p.q + (long)qr * p.q_stride + head * HD + 8 * g;
+#endif
         const u16* dp = p.dout + (long)qr * p.do_stride + head * HD + 8 * g;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -550,7 +579,13 @@ __global__ __launch_bounds__(DQ_THREADS, 2) void attn_bwd_dq16_kernel(const Bwd1
     f32x4 ndl[2];                    // -delta of this lane's query: the dP chains start from it (dS = P * chain result, one multiply per score)
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) ndl[qb] = f32x4{-dl[qb], -dl[qb], -dl[qb], -dl[qb]};
+#if GF_BWD_QSCALE
+    f32x4 nls[2];                    // -lse likewise: S' = Q' K^T - lse is the exponent
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) nls[qb] = f32x4{-lse[qb], -lse[qb], -lse[qb], -lse[qb]};
+#else
     const float c = p.scale_log2e;
+#endif
     const ImgOffsets fo = img_offsets(lane);
     f32x4 dq[8][2];
 #pragma unroll
@@ -616,12 +651,17 @@ __global__ __launch_bounds__(DQ_THREADS, 2) void attn_bwd_dq16_kernel(const Bwd1
         u32x4 dsw[2];            // dS^T as B operand [32 keys x 16 queries] per query block: words 0, 1 = key block 2 h, words 2, 3 = 2 h + 1
         f32x4 sc[2][2], dp[2][2];
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        (void)zero4;
         auto first = [&](int kbb, int lo, int hi) __attribute__((always_inline)) {     // (the chains start from 0 / -delta through the first MFMA's C operand)
 #pragma unroll
             for (int ks = lo; ks < hi; ++ks)
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb) {
+#if GF_BWD_QSCALE
+                    sc[kbb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F[2 * ks], qf[qb][ks], ks == 0 ? nls[qb] : sc[kbb][qb], 0, 0, 0);    // S'^T - lse
+#else
                     sc[kbb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F[2 * ks], qf[qb][ks], ks == 0 ? zero4 : sc[kbb][qb], 0, 0, 0);      // S^T[key 32 h + 16 kbb + 4 g + j, query 16 qb + r]
+#endif
                     dp[kbb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F[2 * ks + 1], dof[qb][ks], ks == 0 ? ndl[qb] : dp[kbb][qb], 0, 0, 0);   // dP^T - delta
                 }
         };
@@ -631,7 +671,11 @@ __global__ __launch_bounds__(DQ_THREADS, 2) void attn_bwd_dq16_kernel(const Bwd1
                 float x[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
+#if GF_BWD_QSCALE
+                    const float pr = __builtin_amdgcn_exp2f(sc[kbb][qb][j]);
+#else
                     const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kbb][qb][j], c, -lse[qb]));
+#endif
                     x[j] = pr * dp[kbb][qb][j];
                 }
                 dsw[qb][2 * kbb] = pack2bf(x[0], x[1]);
@@ -1047,12 +1091,19 @@ __global__ __launch_bounds__(Kv48::THREADS) void attn_bwd_dkv48_kernel(const Bwd
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) acc[db][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int ng = (p.q_len + GR - 1) / GR;
-    const unsigned q_voff = img_src_off(wave & 7, lane, p.q_stride), do_voff = img_src_off(wave & 7, lane, p.do_stride);
+#if GF_BWD_QSCALE
+    const u16* q_src = a.qs;                      // Q' = bf16(c Q), [q_len, heads * 128]
+    const long q_src_stride = (long)p.heads * HD;
+#else
+    const u16* q_src = p.q;
+    const long q_src_stride = p.q_stride;
+#endif
+    const unsigned q_voff = img_src_off(wave & 7, lane, q_src_stride), do_voff = img_src_off(wave & 7, lane, p.do_stride);
     const u32x4s srd_sd = make_srd(a.sd + (long)head * a.ngp * (2 * GR), 0xffffffffu);
     auto issue = [&](int i, int slot2) __attribute__((always_inline)) {        // granule i + 2 -> slot (i + 2) & 3
         const int ga = i + 2;
         GF_LDS char* dst = lds + slot2 * GR_BYTES + wave * 1024;
-        dma16b(rows_srd(p.q, p.q_stride, head, ga * GR, p.q_len), q_voff, 0u, dst + L::Q);
+        dma16b(rows_srd(q_src, q_src_stride, head, ga * GR, p.q_len), q_voff, 0u, dst + L::Q);
         dma16b(rows_srd(p.dout, p.do_stride, head, ga * GR, p.q_len), do_voff, 0u, dst + L::DO);
         if (wave == 0) dma4b(srd_sd, (unsigned)lane * 4u, (unsigned)min(ga, a.ngp - 1) * (2u * GR * 4u), lds + L::S + slot2 * (2 * GR * 4));
     };
@@ -1096,7 +1147,7 @@ __global__ __launch_bounds__(Kv48::THREADS) void attn_bwd_dkv48_kernel(const Bwd
             for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
                 for (int kb = 0; kb < KB; ++kb)
-                    sc[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F[2 * ks + qb], own[kb][ks], ks == 0 ? zero4 : sc[qb][kb], 0, 0, 0);
+                    sc[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F[2 * ks + qb], own[kb][ks], ks == 0 ? (GF_BWD_QSCALE ? l4[qb] : zero4) : sc[qb][kb], 0, 0, 0);
         KV16_SB();
 #pragma unroll
         for (int db = 0; db < 8; ++db) F[db] = tr_frag(L::DO + SLOT * GR_BYTES, db);
@@ -1107,7 +1158,9 @@ __global__ __launch_bounds__(Kv48::THREADS) void attn_bwd_dkv48_kernel(const Bwd
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) sc[qb][kb][j] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[qb][kb][j], c, l4[qb][j]));   // l4 = -lse
+                for (int j = 0; j < 4; ++j)
+                    sc[qb][kb][j] = GF_BWD_QSCALE ? __builtin_amdgcn_exp2f(sc[qb][kb][j])                                   // the chain started from -lse
+                                                  : __builtin_amdgcn_exp2f(__builtin_fmaf(sc[qb][kb][j], c, l4[qb][j]));   // l4 = -lse
                 *(GF_LDS f32x4*)(hbase + ((SLOT & 1) * L::HBUF + (2 * kb + qb) * 1024)) = sc[qb][kb];
             }
             pf[kb] = pack44(sc[0][kb], sc[1][kb]);
@@ -1196,7 +1249,7 @@ __global__ __launch_bounds__(Kv48::THREADS) void attn_bwd_dkv48_kernel(const Bwd
             KV48_ITER(stepB, 3, S3)
         }
     }
-    const float mul = roleB ? p.scale : 1.0f;
+    const float mul = roleB ? (GF_BWD_QSCALE ? 0.6931471805599453f : p.scale) : 1.0f;     // dK = dS^T Q' / log2(e) with Q' = c Q
     u16* outp = roleB ? p.dk : p.dv;
     const long ostride = roleB ? p.dk_stride : p.dv_stride;
 #pragma unroll
@@ -1222,9 +1275,10 @@ static inline int64_t pad64(int64_t n) { return (n + 63) / 64 * 64; }
 static inline int64_t align256(int64_t n) { return (n + 255) / 256 * 256; }
 
 // bytes of the caller-owned workspace of gf_flash_attn_bwd: delta [q_len, heads] fp32 | granule records [heads][pad64(q_len)/32][64] fp32
+// | Q' = bf16(Q * scale * log2 e) [q_len, heads * 128] (GF_BWD_QSCALE)
 extern "C" GF_API int64_t gf_flash_attn_bwd_workspace_bytes(int64_t q_len, int64_t kv_len, int64_t heads) {
     if (q_len <= 0 || kv_len <= 0 || heads <= 0) return 0;
-    return align256(q_len * heads * 4) + align256(heads * pad64(q_len) * 2 * 4);
+    return align256(q_len * heads * 4) + align256(heads * pad64(q_len) * 2 * 4) + (GF_BWD_QSCALE ? align256(q_len * heads * HD * 2) : 0);
 }
 
 #ifndef KV16_NP
@@ -1300,6 +1354,17 @@ extern "C" GF_API int gf_flash_attn_bwd(const void* q, const void* k, const void
     b.ngp = (int)(q_pad / GR);
     float* sd = (float*)((char*)workspace + align256(q_len * heads * 4));
     b.sd = sd;
+#if GF_BWD_QSCALE
+    {
+        u16* qs = (u16*)((char*)sd + align256(heads * q_pad * 2 * 4));
+        b.qs = qs;
+        const long n8 = q_len * heads * (HD / 8);
+        hipLaunchKernelGGL(attn_bwd_qscale_kernel, dim3((unsigned)((n8 + 255) / 256 > 262144 ? 262144 : (n8 + 255) / 256)), dim3(256), 0, s,
+                           (const u16*)q, qs, (long)q_len, (int)(heads * HD), (long)q_stride, a.scale_log2e);
+    }
+#else
+    b.qs = nullptr;
+#endif
     hipLaunchKernelGGL(attn_bwd_delta16_kernel, dim3((unsigned)((q_pad * heads + 255) / 256)), dim3(256), 0, s, b, sd);
     hipLaunchKernelGGL(attn_bwd_dq16_kernel, dim3(nqb * (unsigned)heads), dim3(DQ_THREADS), DQ16_LDS, s, b);
     if (!want_dkv) {

@@ -176,8 +176,10 @@ GF_API int gf_linear_vt32(const void* x, int64_t ldx, const void* w, int64_t ldw
  *   of the scaled scores: softmax row = exp2(scale*log2(e)*S - lse).
  * gf_flash_attn_bwd — dq, dk, dv from (q, k, v, o, dout, lse).  Same layouts / strides as the forward; fp32 accumulation,
  *   bf16 results.  `workspace` is caller-owned, 16-byte aligned, gf_flash_attn_bwd_workspace_bytes(q_len, kv_len, heads) bytes:
- *   rowsum(dout*o) [q_len, heads] fp32 and the dK/dV kernel's per-granule (-lse | -delta) records; scratch, its contents need
- *   not survive the call.
+ *   rowsum(dout*o) [q_len, heads] fp32, the dK/dV kernel's per-granule (-lse | -delta) records and (C ABI 13) the pre-scaled
+ *   copy Q' = bf16(q * scale * log2 e) [q_len, heads*128] — the operand the forward kernel computed its scores and lse from;
+ *   scratch, its contents need not survive the call.  The log-sum-exp must come from gf_flash_attn_fwd_lse (or from
+ *   gf_flash_attn_fwd_vt32 / _vt with a non-NULL lse) with the same `scale`.
  *   dk and dv may be NULL together: only dq is computed (a frozen block's cross-attention: nobody reads the context gradients).
  */
 GF_API int gf_flash_attn_fwd_lse(const void* q, const void* k, const void* v, void* o, float* lse,
