@@ -145,8 +145,8 @@ class CannyDetector:
     def __init__(self, device="cuda"):
         self.device = torch.device(device)
 
-    def edge_state(self, frames, low_threshold=100, high_threshold=200, detect_resolution=512):
-        """-> (state uint8 [T,H',W'] with 2 on edge pixels, (H', W'))."""
+    def resize(self, frames, detect_resolution=512):
+        """controlnet_aux `resize_image`: uint8 [T,H,W,3] -> uint8 [T,H',W',3] (Lanczos-4 when enlarging, area when shrinking)."""
         x = _u8_frames(frames, self.device)
         if not x.is_cuda:
             raise GoalForceError("CannyDetector: no CPU fallback exists — frames must go to a HIP device")
@@ -155,26 +155,37 @@ class CannyDetector:
         lib = _lib.load()
         st = torch.cuda.current_stream(x.device).cuda_stream
         if (Hd, Wd) == (H, W):
-            img = x
-        elif k > 1:
+            return x
+        img = torch.empty((T, Hd, Wd, 3), dtype=torch.uint8, device=x.device)
+        if k > 1:
             xo, xc = lanczos4_tables(W, Wd)
             yo, yc = lanczos4_tables(H, Hd)
-            img = torch.empty((T, Hd, Wd, 3), dtype=torch.uint8, device=x.device)
             tabs = [_dev(a, x.device) for a in (xo, xc, yo, yc)]
             _lib.check(lib.gf_resize_lanczos4_u8(x.data_ptr(), img.data_ptr(), *(t.data_ptr() for t in tabs), T, H, W, Hd, Wd, st),
                        "gf_resize_lanczos4_u8")
         else:
             tabs = [_dev(a, x.device) for a in (*_area_or_identity(W, Wd), *_area_or_identity(H, Hd))]
-            img = torch.empty((T, Hd, Wd, 3), dtype=torch.uint8, device=x.device)
             _lib.check(lib.gf_resize_area_u8(x.data_ptr(), img.data_ptr(), *(t.data_ptr() for t in tabs), T, H, W, Hd, Wd, 0, st),
                        "gf_resize_area_u8")
-        state = torch.empty((T, Hd, Wd), dtype=torch.uint8, device=x.device)
-        ws = torch.empty((2, T * Hd * Wd), dtype=torch.int32, device=x.device)
-        flag = torch.zeros((1,), dtype=torch.int32, device=x.device)
-        _lib.check(lib.gf_canny_u8(img.data_ptr(), state.data_ptr(), ws[0].data_ptr(), ws[1].data_ptr(), flag.data_ptr(), T, Hd, Wd,
-                                   int(math.floor(low_threshold)), int(math.floor(high_threshold)), self.MAX_HYSTERESIS_PASSES, st),
+        return img
+
+    def canny(self, img, low_threshold=100, high_threshold=200):
+        """cv2.Canny on a batch: uint8 [T,H,W,3] on the device -> state uint8 [T,H,W] (2 on edge pixels)."""
+        img = _u8_frames(img, self.device)
+        T, Hd, Wd, _ = img.shape
+        st = torch.cuda.current_stream(img.device).cuda_stream
+        state = torch.empty((T, Hd, Wd), dtype=torch.uint8, device=img.device)
+        ws = torch.empty((2, T * Hd * Wd), dtype=torch.int32, device=img.device)
+        flag = torch.zeros((1,), dtype=torch.int32, device=img.device)
+        _lib.check(_lib.load().gf_canny_u8(img.data_ptr(), state.data_ptr(), ws[0].data_ptr(), ws[1].data_ptr(), flag.data_ptr(), T, Hd, Wd,
+                                           int(math.floor(low_threshold)), int(math.floor(high_threshold)), self.MAX_HYSTERESIS_PASSES, st),
                    "gf_canny_u8")
-        return state, (Hd, Wd)
+        return state
+
+    def edge_state(self, frames, low_threshold=100, high_threshold=200, detect_resolution=512):
+        """-> (state uint8 [T,H',W'] with 2 on edge pixels, (H', W'))."""
+        img = self.resize(frames, detect_resolution)
+        return self.canny(img, low_threshold, high_threshold), (img.shape[1], img.shape[2])
 
     def __call__(self, frames, low_threshold=100, high_threshold=200, detect_resolution=512, image_resolution=512):
         if image_resolution != detect_resolution:

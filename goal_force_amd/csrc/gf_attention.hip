@@ -48,6 +48,9 @@
 #ifndef GF_K3_WHATIF
 #define GF_K3_WHATIF 0   // timing-only variants of kernel 3's steady phase (tools/attn_ab.py); 0 in the shipped library
 #endif
+#ifndef GF_K3_MAP
+#define GF_K3_MAP 0      // kernel 3: workgroup -> (head, query block) order; 1 = plain head-major (fabric-traffic A/B)
+#endif
 #ifndef GF_K3_ORMAX
 #define GF_K3_ORMAX 0    // kernel 3: the steady phase's running-maximum watch on the packed P instead of the fp32 scores (see `phase`)
 #endif
@@ -1012,7 +1015,10 @@ __global__ __launch_bounds__(At3<NQ>::THREADS, (NQ == 2 ? 2 : 1)) void flash_att
     int head, qb0;
     {
         const int pid = blockIdx.x;
-        if ((p.heads & 7) == 0) {
+        // GF_K3_MAP (A/B builds): 0 = XCD-aware (shipped: the 32 CUs of an XCD walk the query blocks of ONE head together, K / V of that
+        // head come from the XCD's L2); 1 = plain head-major order (consecutive workgroups = consecutive query blocks of a head, dealt
+        // round-robin over the 8 XCDs: every XCD streams every head's K / V -> ~8 x the fabric traffic; how much time do fabric bytes cost?)
+        if ((p.heads & 7) == 0 && GF_K3_MAP == 0) {
             const int xcd = pid & 7, idx = pid >> 3;
             head = xcd + 8 * (idx / p.n_qblocks);
             qb0 = idx % p.n_qblocks;
@@ -1205,7 +1211,12 @@ __global__ __launch_bounds__(At3<NQ>::THREADS, (NQ == 2 ? 2 : 1)) void flash_att
         float over = CINIT ? mx[0] : (mx[0] - m_run[0]) * c;        // how far any score of the tile is above its running maximum
 #pragma unroll
         for (int qb = 1; qb < NQ; ++qb) over = fmaxf(over, CINIT ? mx[qb] : (mx[qb] - m_run[qb]) * c);
-        const bool quiet = __all(over <= 6.0f);
+        // GF_K3_ORMAX: the watch on the packed P can only tell "some P >= 2", i.e. a score >= 1 above the stabiliser the scores are
+        // kept relative to.  To rescale as lazily as the shipped kernel (which lets scores rise 6 above the last maximum), the
+        // stabiliser of a row that moved is set HEAD = 5 ABOVE its new maximum: P <= 2^-5 right after an update, and the next
+        // update comes when a score is 6 above that maximum — the same laziness, a different (power-of-two) scale of P, l and O.
+        constexpr float QUIET = GF_K3_ORMAX ? 1.0f : 6.0f, HEAD = GF_K3_ORMAX ? 5.0f : 0.0f;
+        const bool quiet = __all(over <= QUIET);
         if (first || !quiet) {
 #pragma unroll
             for (int qb = 0; qb < NQ; ++qb) {
@@ -1215,6 +1226,7 @@ __global__ __launch_bounds__(At3<NQ>::THREADS, (NQ == 2 ? 2 : 1)) void flash_att
                 float alpha;
                 if constexpr (CINIT) {
                     if (!first) d = fmaxf(d, 0.f);       // the maximum never moves down (the first tile sets it, whatever its sign)
+                    if constexpr (GF_K3_ORMAX != 0) d = (first || d > QUIET) ? d + HEAD : d;
                     const float m_new = d - negm[qb][0];     // CINIT: the running maximum is kept as its negative splat only
                     alpha = __builtin_amdgcn_exp2f(-d);
 #pragma unroll

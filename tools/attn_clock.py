@@ -66,7 +66,7 @@ def run():
     print(f"{'zeros' if '--zeros' in sys.argv else 'random'} data: launch {ms:.3f} ms = {4.0 * s * s * D / ms / 1e9:.1f} TFLOP/s; in-kernel clock median "
           f"{med:.3f} GHz (p5 {float(clk.quantile(0.05)):.3f}, p95 {float(clk.quantile(0.95)):.3f}; {int(ok.sum())} workgroups, steady loop "
           f"median {float(loop_us.median()):.0f} us each); matrix pipe busy at that clock: {mfma_cycles / (ms * 1e-3 * med * 1e9) * 100:.1f} % "
-          f"(bf16 dense peak at that clock: {256 * 4 * 16384 / 16 * med / 1e6:.0f} TFLOP/s)")
+          f"(bf16 dense peak at that clock: {256 * 4 * 16384 / 16 * med * 1e9 / 1e12:.0f} TFLOP/s)")
 
 
 if __name__ == "__main__":

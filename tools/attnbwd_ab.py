@@ -14,9 +14,7 @@ sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, "build", "ab")
 VARIANTS = {      # KV16_WHATIF bits (32-key kernel only; timing only, wrong results): 1 no DMA in the loop, 4 no P hand-off, 8 no barrier, 16 no counted wait, 32 L2-hot DMA
     "base": [],
-    "kv32": ["-DKV_USE_48=0"],
-    "kv32_w8_nobarrier": ["-DKV_USE_48=0", "-DKV16_WHATIF=8"],
-    "dq_nointerleave": ["-DDQ16_NO_INTERLEAVE=1"],
+    "noqscale": ["-DGF_BWD_QSCALE=0"],      # round 3's arithmetic: P rebuilt from the unscaled Q with an fma per score
 }
 for spec in os.environ.get("BWD_AB_EXTRA", "").split(";"):     # name:flag,flag
     if spec:
@@ -28,7 +26,8 @@ def build():
     os.makedirs(OUT, exist_ok=True)
     src = [os.path.join(ROOT, "goal_force_amd", "csrc", f) for f in ("gf_attention_bwd.hip", "gf_abi.hip")]
     for old in os.listdir(OUT):
-        os.remove(os.path.join(OUT, old))
+        if old.startswith("libbwd_"):
+            os.remove(os.path.join(OUT, old))
     for name, flags in VARIANTS.items():
         subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DGF_BUILD", "-fno-slp-vectorize",
                         f"-I{ROOT}/include", f"-I{ROOT}/goal_force_amd/csrc", "-o", os.path.join(OUT, f"libbwd_{name}.so")] + flags + src,

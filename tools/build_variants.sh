@@ -6,7 +6,8 @@
 set -e
 cd "$(dirname "$0")/.."
 make -C goal_force_amd/csrc -j4 > /dev/null
-python3 tools/attn_ab.py --build base: ormax:-DGF_K3_ORMAX=1
+python3 tools/attn_ab.py --build base: ormax:-DGF_K3_ORMAX=1 naivemap:-DGF_K3_MAP=1
+python3 tools/attnbwd_ab.py --build
 python3 tools/attn_clock.py --build
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Igoal_force_amd/csrc -Wall -Wno-unused-function -fvisibility=hidden -DGF_BUILD"
 /opt/rocm/bin/hipcc $F -mllvm -amdgpu-mfma-vgpr-form -DGF_K3_ORMAX=1 -c goal_force_amd/csrc/gf_attention.hip -o build/ab/gf_attention_ormax.o

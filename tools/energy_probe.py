@@ -29,8 +29,8 @@ def smi():
     return (float(p.group(1)) if p else None), (float(c.group(1)) if c else None)
 
 
-def run_variant(v, seconds, data="random"):
-    proc = subprocess.Popen([EXE, str(v), str(seconds)] + (["zeros"] if data == "zeros" else []), stdout=subprocess.PIPE, text=True)
+def run_variant(v, seconds, data="random", one_wave=False):
+    proc = subprocess.Popen([EXE, str(v), str(seconds), data] + (["1"] if one_wave else []), stdout=subprocess.PIPE, text=True)
     samples = []
     t0 = time.time()
     while proc.poll() is None:
@@ -54,11 +54,13 @@ def main():
     print(f"package power limit: {cap_w} W; {seconds:.0f} s per variant, random operands, 2 waves per SIMD on every CU\n")
     recs = [run_variant(i, seconds) for i in range(len(names))]
     zero = run_variant(0, seconds, "zeros")
+    extra = [zero, run_variant(7, seconds, "zeros"), run_variant(0, seconds, one_wave=True), run_variant(7, seconds, one_wave=True),
+             run_variant(9, seconds, one_wave=True), run_variant(9, seconds, "zeros", one_wave=True)]
     print("| variant (per 32 MFMAs and wave) | TFLOP/s | power W | sclk MHz | nJ per MFMA slot |\n|---|---|---|---|---|")
-    for r in recs + [zero]:
+    for r in recs + extra:
         p = r["power_w"] or cap_w
         r["nj_slot"] = p * r["seconds"] / r["mfma_slots"] * 1e9
-        print(f"| {r['name']}{' [ZERO operands]' if r['data'] == 'zeros' else ''} | {r['tflops']:.0f} | {r['power_w'] and round(r['power_w'])} | "
+        print(f"| {r['name']}{' [ZERO operands]' if r['data'] == 'zeros' else ''}{' [ONE wave per SIMD]' if r.get('waves_per_simd') == 1 else ''} | {r['tflops']:.0f} | {r['power_w'] and round(r['power_w'])} | "
               f"{r['sclk_mhz'] and round(r['sclk_mhz'])} | {r['nj_slot']:.2f} |")
     e = {r["variant"]: r["nj_slot"] for r in recs}
     per = {"v_mfma_f32_16x16x32_bf16": e[0], "ds_read_b128 (at 1 per 2 MFMAs)": (e[1] - e[0]) * 2, "ds_read_b128 (at 1 per 4 MFMAs)": (e[2] - e[0]) * 4,
@@ -74,7 +76,7 @@ def main():
     for name, parts, meas in (("kernel 3 (max3, 1 read per 2)", parts3, e[7]), ("ORMAX (or3, 1 read per 2)", partso, e[8]),
                               ("64 query rows per wave (max3, 1 read per 4)", parts4, e[9])):
         print(f"| {name} | {parts:.2f} | {meas:.2f} | {p * 16384 / meas / 1e3:.0f} ({p * 16384 / meas / 1e3 * 32 / 34:.0f}) |")
-    print("\n" + json.dumps({"cap_w": cap_w, "variants": recs, "zero": zero, "per_instruction_nj": per}))
+    print("\n" + json.dumps({"cap_w": cap_w, "variants": recs, "extra": extra, "per_instruction_nj": per}))
 
 
 if __name__ == "__main__":

@@ -5,7 +5,7 @@
 // each pinned as inline asm.  No barriers, no staging, no memory dependences.  One variant runs for a given number of seconds so
 // that tools/energy_probe.py can read package power and clock beside it (rocm-smi); with the chip AT its power limit,
 // energy per MFMA slot = power x time / slots, and differences between variants are the energy of the added instructions.
-//   hipcc --offload-arch=gfx950 -O3 -o build/attn_energy tools/probes/attn_energy.hip;  ./build/attn_energy <variant> <seconds> [zeros]
+//   hipcc --offload-arch=gfx950 -O3 -o build/attn_energy tools/probes/attn_energy.hip;  ./build/attn_energy <variant> <seconds> [zeros|random] [1 = one wave per SIMD]
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
@@ -122,6 +122,7 @@ int main(int argc, char** argv) {
     const int v = atoi(argv[1]);
     const double seconds = atof(argv[2]);
     const bool zeros = argc > 3 && !strcmp(argv[3], "zeros");
+    const bool one_wave = argc > 4 && !strcmp(argv[4], "1");      // 256-thread workgroups: ONE wave per SIMD
     if (v < 0 || v >= nv) return 2;
     const int n = 1 << 16;
     std::vector<unsigned short> h(n * 8);
@@ -138,7 +139,7 @@ int main(int argc, char** argv) {
     }
     if (zeros) hipMemset(d, 0, n * 16);
     else hipMemcpy(d, h.data(), n * 16, hipMemcpyHostToDevice);
-    const int iters = 20000, blocks = 256, threads = 512;
+    const int iters = 20000, blocks = 256, threads = one_wave ? 256 : 512;
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
@@ -157,9 +158,9 @@ int main(int argc, char** argv) {
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
     const double slots = (double)launches * blocks * (threads / 64) * iters * 32.0;       // wave-level MFMA slots executed
-    printf("{\"variant\": %d, \"name\": \"%s\", \"data\": \"%s\", \"seconds\": %.3f, \"mfma_slots\": %.6e, \"tflops\": %.1f, "
+    printf("{\"variant\": %d, \"waves_per_simd\": %d, \"name\": \"%s\", \"data\": \"%s\", \"seconds\": %.3f, \"mfma_slots\": %.6e, \"tflops\": %.1f, "
            "\"per32\": {\"ds_read_b128\": %d, \"v_exp_f32\": %d, \"v_cvt_pk_bf16_f32\": %d, \"v_max3_f32\": %d, \"v_or3_b32\": %d}}\n",
-           v, variants[v].name, zeros ? "zeros" : "random", ms / 1e3, slots, slots * 16384.0 / (ms * 1e-3) / 1e12, variants[v].rd,
+           v, one_wave ? 1 : 2, variants[v].name, zeros ? "zeros" : "random", ms / 1e3, slots, slots * 16384.0 / (ms * 1e-3) / 1e12, variants[v].rd,
            variants[v].ex, variants[v].cv, variants[v].mx, variants[v].orr);
     return 0;
 }

@@ -30,4 +30,11 @@ for sh in dd ffn1 ffn2; do
   done
   pass gemm_${sh}_SQ "$SQ1" "gemm_a4" -- gemm --only $sh --iters 2
 done
+# ---- item 5 of the round-3 verdict: fabric bytes vs tile-group shape (row tiles x column tiles of the 32 workgroups an XCD runs at a time)
+for g in 2 4 16; do
+  export GF_A4_GROUP_M=$g
+  pass gemm_ffn1_group${g}_FETCH_SIZE FETCH_SIZE "gemm_a4" -- gemm --only ffn1 --iters 2
+  pass gemm_ffn2_group${g}_FETCH_SIZE FETCH_SIZE "gemm_a4" -- gemm --only ffn2 --iters 2
+  unset GF_A4_GROUP_M
+done
 ls -la $OUT
