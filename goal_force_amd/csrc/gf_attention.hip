@@ -52,8 +52,8 @@
 #define GF_K3_MAP 0      // kernel 3: workgroup -> (head, query block) order; 1 = plain head-major (fabric-traffic A/B)
 #endif
 #ifndef GF_K3_ORMAX
-#define GF_K3_ORMAX 0    // kernel 3: the steady phase's running-maximum watch on the packed P instead of the fp32 scores (see `phase`)
-#endif
+#define GF_K3_ORMAX 1    // kernel 3: the steady phase's running-maximum watch on the packed P instead of the fp32 scores (see `phase`);
+#endif                   // round 4: +1.0 % in one process against the v_max3 watch (profiles/r04/attn_ab_r04.log), 0 = round 3's kernel
 #ifndef GF_ATTN_BUFFER_DMA
 #define GF_ATTN_BUFFER_DMA 1   // 1: K/V staging by buffer_load ... lds with scalar tile offsets; 0: global_load_lds (A/B builds)
 #endif

@@ -77,19 +77,27 @@ __global__ __launch_bounds__(CN_THREADS) void area_u8_kernel(const unsigned char
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
                     const float s = EDGES ? (px[c] == 2 ? 255.f : 0.f) : (float)px[c];
-                    buf[c] = __fadd_rn(buf[c], __fmul_rn(s, a));          // OpenCV: buf[dx] += S[sx] * alpha (no contraction)
+                    float m = s * a;                                      // OpenCV: buf[dx] += S[sx] * alpha — product and sum round
+                    asm volatile("" : "+v"(m));                           // separately: the empty asm keeps hipcc (-ffp-contract=fast,
+                    buf[c] = buf[c] + m;                                  // which also fuses __fmul_rn / __fadd_rn) from forming an fma
                 }
             }
             const float b = yalpha[jy];
 #pragma unroll
-            for (int c = 0; c < NC; ++c) sum[c] = first ? __fmul_rn(b, buf[c]) : __fadd_rn(sum[c], __fmul_rn(b, buf[c]));
+            for (int c = 0; c < NC; ++c) {
+                float m = b * buf[c];
+                asm volatile("" : "+v"(m));
+                sum[c] = first ? m : sum[c] + m;
+            }
             first = false;
         }
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const int v = clampi((int)__builtin_rintf(sum[c]), 0, 255);                  // saturate_cast<uchar>: cvRound
             if constexpr (EDGES) {
-                const u16 o = f2bf(__fsub_rn(__fdiv_rn((float)v, 127.5f), 1.0f));        // uint8 -> float32 / 127.5 - 1.0 -> bf16
+                float qv = __fdiv_rn((float)v, 127.5f);                                  // uint8 -> float32 / 127.5 - 1.0 -> bf16
+                asm volatile("" : "+v"(qv));
+                const u16 o = f2bf(qv - 1.0f);
                 u16* d = (u16*)dst + i * 3;
                 d[0] = o;
                 d[1] = o;

@@ -132,11 +132,11 @@ def _frames(seed, t, h, w):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(2, 480, 832), (1, 600, 1000), (1, 512, 896), (2, 123, 211)])
+@pytest.mark.parametrize("shape", [(2, 480, 832), (1, 512, 896), (2, 123, 211), (1, 448, 960)])
 def test_hip_control_video_equals_oracle(shape):
     """The whole `_generate_control_video` (resize -> Canny -> area resize back -> x / 127.5 - 1 -> bf16) on the HIP kernels against
-    the numpy oracle, all frames of the clip in one batch: the production size (Lanczos enlarging), a larger frame (area shrinking),
-    a frame already at the detector's size (no resize either way) and a ragged small one."""
+    the numpy oracle, all frames of the clip in one batch: the production size (Lanczos enlarging, area back), a frame already at
+    the detector's size (no resize either way), a ragged small one and another aspect ratio."""
     from goal_force_amd.canny import CannyDetector, ControlSignalDataset_CannyEdge as DS
     fr = _frames(sum(shape), *shape)
     ds = DS(device="cuda")
@@ -147,6 +147,19 @@ def test_hip_control_video_equals_oracle(shape):
     assert 0.002 < float((want.float() > 0).float().mean()) < 0.5, "the case must contain edges"
     det = CannyDetector("cuda")(fr[:1])
     assert torch.equal(det.cpu(), torch.from_numpy(co.canny_detector(fr[0]))[None])
+
+
+@pytest.mark.gpu
+def test_hip_detector_shrinking_path_and_refused_enlarging_area():
+    """A frame larger than the detector's 512 (600 x 1000 -> 512 x 832 by INTER_AREA): detector output == oracle.  The dataset would
+    then ENLARGE the map back with INTER_AREA, where OpenCV switches to a bilinear variant that is not restated: refused loudly
+    (the reference's clips are 480 x 832, DS:563)."""
+    from goal_force_amd.canny import CannyDetector, ControlSignalDataset_CannyEdge as DS
+    fr = _frames(5, 1, 600, 1000)
+    got = CannyDetector("cuda")(fr)
+    assert tuple(got.shape) == (1, 512, 832, 3) and torch.equal(got.cpu()[0], torch.from_numpy(co.canny_detector(fr[0])))
+    with pytest.raises(NotImplementedError):
+        DS(device="cuda")._generate_control_video(fr)
 
 
 @pytest.mark.gpu
