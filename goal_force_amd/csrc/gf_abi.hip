@@ -6,7 +6,7 @@
 #include <cstring>
 #include <mutex>
 
-#define GF_ABI_VERSION 13
+#define GF_ABI_VERSION 14
 
 static thread_local char g_err[512] = "";
 

@@ -118,6 +118,8 @@ struct AttnArgs {
     float* lse;         // optional [q_len, heads] fp32: log2-domain log-sum-exp of the scaled scores (training backward)
     const u16* vt;      // kernel 2, VT form: V^T [heads][128][kv_pad] from gf_transpose_v (keys permuted inside 16-groups)
     long kv_pad;
+    float last_key_bias;   // kernel 2 (gf_flash_attn_fwd_lastmult): added to the RAW scores of key kv_len - 1 = log2(multiplicity) / (scale log2 e):
+                           // that key then counts `multiplicity` times in the softmax — a run of identical trailing keys folded into one
 };
 
 __global__ __launch_bounds__(AT_THREADS, 2) void flash_attn_fwd_kernel(const AttnArgs p) {
@@ -713,13 +715,16 @@ __global__ __launch_bounds__(AT2_THREADS, 2) void flash_attn_fwd_kernel2(const A
     };
     auto softmax_plain = [&](auto par_c, int t) {
         constexpr int PAR = decltype(par_c)::value;
-        if (ragged && t == nt - 1) {
+        if ((ragged || p.last_key_bias != 0.f) && t == nt - 1) {
             const int kbase_i = t * KVB + 4 * h;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int key = kbase_i + (e & 3) + 8 * (e >> 2);
                 if (key >= p.kv_len) sc[PAR][0][e] = -INFINITY;
                 if (key + 32 >= p.kv_len) sc[PAR][1][e] = -INFINITY;
+                // the last key stands for `multiplicity` identical keys: exp2(c s + log2 m) = m exp2(c s)
+                if (key == p.kv_len - 1) sc[PAR][0][e] += p.last_key_bias;
+                if (key + 32 == p.kv_len - 1) sc[PAR][1][e] += p.last_key_bias;
             }
         }
         float mx = sc[PAR][0][0];
@@ -1638,7 +1643,7 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const u16* __restrict_
 static int flash_attn_fwd_impl(const void* q, const void* k, const void* v, void* o, float* lse, int64_t q_len, int64_t kv_len,
                                int64_t heads, int64_t head_dim, int64_t q_stride, int64_t k_stride,
                                int64_t v_stride, int64_t o_stride, float scale, void* stream, const void* vt = nullptr,
-                               int64_t kv_pad = 0) {
+                               int64_t kv_pad = 0, float last_key_multiplicity = 1.0f) {
     if (vt) {   // pre-transposed V: v itself is not read
         v = k;
         v_stride = k_stride;
@@ -1693,6 +1698,12 @@ static int flash_attn_fwd_impl(const void* q, const void* k, const void* v, void
     a.lse = lse;
     a.vt = (const u16*)vt;
     a.kv_pad = kv_pad;
+    a.last_key_bias = 0.f;
+    if (last_key_multiplicity != 1.0f) {
+        GF_CHECK_ARG(last_key_multiplicity >= 1.0f && !vt && use_k2 && scale > 0.f,
+                     "gf_flash_attn_fwd_lastmult: multiplicity >= 1, plain-V kernel 2 only (not the V^T form, not GF_ATTN_KERNEL=1)");
+        a.last_key_bias = log2f(last_key_multiplicity) / a.scale_log2e;
+    }
 #if GF_ATTN_STAMP
     a.dbg = g_attn_dbg;
 #else
@@ -1716,6 +1727,13 @@ extern "C" GF_API int gf_flash_attn_fwd(const void* q, const void* k, const void
                                  int64_t v_stride, int64_t o_stride, float scale, void* stream) {
     return flash_attn_fwd_impl(q, k, v, o, nullptr, q_len, kv_len, heads, head_dim, q_stride, k_stride, v_stride, o_stride, scale,
                                stream);
+}
+
+extern "C" GF_API int gf_flash_attn_fwd_lastmult(const void* q, const void* k, const void* v, void* o, int64_t q_len, int64_t kv_len,
+                                                  int64_t heads, int64_t head_dim, int64_t q_stride, int64_t k_stride, int64_t v_stride,
+                                                  int64_t o_stride, float scale, float last_key_multiplicity, void* stream) {
+    return flash_attn_fwd_impl(q, k, v, o, nullptr, q_len, kv_len, heads, head_dim, q_stride, k_stride, v_stride, o_stride, scale,
+                               stream, nullptr, 0, last_key_multiplicity);
 }
 
 extern "C" GF_API int gf_flash_attn_fwd_lse(const void* q, const void* k, const void* v, void* o, float* lse, int64_t q_len,
@@ -1810,6 +1828,7 @@ extern "C" GF_API int gf_flash_attn_fwd_vt32(const void* q, const void* k, const
 #else
     a.dbg = nullptr;
 #endif
+    a.last_key_bias = 0.f;
     hipLaunchKernelGGL(flash_attn_fwd_kernel3<GF_K3_NQ>, dim3((unsigned)(a.n_qblocks * a.heads)), dim3(At3<GF_K3_NQ>::THREADS), AT3_LDS,
                        (hipStream_t)stream, a);
     GF_CHECK_LAUNCH("gf_flash_attn_fwd_vt32");

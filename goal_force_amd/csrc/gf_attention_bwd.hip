@@ -405,14 +405,15 @@ struct Bwd16Args {
     const u16* qs;       // GF_BWD_QSCALE: Q' = bf16(Q * scale * log2 e) [q_len, heads * 128] — the forward's own operand (below)
 };
 
-// GF_BWD_QSCALE (round 4): the forward kernel multiplies Q by scale * log2(e) ONCE, rounds to bf16, and takes its scores S' = Q' K^T
-// straight in the exp2 domain; the log-sum-exp it returns belongs to THOSE scores.  The backward kernels used to rebuild
-// P = exp2(c * (Q K^T) - lse) from the unscaled Q — one fma per score, and a P that differs from the forward's by the rounding of Q'.
-// With the same Q' (a 0.67 GB pass, 0.13 ms at S = 32760; a copy in the workspace, because the dK/dV kernel streams Q through LDS)
-// the S chains START from -lse (the MFMA's C operand) and leave the matrix pipe as the exponent: no fma per score, and P is the
-// forward's P bit for bit.  dK = scale * dS^T Q = dS^T Q' / log2(e): the dK/dV epilogue multiplies by ln 2 instead of by scale.
+// GF_BWD_QSCALE (round 4, measured and NOT shipped: default 0): the forward kernel multiplies Q by scale * log2(e) once, rounds to
+// bf16, and takes its scores S' = Q' K^T straight in the exp2 domain.  With the same Q' (a 0.67 GB pass, 0.13 ms at S = 32760; a copy
+// in the workspace, because the dK/dV kernel streams Q through LDS) the backward's S chains can START from -lse (the MFMA's C
+// operand) and leave the matrix pipe as the exponent — no fma per score — and dK = dS^T Q' ln 2.  One process, S = 32760 x 40 heads
+// (profiles/r04/attnbwd_ab_qscale.log): 53.9 against 55.0 ms (-2.1 %).  But against fp32 autograd the error of dQ rises from
+// 2.4e-3 to 3.0e-3 (+25 %: the rounding of Q' enters every score; tests/test_training_gpu.py), 335 MB of workspace are added, and
+// the kernel is 1 % of a training step faster: the unscaled-Q arithmetic of round 3 stays the default.
 #ifndef GF_BWD_QSCALE
-#define GF_BWD_QSCALE 1
+#define GF_BWD_QSCALE 0
 #endif
 __global__ __launch_bounds__(256) void attn_bwd_qscale_kernel(const u16* __restrict__ q, u16* __restrict__ qs, long rows, int hd_all,
                                                               long q_stride, float c) {

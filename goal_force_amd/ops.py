@@ -298,9 +298,10 @@ def linear_vt32_fp8(x8, x_scale, w8, bias):
     return vt
 
 
-def flash_attn(q, k, v, num_heads, out=None, scale=None, vt=None):
+def flash_attn(q, k, v, num_heads, out=None, scale=None, vt=None, last_key_mult=1):
     """softmax(q k^T / sqrt(d)) v per head; q [Sq, H*128], k/v [Skv, H*128] (row-strided views OK).  `vt` (instead of v): the
-    V^T operand linear_vt32 produced for these keys."""
+    V^T operand linear_vt32 produced for these keys.  `last_key_mult` = m > 1: the last key counts m times (a run of m identical
+    trailing keys folded into one: gf_flash_attn_fwd_lastmult; key lengths below the V^T threshold only)."""
     for n, t in (("q", q), ("k", k)) + ((("v", v),) if vt is None else ()):
         _req(t, f"flash_attn.{n}")
         if t.dim() != 2 or t.stride(1) != 1:
@@ -322,6 +323,8 @@ def flash_attn(q, k, v, num_heads, out=None, scale=None, vt=None):
         e0.record()
     lib = _lib.load()
     kv_pad = -(-skv // 64) * 64
+    if last_key_mult != 1 and (vt is not None or skv >= VT_MIN_KV):
+        raise GoalForceError("flash_attn: last_key_mult is for short key sequences (the text context), not the V^T path")
     if skv >= VT_MIN_KV and head_dim == 128 and num_heads * 128 * kv_pad < 2 ** 31:
         # long key sequences (the DiT self-attention): hand V over pre-transposed — one LDS read per PV MFMA instead of two;
         # the transpose (0.7 % of the attention's time at S=32760) is inside the timed region
@@ -335,6 +338,10 @@ def flash_attn(q, k, v, num_heads, out=None, scale=None, vt=None):
             raise GoalForceError("flash_attn.vt: buffer smaller than heads*128*kv_pad")
         _lib.check(fa(_ptr(q), _ptr(k), _ptr(vt), _ptr(out), None, sq, skv, kv_pad, num_heads, head_dim,
                       q.stride(0), k.stride(0), out.stride(0), float(scale), _stream(q)), "gf_flash_attn_fwd_vt")
+    elif last_key_mult != 1:
+        _lib.check(lib.gf_flash_attn_fwd_lastmult(_ptr(q), _ptr(k), _ptr(v), _ptr(out), sq, skv, num_heads, head_dim, q.stride(0),
+                                                  k.stride(0), v.stride(0), out.stride(0), float(scale), float(last_key_mult), _stream(q)),
+                   "gf_flash_attn_fwd_lastmult")
     else:
         _lib.check(lib.gf_flash_attn_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), sq, skv, num_heads, head_dim,
                                          q.stride(0), k.stride(0), v.stride(0), out.stride(0), float(scale),

@@ -252,7 +252,7 @@ class DiTBlockFn(torch.autograd.Function):
         ctx.param_needs = [p.requires_grad for p in params]
         keep = ({"wide": True} if _wide_fits(x2) else {}) if KEEP_ATTENTION else None
         with torch.no_grad():
-            out = block(x2, ctx2, t_mod, rope, keep=keep)
+            out = block(x2, ctx2, t_mod, rope, keep=keep, fold_pad_keys=False)   # the backward differentiates the unfolded graph
         # kept for the backward besides the block's inputs: the self-attention output (S x D bf16) and its log-sum-exp
         # (S x heads fp32) — 0.34 GB per block at 32760 tokens against 18.6 ms of attention per block not run again.
         # What the forward actually stored decides the level (a forward that took a memo / sharded path stores less):

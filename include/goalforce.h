@@ -169,6 +169,15 @@ GF_API int gf_flash_attn_fwd_vt32(const void* q, const void* k, const void* vt, 
 GF_API int gf_linear_vt32(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias, void* vt,
                           int64_t kv_len, int64_t kv_pad, int64_t N, int64_t K, void* stream);
 
+/* gf_flash_attn_fwd_lastmult — gf_flash_attn_fwd in which the LAST key (row kv_len - 1 of k / v) counts `last_key_multiplicity`
+ * times in the softmax: softmax over [k_0 .. k_{n-2}, k_{n-1} x m] evaluated on n keys (the key's score gets + log2 m in the exp2
+ * domain).  Cross-attention over a prompt whose padded tail is a run of identical context rows (wan_prompter.py:99-109 zeroes the
+ * text-encoder output past the prompt: every padded row is text_embedding(0), so its K and V rows are identical, DIT:177-186) is
+ * the same function of q evaluated on the distinct keys only.  Key lengths below the V^T threshold only (the 512-token context). */
+GF_API int gf_flash_attn_fwd_lastmult(const void* q, const void* k, const void* v, void* o, int64_t q_len, int64_t kv_len,
+                                      int64_t heads, int64_t head_dim, int64_t q_stride, int64_t k_stride, int64_t v_stride,
+                                      int64_t o_stride, float scale, float last_key_multiplicity, void* stream);
+
 /* ------------------------------------------------------------------------
  * Training (ControlNet training step): training_loss (GF:180-193) calls loss.backward() through
  * F.scaled_dot_product_attention (DIT:28-61) in every block.
@@ -176,10 +185,9 @@ GF_API int gf_linear_vt32(const void* x, int64_t ldx, const void* w, int64_t ldw
  *   of the scaled scores: softmax row = exp2(scale*log2(e)*S - lse).
  * gf_flash_attn_bwd — dq, dk, dv from (q, k, v, o, dout, lse).  Same layouts / strides as the forward; fp32 accumulation,
  *   bf16 results.  `workspace` is caller-owned, 16-byte aligned, gf_flash_attn_bwd_workspace_bytes(q_len, kv_len, heads) bytes:
- *   rowsum(dout*o) [q_len, heads] fp32, the dK/dV kernel's per-granule (-lse | -delta) records and (C ABI 13) the pre-scaled
- *   copy Q' = bf16(q * scale * log2 e) [q_len, heads*128] — the operand the forward kernel computed its scores and lse from;
- *   scratch, its contents need not survive the call.  The log-sum-exp must come from gf_flash_attn_fwd_lse (or from
- *   gf_flash_attn_fwd_vt32 / _vt with a non-NULL lse) with the same `scale`.
+ *   rowsum(dout*o) [q_len, heads] fp32 and the dK/dV kernel's per-granule (-lse | -delta) records (a -DGF_BWD_QSCALE=1 build adds
+ *   a pre-scaled copy of q: always size the buffer with the function); scratch, its contents need not survive the call.  The
+ *   log-sum-exp must come from gf_flash_attn_fwd_lse (or gf_flash_attn_fwd_vt32 / _vt with a non-NULL lse) with the same `scale`.
  *   dk and dv may be NULL together: only dq is computed (a frozen block's cross-attention: nobody reads the context gradients).
  */
 GF_API int gf_flash_attn_fwd_lse(const void* q, const void* k, const void* v, void* o, float* lse,

@@ -243,6 +243,59 @@ def test_flash_attn_lse_same_on_both_v_paths(ops, monkeypatch):
     assert float((l1 - ref).abs().max()) < 2e-2 and float((l3 - ref).abs().max()) < 2e-2
 
 
+def test_flash_attn_last_key_multiplicity_equals_repeated_keys(ops):
+    """gf_flash_attn_fwd_lastmult: n distinct keys + the last one counting m times == attention over the n - 1 + m keys written
+    out (the padded tail of a prompt: identical rows) — against the fp64 formula on the written-out keys and against the kernel on
+    them; 41 keys x 472 (the 40-token prompt of the bench), a key count that fills a tile exactly, two tiles, and m = 1."""
+    g = torch.Generator().manual_seed(77)
+    heads = 3
+    for sq, n, m in ((300, 41, 472), (64, 64, 9), (129, 100, 412), (50, 7, 1)):
+        q = torch.randn(sq, heads * 128, generator=g).to(BF)
+        k = torch.randn(n, heads * 128, generator=g).to(BF)
+        v = torch.randn(n, heads * 128, generator=g).to(BF)
+        kk = torch.cat([k, k[-1:].expand(m - 1, -1)]) if m > 1 else k
+        vv = torch.cat([v, v[-1:].expand(m - 1, -1)]) if m > 1 else v
+        ref = wo.attention_fp64(q[None], kk[None], vv[None], heads)[0]
+        got = ops.flash_attn(dev(q), dev(k), dev(v), heads, last_key_mult=m).cpu()
+        full = ops.flash_attn(dev(q), dev(kk.contiguous()), dev(vv.contiguous()), heads).cpu()
+        e, e_full = rel_l2(got.double(), ref), rel_l2(full.double(), ref)
+        assert e < 4e-3 and e <= 1.2 * e_full + 1e-4, f"n={n} m={m}: folded {e:.3e}, written out {e_full:.3e}"
+        assert rel_l2(got.float(), full.float()) < 2e-3
+    with pytest.raises(Exception):
+        ops.flash_attn(dev(q), dev(torch.randn(4096, heads * 128).to(BF)), dev(torch.randn(4096, heads * 128).to(BF)), heads, last_key_mult=3)
+
+
+def test_cross_attention_folds_the_padded_context_rows(ops):
+    """CrossAttention.context_kv detects the run of identical rows that ends a prompter-padded context (wan_prompter.py:99-109) and
+    attends n + 1 keys with multiplicity instead of 512: same result as the unfolded module (GF_FOLD_PAD_KEYS = 0) within bf16
+    rounding; a context without such a run, and the training forward, are attended in full."""
+    from goal_force_amd import dit
+    g = torch.Generator().manual_seed(5)
+    ca = dit.CrossAttention(256, 2).to(BF).cuda()
+    for p_ in ca.parameters():
+        p_.data.copy_((torch.randn(p_.shape, generator=g) * (0.06 if p_.dim() == 2 else 0.02)).to(BF))
+    ca.norm_q.weight.data.fill_(1.0)
+    ca.norm_k.weight.data.fill_(1.0)
+    x = torch.randn(1, 333, 256, generator=g).to(BF).cuda()
+    ctx = torch.randn(1, 512, 256, generator=g).to(BF)
+    ctx[:, 40:] = ctx[:, 40:41]                               # rows 40 .. 511 identical (text_embedding of zeros)
+    ctx = ctx.cuda()
+    assert dit.pad_run(ctx[0]) == 40 and dit.pad_run(torch.randn(9, 8).cuda()) == 8
+    k, v, m = ca.context_kv(ctx[0])
+    assert m == 472 and k.shape[0] == 41
+    folded = ca(x, ctx)
+    dit._FOLD_PAD_KEYS[0] = False
+    try:
+        k2, v2, m2 = ca.context_kv(ctx[0])
+        assert m2 == 1 and k2.shape[0] == 512 and torch.equal(k2[:41], k) and torch.equal(v2[40], v2[511])
+        full = ca(x, ctx)
+    finally:
+        dit._FOLD_PAD_KEYS[0] = True
+    assert rel_l2(folded.float().cpu(), full.float().cpu()) < 2e-3
+    rnd = torch.randn(1, 64, 256, generator=g).to(BF).cuda()
+    assert ca.context_kv(rnd[0])[2] == 1 and ca.context_kv(ctx[0], fold=False)[2] == 1
+
+
 @pytest.mark.parametrize("sq,skv,heads", [(300, 2100, 3), (1000, 4100, 2), (257, 2048, 1), (33, 2368, 4), (512, 2049, 2)])
 def test_flash_attn_kernel3_vs_fp64(ops, sq, skv, heads):
     """Kernel 3 (the self-attention path: key sequences >= 2048) against the full-tensor fp64 oracle: ragged last key tile,

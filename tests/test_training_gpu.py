@@ -57,10 +57,9 @@ def test_flash_attn_backward(sq, skv, heads):
 @pytest.mark.parametrize("sq,skv,heads", [(1000, 777, 8), (2085, 1999, 8), (96, 4000, 3)])
 def test_flash_attn_backward_kernels_agree_with_the_first_kernels(sq, skv, heads):
     """The 16x16x32 kernels (dQ + paired dK/dV, 7 tile products) against the first kernels (GF_ATTN_BWD=v1: 32x32x16, dQ / dV / dK
-    passes) on ragged lengths and the XCD-ordered grid (heads % 8 == 0).  Since round 4 the new kernels rebuild P from the forward's
-    own pre-scaled Q' = bf16(Q * scale * log2 e) (the operand its log-sum-exp belongs to), the first kernels from the unscaled Q:
-    the two differ by the rounding of Q' (~4e-3 on dQ), so the bar between them is 6e-3 — and against the fp32 autograd reference
-    the new kernels must be at least as close as the first ones."""
+    passes): the same per-element arithmetic, another summation order — ragged lengths, the XCD-ordered grid (heads % 8 == 0).
+    And against fp32 autograd the new kernels must be at least as close as the first ones (a -DGF_BWD_QSCALE=1 build, which
+    rebuilds P from the forward's pre-scaled Q', fails this line by 25 % on dQ: why it is not shipped)."""
     from goal_force_amd import ops
     g = torch.Generator().manual_seed(sq + skv)
     q = torch.randn((sq, heads * HD), generator=g).to(BF).cuda()
@@ -75,7 +74,7 @@ def test_flash_attn_backward_kernels_agree_with_the_first_kernels(sq, skv, heads
     for name, a, b, r in zip(("dq", "dk", "dv"), got, want, ref):
         assert torch.isfinite(a.float()).all(), name
         e = rel_l2(a.float().cpu(), b.float().cpu())
-        assert e < 6e-3, f"{name}: rel_l2={e:.3e}"
+        assert e < 3e-3, f"{name}: rel_l2={e:.3e}"
         e_new, e_old = rel_l2(a.float().cpu(), r), rel_l2(b.float().cpu(), r)
         assert e_new < 1e-2 and e_new <= 1.1 * e_old + 2e-4, f"{name}: vs fp32 autograd new {e_new:.3e}, first kernels {e_old:.3e}"
 

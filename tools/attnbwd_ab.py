@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, "build", "ab")
 VARIANTS = {      # KV16_WHATIF bits (32-key kernel only; timing only, wrong results): 1 no DMA in the loop, 4 no P hand-off, 8 no barrier, 16 no counted wait, 32 L2-hot DMA
     "base": [],
-    "noqscale": ["-DGF_BWD_QSCALE=0"],      # round 3's arithmetic: P rebuilt from the unscaled Q with an fma per score
+    "qscale": ["-DGF_BWD_QSCALE=1"],        # round 4's experiment: P rebuilt from the forward's pre-scaled Q' (no fma per score)
 }
 for spec in os.environ.get("BWD_AB_EXTRA", "").split(";"):     # name:flag,flag
     if spec:
