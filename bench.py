@@ -450,6 +450,9 @@ def main():
                        "schedule": f"FlowMatch 50 steps shift 5, boundary 0.875; timed step ids {step_ids} "
                                    f"({n_hi} high-noise with ControlNet, {k - n_hi} low-noise with the all-zero ControlNet2 elided)",
                        "layers": args.layers,
+                       "cross_attention": "the context's padded rows (identical: the prompter zeroes past the 40-token prompt) are attended as "
+                                          "ONE key with multiplicity 472 (41 keys instead of 512; GF_FOLD_PAD_KEYS=0 attends all 512)"
+                                          if os.environ.get("GF_FOLD_PAD_KEYS", "1") != "0" else "all 512 context keys attended",
                        "parallelism": "1 GPU: sequential CFG (block 0's context-independent half shared by the two branches)" if world == 1 else f"{videos} video(s) x CFG pair, RCCL all-gather of noise_pred per step"
                                       + (f"; head-parallel attention degree {args.sp} (RCCL all-to-all over xGMI)" if args.sp > 1 else ""),
                        "vae_decode": "tiled (30,52)/(15,26) decode of [1,16,21,60,104] on the HIP kernels, measured after the "

