@@ -225,3 +225,21 @@ def test_bench_self_launch_reports_a_failed_rank():
                         "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "stopping the other ranks" in r.stderr
     assert not any(l.startswith("{") for l in r.stdout.splitlines())
+
+
+def test_pad_run_finds_the_run_of_identical_rows_that_ends_a_context():
+    """dit.pad_run (the detection behind the cross-attention's pad-key folding): index of the first row of the trailing run of
+    identical rows; L - 1 when the last two rows differ (a run of one: nothing to fold), 0 when all rows are equal."""
+    from goal_force_amd.dit import pad_run
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(12, 8, generator=g).to(BF)
+    assert pad_run(x) == 11
+    y = x.clone()
+    y[5:] = y[5]
+    assert pad_run(y) == 5
+    y[7, 3] += 1                                   # a different row inside the tail: the run starts after it
+    assert pad_run(y) == 8
+    assert pad_run(x[:1]) == 0 and pad_run(x[3:4].expand(6, -1)) == 0
+    z = torch.zeros(512, 16, dtype=BF)
+    z[:40] = torch.randn(40, 16, generator=g).to(BF)
+    assert pad_run(z) == 40                        # the prompter's layout: 40 real rows, 472 zero rows
