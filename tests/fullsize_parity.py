@@ -198,7 +198,15 @@ def decode_u8(pipe, lat):
     return pipe.frames_uint8(frames)
 
 
-def run(layers=40, cn_layers=10, grid=(21, 60, 104), steps=4, fp8=False, taps=(0, 9, 19, 39), q_chunk=2048, decode=True, log=print):
+def _dump(rep, out_path):
+    if out_path:
+        os.makedirs(os.path.dirname(os.path.abspath(out_path)), exist_ok=True)
+        with open(out_path, "w") as f:
+            json.dump(rep, f, indent=1)
+
+
+def run(layers=40, cn_layers=10, grid=(21, 60, 104), steps=4, fp8=False, taps=(0, 9, 19, 39), q_chunk=2048, decode=True, log=print,
+        out_path=None):
     """Returns the report dict (see the module docstring).  grid = latent (f, H/8, W/8)."""
     from goal_force_amd.dit import enable_fp8
     torch.set_grad_enabled(False)
@@ -244,6 +252,7 @@ def run(layers=40, cn_layers=10, grid=(21, 60, 104), steps=4, fp8=False, taps=(0
                                                "hip_bf16_vs_ref_bf16": psnr_u8(u8["hip"], u8["ref"]),
                                                "note": "all three final latents through the SAME tiled HIP VAE decode (random-init VAE) -> uint8 as UTIL:76-91"}
         log(f"  PSNR of decoded frames: {rep['psnr_db_decoded_uint8_frames']}")
+    _dump(rep, out_path)            # the bf16 part is on disk before the fp8 part starts (a long run cut off late keeps it)
     if fp8:
         del b16_tap, o16
         for m in (pipe.dit, pipe.dit2, pipe.controlnet, pipe.controlnet2):
@@ -280,13 +289,10 @@ def main():
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     t0 = time.time()
-    rep = run(a.layers, a.cn_layers, tuple(a.grid), a.steps, a.fp8, q_chunk=a.q_chunk, decode=not a.no_decode)
+    rep = run(a.layers, a.cn_layers, tuple(a.grid), a.steps, a.fp8, q_chunk=a.q_chunk, decode=not a.no_decode, out_path=a.out)
     rep["wall_s"] = time.time() - t0
     print(json.dumps(rep))
-    if a.out:
-        os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
-        with open(a.out, "w") as f:
-            json.dump(rep, f, indent=1)
+    _dump(rep, a.out)
 
 
 if __name__ == "__main__":
