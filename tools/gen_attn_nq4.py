@@ -21,6 +21,11 @@ import sys
 
 OUT = []
 NO_VALU, NO_DMA, NO_READS = (os.environ.get(k, "0") == "1" for k in ("NQ4_NO_VALU", "NQ4_NO_DMA", "NQ4_NO_READS"))   # what-if builds
+# NQ4_STAGE=reg: K / V^T tiles staged through REGISTERS instead of LDS-DMA: 8 plain buffer_load_dwordx4 into spare AGPRs a[208:239]
+# early in the phase, 8 ds_write_b128 from them late in the phase (a lone wave stalls ~100 cycles on every LDS-DMA piece: 27 % of
+# the loop; profiles/r04/attn_nq4_probe.log).  Slots of the loads / of the LDS writes: NQ4_LD0, NQ4_LDS (first, spacing), NQ4_WR0, NQ4_WRS.
+STAGE_REG = os.environ.get("NQ4_STAGE", "dma") == "reg"
+LD0, LDSP, WR0, WRS = (int(os.environ.get(k, d)) for k, d in (("NQ4_LD0", "2"), ("NQ4_LDS", "4"), ("NQ4_WR0", "100"), ("NQ4_WRS", "4")))
 
 
 def emit(s):
@@ -106,6 +111,11 @@ def phase(par):
             emit(frag_read(f, par))
         issued.append(f)
     dma = {10: ("v", 0), 26: ("v", 1), 42: ("v", 2), 58: ("v", 3), 74: ("k", 0), 90: ("k", 1), 106: ("k", 2), 122: ("k", 3)}
+    pieces = [("v", 0), ("v", 1), ("v", 2), ("v", 3), ("k", 0), ("k", 1), ("k", 2), ("k", 3)]
+    loads = {LD0 + LDSP * i: i for i in range(8)} if STAGE_REG else {}
+    writes = {WR0 + WRS * i: i for i in range(8)} if STAGE_REG else {}
+    if STAGE_REG:
+        dma = {}
     for s in range(136):
         for f in reads.get(s, []):
             if f not in issued:
@@ -144,10 +154,25 @@ def phase(par):
                 emit(f"s_add_u32 m0, s54, 0x{par * 16384 + jj * 4096:x}")
                 emit("s_nop 0")
                 emit("buffer_load_dwordx4 %[ksoff], s[60:63], s76 offen lds")
+        if s in loads and not NO_DMA:
+            i = loads[s]
+            which, jj = pieces[i]
+            if which == "v":
+                emit(f"s_add_u32 s76, s71, s{80 + jj}")
+                emit(f"buffer_load_dwordx4 a[{208 + 4 * i}:{211 + 4 * i}], %[vtoff], s[64:67], s76 offen")
+            else:
+                emit(f"s_add_u32 s76, s70, s{72 + jj}")
+                emit(f"buffer_load_dwordx4 a[{208 + 4 * i}:{211 + 4 * i}], %[ksoff], s[60:63], s76 offen")
+        if s in writes and not NO_DMA:
+            i = writes[s]
+            which, jj = pieces[i]
+            emit(f"s_waitcnt vmcnt({7 - i})")          # loads return in order: piece i has landed when 7 - i younger ones are still out
+            emit(f"ds_write_b128 %[wdst], a[{208 + 4 * i}:{211 + 4 * i}] offset:{(32768 if which == 'v' else 0) + par * 16384 + jj * 4096}")
+            issued.append(("w", i))                    # LDS writes count in lgkmcnt with the reads, in order
         if s == 130:
             emit("s_add_u32 s70, s70, %[kstep]")      # next tile's K / V^T source offsets
             emit("s_add_u32 s71, s71, 128")
-    emit("s_waitcnt vmcnt(0)")
+    emit("s_waitcnt vmcnt(0) lgkmcnt(0)" if STAGE_REG else "s_waitcnt vmcnt(0)")
     emit("s_barrier")
 
 
@@ -219,12 +244,12 @@ def main():
     clob += [f'"v{i}"' for i in range(16, 256)] + [f'"a{i}"' for i in range(256)]
     print("// GENERATED by tools/gen_attn_nq4.py — do not edit.  TIMING-ONLY steady phase of a 64-query-rows-per-wave attention forward.")
     print("#define GF_NQ4_LOOP_ASM(koff0, koff1, koff2, koff3, voff0, voff1, ksoff, vtoff, qoff, qstep, qptr, kLo, kHi, kNr, vLo, vHi, vNr, "
-          "ldsW, npairs, kstep, kpiece, vpiece) \\")
+          "ldsW, npairs, kstep, kpiece, vpiece, wdst) \\")
     print("    asm volatile( \\")
     print(body + " \\")
     print('        : [qoff] "+v"(qoff) \\')
     print('        : [koff0] "v"(koff0), [koff1] "v"(koff1), [koff2] "v"(koff2), [koff3] "v"(koff3), [voff0] "v"(voff0), [voff1] "v"(voff1), '
-          '[ksoff] "v"(ksoff), [vtoff] "v"(vtoff), [qstep] "s"(qstep), [qptr] "s"(qptr), [kLo] "s"(kLo), [kHi] "s"(kHi), [kNr] "s"(kNr), '
+          '[ksoff] "v"(ksoff), [vtoff] "v"(vtoff), [wdst] "v"(wdst), [qstep] "s"(qstep), [qptr] "s"(qptr), [kLo] "s"(kLo), [kHi] "s"(kHi), [kNr] "s"(kNr), '
           '[vLo] "s"(vLo), [vHi] "s"(vHi), [vNr] "s"(vNr), [ldsW] "s"(ldsW), [npairs] "s"(npairs), [kstep] "s"(kstep), [kpiece] "s"(kpiece), '
           '[vpiece] "s"(vpiece) \\')
     print("        : " + ", ".join(clob) + ")")

@@ -46,8 +46,9 @@ __global__ __launch_bounds__(256, 1) void nq4_kernel(const u16* q, const u16* k,
     const unsigned npairs = (unsigned)(tiles / 2);
     const unsigned kstep = (unsigned)(64 * k_stride * 2), kpiece = (unsigned)(16 * k_stride * 2), vpiece = (unsigned)(32 * kv_pad * 2);
     const u16* qptr = q;
+    const unsigned wdst = ldsW + (unsigned)lane * 16u;       // register-staged variant: this lane's 16 bytes of a 1 KiB piece
     GF_NQ4_LOOP_ASM(koff0, koff1, koff2, koff3, voff0, voff1, ksoff, vtoff, qoff, qstep, qptr, kLo, kHi, kNr, vLo, vHi, vNr, ldsW, npairs, kstep,
-                    kpiece, vpiece);
+                    kpiece, vpiece, wdst);
     // keep every accumulator live: a checksum per lane (results are meaningless by construction)
     float s = acc_read<0>() + acc_read<37>() + acc_read<70>() + acc_read<101>() + acc_read<127>() + acc_read<128>() + acc_read<143>();
     out[(long)blockIdx.x * 256 + tid] = s;
