@@ -293,7 +293,7 @@ class CrossAttention(nn.Module):
         m = 1
         if fold and ctx2.is_cuda and _FOLD_PAD_KEYS[0]:
             n = pad_run(ctx2)
-            if ctx2.shape[0] - n >= 2:
+            if ctx2.shape[0] - n >= 2 and n + 1 < ops.VT_MIN_KV:      # (the multiplicity form exists for short key sequences only)
                 m = ctx2.shape[0] - n
                 ctx2 = ctx2[: n + 1]
         cin = QuantizedInput(ctx2) if getattr(self.k, "_gf_w8", None) is not None else ctx2
