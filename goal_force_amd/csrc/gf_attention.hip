@@ -52,8 +52,10 @@
 #define GF_K3_MAP 0      // kernel 3: workgroup -> (head, query block) order; 1 = plain head-major (fabric-traffic A/B)
 #endif
 #ifndef GF_K3_ORMAX
-#define GF_K3_ORMAX 1    // kernel 3: the steady phase's running-maximum watch on the packed P instead of the fp32 scores (see `phase`);
-#endif                   // round 4: +1.0 % in one process against the v_max3 watch (profiles/r04/attn_ab_r04.log), 0 = round 3's kernel
+#define GF_K3_ORMAX 0    // kernel 3, round 4, measured and NOT shipped: the steady phase's running-maximum watch on the packed P instead of
+#endif                   // the fp32 scores (see `phase`).  One process, S = 32760 x 40 heads (profiles/r04/attn_ab_peaky.log): +0.8 % on
+                         // unit-variance logits, but -0.6 / -1.6 / -2.3 / -2.9 % with the logits x 2 / 4 / 8 / 16 (every rescale also
+                         // recomputes the tile's P): the v_max3 watch of round 3 is the one that does not depend on the data.
 #ifndef GF_ATTN_BUFFER_DMA
 #define GF_ATTN_BUFFER_DMA 1   // 1: K/V staging by buffer_load ... lds with scalar tile offsets; 0: global_load_lds (A/B builds)
 #endif

@@ -31,6 +31,8 @@ def run(s, rounds):
     q, k, v = (torch.randn((s, D), device="cuda").to(torch.bfloat16) for _ in range(3))
     if "--zeros" in sys.argv:
         q, k, v = (torch.zeros_like(t) for t in (q, k, v))
+    if "--qscale" in sys.argv:      # logits x f: near-one-hot softmax rows (f = 8 is bench.py --peaky 8), the rescale paths fire more often
+        q = (q.float() * float(sys.argv[sys.argv.index("--qscale") + 1])).to(torch.bfloat16)
     kv_pad = -(-s // 64) * 64
     vt = torch.zeros((H * 128 * kv_pad,), dtype=torch.bfloat16, device="cuda")
     vp, i64 = ctypes.c_void_p, ctypes.c_int64

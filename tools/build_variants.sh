@@ -1,16 +1,16 @@
 #!/bin/bash
 # A/B and diagnostic builds of the attention kernels (CPU container; the .so files under build/ab/ travel to the GPU box):
-#   libgf_base.so / libgf_max3watch.so / libgf_naivemap.so   tools/attn_ab.py   kernel 3 as shipped (ORMAX) / round 3's v_max3 watch / plain head-major block order
+#   libgf_base.so / libgf_max3watch.so / libgf_naivemap.so   tools/attn_ab.py   kernel 3 as shipped / with the ORMAX watch (round 4, not shipped) / plain head-major block order
 #   gfclock.so                       tools/attn_clock.py       kernel 3 with in-kernel clock stamps
-#   libgoalforce_max3watch.so        GOALFORCE_HIP_LIB=...     the whole library with round 3's attention watch (runs the test suite on it)
+#   libgoalforce_ormax.so            GOALFORCE_HIP_LIB=...     the whole library with the ORMAX attention watch (runs the test suite on it)
 set -e
 cd "$(dirname "$0")/.."
 make -C goal_force_amd/csrc -j4 > /dev/null
-python3 tools/attn_ab.py --build base: max3watch:-DGF_K3_ORMAX=0 naivemap:-DGF_K3_MAP=1
+python3 tools/attn_ab.py --build base: ormax:-DGF_K3_ORMAX=1 naivemap:-DGF_K3_MAP=1
 python3 tools/attnbwd_ab.py --build
 python3 tools/attn_clock.py --build
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Igoal_force_amd/csrc -Wall -Wno-unused-function -fvisibility=hidden -DGF_BUILD"
-/opt/rocm/bin/hipcc $F -mllvm -amdgpu-mfma-vgpr-form -DGF_K3_ORMAX=0 -c goal_force_amd/csrc/gf_attention.hip -o build/ab/gf_attention_max3watch.o
+/opt/rocm/bin/hipcc $F -mllvm -amdgpu-mfma-vgpr-form -DGF_K3_ORMAX=1 -c goal_force_amd/csrc/gf_attention.hip -o build/ab/gf_attention_ormax.o
 OBJS=$(ls build/csrc/gf_*.o | grep -v -e "gf_attention.o" -e "gf_gemm-")
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/ab/libgoalforce_max3watch.so $OBJS build/ab/gf_attention_max3watch.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/ab/libgoalforce_ormax.so $OBJS build/ab/gf_attention_ormax.o
 ls -la build/ab/

@@ -22,6 +22,7 @@ pass attn_WRITE_SIZE WRITE_SIZE "flash_attn|transpose_v32" -- attn --iters 2
 pass attn_SQ "$SQ1" "flash_attn" -- attn --iters 2
 pass attn_SQ2 "$SQ2" "flash_attn" -- attn --iters 2
 pass attn_SQ3 "$SQ3" "flash_attn" -- attn --iters 2
+[ "${ONLY:-}" = attn ] && { ls -la $OUT; exit 0; }     # ONLY=attn: the attention passes alone (after a change to gf_attention.hip)
 # ---- the block GEMMs, one shape per pass (so that a table row is one shape), bf16 and e4m3
 for sh in dd ffn1 ffn2; do
   for c in FETCH_SIZE WRITE_SIZE; do
