@@ -361,6 +361,10 @@ class DiTBlock(nn.Module):
         fp8 = getattr(self.ffn[0], "_gf_w8", None) is not None
         if self_attn_memo is not None and "x" in self_attn_memo:
             x_new = self_attn_memo.pop("x")
+            ev = self_attn_memo.pop("ev", None)
+            if ev is not None:      # the other CFG branch may run on another stream (pipeline.cfg_streams): order after its write
+                torch.cuda.current_stream(x_new.device).wait_event(ev)
+                x_new.record_stream(torch.cuda.current_stream(x_new.device))
             if out is not None:
                 x_new = out.copy_(x_new)
             h = None if fp8 else torch.empty_like(x2)
@@ -376,6 +380,9 @@ class DiTBlock(nn.Module):
                 keep["x1"] = x_new.clone()               # (the rest of the block updates x_new in place)
             if self_attn_memo is not None:
                 self_attn_memo["x"] = x_new.clone()      # the rest of the block updates x_new in place
+                if x_new.is_cuda:
+                    self_attn_memo["ev"] = torch.cuda.Event()
+                    self_attn_memo["ev"].record(torch.cuda.current_stream(x_new.device))
         if fp8:
             h = QuantizedInput.layernorm(x_new, weight=self.norm3.weight, bias=self.norm3.bias, eps=self.eps)
         else:

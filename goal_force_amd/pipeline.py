@@ -14,6 +14,7 @@ the models are attached; it can also be supplied pre-computed: `context_posi`, `
 from __future__ import annotations
 
 import copy
+import os
 from typing import Optional
 
 import numpy as np
@@ -50,6 +51,10 @@ class WanVideoPipeline:
         self.controlnet2: Optional[ControlNet] = None
         self.model_fn = model_fn_wan_video  # GF:161 — the reference's own swap point
         self.share_cfg_prefix = True        # denoise(): block 0's self-attention half once per CFG step (bit-identical)
+        # denoise(): the uncond forward of a CFG step on a second HIP stream, concurrent with the cond forward (same kernels, same
+        # bits).  Measured (3 % slower at full size) and left off: GF_CFG_STREAMS=1 switches it on for A/Bs.
+        self.cfg_streams = os.environ.get("GF_CFG_STREAMS", "0") == "1"
+        self._cfg_side_stream = None
         self.vram_management_enabled = False
         self.elide_zero_controlnet = True
         self.num_layers = controlnet_num_layers
@@ -232,9 +237,24 @@ class WanVideoPipeline:
                 # both branches on this GPU: the context-independent half of block 0 is computed once (model_fn: cfg_shared)
                 pair = {} if (cfg_scale != 1.0 and self.share_cfg_prefix and self.model_fn is model_fn_wan_video) else None
                 extra = {} if pair is None else {"cfg_shared": pair}
+                two = self.cfg_streams and cfg_scale != 1.0 and sequence_parallel is None
+                if two:
+                    main = torch.cuda.current_stream(self.device)
+                    if self._cfg_side_stream is None:
+                        self._cfg_side_stream = torch.cuda.Stream(self.device)
+                    inputs_ready = torch.cuda.Event()
+                    inputs_ready.record(main)
                 posi = self.model_fn(**models, **shared, **extra, context=context_posi, context_cache=caches[key][0])
                 nega = None
-                if cfg_scale != 1.0:
+                if two:
+                    # enqueued after the whole cond forward (so the events of its block-0 halves exist), running beside it
+                    side = self._cfg_side_stream
+                    side.wait_event(inputs_ready)
+                    with torch.cuda.stream(side):
+                        nega = self.model_fn(**models, **shared, **extra, context=context_nega, context_cache=caches[key][1])
+                    main.wait_stream(side)
+                    nega.record_stream(main)
+                elif cfg_scale != 1.0:
                     nega = self.model_fn(**models, **shared, **extra, context=context_nega, context_cache=caches[key][1])
             sigma, sigma_ = self.scheduler.sigma_pair(self.scheduler.timesteps[progress_id])
             # noise_pred = nega + cfg*(posi - nega); latents += noise_pred*(sigma_next - sigma)  (GF:716, FM:81)

@@ -231,6 +231,25 @@ def test_denoise_loop_same_bits_with_and_without_shared_prefix():
     assert torch.equal(a, run())
 
 
+def test_denoise_loop_same_bits_with_the_cfg_pair_on_two_streams():
+    """pipeline.cfg_streams (GF_CFG_STREAMS=1): the uncond forward on a second HIP stream, ordered after the cond forward's block-0
+    halves by events — an A/B switch (measured slower at full size), but it must produce the same bits."""
+    from goal_force_amd.pipeline import WanVideoPipeline
+    inp = {k: v.cuda() for k, v in gi.tiny_inputs().items()}
+    dit1, cn1 = _tiny_pipeline(False)
+    dit2, cn2 = _tiny_pipeline(True, dit_seed=43)
+    pipe = WanVideoPipeline.from_modules(dit1, dit2, cn1, cn2)
+    run = lambda: pipe.denoise(inp["latents"], inp["ctx_posi"], inp["ctx_nega"], inp["y"], inp["control"],
+                               num_inference_steps=3, cfg_scale=5.0, controlnet=True)
+    assert not pipe.cfg_streams
+    a = run()
+    pipe.cfg_streams = True
+    for _ in range(3):
+        assert torch.equal(a, run())
+    assert pipe._cfg_side_stream is not None
+    torch.cuda.synchronize()
+
+
 def test_three_step_cfg_loop_vs_golden():
     """GF:697-723 at tiny size: expert switch after step 2, CFG 5.0, Euler update; final latents."""
     from goal_force_amd.pipeline import WanVideoPipeline
