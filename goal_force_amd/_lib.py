@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("GOALFORCE_HIP_LIB", LIB_PATH)
 
 # every symbol include/goalforce.h declares (tests check the .so exports exactly these)
 SYMBOLS = (
-    "gf_version", "gf_last_error", "gf_abi_version", "gf_reload_options",
+    "gf_version", "gf_last_error", "gf_abi_version", "gf_set_option", "gf_reset_options",
     "gf_modulation", "gf_layernorm_modulate", "gf_rmsnorm_rope", "gf_gemm_bf16", "gf_flash_attn_fwd",
     "gf_patchify_im2col", "gf_unpatchify", "gf_cfg_euler_step", "gf_act", "gf_add_bf16",
     "gf_force_map",
@@ -33,7 +33,7 @@ SYMBOLS = (
 # the C ABI revision these bindings were written against (csrc/gf_abi.hip: GF_ABI_VERSION).  A stale or foreign .so whose entry
 # points take differently sized buffers (gf_flash_attn_bwd's workspace grew 3x between revisions 7 and 10 under an unchanged
 # signature) is refused at load time instead of overrunning memory.
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 EPI_BIAS, EPI_BIAS_GELU_TANH, EPI_BIAS_GATE_RESID, EPI_BIAS_RESID, EPI_BIAS_SILU, EPI_BIAS_MUL = range(6)
 
@@ -55,8 +55,10 @@ def _declare(lib):
     lib.gf_last_error.argtypes = []
     lib.gf_abi_version.restype = _int
     lib.gf_abi_version.argtypes = []
-    lib.gf_reload_options.restype = None
-    lib.gf_reload_options.argtypes = []
+    lib.gf_set_option.restype = _int
+    lib.gf_set_option.argtypes = [ctypes.c_char_p, _int]
+    lib.gf_reset_options.restype = None
+    lib.gf_reset_options.argtypes = []
     sigs = {
         "gf_layernorm_modulate": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _vp],
         "gf_modulation": [_vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_uint32, _vp],
@@ -135,11 +137,21 @@ def load():
                 lib = ctypes.CDLL(LIB_PATH)
             except OSError as e:  # pragma: no cover
                 raise GoalForceError(f"cannot load {LIB_PATH}: {e}") from e
-            _declare(lib)
-            have = int(lib.gf_abi_version())
+            # the revision is compared BEFORE the symbols are bound: a stale build usually lacks a symbol, and the rebuild hint
+            # must reach the user instead of a bare AttributeError out of _declare
+            rebuild = "rebuild the library (`make -C goal_force_amd/csrc`)"
+            try:
+                lib.gf_abi_version.restype = _int
+                have = int(lib.gf_abi_version())
+            except AttributeError as e:
+                raise GoalForceError(f"{LIB_PATH} predates the C ABI revision export: {rebuild}") from e
             if have != ABI_VERSION:
-                raise GoalForceError(f"{LIB_PATH} speaks C ABI revision {have}, these bindings revision {ABI_VERSION}: rebuild the "
-                                     "library (`make -C goal_force_amd/csrc`) — mixing revisions can overrun caller-owned workspaces")
+                raise GoalForceError(f"{LIB_PATH} speaks C ABI revision {have}, these bindings revision {ABI_VERSION}: {rebuild} "
+                                     "— mixing revisions can overrun caller-owned workspaces")
+            try:
+                _declare(lib)
+            except AttributeError as e:
+                raise GoalForceError(f"{LIB_PATH} lacks a symbol these bindings declare ({e}): {rebuild}") from e
             _lib = lib
     return _lib
 

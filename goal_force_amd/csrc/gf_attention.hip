@@ -2,111 +2,38 @@
 // Replaces flash_attention() (reference diffsynth/models/wan_video_dit.py:28-61): self-attention over
 // S = f*h*w video tokens (32760 at 832x480x81f) and cross-attention over 512 text tokens.
 //
-// CDNA4 design (gfx950), one workgroup = 8 waves = 256 query rows of one head, 32 rows per wave:
-//   * swapped QK^T: S^T = K_tile · Q^T with v_mfma_f32_32x32x16_bf16, so the query is on the LANE and
-//     the 64 keys of a KV tile sit in 2x16 accumulator registers of lanes l and l^32.  Row max / row
-//     sum are in-register plus ONE cross-lane exchange; no LDS round trip for P.
-//   * O^T = V^T · P^T: the S^T accumulator, converted pairwise to bf16, IS the B operand of the PV
-//     MFMA (k order of the accumulator layout), and V^T fragments come from the row-major V tile by
-//     ds_read_b64_tr_b16 (hardware transpose).  O^T keeps the query on the lane, so the online
-//     softmax rescale is a per-lane scalar multiply.
-//   * K and V tiles (64 keys x 128 d, 16 KiB each) are triple buffered in LDS in ONE image,
-//     off(row,ch) = 256*row + 16*(ch ^ (((row&3)<<2) | ((row>>2)&3))), which is conflict-free for both
-//     the ds_read_b128 row reads (K) and the transposed reads (V).  Global->register loads of tile
-//     t+1 go straight into the next LDS stage by LDS-DMA (global_load_lds_dwordx4, swizzle applied to the per-lane
-//     source chunk) at the top of tile t and are waited for at its end; one barrier per tile.
-//   * the two waves of a SIMD (w, w+4) run rotated by one phase: waves 4-7 defer each tile's PV product to the next
-//     iteration, so one partner's MFMA phase runs beside the other's softmax (VALU/transcendental) phase instead
-//     of both contending for the matrix pipe and then for the VALU in lockstep.
-//   * blockIdx -> (head, q-block) is XCD-aware: the 32 CUs of an XCD work on the same head at the
-//     same time so its K/V stream (16.8 MB at S=32760) is shared through that XCD's L2.
-//   * softmax in fp32 with exp2 and the scale folded into one FMA; lazy rescale (skip the O
-//     rescale while the running max grows by less than 2^THR_LOG2; exact in exact arithmetic).
+// Two kernels ship, both with one workgroup = 8 waves = 256 query rows of one head, 32 rows per wave, two waves per SIMD:
+//   * kernel 2 (`flash_attn_fwd_kernel2`, v_mfma_f32_32x32x16_bf16): key sequences below 2048 — the cross-attention over the
+//     text tokens, with the optional multiplicity of the last key (gf_flash_attn_fwd_lastmult) — and the plain-V entry points;
+//   * kernel 3 (`flash_attn_fwd_kernel3`, v_mfma_f32_16x16x32_bf16): the self-attention of the DiT / ControlNet blocks, V^T
+//     written by the V projection (gf_linear_vt32) or by gf_transpose_v32.
+// Common to both:
+//   * swapped QK^T: S^T = K_tile · Q^T, so a query stays on ONE lane; row maxima and sums are in-register, no LDS round trip for P;
+//   * O^T = V^T · P^T: the S^T accumulator, converted pairwise to bf16, IS the B operand of the PV MFMA, and O^T keeps the query
+//     on the lane, so the online-softmax rescale is a per-lane scalar multiply;
+//   * K / V tiles (64 keys) are staged by LDS-DMA (`buffer_load ... lds`, tile offset as an SGPR); one barrier per tile;
+//   * a tile-level software pipeline inside ONE instruction stream per wave (PV of tile p-1 and QK^T of tile p+1 beside the
+//     softmax of tile p), pinned with sched_group_barriers;
+//   * blockIdx -> (head, q-block) is XCD-aware: the 32 CUs of an XCD work on the same head at the same time so its K/V stream
+//     (16.8 MB at S = 32760) is shared through that XCD's L2;
+//   * softmax in fp32 in the exp2 domain; lazy rescale (O is only rescaled when the running maximum has moved far enough).
+// The phase-serial first kernel and the measured-and-dropped variants of kernel 3 (ORMAX watch, head-major map, what-if and clock
+// builds) are NOT in this file: tools/patches/attention_experiments.patch re-creates them on top of it (tools/build_variants.sh).
 #include "gf_common.h"
 #include <cstdlib>
 #include <type_traits>
 
-#ifndef GF_ATTN_SCHED
-#define GF_ATTN_SCHED 1
-#endif
-#ifndef GF_K3_CINIT
-#define GF_K3_CINIT 1    // kernel 3: Q carries scale*log2(e) and the QK^T chains start from -max: no scale-and-subtract per score
-#endif
-#ifndef GF_K3_SUMMFMA
-#define GF_K3_SUMMFMA 1  // kernel 3: row sums on the matrix pipe (a ninth "d block" against a ones fragment) instead of 32 v_add_f32
-#endif
-#ifndef GF_K3_RING
-#define GF_K3_RING 2     // kernel 3: operand fragments in flight (registers are the scarce resource at two waves per SIMD)
-#endif
-#ifndef GF_K3_SNAKE
-#define GF_K3_SNAKE 1    // kernel 3: query-block order reversed on odd fragments (one MFMA operand changes per slot instead of both)
-#endif
-#ifndef GF_K3_DMA0
-#define GF_K3_DMA0 10    // kernel 3: slot of the phase's first staging piece ...
-#define GF_K3_DMAS 8     // ... and the slot distance between pieces (4 per wave and phase)
-#endif
-#ifndef GF_K3_WHATIF
-#define GF_K3_WHATIF 0   // timing-only variants of kernel 3's steady phase (tools/attn_ab.py); 0 in the shipped library
-#endif
-#ifndef GF_K3_MAP
-#define GF_K3_MAP 0      // kernel 3: workgroup -> (head, query block) order; 1 = plain head-major (fabric-traffic A/B)
-#endif
-#ifndef GF_K3_ORMAX
-#define GF_K3_ORMAX 0    // kernel 3, round 4, measured and NOT shipped: the steady phase's running-maximum watch on the packed P instead of
-#endif                   // the fp32 scores (see `phase`).  One process, S = 32760 x 40 heads (profiles/r04/attn_ab_peaky.log): +0.8 % on
-                         // unit-variance logits, but -0.6 / -1.6 / -2.3 / -2.9 % with the logits x 2 / 4 / 8 / 16 (every rescale also
-                         // recomputes the tile's P): the v_max3 watch of round 3 is the one that does not depend on the data.
-#ifndef GF_ATTN_BUFFER_DMA
-#define GF_ATTN_BUFFER_DMA 1   // 1: K/V staging by buffer_load ... lds with scalar tile offsets; 0: global_load_lds (A/B builds)
-#endif
-#ifndef GF_ATTN_LATE_PRIO
-#define GF_ATTN_LATE_PRIO 1
-#endif
-
-// GF_ATTN_STAMP: diagnostic build only (tools/attn_stamps.py) — per-segment s_memtime sums of waves 0 and 4 of
-// workgroup 0, written to a debug buffer; the shipped library is built without it.
-#ifndef GF_ATTN_STAMP
-#define GF_ATTN_STAMP 0
-#endif
-// GF_K3_CLOCK: diagnostic build only (tools/attn_clock.py) — kernel 3 reads s_memtime (shader cycles) and s_memrealtime
-// (100 MHz) once before and once after its steady loop and writes the two differences per workgroup to a debug buffer of its
-// own: the clock the chip holds INSIDE the loop = d(memtime) / d(memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS item 6).
-// No output value depends on the stamps; the shipped library is built without them.
-#ifndef GF_K3_CLOCK
-#define GF_K3_CLOCK 0
-#endif
-#if GF_ATTN_STAMP || GF_K3_CLOCK
-static unsigned long long* g_attn_dbg = nullptr;
-extern "C" GF_API void gf_debug_set_attn_buffer(void* p) { g_attn_dbg = (unsigned long long*)p; }
-#endif
-#if GF_ATTN_STAMP
-#define STAMP(i)                                                                            \
-    {                                                                                       \
-        unsigned long long t_;                                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                  \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
-        __builtin_amdgcn_sched_barrier(0);                                                  \
-        seg[i] += t_ - tprev;                                                               \
-        tprev = t_;                                                                         \
-    }
-#else
-#define STAMP(i)
-#endif
-
 namespace {
 
-constexpr int AT_THREADS = 512;
 constexpr int QB = 256;          // query rows per workgroup
 constexpr int KVB = 64;          // keys per tile
 constexpr int HD = 128;          // head dim
 constexpr int KV_TILE_BYTES = KVB * HD * 2;        // 16 KiB
-constexpr int AT_STAGES = 3;
-constexpr int AT_V_BASE = AT_STAGES * KV_TILE_BYTES;   // K stages at [0, 48K), V stages at [48K, 96K)
-constexpr int AT_LDS = 2 * AT_STAGES * KV_TILE_BYTES;  // 96 KiB
 
-__device__ __forceinline__ int kv_off(int row, int ch) {
-    return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
-}
+// kernel 3's schedule parameters (A/B history: EXPERIMENTS.md appendix B)
+constexpr int K3_RING = 2;       // operand fragments in flight (registers are the scarce resource at two waves per SIMD)
+constexpr int K3_DMA0 = 10;      // slot of the phase's first staging piece ...
+constexpr int K3_DMAS = 8;       // ... and the slot distance between pieces (4 per wave and phase)
 
 struct AttnArgs {
     const u16* q;
@@ -116,7 +43,7 @@ struct AttnArgs {
     int q_len, kv_len, heads, n_qblocks;
     long q_stride, k_stride, v_stride, o_stride;
     float scale_log2e;  // softmax scale * log2(e)
-    unsigned long long* dbg;
+    unsigned long long* dbg;   // unused (kept so that diagnostic builds from tools/patches need no ABI change inside the library)
     float* lse;         // optional [q_len, heads] fp32: log2-domain log-sum-exp of the scaled scores (training backward)
     const u16* vt;      // kernel 2, VT form: V^T [heads][128][kv_pad] from gf_transpose_v (keys permuted inside 16-groups)
     long kv_pad;
@@ -124,322 +51,9 @@ struct AttnArgs {
                            // that key then counts `multiplicity` times in the softmax — a run of identical trailing keys folded into one
 };
 
-__global__ __launch_bounds__(AT_THREADS, 2) void flash_attn_fwd_kernel(const AttnArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    GF_LDS char* lds = (GF_LDS char*)smem;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31;   // query column of this lane / row index inside a 32-row operand
-    const int h = lane >> 5;   // lane half
-
-    // ---- block -> (head, q-block) ---------------------------------------------------------------
-    int head, qb;
-    {
-        const int pid = blockIdx.x;
-        if ((p.heads & 7) == 0) {
-            const int xcd = pid & 7, idx = pid >> 3;
-            head = xcd + 8 * (idx / p.n_qblocks);
-            qb = idx % p.n_qblocks;
-        } else {
-            head = pid / p.n_qblocks;
-            qb = pid % p.n_qblocks;
-        }
-    }
-    const int q0 = qb * QB + wave * 32;
-
-    // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[q0+r][16*kd + 8h .. +8) ------------
-    bf16x8 qf[8];
-    {
-        const int qr = min(q0 + r, p.q_len - 1);
-        const u16* qp = p.q + (long)qr * p.q_stride + head * HD + 8 * h;
-#pragma unroll
-        for (int kd = 0; kd < 8; ++kd) qf[kd] = *reinterpret_cast<const bf16x8*>(qp + 16 * kd);
-    }
-
-    // ---- K/V staging by LDS-DMA (global_load_lds_dwordx4): one wave instruction fills 4 rows x 256 B of a tile image;
-    // wave w issues row-groups j = 2w, 2w+1 of the K tile and of the V tile (4 DMAs per wave per tile, no VGPRs, no
-    // ds_write).  The DMA writes lane-linear, so the image's chunk swizzle is applied to the per-lane SOURCE chunk:
-    // lane i fills physical chunk (i&15) of row 4j+(i>>4), which must hold logical chunk (i&15) ^ swz(row).
-    const int dma_r = lane >> 4;  // row inside the 4-row group ( = row & 3 )
-    unsigned dma_off[2][2];       // [jj][K/V] element offset of this lane's 16-byte piece inside tile 0
-    int dma_row[2];
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
-        const int j = 2 * wave + jj;
-        const int row = 4 * j + dma_r;
-        const int lch = (lane & 15) ^ ((dma_r << 2) | (j & 3));
-        dma_row[jj] = row;
-        dma_off[jj][0] = (unsigned)row * (unsigned)p.k_stride + head * HD + lch * 8;
-        dma_off[jj][1] = (unsigned)row * (unsigned)p.v_stride + head * HD + lch * 8;
-    }
-    const unsigned kstep = KVB * (unsigned)p.k_stride, vstep = KVB * (unsigned)p.v_stride;
-    // The DMA is issued from inline asm: hipcc otherwise treats every outstanding LDS-DMA as a possible alias of the
-    // ds_read_b64_tr_b16 reads and puts `s_waitcnt vmcnt(0)` in front of them (the whole HBM latency, every tile).
-    // M0 (LDS destination) is written in the same statement that uses it and restored; completion is waited for by
-    // hand (vmcnt(0) before the tile's closing barrier).
-    auto dma16 = [&](const u16* g, GF_LDS char* l) {
-        unsigned keep;
-        const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)l);
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep)
-                     : "v"(g), "s"(dst)
-                     : "memory");
-    };
-    auto stage_tile = [&](int t, int stg) {
-        GF_LDS char* kb = lds + stg * KV_TILE_BYTES + wave * 2048;
-        GF_LDS char* vb = kb + AT_V_BASE;
-        if ((t + 1) * KVB <= p.kv_len) {
-            const unsigned tk = (unsigned)t * kstep, tv = (unsigned)t * vstep;  // scalar
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                dma16(p.k + (dma_off[jj][0] + tk), kb + jj * 1024);
-                dma16(p.v + (dma_off[jj][1] + tv), vb + jj * 1024);
-            }
-        } else {  // ragged last tile: clamp the key row (the scores of the padding keys are masked)
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                const long rr = min(t * KVB + dma_row[jj], p.kv_len - 1);
-                const int j = 2 * wave + jj;
-                const int lch = (lane & 15) ^ ((dma_r << 2) | (j & 3));
-                dma16(p.k + rr * p.k_stride + head * HD + lch * 8, kb + jj * 1024);
-                dma16(p.v + rr * p.v_stride + head * HD + lch * 8, vb + jj * 1024);
-            }
-        }
-    };
-
-    // ---- per-lane LDS read offsets, all lane-dependent parts precomputed so every read is base register + immediate ----
-    // K row read (subtile kt, d-step kd): row = 32kt + r, logical chunk 2kd + h:
-    //   koff[kd] = 256 r + 16 ((2kd + h) ^ sK), sK = ((r&3)<<2) | ((r>>2)&3);   + stage*16K + kt*8K as immediate
-    // V transposed read (ds_read_b64_tr_b16; 16-lane group g, i = lane&15, qd = i>>2, pp = i&3), fragment half hf:
-    //   row = 32kt + 16s + 8hf + 4h + qd, logical chunk 4d + 2(g&1) + (pp>>1), byte + 8 (pp&1)
-    //   voff[hf][d] = 48K + 256 (8hf + 4h + qd) + 16 ((4d + vcl) ^ sV[hf]) + 8 (pp&1);   + stage*16K + 256 (32kt + 16s) immediate
-    int koff[8], voff[2][4];
-    {
-        const int sK = ((r & 3) << 2) | ((r >> 2) & 3);
-#pragma unroll
-        for (int kd = 0; kd < 8; ++kd) koff[kd] = 256 * r + 16 * ((2 * kd + h) ^ sK);
-        const int qd = (lane & 15) >> 2, pp = lane & 3;
-        const int vcl = 2 * ((lane >> 4) & 1) + (pp >> 1);
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            const int sV = (qd << 2) | ((2 * hf + h) & 3);
-#pragma unroll
-            for (int d = 0; d < 4; ++d)
-                voff[hf][d] = AT_V_BASE + 256 * (8 * hf + 4 * h + qd) + 16 * ((4 * d + vcl) ^ sV) + 8 * (pp & 1);
-        }
-    }
-
-    f32x16 oacc[4];
-#pragma unroll
-    for (int d = 0; d < 4; ++d)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
-    float m_run = -1.0e30f;  // running max (raw score units)
-    float l_run = 0.f;       // partial row sum of this lane's 32 keys per tile
-    const float c = p.scale_log2e;
-    const int nt = (p.kv_len + KVB - 1) / KVB;
-    bf16x8 pf[2][2];  // P^T fragments of the tile whose PV product is pending
-#if GF_ATTN_STAMP
-    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
-#endif
-
-    // ---- S^T = K · Q^T for the tile in stage `kb`, online softmax, P^T fragments into pf -------------
-    auto scores_softmax = [&](auto stg_c, int t) {
-        constexpr int STG = decltype(stg_c)::value;
-        f32x16 s0, s1;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            s0[e] = 0.f;
-            s1[e] = 0.f;
-        }
-#pragma unroll
-        for (int kd = 0; kd < 8; ++kd) {
-            const bf16x8 k0f = *(GF_LDS bf16x8*)(lds + koff[kd] + STG * KV_TILE_BYTES);
-            const bf16x8 k1f = *(GF_LDS bf16x8*)(lds + koff[kd] + STG * KV_TILE_BYTES + 32 * 256);
-            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0f, qf[kd], s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1f, qf[kd], s1, 0, 0, 0);
-        }
-#if GF_ATTN_SCHED
-        // software-pipeline the K fragment reads two d-steps (4 ds_read_b128) ahead of the MFMAs that consume them
-        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-#endif
-        // s{kt}[e] = score(key = 64t + 32kt + (e&3) + 8*(e>>2) + 4h, query q0 + r)
-        if (t == nt - 1 && (p.kv_len & (KVB - 1)) != 0) {  // mask the ragged tail (wave-uniform branch)
-            const int kbase_i = t * KVB + 4 * h;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int key = kbase_i + (e & 3) + 8 * (e >> 2);
-                if (key >= p.kv_len) s0[e] = -INFINITY;
-                if (key + 32 >= p.kv_len) s1[e] = -INFINITY;
-            }
-        }
-        STAMP(1)
-        float mx = s0[0];
-#pragma unroll
-        for (int e = 1; e < 16; ++e) mx = fmaxf(mx, s0[e]);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s1[e]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        // lazy rescale: keep the old max while no row of the wave grew by more than 2^6 (p <= 64: harmless for
-        // bf16 P and fp32 sums; exact in exact arithmetic).  Everything still at the old scale (O, l) is rescaled
-        // exactly once; P of this tile is exponentiated after the decision.
-        if (!__all((mx - m_run) * c <= 6.0f)) {
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-            m_run = m_new;
-            l_run *= alpha;
-#pragma unroll
-            for (int d = 0; d < 4; ++d)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
-        }
-        STAMP(2)
-        const float mc = m_run * c;
-        float rs = 0.f;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            s0[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[e], c, -mc));
-            s1[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[e], c, -mc));
-            rs += s0[e] + s1[e];
-        }
-        l_run += rs;
-        // P^T fragments (B operand of O^T = V^T P^T): k-step s of subtile kt = registers 8s..8s+7
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                pf[0][s][e] = (__bf16)s0[8 * s + e];
-                pf[1][s][e] = (__bf16)s1[8 * s + e];
-            }
-        STAMP(3)
-    };
-
-    // ---- O^T += V^T · P^T for the V tile in stage `vb` and the pending pf ------------------------------
-    auto pv = [&](auto stg_c) {
-        constexpr int STG = decltype(stg_c)::value;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                constexpr int dummy = 0;
-                (void)dummy;
-                const int imm = STG * KV_TILE_BYTES + 256 * (32 * kt + 16 * s);
-#pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GF_LDS s16x4*)(lds + voff[0][d] + imm));
-                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GF_LDS s16x4*)(lds + voff[1][d] + imm));
-                    typedef __attribute__((ext_vector_type(8))) short s16x8;
-                    const s16x8 vv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                    oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf[kt][s],
-                                                                      oacc[d], 0, 0, 0);
-                }
-            }
-#if GF_ATTN_SCHED
-        // V^T fragment reads (2 ds_read_b64_tr_b16 per MFMA) run two MFMAs ahead
-        __builtin_amdgcn_sched_group_barrier(0x100, 4, 1);
-#pragma unroll
-        for (int i = 0; i < 14; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 1);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 1);
-#endif
-    };
-
-    stage_tile(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    // Three LDS stages; tile t lives in stage t % 3.  The two waves that share a SIMD (w and w+4) run the same
-    // work rotated by one phase so that one's MFMA phase meets the other's softmax (VALU) phase:
-    //   waves 0-3:  [QK^T(t), softmax(t)]  [PV(t)]                 | barrier
-    //   waves 4-7:  [PV(t-1)]              [QK^T(t), softmax(t)]   | barrier      (+ PV(nt-1) after the loop)
-    // Tile t+1 is written into stage (t+1)%3 at the end of iteration t; its previous tenant (tile t-2) was last read
-    // by waves 4-7 in iteration t-1, which the barrier of t-1 fences.
-    typedef std::integral_constant<int, 0> S0;
-    typedef std::integral_constant<int, 1> S1;
-    typedef std::integral_constant<int, 2> S2;
-    // the second-dispatched half of the workgroup loses every issue arbitration to its older SIMD partner (priority,
-    // then age); one static priority raise lets its deferred PV product run beside the partner's softmax
-    if (wave >= 4) __builtin_amdgcn_s_setprio(GF_ATTN_LATE_PRIO);
-    // The tile loop is unrolled by the three stages so that the stage offset is an immediate of every ds_read.
-    if (wave < 4) {
-        auto iter = [&](auto cur_c, auto nxt_c, int t) {
-            STAMP(0)
-            if (t + 1 < nt) stage_tile(t + 1, decltype(nxt_c)::value);  // DMA in flight during this tile's matrix work
-            scores_softmax(cur_c, t);
-            pv(cur_c);
-            STAMP(4)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            STAMP(5)
-            __syncthreads();
-            STAMP(6)
-        };
-        for (int t = 0; t < nt; t += 3) {
-            iter(S0{}, S1{}, t);
-            if (t + 1 < nt) iter(S1{}, S2{}, t + 1);
-            if (t + 2 < nt) iter(S2{}, S0{}, t + 2);
-        }
-    } else {
-        auto iter = [&](auto cur_c, auto prev_c, auto nxt_c, int t) {
-            STAMP(0)
-            if (t + 1 < nt) stage_tile(t + 1, decltype(nxt_c)::value);
-            if (t > 0) pv(prev_c);
-            STAMP(4)
-            scores_softmax(cur_c, t);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            STAMP(5)
-            __syncthreads();
-            STAMP(6)
-        };
-        for (int t = 0; t < nt; t += 3) {
-            iter(S0{}, S2{}, S1{}, t);
-            if (t + 1 < nt) iter(S1{}, S0{}, S2{}, t + 1);
-            if (t + 2 < nt) iter(S2{}, S1{}, S0{}, t + 2);
-        }
-        // the deferred product of the last tile (its stage is not written after the loop)
-        const int last = (nt - 1) % 3;
-        if (last == 0) pv(S0{});
-        else if (last == 1) pv(S1{});
-        else pv(S2{});
-    }
-
-#if GF_ATTN_STAMP
-    if (p.dbg && blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0)
-        for (int i = 0; i < 8; ++i) p.dbg[(wave >> 2) * 8 + i] = seg[i];
-#endif
-    // ---- epilogue: O = O^T / l ----------------------------------------------------------------------
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
-    const float inv = 1.0f / l_tot;
-    const int qrow = q0 + r;
-    if (p.lse && h == 0 && qrow < p.q_len) p.lse[(long)qrow * p.heads + head] = m_run * c + __builtin_amdgcn_logf(l_tot);
-    if (qrow < p.q_len) {
-        u16* op = p.o + (long)qrow * p.o_stride + head * HD + 4 * h;
-#pragma unroll
-        for (int d = 0; d < 4; ++d)
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                // registers 4rg..4rg+3 = d index 32d + 8rg + 4h + {0..3}
-                u32x2 pk;
-                pk[0] = pack2bf(oacc[d][4 * rg + 0] * inv, oacc[d][4 * rg + 1] * inv);
-                pk[1] = pack2bf(oacc[d][4 * rg + 2] * inv, oacc[d][4 * rg + 3] * inv);
-                *reinterpret_cast<u32x2*>(op + 32 * d + 8 * rg) = pk;
-            }
-    }
-}
-
-
 // ================================================================================================================
-// Kernel 2: same workgroup shape as kernel 1 (8 waves x 32 query rows, two waves per SIMD), but every wave runs a
-// tile-level software pipeline inside ONE instruction stream.  Phase p of a wave:
+// Kernel 2: 8 waves x 32 query rows, two waves per SIMD; every wave runs a tile-level software pipeline inside ONE
+// instruction stream.  Phase p of a wave:
 //     matrix stream :  O^T += V(p-1)^T P(p-1)^T   (16 MFMAs)   then   S(p+1)^T = K(p+1) Q^T   (16 MFMAs)
 //     VALU stream   :  softmax of S(p)  ->  P(p)  (row max, 32 exp2, row sum, bf16 pack)
 // tools/issue_probe.py (profiles/r01/issue_probe.txt) measured what bounds this loop on gfx950: a wave issues serially
@@ -454,13 +68,6 @@ __global__ __launch_bounds__(AT_THREADS, 2) void flash_attn_fwd_kernel(const Att
 //     against it, but O (still receiving PV(p-1), which is in the OLD scale) is multiplied at the top of phase p+1.
 //   * K and V tiles are staged separately by LDS-DMA, two buffers each (64 KiB): K(p+2) and V(p) are issued at the top
 //     of phase p and waited for at its closing barrier (K(j) is consumed in phase j-1, V(j) in phase j+1).
-// GF_ATTN_WHATIF (tools/attn_whatif.py): timing-only builds of kernel 2 with parts of the steady phase left out — RESULTS ARE
-// WRONG, never shipped: 1 no fma/exp2/sum/pack, 2 no row max / rescale decision, 4 no fragment LDS reads, 8 no closing wait +
-// barrier, 16 no K/V staging, 32 no deferred O rescale, 128 no V staging, 256 no K staging; 64 = (correct results) the DMA pieces issued at the
-// top of the phase (the first version) instead of inside its slots.
-#ifndef GF_ATTN_WHATIF
-#define GF_ATTN_WHATIF 0
-#endif
 constexpr int AT2_THREADS = 512;
 constexpr int AT2_V_BASE = 2 * KV_TILE_BYTES;
 constexpr int AT2_LDS = 4 * KV_TILE_BYTES;
@@ -571,8 +178,7 @@ __global__ __launch_bounds__(AT2_THREADS, 2) void flash_attn_fwd_kernel2(const A
             if (which) {
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj) {
-                    if constexpr (GF_ATTN_BUFFER_DMA) dma16b(srd_v, vt_off[jj] * 2u, (unsigned)t * (KVB * 2u), base + jj * 1024);
-                    else dma16(p.vt + (vt_off[jj] + (unsigned)t * KVB), base + jj * 1024);
+                    dma16b(srd_v, vt_off[jj] * 2u, (unsigned)t * (KVB * 2u), base + jj * 1024);
                 }
                 return;
             }
@@ -582,8 +188,7 @@ __global__ __launch_bounds__(AT2_THREADS, 2) void flash_attn_fwd_kernel2(const A
             const unsigned tt = (unsigned)t * (which ? vstep : kstep);
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
-                if constexpr (GF_ATTN_BUFFER_DMA) dma16b(which ? srd_v : srd_k, dma_off[jj][which] * 2u, tt * 2u, base + jj * 1024);
-                else dma16(g + (dma_off[jj][which] + tt), base + jj * 1024);
+                dma16b(which ? srd_v : srd_k, dma_off[jj][which] * 2u, tt * 2u, base + jj * 1024);
             }
         } else {   // ragged last tile: clamp the row (masked later), 64-bit addressing
             const long stride = which ? p.v_stride : p.k_stride;
@@ -602,16 +207,14 @@ __global__ __launch_bounds__(AT2_THREADS, 2) void flash_attn_fwd_kernel2(const A
         GF_LDS char* base = lds + which * AT2_V_BASE + buf * KV_TILE_BYTES + wave * 2048;
         if constexpr (VT) {
             if (which) {
-                if constexpr (GF_ATTN_BUFFER_DMA) dma16b(srd_v, vt_off[jj] * 2u, (unsigned)t * (KVB * 2u), base + jj * 1024);
-                else dma16(p.vt + (vt_off[jj] + (unsigned)t * KVB), base + jj * 1024);
+                dma16b(srd_v, vt_off[jj] * 2u, (unsigned)t * (KVB * 2u), base + jj * 1024);
                 return;
             }
         }
         const u16* g = which ? p.v : p.k;
         if ((t + 1) * KVB <= p.kv_len) {
             const unsigned tt = (unsigned)t * (which ? vstep : kstep);
-            if constexpr (GF_ATTN_BUFFER_DMA) dma16b(which ? srd_v : srd_k, dma_off[jj][which] * 2u, tt * 2u, base + jj * 1024);
-            else dma16(g + (dma_off[jj][which] + tt), base + jj * 1024);
+            dma16b(which ? srd_v : srd_k, dma_off[jj][which] * 2u, tt * 2u, base + jj * 1024);
         } else {
             const long stride = which ? p.v_stride : p.k_stride;
             const int j = 2 * wave + jj;
@@ -762,16 +365,9 @@ __global__ __launch_bounds__(AT2_THREADS, 2) void flash_attn_fwd_kernel2(const A
     // slot pins the written order; the empty volatile asms pin each score's VALU work INTO its slot (instruction
     // selection would otherwise hoist all 32 exps to the top of the phase).
     bf16x8 fr[4];
-    if constexpr ((GF_ATTN_WHATIF & 4) != 0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fr[i] = qf[i];
-    }
     auto frag_load = [&](auto g_c, auto par_c) {
         constexpr int G = decltype(g_c)::value, PAR = decltype(par_c)::value;
-        if constexpr ((GF_ATTN_WHATIF & 4) != 0) {
-            bf16x8& f = fr[G & 3];
-            asm volatile("" : "+v"(f));
-        } else if constexpr (G < 16) {
+        if constexpr (G < 16) {
             constexpr int kt = G >> 3, sq = (G >> 2) & 1, d = G & 3;
             if constexpr (VT) {
                 fr[G & 3] = *(GF_LDS bf16x8*)(lds + vt_rd[2 * kt + sq] + (1 - PAR) * KV_TILE_BYTES + d * 4096);
@@ -805,25 +401,17 @@ __global__ __launch_bounds__(AT2_THREADS, 2) void flash_attn_fwd_kernel2(const A
     };
     // The four DMA pieces of a phase are issued inside its slots (V(p) in slots 5 and 9, K(p+2) in 13 and 17) instead of back to
     // back at its top: +1 % (18 of the phase's 32 slots still lie between the last piece and the closing wait).  Staggering them
-    // over the waves as well (two waves per slot) measured 1.7 % SLOWER.  GF_ATTN_WHATIF & 64 restores the issue at the top.
+    // over the waves as well (two waves per slot) measured 1.7 % SLOWER.
     auto dma_slot = [&](auto g_c, auto par_c, int pidx) {
         constexpr int G = decltype(g_c)::value, PAR = decltype(par_c)::value;
-        if constexpr (!(GF_ATTN_WHATIF & (16 | 64))) {
-            if constexpr (G == 5 && !(GF_ATTN_WHATIF & 128)) stage_piece(1, pidx, PAR, 0);
-            if constexpr (G == 9 && !(GF_ATTN_WHATIF & 128)) stage_piece(1, pidx, PAR, 1);
-            if constexpr (G == 13 && !(GF_ATTN_WHATIF & 256)) { if (pidx + 2 < nt) stage_piece(0, pidx + 2, PAR, 0); }
-            if constexpr (G == 17 && !(GF_ATTN_WHATIF & 256)) { if (pidx + 2 < nt) stage_piece(0, pidx + 2, PAR, 1); }
-        }
+        if constexpr (G == 5) stage_piece(1, pidx, PAR, 0);
+        if constexpr (G == 9) stage_piece(1, pidx, PAR, 1);
+        if constexpr (G == 13) { if (pidx + 2 < nt) stage_piece(0, pidx + 2, PAR, 0); }
+        if constexpr (G == 17) { if (pidx + 2 < nt) stage_piece(0, pidx + 2, PAR, 1); }
     };
     auto phase = [&](auto par_c, int pidx) {
         constexpr int PAR = decltype(par_c)::value;
-        if constexpr ((GF_ATTN_WHATIF & 64) != 0 && !(GF_ATTN_WHATIF & 16)) {
-            if constexpr (!(GF_ATTN_WHATIF & 256)) {
-                if (pidx + 2 < nt) stage(0, pidx + 2, PAR);
-            }
-            if constexpr (!(GF_ATTN_WHATIF & 128)) stage(1, pidx, PAR);
-        }
-        if constexpr (!(GF_ATTN_WHATIF & 32)) apply_pending();
+        apply_pending();
         frag_load(std::integral_constant<int, 0>{}, par_c);
         frag_load(std::integral_constant<int, 1>{}, par_c);
         frag_load(std::integral_constant<int, 2>{}, par_c);
@@ -833,8 +421,7 @@ __global__ __launch_bounds__(AT2_THREADS, 2) void flash_attn_fwd_kernel2(const A
             mfma_op(i_c, par_c);
             frag_load(std::integral_constant<int, G + 3>{}, par_c);
             dma_slot(i_c, par_c, pidx);
-            if constexpr ((GF_ATTN_WHATIF & 2) != 0) {
-            } else if constexpr (G == 1 || G == 2) {   // two independent v_max3 chains per slot (a wave issues in order)
+            if constexpr (G == 1 || G == 2) {   // two independent v_max3 chains per slot (a wave issues in order)
                 float m0 = mx, m1 = -INFINITY;
 #pragma unroll
                 for (int e = 0; e < 16; e += 4) {
@@ -848,7 +435,7 @@ __global__ __launch_bounds__(AT2_THREADS, 2) void flash_attn_fwd_kernel2(const A
             }
             __builtin_amdgcn_sched_barrier(0);
         });
-        if constexpr (!(GF_ATTN_WHATIF & 2)) new_max(mx);
+        new_max(mx);
         const float mc = m_run * c;
         float rs = 0.f, pe[2];
         static_for<4, 32>([&](auto i_c) {
@@ -859,7 +446,7 @@ __global__ __launch_bounds__(AT2_THREADS, 2) void flash_attn_fwd_kernel2(const A
             // scores 0..7 two per slot in slots 4-7, scores 8..31 one per slot in slots 8-31
             constexpr int n_el = (G < 8) ? 2 : 1;
             constexpr int el0 = (G < 8) ? 2 * (G - 4) : G;
-            static_for<0, (GF_ATTN_WHATIF & 1) ? 0 : n_el>([&](auto k_c) {
+            static_for<0, n_el>([&](auto k_c) {
                 constexpr int el = el0 + decltype(k_c)::value, half = el >> 4, e = el & 15;
                 float sv = sc[PAR][half][e];
                 asm volatile("" : "+v"(sv));
@@ -874,10 +461,8 @@ __global__ __launch_bounds__(AT2_THREADS, 2) void flash_attn_fwd_kernel2(const A
             __builtin_amdgcn_sched_barrier(0);
         });
         l_run += rs;
-        if constexpr (!(GF_ATTN_WHATIF & 8)) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
     };
 
     // ---- prologue: K(0), K(1) staged; S(0)
@@ -895,10 +480,6 @@ __global__ __launch_bounds__(AT2_THREADS, 2) void flash_attn_fwd_kernel2(const A
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // ---- steady phases 1 .. nt-2
-#if GF_K3_CLOCK
-    unsigned long long clk_t0, clk_r0;
-    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk_t0), "=s"(clk_r0)::"memory");
-#endif
     int pi = 1;
     for (; pi + 1 <= nt - 2; pi += 2) {
         phase(C1{}, pi);
@@ -908,16 +489,6 @@ __global__ __launch_bounds__(AT2_THREADS, 2) void flash_attn_fwd_kernel2(const A
         phase(C1{}, pi);
         ++pi;
     }
-#if GF_K3_CLOCK
-    {
-        unsigned long long clk_t1, clk_r1;
-        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk_t1), "=s"(clk_r1)::"memory");
-        if (p.dbg && tid == 0) {
-            p.dbg[2 * (long)blockIdx.x] = clk_t1 - clk_t0;
-            p.dbg[2 * (long)blockIdx.x + 1] = clk_r1 - clk_r0;
-        }
-    }
-#endif
     // ---- last phase p = nt-1 (nt >= 2): V(nt-1) in flight; PV(nt-2); softmax(nt-1)
     if (nt >= 2) {
         const int par = (nt - 1) & 1;
@@ -984,7 +555,7 @@ __global__ __launch_bounds__(AT2_THREADS, 2) void flash_attn_fwd_kernel2(const A
 //                 D = sc[kb][qb] (f32x4): query 16 qb + r, keys 16 kb + 4 g + j.
 //   The lane's 32 scores of a tile belong to ONE query per qb, spread over the four g-lanes of that query: the running max is
 //   kept identical in those four lanes, the lazy-rescale test `all scores <= max + 6` needs no cross-lane step (it is the same
-//   test on the partial maxima), row sums are taken on the matrix pipe (GF_K3_SUMMFMA; per lane until the epilogue without it);
+//   test on the partial maxima), row sums are taken on the matrix pipe (a ninth "d block" against a ones fragment);
 //   only the rare rescale reduces over g.
 //   O^T += V^T P^T : B = P^T[32 keys x 16 queries] = {sc[2kk][qb][0..3], sc[2kk+1][qb][0..3]} converted in place (lane-local),
 //                 A = V^T[16 d x 32 keys] (one ds_read_b128: row 16 db + r, chunk 4 kk + g of the pre-transposed copy, whose
@@ -995,9 +566,7 @@ __global__ __launch_bounds__(AT2_THREADS, 2) void flash_attn_fwd_kernel2(const A
 //   two query blocks), the same 32 scores per lane.  K image: 256-byte rows, chunk ^ (row & 15) (conflict-free for the
 //   16-row x 4-chunk fragment read; the 32x32x16 image is 2-way here); V^T image as in kernel 2.
 // NQ = 16-query blocks per wave: 2 -> 8 waves x 32 rows, two waves per SIMD (256 registers each).
-#ifndef GF_K3_NQ
-#define GF_K3_NQ 2
-#endif
+constexpr int K3_NQ = 2;
 template <int NQ> struct At3 {
     static constexpr int WAVES = 16 / NQ, THREADS = 64 * WAVES, ROWS = 16 * NQ, PIECES = NQ;   // PIECES: 1-KiB DMA pieces per wave and tile
     static constexpr int SLOTS = 32 * NQ;
@@ -1012,7 +581,6 @@ __device__ __forceinline__ void mfma16(f32x4& acc, const bf16x8& a, const bf16x8
 template <int NQ>
 __global__ __launch_bounds__(At3<NQ>::THREADS, (NQ == 2 ? 2 : 1)) void flash_attn_fwd_kernel3(const AttnArgs p) {
     constexpr int NP = At3<NQ>::PIECES, NW = At3<NQ>::WAVES, RW = At3<NQ>::ROWS, NS = At3<NQ>::SLOTS;
-    constexpr bool CINIT = GF_K3_CINIT != 0, SUMMFMA = GF_K3_SUMMFMA != 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     GF_LDS char* lds = (GF_LDS char*)smem;
     const int tid = threadIdx.x;
@@ -1022,10 +590,8 @@ __global__ __launch_bounds__(At3<NQ>::THREADS, (NQ == 2 ? 2 : 1)) void flash_att
     int head, qb0;
     {
         const int pid = blockIdx.x;
-        // GF_K3_MAP (A/B builds): 0 = XCD-aware (shipped: the 32 CUs of an XCD walk the query blocks of ONE head together, K / V of that
-        // head come from the XCD's L2); 1 = plain head-major order (consecutive workgroups = consecutive query blocks of a head, dealt
-        // round-robin over the 8 XCDs: every XCD streams every head's K / V -> ~8 x the fabric traffic; how much time do fabric bytes cost?)
-        if ((p.heads & 7) == 0 && GF_K3_MAP == 0) {
+        // XCD-aware: the 32 CUs of an XCD walk the query blocks of ONE head together, K / V of that head come from the XCD's L2
+        if ((p.heads & 7) == 0) {
             const int xcd = pid & 7, idx = pid >> 3;
             head = xcd + 8 * (idx / p.n_qblocks);
             qb0 = idx % p.n_qblocks;
@@ -1124,22 +690,18 @@ __global__ __launch_bounds__(At3<NQ>::THREADS, (NQ == 2 ? 2 : 1)) void flash_att
     // oacc[db][qb], db < 8: O^T;  oacc[8][qb]: the row sums — a ninth "d block" whose V^T fragment is the constant `ones` (row 0
     // all ones): the matrix pipe adds up the bf16 P it multiplies with anyway (4 MFMAs per tile instead of 32 v_add_f32), and the
     // sums are rescaled together with O.  sc[tile parity][kb][qb] = S' - m_run (log2 domain).
-    constexpr int NDB = SUMMFMA ? 9 : 8;
+    constexpr int NDB = 9;
     f32x4 oacc[NDB][NQ], sc[2][4][NQ];
     u32x4 pfw[2][NQ];                // P fragments [kk][qb] as four packed bf16 pairs (word w = keys 2w, 2w+1 of the B operand)
     auto pf = [&](int kk, int qb) __attribute__((always_inline)) { return __builtin_bit_cast(bf16x8, pfw[kk][qb]); };
-    // CINIT: m_run is the running maximum in the exp2 domain and the scores are kept relative to it; otherwise m_run is the
-    // maximum of the raw scores (times c in the exponent) as in kernel 2.  l_run: per-lane partial row sums (SUMMFMA = 0).
-    float m_run[NQ], alpha_pend[NQ], l_run[NQ];
-    f32x4 negm[NQ];                  // -m_run splat: the QK^T chains start from it
+    // The running maximum lives in the exp2 domain as its negative splat only (negm), and the scores are kept relative to it.
+    float alpha_pend[NQ];
+    f32x4 negm[NQ];                  // -(running maximum) splat: the QK^T chains start from it
 #pragma unroll
     for (int qb = 0; qb < NQ; ++qb) {
-        m_run[qb] = CINIT ? 0.f : -1.0e30f;
         alpha_pend[qb] = 1.f;
-        l_run[qb] = 0.f;
         negm[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const float c = CINIT ? 1.0f : p.scale_log2e;
     bool pend = false;               // wave-uniform: O still has to be multiplied by alpha_pend
 #pragma unroll
     for (int db = 0; db < NDB; ++db)
@@ -1172,7 +734,7 @@ __global__ __launch_bounds__(At3<NQ>::THREADS, (NQ == 2 ? 2 : 1)) void flash_att
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-            for (int qb = 0; qb < NQ; ++qb) sc[PAR][kb][qb] = CINIT ? negm[qb] : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int qb = 0; qb < NQ; ++qb) sc[PAR][kb][qb] = negm[qb];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -1192,12 +754,10 @@ __global__ __launch_bounds__(At3<NQ>::THREADS, (NQ == 2 ? 2 : 1)) void flash_att
 #pragma unroll
                 for (int qb = 0; qb < NQ; ++qb) mfma_pv(oacc[db][qb], vf, pf(kk, qb));
             }
-        if constexpr (SUMMFMA) {
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                for (int qb = 0; qb < NQ; ++qb) mfma_pv(oacc[NDB - 1][qb], ones, pf(kk, qb));
-        }
+            for (int qb = 0; qb < NQ; ++qb) mfma_pv(oacc[NDB - 1][qb], ones, pf(kk, qb));
     };
     auto apply_pending = [&]() __attribute__((always_inline)) {
         if (pend) {
@@ -1215,14 +775,10 @@ __global__ __launch_bounds__(At3<NQ>::THREADS, (NQ == 2 ? 2 : 1)) void flash_att
     // matrix pipe produced against the old maximum, are corrected here, later tiles start from the new one (negm).
     auto new_max = [&](auto par_c, const float (&mx)[NQ], bool first) {
         constexpr int PAR = decltype(par_c)::value;
-        float over = CINIT ? mx[0] : (mx[0] - m_run[0]) * c;        // how far any score of the tile is above its running maximum
+        float over = mx[0];        // how far any score of the tile is above its running maximum
 #pragma unroll
-        for (int qb = 1; qb < NQ; ++qb) over = fmaxf(over, CINIT ? mx[qb] : (mx[qb] - m_run[qb]) * c);
-        // GF_K3_ORMAX: the watch on the packed P can only tell "some P >= 2", i.e. a score >= 1 above the stabiliser the scores are
-        // kept relative to.  To rescale as lazily as the shipped kernel (which lets scores rise 6 above the last maximum), the
-        // stabiliser of a row that moved is set HEAD = 5 ABOVE its new maximum: P <= 2^-5 right after an update, and the next
-        // update comes when a score is 6 above that maximum — the same laziness, a different (power-of-two) scale of P, l and O.
-        constexpr float QUIET = GF_K3_ORMAX ? 1.0f : 6.0f, HEAD = GF_K3_ORMAX ? 5.0f : 0.0f;
+        for (int qb = 1; qb < NQ; ++qb) over = fmaxf(over, mx[qb]);
+        constexpr float QUIET = 6.0f;      // lazy rescale: scores may rise 6 (a factor 64 in P) above the last maximum
         const bool quiet = __all(over <= QUIET);
         if (first || !quiet) {
 #pragma unroll
@@ -1230,28 +786,18 @@ __global__ __launch_bounds__(At3<NQ>::THREADS, (NQ == 2 ? 2 : 1)) void flash_att
                 float d = mx[qb];                        // reduce over the four g-lanes of the query
                 d = fmaxf(d, __shfl_xor(d, 16));
                 d = fmaxf(d, __shfl_xor(d, 32));
-                float alpha;
-                if constexpr (CINIT) {
-                    if (!first) d = fmaxf(d, 0.f);       // the maximum never moves down (the first tile sets it, whatever its sign)
-                    if constexpr (GF_K3_ORMAX != 0) d = (first || d > QUIET) ? d + HEAD : d;
-                    const float m_new = d - negm[qb][0];     // CINIT: the running maximum is kept as its negative splat only
-                    alpha = __builtin_amdgcn_exp2f(-d);
+                if (!first) d = fmaxf(d, 0.f);       // the maximum never moves down (the first tile sets it, whatever its sign)
+                const float m_new = d - negm[qb][0];
+                const float alpha = __builtin_amdgcn_exp2f(-d);
 #pragma unroll
-                    for (int kb = 0; kb < 4; ++kb)
+                for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) sc[PAR][kb][qb][e] -= d;
+                    for (int e = 0; e < 4; ++e) sc[PAR][kb][qb][e] -= d;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) negm[qb][e] = -m_new;
-                } else {
-                    const float m_new = fmaxf(m_run[qb], d);
-                    alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * c);
-                    m_run[qb] = m_new;
-                }
-                l_run[qb] *= alpha;
+                for (int e = 0; e < 4; ++e) negm[qb][e] = -m_new;
                 alpha_pend[qb] = alpha;   // at most one outstanding: applied at the top of the next phase
             }
-            pend = !(CINIT && first) || pend;
-            if (CINIT && first) pend = false;
+            pend = !first;                // (nothing has been accumulated yet when the first tile sets the maximum)
         }
     };
     auto mask_ragged = [&](auto par_c, int t) __attribute__((always_inline)) {
@@ -1282,19 +828,14 @@ __global__ __launch_bounds__(At3<NQ>::THREADS, (NQ == 2 ? 2 : 1)) void flash_att
         new_max(par_c, mx, t == 0);
 #pragma unroll
         for (int qb = 0; qb < NQ; ++qb) {
-            const float mc = CINIT ? 0.f : m_run[qb] * c;
-            float rs = 0.f;
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
                 for (int j = 0; j < 4; j += 2) {
-                    const float s0 = sc[PAR][kb][qb][j], s1 = sc[PAR][kb][qb][j + 1];
-                    const float p0 = __builtin_amdgcn_exp2f(CINIT ? s0 : __builtin_fmaf(s0, c, -mc));
-                    const float p1 = __builtin_amdgcn_exp2f(CINIT ? s1 : __builtin_fmaf(s1, c, -mc));
-                    rs += p0 + p1;
+                    const float p0 = __builtin_amdgcn_exp2f(sc[PAR][kb][qb][j]);
+                    const float p1 = __builtin_amdgcn_exp2f(sc[PAR][kb][qb][j + 1]);
                     pfw[kb >> 1][qb][(kb & 1) * 2 + (j >> 1)] = pack2bf(p0, p1);
                 }
-            if constexpr (!SUMMFMA) l_run[qb] += rs;
         }
     };
 
@@ -1304,13 +845,11 @@ __global__ __launch_bounds__(At3<NQ>::THREADS, (NQ == 2 ? 2 : 1)) void flash_att
     //   f >= 16: QK(p+1)  ks = (f-16) >> 2, kb = (f-16) & 3  A = K fragment (kb, ks) of K buffer 1-PAR
     // Fragment f is read RING - 1 fragments ahead into ring entry f % RING.  The partial maxima of S(p) are taken in slots
     // 0 .. 4 NQ - 1, the rescale test follows, its 16 NQ scores per lane are exponentiated in slots 8 NQ .. NS - 1.
-    constexpr int RING = GF_K3_RING;
+    constexpr int RING = K3_RING;
     bf16x8 fr[RING];
     auto frag_load = [&](auto f_c, auto par_c) __attribute__((always_inline)) {
         constexpr int F = decltype(f_c)::value, PAR = decltype(par_c)::value;
-        if constexpr ((GF_K3_WHATIF & 4) != 0) {
-            if (p.kv_len < 0) fr[F % RING] = *(GF_LDS bf16x8*)(lds + voff[0]);
-        } else if constexpr (F < 16) {
+        if constexpr (F < 16) {
             constexpr int kk = F >> 3, db = F & 7;
             fr[F % RING] = *(GF_LDS bf16x8*)(lds + voff[kk] + db * 2048 + (1 - PAR) * KV_TILE_BYTES);
         } else if constexpr (F < 32) {
@@ -1320,26 +859,25 @@ __global__ __launch_bounds__(At3<NQ>::THREADS, (NQ == 2 ? 2 : 1)) void flash_att
     };
     auto mfma_op = [&](auto s_c, auto par_c) __attribute__((always_inline)) {
         constexpr int S = decltype(s_c)::value, PAR = decltype(par_c)::value;
-        constexpr int F = S / NQ, qb = (GF_K3_SNAKE && (F & 1)) ? NQ - 1 - S % NQ : S % NQ;
+        // query-block order reversed on odd fragments: one MFMA operand changes per slot instead of both
+        constexpr int F = S / NQ, qb = (F & 1) ? NQ - 1 - S % NQ : S % NQ;
         if constexpr (F < 16) {
             constexpr int kk = F >> 3, db = F & 7;
             mfma_pv(oacc[db][qb], fr[F % RING], pf(kk, qb));
         } else {
             constexpr int ks = (F - 16) >> 2, kb = (F - 16) & 3;
             if constexpr (ks == 0) {
-                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-                mfma_qk_first(sc[1 - PAR][kb][qb], fr[F % RING], qf[qb][ks], CINIT ? negm[qb] : zero);
+                mfma_qk_first(sc[1 - PAR][kb][qb], fr[F % RING], qf[qb][ks], negm[qb]);
             } else {
                 mfma_qk(sc[1 - PAR][kb][qb], fr[F % RING], qf[qb][ks]);
             }
         }
     };
-    // staging: the wave's NP V^T pieces of tile p, then its NP K pieces of tile p+2, one every GF_K3_DMAS slots from slot GF_K3_DMA0
+    // staging: the wave's NP V^T pieces of tile p, then its NP K pieces of tile p+2, one every K3_DMAS slots from slot K3_DMA0
     auto dma_slot = [&](auto s_c, auto par_c, int pidx) __attribute__((always_inline)) {
         constexpr int S = decltype(s_c)::value, PAR = decltype(par_c)::value;
-        if constexpr ((GF_K3_WHATIF & 8) != 0) return;
-        if constexpr (S >= GF_K3_DMA0 && (S - GF_K3_DMA0) % GF_K3_DMAS == 0 && (S - GF_K3_DMA0) / GF_K3_DMAS < 2 * NP) {
-            constexpr int i = (S - GF_K3_DMA0) / GF_K3_DMAS;
+        if constexpr (S >= K3_DMA0 && (S - K3_DMA0) % K3_DMAS == 0 && (S - K3_DMA0) / K3_DMAS < 2 * NP) {
+            constexpr int i = (S - K3_DMA0) / K3_DMAS;
             if constexpr (i < NP) {
                 stage_piece(1, pidx, PAR, i);
             } else {
@@ -1359,7 +897,7 @@ __global__ __launch_bounds__(At3<NQ>::THREADS, (NQ == 2 ? 2 : 1)) void flash_att
             mfma_op(s_c, par_c);
             if constexpr (S % NQ == 0) frag_load(std::integral_constant<int, S / NQ + RING - 1>{}, par_c);
             // partial maxima: slot S takes key block S / NQ of query block S % NQ (4 scores: two v_max3)
-            if constexpr ((GF_K3_WHATIF & 16) == 0 && !GF_K3_ORMAX) {
+            {
                 constexpr int kb = S / NQ, qb = S % NQ;
                 const f32x4& v = sc[PAR][kb][qb];
                 mx[qb] = fmaxf(fmaxf(mx[qb], v[0]), v[1]);
@@ -1367,25 +905,13 @@ __global__ __launch_bounds__(At3<NQ>::THREADS, (NQ == 2 ? 2 : 1)) void flash_att
             }
             __builtin_amdgcn_sched_barrier(0);
         });
-        if constexpr ((GF_K3_WHATIF & 16) == 0 && !GF_K3_ORMAX) new_max(par_c, mx, false);
-        float mc[NQ], pe[2];
-        // GF_K3_ORMAX: no maximum is taken before the exponentials.  P = exp2(S' - m) is >= 2 exactly when a score exceeds the
-        // running maximum by >= 1, and a bf16 >= 2 (Inf included) has bit 14 set while every bf16 in [0, 2) has it clear: the
-        // bitwise OR of the tile's packed P words (v_or3_b32: two words per instruction, 8 per wave and phase instead of 16
-        // v_max3 on the fp32 scores) tells whether ANY score did.  Only then (a few per cent of the phases on random data, never
-        // on the common path) are the true maxima taken from S(p) — still intact in its registers — and, if one is more than 6
-        // above the running maximum, the rescale of `new_max` runs and the tile's P is recomputed; an overflow to Inf cannot
-        // escape, it sets bit 14 as well.
-        unsigned orp[NQ];
-#pragma unroll
-        for (int qb = 0; qb < NQ; ++qb) orp[qb] = 0u;
-#pragma unroll
-        for (int qb = 0; qb < NQ; ++qb) mc[qb] = CINIT ? 0.f : m_run[qb] * c;
+        new_max(par_c, mx, false);
+        float pe[2];
         static_for<4 * NQ, NS>([&](auto s_c) {
             constexpr int S = decltype(s_c)::value;
             mfma_op(s_c, par_c);
             // the row-sum MFMAs of PV(p-1) ride in the PV half: after the last slot that reads pf[kk]
-            if constexpr (SUMMFMA && (S == 8 * NQ - 1 || S == 16 * NQ - 1)) {
+            if constexpr (S == 8 * NQ - 1 || S == 16 * NQ - 1) {
 #pragma unroll
                 for (int qb = 0; qb < NQ; ++qb) mfma_pv(oacc[NDB - 1][qb], ones, pf(S / (8 * NQ), qb));
             }
@@ -1399,85 +925,33 @@ __global__ __launch_bounds__(At3<NQ>::THREADS, (NQ == 2 ? 2 : 1)) void flash_att
             // per score: 5.8 issue slots per score instead of 2).  v_exp_f32 is a transcendental op: its result may not be read
             // by the next instruction — the row-sum add of a score sits one slot after its exp2, the pack of a pair in the pair's
             // third slot, each behind that slot's MFMA.
-            if constexpr (S >= 8 * NQ && (GF_K3_WHATIF & 2) == 0) {
+            if constexpr (S >= 8 * NQ) {
                 constexpr int T = (S - 8 * NQ) % 3, e = ((S - 8 * NQ) / 3) * 2 + (T == 2 ? 1 : T);
                 constexpr int kk = e / (8 * NQ), qb = (e >> 3) % NQ, kb = 2 * kk + ((e >> 2) & 1), j = e & 3;
                 if constexpr (T != 2) {
-                    float arg = sc[PAR][kb][qb][j];
-                    if constexpr (!CINIT) arg = __builtin_fmaf(arg, c, -mc[qb]);
-                    asm volatile("v_exp_f32 %0, %1" : "=v"(pe[T]) : "v"(arg));
-                    if constexpr (!SUMMFMA && T == 1) asm volatile("v_add_f32 %0, %0, %1" : "+v"(l_run[qb]) : "v"(pe[0]));
+                    asm volatile("v_exp_f32 %0, %1" : "=v"(pe[T]) : "v"(sc[PAR][kb][qb][j]));
                 } else {
                     unsigned w;
                     asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(pe[0]), "v"(pe[1]));
                     pfw[kk][qb][(kb & 1) * 2 + (j >> 1)] = w;
-                    if constexpr (GF_K3_ORMAX != 0) {      // every second pack folds its word and the one before it into the watch
-                        constexpr int widx = (kb & 1) * 2 + (j >> 1);
-                        if constexpr (widx & 1)
-                            asm volatile("v_or3_b32 %0, %0, %1, %2" : "+v"(orp[qb]) : "v"(pfw[kk][qb][widx - 1]), "v"(w));
-                    }
-                    if constexpr (!SUMMFMA) asm volatile("v_add_f32 %0, %0, %1" : "+v"(l_run[qb]) : "v"(pe[1]));
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
         });
-        if constexpr (GF_K3_ORMAX != 0 && (GF_K3_WHATIF & 16) == 0) {
-            unsigned any = orp[0];
-#pragma unroll
-            for (int qb = 1; qb < NQ; ++qb) any |= orp[qb];
-            if (__builtin_expect(!__all((any & 0x40004000u) == 0u), 0)) {
-                // rare: some P >= 2.  True partial maxima of S(p) (relative to the running maximum) ...
-                float mxr[NQ];
-#pragma unroll
-                for (int qb = 0; qb < NQ; ++qb) {
-                    mxr[qb] = sc[PAR][0][qb][0];
-#pragma unroll
-                    for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) mxr[qb] = fmaxf(mxr[qb], sc[PAR][kb][qb][j]);
-                }
-                f32x4 negm_old[NQ];
-#pragma unroll
-                for (int qb = 0; qb < NQ; ++qb) negm_old[qb] = negm[qb];
-                const bool pend_old = pend;
-                new_max(par_c, mxr, false);        // ... moves the running maximum (and corrects S(p)) only if one is > 6 above it
-#pragma unroll
-                for (int qb = 0; qb < NQ; ++qb) {
-                    const float d = negm_old[qb][0] - negm[qb][0];      // how far this query block's maximum moved (0: untouched)
-                    if (__builtin_expect(!__all(d == 0.f), 0)) {
-                        // S(p+1) was started from the OLD maximum during this phase: move it along, and redo the tile's P
-#pragma unroll
-                        for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) sc[1 - PAR][kb][qb][e] -= d;
-#pragma unroll
-                        for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-                            for (int j = 0; j < 4; j += 2)
-                                pfw[kb >> 1][qb][(kb & 1) * 2 + (j >> 1)] =
-                                    pack2bf(__builtin_amdgcn_exp2f(sc[PAR][kb][qb][j]), __builtin_amdgcn_exp2f(sc[PAR][kb][qb][j + 1]));
-                    }
-                }
-                (void)pend_old;
-            }
-        }
-        if constexpr ((GF_K3_WHATIF & 1) == 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
     };
 
     // ---- prologue: K(0), K(1) staged; S(0)
     stage(0, 0, 0);
     if (nt > 1) stage(0, 1, 1);
-    if constexpr (CINIT) {   // Q <- bf16(Q * scale * log2 e), under the latency of the staging just issued
+    // Q <- bf16(Q * scale * log2 e), under the latency of the staging just issued
 #pragma unroll
-        for (int qb = 0; qb < NQ; ++qb)
+    for (int qb = 0; qb < NQ; ++qb)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
+        for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) qf[qb][ks][e] = (__bf16)((float)qf[qb][ks][e] * p.scale_log2e);
-    }
+            for (int e = 0; e < 8; ++e) qf[qb][ks][e] = (__bf16)((float)qf[qb][ks][e] * p.scale_log2e);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     qk_plain(C0{});
@@ -1485,20 +959,11 @@ __global__ __launch_bounds__(At3<NQ>::THREADS, (NQ == 2 ? 2 : 1)) void flash_att
     // ---- phase 0 (no PV yet): K(2), V(0) in flight; S(1); softmax(0)
     if (nt > 2) stage(0, 2, 0);
     stage(1, 0, 0);
-    if constexpr (CINIT) {
-        softmax_plain(C0{}, 0);          // sets the running maximum (tile 0's row maximum) ...
-        if (nt > 1) qk_plain(C1{});      // ... which S(1) already starts from
-    } else {
-        if (nt > 1) qk_plain(C1{});
-        softmax_plain(C0{}, 0);
-    }
+    softmax_plain(C0{}, 0);          // sets the running maximum (tile 0's row maximum) ...
+    if (nt > 1) qk_plain(C1{});      // ... which S(1) already starts from
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // ---- steady phases 1 .. nt-2
-#if GF_K3_CLOCK
-    unsigned long long clk_t0, clk_r0;
-    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk_t0), "=s"(clk_r0)::"memory");
-#endif
     int pi = 1;
     for (; pi + 1 <= nt - 2; pi += 2) {
         phase(C1{}, pi);
@@ -1508,16 +973,6 @@ __global__ __launch_bounds__(At3<NQ>::THREADS, (NQ == 2 ? 2 : 1)) void flash_att
         phase(C1{}, pi);
         ++pi;
     }
-#if GF_K3_CLOCK
-    {
-        unsigned long long clk_t1, clk_r1;
-        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk_t1), "=s"(clk_r1)::"memory");
-        if (p.dbg && tid == 0) {
-            p.dbg[2 * (long)blockIdx.x] = clk_t1 - clk_t0;
-            p.dbg[2 * (long)blockIdx.x + 1] = clk_r1 - clk_r0;
-        }
-    }
-#endif
     // ---- last phase p = nt-1 (nt >= 2): V(nt-1) in flight; PV(nt-2); softmax(nt-1)
     if (nt >= 2) {
         const int par = (nt - 1) & 1;
@@ -1545,17 +1000,10 @@ __global__ __launch_bounds__(At3<NQ>::THREADS, (NQ == 2 ? 2 : 1)) void flash_att
         float inv[NQ];
 #pragma unroll
         for (int qb = 0; qb < NQ; ++qb) {
-            float l;
-            if constexpr (SUMMFMA) {
-                l = __shfl(oacc[NDB - 1][qb][0], r);        // row 0 of the ninth block: lane g == 0 of the query holds it
-            } else {
-                l = l_run[qb];
-                l += __shfl_xor(l, 16);
-                l += __shfl_xor(l, 32);
-            }
+            const float l = __shfl(oacc[NDB - 1][qb][0], r);        // row 0 of the ninth block: lane g == 0 of the query holds it
             inv[qb] = 1.0f / l;
             const int qrow = q0 + 16 * qb + r;
-            if (p.lse && g == 0 && qrow < p.q_len) p.lse[(long)qrow * p.heads + head] = (CINIT ? -negm[qb][0] : m_run[qb] * c) + __builtin_amdgcn_logf(l);
+            if (p.lse && g == 0 && qrow < p.q_len) p.lse[(long)qrow * p.heads + head] = -negm[qb][0] + __builtin_amdgcn_logf(l);
         }
         // O leaves through LDS as whole 256-byte rows: the wave's RW x 256 B image, 16-byte chunk ch of row q at chunk ch ^ (q & 15);
         // a lane holds the 8-byte pieces d = 16 db + 4 g .. +3 of its NQ rows.  The K/V tiles are dead at this barrier.
@@ -1667,13 +1115,10 @@ static int flash_attn_fwd_impl(const void* q, const void* k, const void* v, void
     GF_CHECK_ARG((kv_len + 64) * k_stride < (1LL << 31) && (kv_len + 64) * v_stride < (1LL << 31),
                  "gf_flash_attn_fwd: kv_len*stride must stay below 2^31 elements");
     if (q_len == 0) return GF_OK;
-    // tuning switch: GF_ATTN_KERNEL=1 = the phase-serial kernel, otherwise the slot-pipelined kernel 2
-    static const bool use_k2 = !gf_options().attn_kernel1.load(std::memory_order_relaxed);   // fixed at the first launch
     static GfDeviceOnce once;
     hipError_t e = gf_once_per_device(once, [] {
-        hipError_t r = hipFuncSetAttribute(use_k2 ? reinterpret_cast<const void*>(flash_attn_fwd_kernel2<false>)
-                                                  : reinterpret_cast<const void*>(flash_attn_fwd_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, use_k2 ? AT2_LDS : AT_LDS);
+        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_fwd_kernel2<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, AT2_LDS);
         if (r == hipSuccess)
             r = hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_fwd_kernel2<true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, AT2_LDS);
@@ -1702,23 +1147,16 @@ static int flash_attn_fwd_impl(const void* q, const void* k, const void* v, void
     a.kv_pad = kv_pad;
     a.last_key_bias = 0.f;
     if (last_key_multiplicity != 1.0f) {
-        GF_CHECK_ARG(last_key_multiplicity >= 1.0f && !vt && use_k2 && scale > 0.f,
-                     "gf_flash_attn_fwd_lastmult: multiplicity >= 1, plain-V kernel 2 only (not the V^T form, not GF_ATTN_KERNEL=1)");
+        GF_CHECK_ARG(last_key_multiplicity >= 1.0f && !vt && scale > 0.f,
+                     "gf_flash_attn_fwd_lastmult: multiplicity >= 1, plain-V form only (not the V^T form)");
         a.last_key_bias = log2f(last_key_multiplicity) / a.scale_log2e;
     }
-#if GF_ATTN_STAMP
-    a.dbg = g_attn_dbg;
-#else
     a.dbg = nullptr;
-#endif
     if (vt)
         hipLaunchKernelGGL(flash_attn_fwd_kernel2<true>, dim3((unsigned)(a.n_qblocks * a.heads)), dim3(AT2_THREADS), AT2_LDS,
                            (hipStream_t)stream, a);
-    else if (use_k2)
-        hipLaunchKernelGGL(flash_attn_fwd_kernel2<false>, dim3((unsigned)(a.n_qblocks * a.heads)), dim3(AT2_THREADS), AT2_LDS,
-                           (hipStream_t)stream, a);
     else
-        hipLaunchKernelGGL(flash_attn_fwd_kernel, dim3((unsigned)(a.n_qblocks * a.heads)), dim3(AT_THREADS), AT_LDS,
+        hipLaunchKernelGGL(flash_attn_fwd_kernel2<false>, dim3((unsigned)(a.n_qblocks * a.heads)), dim3(AT2_THREADS), AT2_LDS,
                            (hipStream_t)stream, a);
     GF_CHECK_LAUNCH("gf_flash_attn_fwd");
     return GF_OK;
@@ -1801,7 +1239,7 @@ extern "C" GF_API int gf_flash_attn_fwd_vt32(const void* q, const void* k, const
     if (q_len == 0) return GF_OK;
     static GfDeviceOnce once;
     hipError_t e = gf_once_per_device(once, [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_fwd_kernel3<GF_K3_NQ>),
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_fwd_kernel3<K3_NQ>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, AT3_LDS);
     });
     if (e != hipSuccess) {
@@ -1825,13 +1263,9 @@ extern "C" GF_API int gf_flash_attn_fwd_vt32(const void* q, const void* k, const
     a.lse = lse;
     a.vt = (const u16*)vt;
     a.kv_pad = kv_pad;
-#if GF_K3_CLOCK
-    a.dbg = g_attn_dbg;
-#else
     a.dbg = nullptr;
-#endif
     a.last_key_bias = 0.f;
-    hipLaunchKernelGGL(flash_attn_fwd_kernel3<GF_K3_NQ>, dim3((unsigned)(a.n_qblocks * a.heads)), dim3(At3<GF_K3_NQ>::THREADS), AT3_LDS,
+    hipLaunchKernelGGL(flash_attn_fwd_kernel3<K3_NQ>, dim3((unsigned)(a.n_qblocks * a.heads)), dim3(At3<K3_NQ>::THREADS), AT3_LDS,
                        (hipStream_t)stream, a);
     GF_CHECK_LAUNCH("gf_flash_attn_fwd_vt32");
     return GF_OK;

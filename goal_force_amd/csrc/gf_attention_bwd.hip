@@ -4,15 +4,11 @@
 //
 // With P = softmax(scale Q K^T) rebuilt from the forward's log-sum-exp (P = exp2(c S - lse), c = scale log2 e) and
 // delta = rowsum(dO . O):   dV = P^T dO,   dP = dO V^T,   dS = P . (dP - delta),   dQ = scale dS K,   dK = scale dS^T Q.
-// Two kernels, no atomics (S and dP are recomputed in both; 7 tile products instead of the minimal 5):
-//   * attn_bwd_dq_kernel : one wave owns 32 QUERIES (on the lane, as in the forward) and walks the KV tiles;
-//   * attn_bwd_dkv_kernel: one wave owns 32 KEYS (on the lane) and walks the query tiles.
-// Same operand algebra as the forward (gf_attention.hip): swapped products with v_mfma_f32_32x32x16_bf16 so the owned
-// row is on the lane and the per-row scalars (lse, delta) are per-lane (dQ) or per-register broadcast reads (dK/dV); the
-// fp32 accumulator converted pairwise to bf16 is the B operand of the second product; row fragments by ds_read_b128
-// and transposed fragments by ds_read_b64_tr_b16 from ONE XOR-swizzled 64 x 128 tile image staged by LDS-DMA.
-// Round-1 shape: tiles double buffered (the DMA of tile t+1 flies during the products of tile t, one barrier per tile),
-// plain per-tile product order — the forward's slot pipeline is the template for the next step.
+// Two kernels, no atomics (S and dP are recomputed in both; 7 tile products instead of the minimal 5): attn_bwd_dq16_kernel (a wave
+// owns 32 QUERIES and walks the key tiles) and attn_bwd_dkv48_kernel (wave pairs own 48 KEYS and walk 32-query granules), both on
+// v_mfma_f32_16x16x32_bf16; the design notes stand in front of them below.  The first kernels (32x32x16 MFMAs, separate dQ / dV / dK
+// passes, 8 products), the 32-key dK/dV kernel and the pre-scaled-Q variant are NOT in this file:
+// tools/patches/attention_bwd_experiments.patch re-creates them.
 #include "gf_common.h"
 #include <type_traits>
 
@@ -21,8 +17,6 @@ namespace {
 constexpr int KVB = 64, HD = 128;
 constexpr int TILE_BYTES = KVB * HD * 2;   // 16 KiB
 constexpr int DQ_THREADS = 512, DQ_ROWS = 256;     // dQ: 8 waves x 32 queries, two waves per SIMD (<= 256 registers)
-constexpr int DKV_THREADS = 256, DKV_ROWS = 128;   // dK/dV: 4 waves x 32 keys, one wave per SIMD (~300 registers)
-constexpr int BWD_LDS = 4 * TILE_BYTES + 4 * KVB * (int)sizeof(float);   // two stages of (two tiles + lse + delta)
 
 struct BwdArgs {
     const u16 *q, *k, *v, *o, *dout;
@@ -34,334 +28,8 @@ struct BwdArgs {
     float scale, scale_log2e;
 };
 
-// delta[s, h] = sum_d dO[s, h, d] * O[s, h, d]
-__global__ __launch_bounds__(256) void attn_bwd_delta_kernel(const BwdArgs p) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long)p.q_len * p.heads) return;
-    const int s = (int)(idx / p.heads), h = (int)(idx % p.heads);
-    const u16* op = p.o + (long)s * p.o_stride + h * HD;
-    const u16* dp = p.dout + (long)s * p.do_stride + h * HD;
-    float acc = 0.f;
-#pragma unroll 4
-    for (int i = 0; i < HD / 8; ++i) {
-        const u16x8 a = *reinterpret_cast<const u16x8*>(op + 8 * i);
-        const u16x8 b = *reinterpret_cast<const u16x8*>(dp + 8 * i);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc += bf2f(a[e]) * bf2f(b[e]);
-    }
-    p.delta[idx] = acc;
-}
-
-__device__ __forceinline__ void dma16(const u16* g, GF_LDS char* l) {
-    unsigned keep;
-    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)l);
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(g), "s"(dst)
-                 : "memory");
-}
-
-// 64 rows x 256 B of `base` (rows row0.., clamped to len-1; head column offset included in base) -> swizzled LDS image.
-// NW waves: wave w fills row-groups j = (16/NW) w .. (4 rows x 256 B each); the DMA writes lane-linear, so the image's chunk
-// swizzle off(row,ch) = 256 row + 16 (ch ^ (((row&3)<<2) | ((row>>2)&3))) is applied to the per-lane SOURCE chunk.
-template <int NW>
-__device__ __forceinline__ void stage_tile(const u16* base, long stride, int row0, int len, GF_LDS char* dst, int wave, int lane) {
-    constexpr int PER = 16 / NW;
-    const int dma_r = lane >> 4;
-#pragma unroll
-    for (int jj = 0; jj < PER; ++jj) {
-        const int j = PER * wave + jj;
-        const long rr = min(row0 + 4 * j + dma_r, len - 1);
-        const int lch = (lane & 15) ^ ((dma_r << 2) | (j & 3));
-        dma16(base + rr * stride + lch * 8, dst + j * 1024);
-    }
-}
-
-struct FragOffsets {
-    int row[8];      // row-read offsets of fragment kd (rows 0..31; +32*256 for rows 32..63)
-    int tr[2][4];    // transposed-read offsets [hf][d]
-};
-
-__device__ __forceinline__ FragOffsets frag_offsets(int lane) {
-    FragOffsets f;
-    const int r = lane & 31, h = lane >> 5;
-    const int sK = ((r & 3) << 2) | ((r >> 2) & 3);
-#pragma unroll
-    for (int kd = 0; kd < 8; ++kd) f.row[kd] = 256 * r + 16 * ((2 * kd + h) ^ sK);
-    const int qd = (lane & 15) >> 2, pp = lane & 3;
-    const int vcl = 2 * ((lane >> 4) & 1) + (pp >> 1);
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-        const int sV = (qd << 2) | ((2 * hf + h) & 3);
-#pragma unroll
-        for (int d = 0; d < 4; ++d) f.tr[hf][d] = 256 * (8 * hf + 4 * h + qd) + 16 * ((4 * d + vcl) ^ sV) + 8 * (pp & 1);
-    }
-    return f;
-}
-
-__device__ __forceinline__ bf16x8 tr_frag(GF_LDS char* buf, const FragOffsets& f, int d, int kt, int s) {
-    const int imm = 256 * (32 * kt + 16 * s);
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GF_LDS s16x4*)(buf + f.tr[0][d] + imm));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GF_LDS s16x4*)(buf + f.tr[1][d] + imm));
-    typedef __attribute__((ext_vector_type(8))) short s16x8;
-    const s16x8 vv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    return __builtin_bit_cast(bf16x8, vv);
-}
-
-__device__ __forceinline__ void mfma32(f32x16& acc, const bf16x8& a, const bf16x8& b) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
-}
-
-__device__ __forceinline__ void zero16(f32x16& a) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) a[e] = 0.f;
-}
-// 8 fp32 -> one bf16x8 fragment, two values per v_cvt_pk_bf16_f32
-__device__ __forceinline__ bf16x8 pack8(const float (&x)[8]) {
-    const u32x4 w = {pack2bf(x[0], x[1]), pack2bf(x[2], x[3]), pack2bf(x[4], x[5]), pack2bf(x[6], x[7])};
-    return __builtin_bit_cast(bf16x8, w);
-}
-// transposed accumulator acc[d][e] (lane = owned row, register e of block d = column 32d + (e&3) + 8(e>>2) + 4h) -> row of out
-__device__ __forceinline__ void store_rows(u16* rowp, const f32x16 (&acc)[4], float mul, int h) {
-#pragma unroll
-    for (int d = 0; d < 4; ++d)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-            u32x2 pk;
-            pk[0] = pack2bf(acc[d][4 * rg + 0] * mul, acc[d][4 * rg + 1] * mul);
-            pk[1] = pack2bf(acc[d][4 * rg + 2] * mul, acc[d][4 * rg + 3] * mul);
-            *reinterpret_cast<u32x2*>(rowp + 4 * h + 32 * d + 8 * rg) = pk;
-        }
-}
-
-// ---- dQ: wave owns queries q0 + r ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(DQ_THREADS, 2) void attn_bwd_dq_kernel(const BwdArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    GF_LDS char* lds = (GF_LDS char*)smem;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, h = lane >> 5;
-    const int nqb = (p.q_len + DQ_ROWS - 1) / DQ_ROWS;
-    const int head = blockIdx.x / nqb, qb = blockIdx.x % nqb;
-    const int q0 = qb * DQ_ROWS + wave * 32;
-    const int qr = min(q0 + r, p.q_len - 1);
-
-    bf16x8 qf[8], dof[8];
-    {
-        const u16* qp = p.q + (long)qr * p.q_stride + head * HD + 8 * h;
-        const u16* dp = p.dout + (long)qr * p.do_stride + head * HD + 8 * h;
-#pragma unroll
-        for (int kd = 0; kd < 8; ++kd) {
-            qf[kd] = *reinterpret_cast<const bf16x8*>(qp + 16 * kd);
-            dof[kd] = *reinterpret_cast<const bf16x8*>(dp + 16 * kd);
-        }
-    }
-    const float lse = p.lse[(long)qr * p.heads + head];
-    const float dl = p.delta[(long)qr * p.heads + head];
-    const float c = p.scale_log2e;
-    const FragOffsets fo = frag_offsets(lane);
-    f32x16 dq[4];
-#pragma unroll
-    for (int d = 0; d < 4; ++d) zero16(dq[d]);
-
-    const int nt = (p.kv_len + KVB - 1) / KVB;
-    auto stage = [&](int t) {   // stage s = t & 1: K at s*32K, V at s*32K + 16K
-        GF_LDS char* b = lds + (t & 1) * 2 * TILE_BYTES;
-        stage_tile<8>(p.k + head * HD, p.k_stride, t * KVB, p.kv_len, b, wave, lane);
-        stage_tile<8>(p.v + head * HD, p.v_stride, t * KVB, p.kv_len, b + TILE_BYTES, wave, lane);
-    };
-    // MASKED: the last tile when kv_len is not a multiple of 64 (its staged rows past the end are clamped copies: their p is 0)
-    auto tile = [&](int t, auto masked) {
-        constexpr bool MASKED = decltype(masked)::value;
-        GF_LDS char* kbuf = lds + (t & 1) * 2 * TILE_BYTES;
-        GF_LDS char* vbuf = kbuf + TILE_BYTES;
-        bf16x8 dsf[2][2];
-        auto softmax_half = [&](int half, const f32x16& sc, const f32x16& dp) {
-#pragma unroll
-            for (int s8 = 0; s8 < 2; ++s8) {
-                float x[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int e = 8 * s8 + j;
-                    float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[e], c, -lse));
-                    if constexpr (MASKED) pr = (t * KVB + 32 * half + (e & 3) + 8 * (e >> 2) + 4 * h < p.kv_len) ? pr : 0.f;
-                    x[j] = pr * (dp[e] - dl);
-                }
-                dsf[half][s8] = pack8(x);
-            }
-        };
-        {
-            f32x16 sc[2], dp[2];
-            zero16(sc[0]);
-            zero16(sc[1]);
-            zero16(dp[0]);
-            zero16(dp[1]);
-#pragma unroll
-            for (int kd = 0; kd < 8; ++kd) {
-                const bf16x8 k0 = *(GF_LDS bf16x8*)(kbuf + fo.row[kd]);
-                const bf16x8 k1 = *(GF_LDS bf16x8*)(kbuf + fo.row[kd] + 32 * 256);
-                const bf16x8 v0 = *(GF_LDS bf16x8*)(vbuf + fo.row[kd]);
-                const bf16x8 v1 = *(GF_LDS bf16x8*)(vbuf + fo.row[kd] + 32 * 256);
-                mfma32(sc[0], k0, qf[kd]);
-                mfma32(sc[1], k1, qf[kd]);
-                mfma32(dp[0], v0, dof[kd]);
-                mfma32(dp[1], v1, dof[kd]);
-            }
-            softmax_half(0, sc[0], dp[0]);
-            softmax_half(1, sc[1], dp[1]);
-        }
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int d = 0; d < 4; ++d) mfma32(dq[d], tr_frag(kbuf, fo, d, kt, s), dsf[kt][s]);   // dQ^T += K^T dS^T
-    };
-    stage(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    const bool ragged = (p.kv_len % KVB) != 0;
-    for (int t = 0; t < nt; ++t) {
-        if (t + 1 < nt) stage(t + 1);          // lands while this tile is multiplied; its buffer was released by the last barrier
-        if (ragged && t == nt - 1) tile(t, std::true_type{});
-        else tile(t, std::false_type{});
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-    if (q0 + r < p.q_len) store_rows(p.dq + (long)(q0 + r) * p.dq_stride + head * HD, dq, p.scale, h);
-}
-
-// ---- dK, dV: wave owns keys k0 + r -------------------------------------------------------------------------------------
-// PART 0: dK and dV in one pass (≈320 registers: ONE wave per SIMD).  PART 1: dV only (S, dV: 2 products), PART 2: dK only (S, dP,
-// dK: 3 products) — each fits 256 registers, so two workgroups share a CU (two waves per SIMD) like the dQ kernel; the pair
-// recomputes S once more (5 products instead of 4) and still takes less time than PART 0: a lone wave per SIMD leaves the matrix
-// pipe idle through every one of its own waits.
-template <int PART>
-__global__ __launch_bounds__(DKV_THREADS, 2) void attn_bwd_dkv_kernel(const BwdArgs p) {
-    constexpr bool DO_V = PART != 2, DO_K = PART != 1;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    GF_LDS char* lds = (GF_LDS char*)smem;
-    GF_LDS float* scal = (GF_LDS float*)(lds + 4 * TILE_BYTES);    // [stage][lse 64 | delta 64]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, h = lane >> 5;
-    const int nkb = (p.kv_len + DKV_ROWS - 1) / DKV_ROWS;
-    const int head = blockIdx.x / nkb, kb = blockIdx.x % nkb;
-    const int k0 = kb * DKV_ROWS + wave * 32;
-    const int kr = min(k0 + r, p.kv_len - 1);
-
-    bf16x8 kf[8], vf[8];
-    {
-        const u16* kp = p.k + (long)kr * p.k_stride + head * HD + 8 * h;
-        const u16* vp = p.v + (long)kr * p.v_stride + head * HD + 8 * h;
-#pragma unroll
-        for (int kd = 0; kd < 8; ++kd) {
-            kf[kd] = *reinterpret_cast<const bf16x8*>(kp + 16 * kd);
-            if constexpr (DO_K) vf[kd] = *reinterpret_cast<const bf16x8*>(vp + 16 * kd);
-        }
-    }
-    const float c = p.scale_log2e;
-    const FragOffsets fo = frag_offsets(lane);
-    f32x16 dk[4], dv[4];
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        zero16(dk[d]);
-        zero16(dv[d]);
-    }
-
-    const int nt = (p.q_len + KVB - 1) / KVB;
-    auto stage = [&](int t) {   // stage s = t & 1: Q at s*32K, dO at s*32K + 16K, lse/delta at scal + s*128
-        GF_LDS char* b = lds + (t & 1) * 2 * TILE_BYTES;
-        if (tid < KVB) {   // before the DMA pieces: the wait for these two loads must not cover the tiles in flight
-            const long qi = min(t * KVB + tid, p.q_len - 1);
-            scal[(t & 1) * 2 * KVB + tid] = p.lse[qi * p.heads + head];
-            if constexpr (DO_K) scal[(t & 1) * 2 * KVB + KVB + tid] = p.delta[qi * p.heads + head];
-        }
-        stage_tile<4>(p.q + head * HD, p.q_stride, t * KVB, p.q_len, b, wave, lane);
-        stage_tile<4>(p.dout + head * HD, p.do_stride, t * KVB, p.q_len, b + TILE_BYTES, wave, lane);
-    };
-    auto tile = [&](int t, auto masked) {
-        constexpr bool MASKED = decltype(masked)::value;   // the last query tile when q_len % 64 != 0: clamped copies get p = 0
-        GF_LDS char* qbuf = lds + (t & 1) * 2 * TILE_BYTES;
-        GF_LDS char* dobuf = qbuf + TILE_BYTES;
-        GF_LDS float* lse_s = scal + (t & 1) * 2 * KVB;
-        GF_LDS float* dl_s = lse_s + KVB;
-        bf16x8 pf[2][2], dsf[2][2];
-        auto softmax_half = [&](int half, const f32x16& sc, const f32x16& dp) {
-#pragma unroll
-            for (int s8 = 0; s8 < 2; ++s8) {
-                float xp[8], xs[8];
-                f32x4 l4[2], d4[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-                for (int g2 = 0; g2 < 2; ++g2) {
-                    const int qi = 32 * half + 8 * (2 * s8 + g2) + 4 * h;
-                    l4[g2] = *(GF_LDS f32x4*)(lse_s + qi);
-                    if constexpr (DO_K) d4[g2] = *(GF_LDS f32x4*)(dl_s + qi);
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int e = 8 * s8 + j;
-                    float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[e], c, -l4[j >> 2][j & 3]));
-                    if constexpr (MASKED) pr = (t * KVB + 32 * half + 8 * (e >> 2) + 4 * h + (e & 3) < p.q_len) ? pr : 0.f;
-                    xp[j] = pr;
-                    if constexpr (DO_K) xs[j] = pr * (dp[e] - d4[j >> 2][j & 3]);
-                }
-                if constexpr (DO_V) pf[half][s8] = pack8(xp);
-                if constexpr (DO_K) dsf[half][s8] = pack8(xs);
-            }
-        };
-        {
-            f32x16 sc[2], dp[2];
-            zero16(sc[0]);
-            zero16(sc[1]);
-            zero16(dp[0]);
-            zero16(dp[1]);
-#pragma unroll
-            for (int kd = 0; kd < 8; ++kd) {
-                const bf16x8 q0f = *(GF_LDS bf16x8*)(qbuf + fo.row[kd]);
-                const bf16x8 q1f = *(GF_LDS bf16x8*)(qbuf + fo.row[kd] + 32 * 256);
-                mfma32(sc[0], q0f, kf[kd]);
-                mfma32(sc[1], q1f, kf[kd]);
-                if constexpr (DO_K) {
-                    const bf16x8 d0f = *(GF_LDS bf16x8*)(dobuf + fo.row[kd]);
-                    const bf16x8 d1f = *(GF_LDS bf16x8*)(dobuf + fo.row[kd] + 32 * 256);
-                    mfma32(dp[0], d0f, vf[kd]);
-                    mfma32(dp[1], d1f, vf[kd]);
-                }
-            }
-            softmax_half(0, sc[0], dp[0]);
-            softmax_half(1, sc[1], dp[1]);
-        }
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    if constexpr (DO_V) mfma32(dv[d], tr_frag(dobuf, fo, d, kt, s), pf[kt][s]);    // dV^T += dO^T P
-                    if constexpr (DO_K) mfma32(dk[d], tr_frag(qbuf, fo, d, kt, s), dsf[kt][s]);    // dK^T += Q^T dS
-                }
-    };
-    stage(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    const bool ragged = (p.q_len % KVB) != 0;
-    for (int t = 0; t < nt; ++t) {
-        if (t + 1 < nt) stage(t + 1);
-        if (ragged && t == nt - 1) tile(t, std::true_type{});
-        else tile(t, std::false_type{});
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-    if (k0 + r < p.kv_len) {
-        if constexpr (DO_K) store_rows(p.dk + (long)(k0 + r) * p.dk_stride + head * HD, dk, p.scale, h);
-        if constexpr (DO_V) store_rows(p.dv + (long)(k0 + r) * p.dv_stride + head * HD, dv, 1.0f, h);
-    }
-}
-
-
 // =====================================================================================================================
-// Round 3: the backward on v_mfma_f32_16x16x32_bf16 (the forward's kernel 3 algebra: 12 % less power per FLOP than 32x32x16 on
+// The backward on v_mfma_f32_16x16x32_bf16 (the forward's kernel 3 algebra: 12 % less power per FLOP than 32x32x16 on
 // random data) with 7 tile products instead of 8:
 //   * ONE LDS image per operand tile serves row fragments (ds_read_b128: A = X[16 rows x 32 d]) and transposed fragments (two
 //     ds_read_b64_tr_b16: A = X^T[16 d x 32 rows], rows in the order of a B operand built from two accumulator tiles): rows of 256
@@ -372,8 +40,7 @@ __global__ __launch_bounds__(DKV_THREADS, 2) void attn_bwd_dkv_kernel(const BwdA
 //     (num_records), which also makes masking unnecessary: a padded key / query meets a zero row in the last product;
 //   * dQ: a wave owns 32 queries (two 16-query blocks on the lane) and walks 64-key tiles — S^T = K Q^T, dP^T = V dO^T,
 //     dQ^T += K^T dS^T: 96 MFMAs per tile;
-//   * dK and dV in ONE kernel by wave PAIRS that own the same keys (48 per pair in the shipped attn_bwd_dkv48_kernel, 32 in
-//     attn_bwd_dkv16_kernel, its A/B partner) and walk 32-query granules:
+//   * dK and dV in ONE kernel by wave PAIRS that own the same 48 keys (attn_bwd_dkv48_kernel) and walk 32-query granules:
 //       wave A: S = Q K^T, P = exp2(c S - lse), P (fp32, accumulator layout) -> LDS hand-off, dV^T += dO^T P;
 //       wave B: dP = dO V^T, dS = P (dP - delta) with the P wave A left one granule earlier, dK^T += Q^T dS.
 //     A SIMD holds one A and one B wave, so the exp2 of one role overlaps the MFMAs of the other; S is computed once for dK and dV
@@ -388,13 +55,6 @@ __global__ __launch_bounds__(DKV_THREADS, 2) void attn_bwd_dkv_kernel(const BwdA
 constexpr int GR = 32;                         // queries per granule of the dK/dV kernel
 constexpr int GR_BYTES = GR * HD * 2;          // 8 KiB: one operand array of one granule
 constexpr int KV16_RING = 4;
-template <int NP> struct Kv16 {                // NP wave pairs = 32 NP keys per workgroup
-    static constexpr int WAVES = 2 * NP, THREADS = 64 * WAVES, ROWS = 32 * NP;
-    static constexpr int Q = 0, DO = KV16_RING * GR_BYTES, H = 2 * KV16_RING * GR_BYTES;      // Q ring | dO ring | hand-off | scalars
-    static constexpr int HBUF = NP * 4096;     // one hand-off buffer: NP pairs x (2 x 2 accumulator tiles x 1 KiB)
-    static constexpr int S = H + 2 * HBUF;     // scalars: 4 slots x (32 lse | 32 delta) floats
-    static constexpr int LDS = S + KV16_RING * 2 * GR * (int)sizeof(float);
-};
 constexpr int DQ16_STAGE = 2 * TILE_BYTES;     // K rows | V rows
 constexpr int DQ16_LDS = 2 * DQ16_STAGE;
 
@@ -402,33 +62,8 @@ struct Bwd16Args {
     BwdArgs b;
     const float* sd;     // [heads][ngp][32 lse | 32 delta]
     int ngp;             // granule records per head
-    const u16* qs;       // GF_BWD_QSCALE: Q' = bf16(Q * scale * log2 e) [q_len, heads * 128] — the forward's own operand (below)
+    const u16* qs;       // unused (null): the slot of the measured-and-dropped pre-scaled Q copy (tools/patches/attention_bwd_experiments.patch)
 };
-
-// GF_BWD_QSCALE (round 4, measured and NOT shipped: default 0): the forward kernel multiplies Q by scale * log2(e) once, rounds to
-// bf16, and takes its scores S' = Q' K^T straight in the exp2 domain.  With the same Q' (a 0.67 GB pass, 0.13 ms at S = 32760; a copy
-// in the workspace, because the dK/dV kernel streams Q through LDS) the backward's S chains can START from -lse (the MFMA's C
-// operand) and leave the matrix pipe as the exponent — no fma per score — and dK = dS^T Q' ln 2.  One process, S = 32760 x 40 heads
-// (profiles/r04/attnbwd_ab_qscale.log): 53.9 against 55.0 ms (-2.1 %).  But against fp32 autograd the error of dQ rises from
-// 2.4e-3 to 3.0e-3 (+25 %: the rounding of Q' enters every score; tests/test_training_gpu.py), 335 MB of workspace are added, and
-// the kernel is 1 % of a training step faster: the unscaled-Q arithmetic of round 3 stays the default.
-#ifndef GF_BWD_QSCALE
-#define GF_BWD_QSCALE 0
-#endif
-__global__ __launch_bounds__(256) void attn_bwd_qscale_kernel(const u16* __restrict__ q, u16* __restrict__ qs, long rows, int hd_all,
-                                                              long q_stride, float c) {
-    const int cpr = hd_all >> 3;
-    const long total = rows * cpr;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const long r = i / cpr;
-        const int col = (int)(i - r * cpr) << 3;
-        const u16x8 x = *reinterpret_cast<const u16x8*>(q + r * q_stride + col);
-        u16x8 y;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) y[e] = f2bf(bf2f(x[e]) * c);         // exactly the forward's `(__bf16)((float)q * scale_log2e)`
-        *reinterpret_cast<u16x8*>(qs + r * hd_all + col) = y;
-    }
-}
 
 // delta[s, h] = sum_d dO[s, h, d] O[s, h, d], stored twice: [q_len, heads] (per-lane reads of the dQ kernel) and with lse as the
 // dK/dV kernel's granule records sd[h][s / 32][32 x -lse | 32 x -delta] (zeros past q_len)
@@ -552,11 +187,7 @@ __global__ __launch_bounds__(DQ_THREADS, 2) void attn_bwd_dq16_kernel(const Bwd1
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
         const int qr = min(q0 + 16 * qb + r, p.q_len - 1);
-#if GF_BWD_QSCALE
-        const u16* qp = a.qs + (long)qr * (p.heads * HD) + head * HD + 8 * g;     // Q' = bf16(c Q): the forward's operand
-#else
         const u16* qp = p.q + (long)qr * p.q_stride + head * HD + 8 * g;
-#endif
         const u16* dp = p.dout + (long)qr * p.do_stride + head * HD + 8 * g;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -580,13 +211,7 @@ __global__ __launch_bounds__(DQ_THREADS, 2) void attn_bwd_dq16_kernel(const Bwd1
     f32x4 ndl[2];                    // -delta of this lane's query: the dP chains start from it (dS = P * chain result, one multiply per score)
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) ndl[qb] = f32x4{-dl[qb], -dl[qb], -dl[qb], -dl[qb]};
-#if GF_BWD_QSCALE
-    f32x4 nls[2];                    // -lse likewise: S' = Q' K^T - lse is the exponent
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) nls[qb] = f32x4{-lse[qb], -lse[qb], -lse[qb], -lse[qb]};
-#else
     const float c = p.scale_log2e;
-#endif
     const ImgOffsets fo = img_offsets(lane);
     f32x4 dq[8][2];
 #pragma unroll
@@ -632,9 +257,6 @@ __global__ __launch_bounds__(DQ_THREADS, 2) void attn_bwd_dq16_kernel(const Bwd1
     //   8 MFMAs; F[4..7] <- d blocks 4..7;  arithmetic of block 2 h + 1 (covers the reads);
     //   dQ^T: 8 MFMAs, F[0..3] <- next half's first fragments, 8 MFMAs, F[4..7] <- the rest.
     bf16x8 F[8];
-#ifndef DQ16_NO_INTERLEAVE
-#define DQ16_NO_INTERLEAVE 0
-#endif
 #define DQ16_SB() __builtin_amdgcn_sched_barrier(0)
     auto load_kb = [&](int sto, int kb, int lo, int hi) __attribute__((always_inline)) {      // F[2 ks] = K, F[2 ks + 1] = V fragment (kb, ks); sto = stage offset
 #pragma unroll
@@ -658,11 +280,7 @@ __global__ __launch_bounds__(DQ_THREADS, 2) void attn_bwd_dq16_kernel(const Bwd1
             for (int ks = lo; ks < hi; ++ks)
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb) {
-#if GF_BWD_QSCALE
-                    sc[kbb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F[2 * ks], qf[qb][ks], ks == 0 ? nls[qb] : sc[kbb][qb], 0, 0, 0);    // S'^T - lse
-#else
                     sc[kbb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F[2 * ks], qf[qb][ks], ks == 0 ? zero4 : sc[kbb][qb], 0, 0, 0);      // S^T[key 32 h + 16 kbb + 4 g + j, query 16 qb + r]
-#endif
                     dp[kbb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F[2 * ks + 1], dof[qb][ks], ks == 0 ? ndl[qb] : dp[kbb][qb], 0, 0, 0);   // dP^T - delta
                 }
         };
@@ -672,11 +290,7 @@ __global__ __launch_bounds__(DQ_THREADS, 2) void attn_bwd_dq16_kernel(const Bwd1
                 float x[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-#if GF_BWD_QSCALE
-                    const float pr = __builtin_amdgcn_exp2f(sc[kbb][qb][j]);
-#else
                     const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kbb][qb][j], c, -lse[qb]));
-#endif
                     x[j] = pr * dp[kbb][qb][j];
                 }
                 dsw[qb][2 * kbb] = pack2bf(x[0], x[1]);
@@ -694,14 +308,12 @@ __global__ __launch_bounds__(DQ_THREADS, 2) void attn_bwd_dq16_kernel(const Bwd1
         DQ16_SB();
         softmax(0);
         first(1, 0, 2);
-#if !DQ16_NO_INTERLEAVE
 #pragma unroll
         for (int i = 0; i < 8; ++i) {        // one MFMA, then its share of the 8 exp2 and ~30 other arithmetic instructions
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
         }
-#endif
         DQ16_SB();
 #pragma unroll
         for (int db = 0; db < 4; ++db) F[db] = load_tr(sto, h, db);
@@ -761,286 +373,10 @@ __global__ __launch_bounds__(DQ_THREADS, 2) void attn_bwd_dq16_kernel(const Bwd1
 }
 
 // ---- dK, dV: wave pair (w, w + NP) owns keys k0 .. k0 + 31 (block kb: key k0 + 16 kb + (lane & 15)) ---------------------------
-#ifndef KV16_WHATIF      // timing-only builds (wrong results; tools/attnbwd_ab.py): 1 no DMA in the loop, 4 no hand-off, 8 no barrier,
-#define KV16_WHATIF 0    // 16 no counted wait, 32 every batch fetches the same granule
-#endif
-#if KV16_WHATIF & 8
-#define KV16_WAIT_BARRIER(N) asm volatile("s_waitcnt vmcnt(" #N ")\n\ts_waitcnt lgkmcnt(0)" ::: "memory")
-#elif KV16_WHATIF & 16
-#define KV16_WAIT_BARRIER(N) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-#else
 #define KV16_WAIT_BARRIER(N) asm volatile("s_waitcnt vmcnt(" #N ")\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-#endif
-template <int NP>
-__global__ __launch_bounds__(Kv16<NP>::THREADS) void attn_bwd_dkv16_kernel(const Bwd16Args a) {
-    using L = Kv16<NP>;
-    const BwdArgs& p = a.b;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    GF_LDS char* lds = (GF_LDS char*)smem;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 15, g = lane >> 4;
-    const bool roleB = wave >= NP;
-    const int pair = roleB ? wave - NP : wave;
-    const int nkb = (p.kv_len + L::ROWS - 1) / L::ROWS;
-    int head, kblk;
-    head_block(blockIdx.x, p.heads, nkb, head, kblk);
-    const int k0 = kblk * L::ROWS + pair * 32;
-
-    // the pair's register-resident B operand: wave A K^T, wave B V^T [32 d x 16 keys]: lane = key column, 8 d at 32 ks + 8 g
-    bf16x8 own[2][4];
-    {
-        const u16* base = roleB ? p.v : p.k;
-        const long stride = roleB ? p.v_stride : p.k_stride;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            const int kr = min(k0 + 16 * kb + r, p.kv_len - 1);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                own[kb][ks] = *reinterpret_cast<const bf16x8*>(base + (long)kr * stride + head * HD + 8 * g + 32 * ks);
-        }
-    }
-    // the compiler must see these loads completed HERE: it cannot count the asm LDS-DMA requests, and a vmcnt wait it placed at the first
-    // use inside the loop would wait for the newest DMA batch as well (every iteration)
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(own[kb][ks]));
-    // Row constants as initial accumulators where that is exact: wave B's dP chains START from -delta (the records hold -delta), so
-    // dS = P * chain result.  Wave A keeps p = exp2(fma(S, c, -lse)): starting its chains from -lse needs K (or Q) pre-multiplied by
-    // c = scale log2 e and rounded to bf16 again, which measured +25 % error on dK / dV against an fp64 reference (2.9e-3 instead of
-    // 2.35e-3) for 0.6 ms.  The vector issue port, which an MFMA holds for 8 of its 16 cycles, is the limit of this kernel: MFMAs +
-    // arithmetic + LDS address adds came to ~1150 issue cycles per 1024-cycle iteration before the address adds and B's subtracts went.
-    const float c = p.scale_log2e;
-    const ImgOffsets fo = img_offsets(lane);
-    f32x4 acc[8][2];                 // wave A: dV^T, wave B: dK^T — [db][kb]: key 16 kb + r, d = 16 db + 4 g + j
-#pragma unroll
-    for (int db = 0; db < 8; ++db)
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) acc[db][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int ng = (p.q_len + GR - 1) / GR;
-    // DMA batch of iteration i (i >= -2): Q rows and dO rows of granule i + 2 (8 pieces each: waves 0 .. 7 take piece `wave` of both)
-    // and its scalars (wave 0).  Always the same number of instructions per wave (a granule past the end arrives as zeros): the counted
-    // wait relies on it.  The loop is unrolled four times so that every ring slot is a compile-time constant: each LDS address is a
-    // per-lane offset computed once + an immediate.
-    const unsigned q_voff = img_src_off(wave & 7, lane, p.q_stride), do_voff = img_src_off(wave & 7, lane, p.do_stride);
-    const u32x4s srd_sd = make_srd(a.sd + (long)head * a.ngp * (2 * GR), 0xffffffffu);
-    auto issue = [&](int i, int slot2) __attribute__((always_inline)) {        // slot2 = (i + 2) & 3
-#if KV16_WHATIF & 32
-        i = 0;
-#endif
-        const int ga = i + 2;
-        if (wave < 8) {
-            GF_LDS char* dst = lds + slot2 * GR_BYTES + wave * 1024;
-            dma16b(rows_srd(p.q, p.q_stride, head, ga * GR, p.q_len), q_voff, 0u, dst + L::Q);
-            dma16b(rows_srd(p.dout, p.do_stride, head, ga * GR, p.q_len), do_voff, 0u, dst + L::DO);
-        }
-        if (wave == 0) dma4b(srd_sd, (unsigned)lane * 4u, (unsigned)min(ga, a.ngp - 1) * (2u * GR * 4u), lds + L::S + slot2 * (2 * GR * 4));
-    };
-    // (no masking of a ragged last granule: its rows past q_len arrive as zeros, so the finite P and dS of those queries meet zero rows
-    // of dO / Q in the second product)
-    // Order inside a step (pinned by scheduling barriers: left alone, hipcc reads one fragment, waits for it, issues its two MFMAs and
-    // so on — the matrix pipe then idles through every LDS round trip): the first product's 8 row fragments are requested, the SECOND
-    // product of the previous granule runs from registers (transposed fragments + packed P / dS carried over the barrier), then the
-    // first product, then this granule's transposed fragments are requested and land during the exp2 / dS arithmetic.
-    bf16x8 carry_a[8], carry_b[2];
 #define KV16_SB() __builtin_amdgcn_sched_barrier(0)
-    // Per-lane LDS POINTERS, made once and pinned in registers: the dynamic LDS base is a link-time symbol, so `lds + offset` inside
-    // the loop costs a v_add_u32 per read (110 of them per four iterations before this) — with these every address is register + immediate.
-    GF_LDS char* prow[4];                                                            // + slot * GR_BYTES (+ L::DO) + 4096 * block
-    GF_LDS char* ptr[8];                                                             // + slot * GR_BYTES (+ L::DO) (+ 4096: second read)
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        prow[ks] = lds + fo.row[ks];
-        asm volatile("" : "+v"(prow[ks]));
-    }
-#pragma unroll
-    for (int db = 0; db < 8; ++db) {
-        ptr[db] = lds + fo.tr[db];
-        asm volatile("" : "+v"(ptr[db]));
-    }
-    GF_LDS char* hbase = lds + L::H + pair * 4096 + lane * 16;                       // + (granule & 1) * HBUF + 1024 * tile
-    GF_LDS char* sbase = lds + L::S + 16 * g;                                        // + slot * 256 + 64 qb (+ 128: delta)
-    asm volatile("" : "+v"(hbase), "+v"(sbase));
-    // wave A, iteration i (slot = i & 3): dV of granule i - 1 from registers; S, P of granule i
-    auto stepA = [&](int i, auto slot_c) __attribute__((always_inline)) {
-        constexpr int SLOT = decltype(slot_c)::value;
-        const bool first = i < ng, second = i >= 1 && i <= ng;
-        bf16x8 qfr[2][4];            // (read whether or not the granule exists: the slot is valid LDS, the values go unused)
-        f32x4 l4[2];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int qb = 0; qb < 2; ++qb) qfr[qb][ks] = *(GF_LDS bf16x8*)(prow[ks] + (L::Q + SLOT * GR_BYTES + 4096 * qb));
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb) l4[qb] = *(GF_LDS f32x4*)(sbase + (SLOT * 256 + 64 * qb));
-        KV16_SB();
-        if (second) {
-#pragma unroll
-            for (int db = 0; db < 8; ++db)
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb) mfma16(acc[db][kb], carry_a[db], carry_b[kb]);       // dV^T[d, key] += dO^T P
-        }
-        KV16_SB();
-        if (!first) return;
-        f32x4 sc[2][2];
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) sc[qb][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb) mfma16(sc[qb][kb], qfr[qb][ks], own[kb][ks]);        // S[query 16 qb + 4 g + j, key 16 kb + r]
-        KV16_SB();
-#pragma unroll
-        for (int db = 0; db < 8; ++db) {
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GF_LDS s16x4*)(ptr[db] + (L::DO + SLOT * GR_BYTES)));
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GF_LDS s16x4*)(ptr[db] + (L::DO + SLOT * GR_BYTES + 4096)));
-            carry_a[db] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-        }
-        KV16_SB();
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) sc[qb][kb][j] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[qb][kb][j], c, l4[qb][j]));   // l4 = -lse
-#if !(KV16_WHATIF & 4)
-                *(GF_LDS f32x4*)(hbase + ((SLOT & 1) * L::HBUF + (2 * qb + kb) * 1024)) = sc[qb][kb];
-#endif
-            }
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) carry_b[kb] = pack44(sc[0][kb], sc[1][kb]);
-    };
-    // wave B, iteration i (slot = i & 3): dS of granule i - 1 (its dP - delta is in registers since the last iteration, its P in the
-    // hand-off buffer), dK of granule i - 1 (Q^T fragments in registers), then dP of granule i.  B starts an iteration with arithmetic
-    // and ends with its MFMAs, A the other way round: after the barrier the two waves of a SIMD are in opposite phases.
-    f32x4 dpc[2][2];                 // dP - delta of the granule whose dS comes next
-    auto stepB = [&](int i, auto slot_c) __attribute__((always_inline)) {
-        constexpr int SLOT = decltype(slot_c)::value, PREV = (SLOT + 3) & 3;
-        const int gd = i - 1;        // granule of the dS / dK part
-        const bool second = gd >= 0 && gd < ng, first = i < ng;
-        f32x4 d4[2], pp[2][2];
-        bf16x8 dofr[2][4];
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-#if KV16_WHATIF & 4
-                pp[qb][kb] = dpc[qb][kb];
-#else
-                pp[qb][kb] = *(GF_LDS f32x4*)(hbase + ((PREV & 1) * L::HBUF + (2 * qb + kb) * 1024));
-#endif
-            }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int qb = 0; qb < 2; ++qb) dofr[qb][ks] = *(GF_LDS bf16x8*)(prow[ks] + (L::DO + SLOT * GR_BYTES + 4096 * qb));
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb) d4[qb] = *(GF_LDS f32x4*)(sbase + (SLOT * 256 + 128 + 64 * qb));
-        KV16_SB();
-        if (second) {
-#pragma unroll
-            for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) dpc[qb][kb][j] *= pp[qb][kb][j];
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) carry_b[kb] = pack44(dpc[0][kb], dpc[1][kb]);
-            KV16_SB();
-#pragma unroll
-            for (int db = 0; db < 8; ++db)
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb) mfma16(acc[db][kb], carry_a[db], carry_b[kb]);       // dK^T[d, key] += Q^T dS
-        }
-        KV16_SB();
-        if (!first) return;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)                                                       // dP - delta [query, key] = dO V^T - delta:
-                    dpc[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dofr[qb][ks], own[kb][ks], ks == 0 ? d4[qb] : dpc[qb][kb], 0, 0, 0);   // the chain starts from -delta (no copy)
-        KV16_SB();
-#pragma unroll
-        for (int db = 0; db < 8; ++db) {
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GF_LDS s16x4*)(ptr[db] + (L::Q + SLOT * GR_BYTES)));
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GF_LDS s16x4*)(ptr[db] + (L::Q + SLOT * GR_BYTES + 4096)));
-            carry_a[db] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-        }
-        KV16_SB();
-    };
-    issue(-2, 0);
-    issue(-1, 1);
-    // One loop per role (the register allocator then sees each role's live ranges alone; both execute the same number of barriers).
-    // At the top of iteration i: this wave's pieces of batch i - 2 have landed (batch i - 1 stays in flight), its hand-off stores and
-    // LDS reads are done; behind the barrier that holds for every wave: granule i is readable, the slot batch i goes to (granule
-    // i - 2's) is free.
-#if KV16_WHATIF & 1
-#define KV16_ISSUE(i, s) (void)issue
-#else
-#define KV16_ISSUE(i, s) issue(i, s)
-#endif
-    auto wait_barrier = [&]() __attribute__((always_inline)) {
-        if (wave == 0) KV16_WAIT_BARRIER(3);
-        else if (wave < 8) KV16_WAIT_BARRIER(2);
-        else KV16_WAIT_BARRIER(0);
-    };
-    typedef std::integral_constant<int, 0> S0;
-    typedef std::integral_constant<int, 1> S1;
-    typedef std::integral_constant<int, 2> S2;
-    typedef std::integral_constant<int, 3> S3;
-#define KV16_ITER(STEP, k, SC)                                   \
-    if (i + k <= ng) {                                           \
-        wait_barrier();                                          \
-        KV16_ISSUE(i + k, (k + 2) & 3);                          \
-        STEP(i + k, SC{});                                       \
-    }
-    if (!roleB) {
-#pragma unroll 1
-        for (int i = 0; i <= ng; i += 4) {
-            KV16_ITER(stepA, 0, S0)
-            KV16_ITER(stepA, 1, S1)
-            KV16_ITER(stepA, 2, S2)
-            KV16_ITER(stepA, 3, S3)
-        }
-    } else {
-#pragma unroll 1
-        for (int i = 0; i <= ng; i += 4) {
-            KV16_ITER(stepB, 0, S0)
-            KV16_ITER(stepB, 1, S1)
-            KV16_ITER(stepB, 2, S2)
-            KV16_ITER(stepB, 3, S3)
-        }
-    }
-    const float mul = roleB ? p.scale : 1.0f;
-    u16* outp = roleB ? p.dk : p.dv;
-    const long ostride = roleB ? p.dk_stride : p.dv_stride;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-        const int krow = k0 + 16 * kb + r;
-        if (krow < p.kv_len) {
-            u16* rowp = outp + (long)krow * ostride + head * HD + 4 * g;
-#pragma unroll
-            for (int db = 0; db < 8; ++db) {
-                u32x2 pk;
-                pk[0] = pack2bf(acc[db][kb][0] * mul, acc[db][kb][1] * mul);
-                pk[1] = pack2bf(acc[db][kb][2] * mul, acc[db][kb][3] * mul);
-                *reinterpret_cast<u32x2*>(rowp + 16 * db) = pk;
-            }
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the last batches must not outlive the workgroup's LDS
-}
-
 // ---- dK, dV with THREE key blocks per wave (48 keys; 192 per workgroup of four pairs) -------------------------------------------
-// SHIPPED (KV_USE_48 = 1; the 32-key kernel above stays as the A/B partner).  With 48 keys per wave every row / transposed fragment
+// With 48 keys per wave (the 32-key predecessor: tools/patches/attention_bwd_experiments.patch) every row / transposed fragment
 // feeds three MFMAs instead of two and a granule's staged bytes serve 192 keys: two thirds of the LDS traffic, DMA bytes and barriers
 // per MFMA.  96 accumulators + a 48-register operand leave no room to carry the second product over the barrier: an iteration is
 // S / dP (24 MFMAs), the transposed reads, the arithmetic, dV / dK (24 MFMAs); wave B works one granule behind wave A as before.
@@ -1092,13 +428,8 @@ __global__ __launch_bounds__(Kv48::THREADS) void attn_bwd_dkv48_kernel(const Bwd
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) acc[db][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int ng = (p.q_len + GR - 1) / GR;
-#if GF_BWD_QSCALE
-    const u16* q_src = a.qs;                      // Q' = bf16(c Q), [q_len, heads * 128]
-    const long q_src_stride = (long)p.heads * HD;
-#else
     const u16* q_src = p.q;
     const long q_src_stride = p.q_stride;
-#endif
     const unsigned q_voff = img_src_off(wave & 7, lane, q_src_stride), do_voff = img_src_off(wave & 7, lane, p.do_stride);
     const u32x4s srd_sd = make_srd(a.sd + (long)head * a.ngp * (2 * GR), 0xffffffffu);
     auto issue = [&](int i, int slot2) __attribute__((always_inline)) {        // granule i + 2 -> slot (i + 2) & 3
@@ -1148,7 +479,7 @@ __global__ __launch_bounds__(Kv48::THREADS) void attn_bwd_dkv48_kernel(const Bwd
             for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
                 for (int kb = 0; kb < KB; ++kb)
-                    sc[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F[2 * ks + qb], own[kb][ks], ks == 0 ? (GF_BWD_QSCALE ? l4[qb] : zero4) : sc[qb][kb], 0, 0, 0);
+                    sc[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F[2 * ks + qb], own[kb][ks], ks == 0 ? zero4 : sc[qb][kb], 0, 0, 0);
         KV16_SB();
 #pragma unroll
         for (int db = 0; db < 8; ++db) F[db] = tr_frag(L::DO + SLOT * GR_BYTES, db);
@@ -1160,8 +491,7 @@ __global__ __launch_bounds__(Kv48::THREADS) void attn_bwd_dkv48_kernel(const Bwd
             for (int qb = 0; qb < 2; ++qb) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    sc[qb][kb][j] = GF_BWD_QSCALE ? __builtin_amdgcn_exp2f(sc[qb][kb][j])                                   // the chain started from -lse
-                                                  : __builtin_amdgcn_exp2f(__builtin_fmaf(sc[qb][kb][j], c, l4[qb][j]));   // l4 = -lse
+                    sc[qb][kb][j] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[qb][kb][j], c, l4[qb][j]));   // l4 = -lse
                 *(GF_LDS f32x4*)(hbase + ((SLOT & 1) * L::HBUF + (2 * kb + qb) * 1024)) = sc[qb][kb];
             }
             pf[kb] = pack44(sc[0][kb], sc[1][kb]);
@@ -1250,7 +580,7 @@ __global__ __launch_bounds__(Kv48::THREADS) void attn_bwd_dkv48_kernel(const Bwd
             KV48_ITER(stepB, 3, S3)
         }
     }
-    const float mul = roleB ? (GF_BWD_QSCALE ? 0.6931471805599453f : p.scale) : 1.0f;     // dK = dS^T Q' / log2(e) with Q' = c Q
+    const float mul = roleB ? p.scale : 1.0f;
     u16* outp = roleB ? p.dk : p.dv;
     const long ostride = roleB ? p.dk_stride : p.dv_stride;
 #pragma unroll
@@ -1276,18 +606,11 @@ static inline int64_t pad64(int64_t n) { return (n + 63) / 64 * 64; }
 static inline int64_t align256(int64_t n) { return (n + 255) / 256 * 256; }
 
 // bytes of the caller-owned workspace of gf_flash_attn_bwd: delta [q_len, heads] fp32 | granule records [heads][pad64(q_len)/32][64] fp32
-// | Q' = bf16(Q * scale * log2 e) [q_len, heads * 128] (GF_BWD_QSCALE)
 extern "C" GF_API int64_t gf_flash_attn_bwd_workspace_bytes(int64_t q_len, int64_t kv_len, int64_t heads) {
     if (q_len <= 0 || kv_len <= 0 || heads <= 0) return 0;
-    return align256(q_len * heads * 4) + align256(heads * pad64(q_len) * 2 * 4) + (GF_BWD_QSCALE ? align256(q_len * heads * HD * 2) : 0);
+    return align256(q_len * heads * 4) + align256(heads * pad64(q_len) * 2 * 4);
 }
 
-#ifndef KV16_NP
-#define KV16_NP 4
-#endif
-#ifndef KV_USE_48
-#define KV_USE_48 1
-#endif
 extern "C" GF_API int gf_flash_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,
                                         const float* lse, void* workspace, void* dq, void* dk, void* dv, int64_t q_len,
                                         int64_t kv_len, int64_t heads, int64_t head_dim, int64_t q_stride, int64_t k_stride,
@@ -1313,18 +636,9 @@ extern "C" GF_API int gf_flash_attn_bwd(const void* q, const void* k, const void
                  "gf_flash_attn_bwd: a sequence (len x stride) must stay below 4 GiB");
     static GfDeviceOnce once;
     hipError_t e = gf_once_per_device(once, [] {
-        const void* fns[3] = {reinterpret_cast<const void*>(attn_bwd_dq_kernel), reinterpret_cast<const void*>(attn_bwd_dkv_kernel<1>),
-                              reinterpret_cast<const void*>(attn_bwd_dkv_kernel<2>)};
-        for (const void* fn : fns) {
-            hipError_t r = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
-            if (r != hipSuccess) return r;
-        }
         hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DQ16_LDS);
         if (r != hipSuccess) return r;
-        r = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv48_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, Kv48::LDS);
-        if (r != hipSuccess) return r;
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv16_kernel<KV16_NP>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   Kv16<KV16_NP>::LDS);
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv48_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, Kv48::LDS);
     });
     if (e != hipSuccess) {
         gf_set_error("gf_flash_attn_bwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -1340,45 +654,20 @@ extern "C" GF_API int gf_flash_attn_bwd(const void* q, const void* k, const void
     a.dq_stride = dq_stride; a.dk_stride = dk_stride; a.dv_stride = dv_stride;
     a.scale = scale; a.scale_log2e = scale * 1.4426950408889634f;
     hipStream_t s = (hipStream_t)stream;
-    const unsigned nqb = (unsigned)((q_len + DQ_ROWS - 1) / DQ_ROWS), nkb = (unsigned)((kv_len + DKV_ROWS - 1) / DKV_ROWS);
-    if (gf_options().bwd_v1.load(std::memory_order_relaxed)) {      // GF_ATTN_BWD=v1: the first kernels (32x32x16, 8 tile products), A/B
-        hipLaunchKernelGGL(attn_bwd_delta_kernel, dim3((unsigned)((q_len * heads + 255) / 256)), dim3(256), 0, s, a);
-        hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(nqb * (unsigned)heads), dim3(DQ_THREADS), BWD_LDS, s, a);
-        if (want_dkv) {
-            hipLaunchKernelGGL(attn_bwd_dkv_kernel<1>, dim3(nkb * (unsigned)heads), dim3(DKV_THREADS), BWD_LDS, s, a);
-            hipLaunchKernelGGL(attn_bwd_dkv_kernel<2>, dim3(nkb * (unsigned)heads), dim3(DKV_THREADS), BWD_LDS, s, a);
-        }
-        GF_CHECK_LAUNCH("gf_flash_attn_bwd");
-        return GF_OK;
-    }
+    const unsigned nqb = (unsigned)((q_len + DQ_ROWS - 1) / DQ_ROWS);
     const int64_t q_pad = pad64(q_len);
     b.ngp = (int)(q_pad / GR);
     float* sd = (float*)((char*)workspace + align256(q_len * heads * 4));
     b.sd = sd;
-#if GF_BWD_QSCALE
-    {
-        u16* qs = (u16*)((char*)sd + align256(heads * q_pad * 2 * 4));
-        b.qs = qs;
-        const long n8 = q_len * heads * (HD / 8);
-        hipLaunchKernelGGL(attn_bwd_qscale_kernel, dim3((unsigned)((n8 + 255) / 256 > 262144 ? 262144 : (n8 + 255) / 256)), dim3(256), 0, s,
-                           (const u16*)q, qs, (long)q_len, (int)(heads * HD), (long)q_stride, a.scale_log2e);
-    }
-#else
     b.qs = nullptr;
-#endif
     hipLaunchKernelGGL(attn_bwd_delta16_kernel, dim3((unsigned)((q_pad * heads + 255) / 256)), dim3(256), 0, s, b, sd);
     hipLaunchKernelGGL(attn_bwd_dq16_kernel, dim3(nqb * (unsigned)heads), dim3(DQ_THREADS), DQ16_LDS, s, b);
     if (!want_dkv) {
         GF_CHECK_LAUNCH("gf_flash_attn_bwd");
         return GF_OK;
     }
-#if KV_USE_48
     const unsigned nkb48 = (unsigned)((kv_len + Kv48::ROWS - 1) / Kv48::ROWS);
     hipLaunchKernelGGL(attn_bwd_dkv48_kernel, dim3(nkb48 * (unsigned)heads), dim3(Kv48::THREADS), Kv48::LDS, s, b);
-#else
-    const unsigned nkb16 = (unsigned)((kv_len + Kv16<KV16_NP>::ROWS - 1) / Kv16<KV16_NP>::ROWS);
-    hipLaunchKernelGGL(attn_bwd_dkv16_kernel<KV16_NP>, dim3(nkb16 * (unsigned)heads), dim3(Kv16<KV16_NP>::THREADS), Kv16<KV16_NP>::LDS, s, b);
-#endif
     GF_CHECK_LAUNCH("gf_flash_attn_bwd");
     return GF_OK;
 }

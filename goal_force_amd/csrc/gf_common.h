@@ -98,24 +98,19 @@ void gf_set_error(const char* fmt, ...);
     } while (0)
 static inline bool gf_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
-// A/B and diagnostic knobs of the launchers (GF_GEMM_KERNEL, GF_A4_STAGGER, ...).  They are read from the environment ONCE per
-// process (first use) into atomics and validated there; the launch path only does relaxed loads — no getenv per launch (getenv
-// is not thread-safe against setenv, and a forward makes ~1000 launches).  A process that changes one of the variables at run
-// time (tests, tools/*_ab.py) calls gf_reload_options() afterwards.  Defaults = the shipped configuration.
+// Dispatch overrides of the launchers.  Every kernel in this library ships: each serves the shapes its launcher sends it.  The
+// parity tests cross-check two of them on the SAME operands (bit-identical by construction), which needs a way to send a shape to
+// the kernel that would not get it by default: gf_set_option(name, value) (gf_abi.hip).  The library reads NO environment variable;
+// the defaults below are the shipped dispatch, and nothing but an explicit call changes them.  Launch paths do relaxed loads.
 #include <atomic>
 struct GfOptions {
-    std::atomic<int> gemm_kernel{0};    // GF_GEMM_KERNEL: 0 = shipped (a4 for M >= 512), 1 = "ph" (8-wave kernels), 2 = "sl", 3 = "sl8"
-    std::atomic<int> gemm_v1{-1};       // GF_GEMM_V1: -1 = per dtype default, 0 / 1 forced
-    std::atomic<int> a4_stagger{2};     // GF_A4_STAGGER: K tiles between the K-loop starts of neighbouring column tiles (>= 0; 0 = off)
-    std::atomic<int> a4_group_m{0};     // GF_A4_GROUP_M: 0 = by K
-    std::atomic<int> a4_loop_h{0};      // GF_A4_LOOP=h (-DGF_A4_HALFTILE_AB builds only)
-    std::atomic<int> a4_whatif{0};      // GF_A4_WHATIF (-DGF_A4_WHATIF builds only)
-    std::atomic<int> attn_kernel1{0};   // GF_ATTN_KERNEL=1: gf_flash_attn_fwd on the phase-serial kernel 1
-    std::atomic<int> bwd_v1{0};         // GF_ATTN_BWD=v1: gf_flash_attn_bwd on the first kernels (32x32x16 MFMAs, dQ / dV / dK passes)
-    std::atomic<int> conv_nb{0};        // GF_CONV_NB: 0 = by Cout, 1 / 2 forced
-    std::atomic<int> conv_gather{0};    // GF_CONV_GATHER=1: the general gather
-    std::atomic<int> vae_rms3{1};       // GF_VAE_RMS3=0: RMS_norm+SiLU at C = 96 / 192 / 384 on the power-of-two kernel (a quarter of its lanes idle), A/B
-    std::atomic<int> conv_direct{1};    // GF_CONV_DIRECT=0: the 96-channel 3x3x3 convolutions on the implicit GEMM instead of gf_conv_direct.hip
+    std::atomic<int> prefer_8wave{0};   // "prefer_8wave": 1 = GEMMs with M >= 512 on the 8-wave kernels (default: the 4-wave kernel)
+    std::atomic<int> a4_stagger{2};     // "a4_stagger": K tiles between the K-loop starts of neighbouring column tiles (>= 0; 0 = off)
+    std::atomic<int> a4_group_m{0};     // "a4_group_m": row tiles per XCD group of the 4-wave kernel; 0 = by K
+    std::atomic<int> conv_nb{0};        // "conv_nb": N-tile width of the implicit-GEMM convolution; 0 = by Cout, 1 / 2 forced
+    std::atomic<int> conv_gather{0};    // "conv_gather": 1 = the general (pointer-free) gather
+    std::atomic<int> vae_rms3{1};       // "vae_rms3": 0 = RMS_norm+SiLU at C = 96 / 192 / 384 on the power-of-two kernel
+    std::atomic<int> conv_direct{1};    // "conv_direct": 0 = the 96-channel 3x3x3 / 192-channel upsample convolutions on the implicit GEMM
 };
 // gf_conv_direct.hip: direct convolution of the 96-channel level; GF_ERR_UNSUPPORTED = shape not covered (caller falls back)
 int gf_conv3d_direct_c96(const void* src_walk, const void* Wm, int64_t ldw, const void* bias, void* out, int64_t T_out, int64_t H,
@@ -123,7 +118,6 @@ int gf_conv3d_direct_c96(const void* src_walk, const void* Wm, int64_t ldw, cons
 int gf_conv2d_up_direct_c192(const void* src0, const void* Wm, int64_t ldw, const void* bias, void* out, int64_t T_out, int64_t Hs,
                              int64_t Ws, const void* zero_page, void* stream);
 const GfOptions& gf_options();          // gf_abi.hip
-extern "C" GF_API void gf_reload_options(void);
 
 // One-time, per-DEVICE, thread-safe launcher setup (hipFuncSetAttribute is a property of the function on the current
 // device: a process that drives a second GPU must set it there too).  `f()` runs at most once per device and returns

@@ -24,26 +24,8 @@
 #include <cstdlib>
 #include <type_traits>
 
-// GF_GEMM_STAMP: diagnostic build only (tools/gemm_stamps.py) — per-segment s_memtime sums of waves 0 and 4 of
-// workgroup 0 of the phased kernel, written to a debug buffer; the shipped library is built without it.
-#ifndef GF_GEMM_STAMP
-#define GF_GEMM_STAMP 0
-#endif
-#if GF_GEMM_STAMP
-static unsigned long long* g_gemm_dbg = nullptr;
-extern "C" GF_API void gf_debug_set_gemm_buffer(void* p) { g_gemm_dbg = (unsigned long long*)p; }
-#define GSTAMP(i)                                                                           \
-    {                                                                                       \
-        unsigned long long t_;                                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                  \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
-        __builtin_amdgcn_sched_barrier(0);                                                  \
-        seg[i] += t_ - tprev;                                                               \
-        tprev = t_;                                                                         \
-    }
-#else
-#define GSTAMP(i)
-#endif
+// The first bf16 kernels that no longer ship (the one-barrier 8-wave kernel in bf16, the slot-scheduled `sl` / `sl8` kernels) and the
+// stamp / what-if / alternative-loop diagnostic builds are NOT in this file: tools/patches/gemm_experiments.patch re-creates them.
 
 namespace {
 
@@ -52,10 +34,7 @@ constexpr int GEMM_THREADS = 512;
 constexpr int TILE_BYTES = BM * BK * 2;       // 32 KiB per operand tile
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;   // A + B
 constexpr int GEMM_LDS = 2 * STAGE_BYTES;     // 128 KiB
-#ifndef GF_GROUP_M
-#define GF_GROUP_M 8           // 16: -14 % (18 instead of 12 operand slices per K step and XCD), 4: +-2 % (tools/gemm_variants.py)
-#endif
-constexpr int GROUP_M = GF_GROUP_M;
+constexpr int GROUP_M = 8;           // 16: -14 % (18 instead of 12 operand slices per K step and XCD), 4: +-2 % (EXPERIMENTS.md)
 
 // Implicit-GEMM convolution (CONV = true instantiations of the phased kernel): the A operand is never materialised — row m
 // = output pixel (j, Y, X), column k = (tap, channel) with tap = (dt*ks + dy)*ks + dx, exactly the patch matrix of
@@ -84,14 +63,14 @@ struct GemmArgs {
     long lda, ldw, ldc, ldr;
     long sA = 0, sW = 0, sC = 0;   // gf_gemm_bf16_batched (gemm_ph_kernel, blockIdx.y = batch index): element strides between the problems
     int tiles_m, tiles_n;
-    unsigned long long* dbg;
+    unsigned long long* rsv0 = nullptr;   // reserved: the kernarg layout the shipped kernels were scheduled and measured with is kept
     ConvGeom cv;
-    int whatif;   // -DGF_A4_WHATIF diagnostic builds only (tools/gemm_a4_whatif.py)
-    int stagger;  // gemm_a4_kernel: column tile j starts its K loop at K tile (stagger * j) mod nk (GF_A4_STAGGER, default 2; 0 = off)
+    int rsv1 = 0;
+    int stagger;  // gemm_a4_kernel: column tile j starts its K loop at K tile (stagger * j) mod nk (option "a4_stagger", default 2; 0 = off)
     int wrows;    // gemm_a4_kernel: rows of W that exist (= N except for GF_EPI_VT32, where N = kv_pad covers zero columns past kv_len)
     int stagger_rows;   // gemm_a4_kernel: the K-loop rotation follows the ROW tile (GF_EPI_VT32: the operands are swapped, see gf_linear_vt32)
     int group_m;        // gemm_a4_kernel: row tiles per workgroup-order group (set by launch_gemm_a4)
-    int halftile;       // -DGF_A4_HALFTILE_AB builds only: the half-tile K loop instead of the k-sub-step loop for bf16 (GF_A4_LOOP=h)
+    int rsv2 = 0;
 };
 
 // internal epilogue of gf_linear_vt32 (not in goalforce.h's enum): C rows = output features, C columns = keys in kernel 3's
@@ -122,6 +101,7 @@ __device__ __forceinline__ float gf_epi_act(float lin) {
 // p.lda / p.ldw / p.K are in ELEMENTS of the operand type; the staging code works in 16-byte chunks.
 template <int EPI, bool FP8>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmArgs p) {
+    static_assert(FP8, "only the fp8 form of this kernel ships (launch_gemm); bf16 with M < 512 runs gemm_ph_kernel");
     constexpr int ESZ = FP8 ? 1 : 2;          // bytes per operand element
     constexpr int BKE = 128 / ESZ;            // K elements per 128-byte tile row
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -431,14 +411,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs
             if (kind == 0 || kind == 3) {
                 const ConvGeom& g = p.cv;
                 const int a = kind == 3;
-#if GF_CONV_WHATIF   // timing only (wrong results): the gather without its address arithmetic
-                if (CONV == 1 && g.mode == 0) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-                    glds16(g.src + (long)(cyx[a][i] & 0xffff) * g.C + ((cyx[a][i] >> 16) * g.W) * g.C + ((tile * 8) & 63), dst + i * 1024);
-                return;
-                }
-#endif
                 if constexpr (CONV == 2) {
                     if (g.c64) {
                         const int hf = g.ks >> 1;
@@ -619,27 +591,17 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs
     if (wr == 1) __builtin_amdgcn_s_barrier();  // wave row 1 runs half a phase behind wave row 0
 
 #define GF_PHASE_END(SEQ_ISSUED)                                                  \
-    GSTAMP(1)                                                                    \
     if ((SEQ_ISSUED) >= total) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  \
     else if constexpr (NB == 3) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); \
     else if constexpr (NB == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); \
     else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                        \
-    GSTAMP(2)                                                                    \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                           \
-    GSTAMP(3)                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                           \
-    __builtin_amdgcn_s_barrier();                                                \
-    GSTAMP(4)
+    __builtin_amdgcn_s_barrier();
 
-#if GF_GEMM_STAMP
-    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
-#endif
 #define GF_AFTER_MMA                       \
-    GSTAMP(5)                              \
     __builtin_amdgcn_sched_barrier(0);     \
-    __builtin_amdgcn_s_barrier();          \
-    GSTAMP(6)
+    __builtin_amdgcn_s_barrier();
     if constexpr (NB == 1) {
         for (int c = 0; c < nk; ++c) {
             GF_LDS char* buf = lds + (c & 1) * STAGE_BYTES;
@@ -667,7 +629,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs
         const int g = 4 * c;
         // ---- phase 0: stream B1(c+1); read A-sub0, B-sub0; quadrant (0,0)
         if (g + 6 < total) stage(c + 1, 2);
-        GSTAMP(0)
         read_b(buf, 0);
         read_a(buf, 0);
         GF_PHASE_END(g + 6)
@@ -675,30 +636,23 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs
         GF_AFTER_MMA
         // ---- phase 1: stream A1(c+1); read B-sub1; quadrant (0,1)
         if (g + 7 < total) stage(c + 1, 3);
-        GSTAMP(0)
         read_b(buf, 1);
         GF_PHASE_END(g + 7)
         mma(0, 1);
         GF_AFTER_MMA
         // ---- phase 2: stream A0(c+2); read A-sub1; quadrant (1,1)
         if (g + 8 < total) stage(c + 2, 0);
-        GSTAMP(0)
         read_a(buf, 1);
         GF_PHASE_END(g + 8)
         mma(1, 1);
         GF_AFTER_MMA
         // ---- phase 3: stream B0(c+2); no LDS read (B-sub0 still in registers); quadrant (1,0)
         if (g + 9 < total) stage(c + 2, 1);
-        GSTAMP(0)
         GF_PHASE_END(g + 9)
         mma(1, 0);
         GF_AFTER_MMA
     }
 #undef GF_AFTER_MMA
-#if GF_GEMM_STAMP
-    if (p.dbg && blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0)
-        for (int i = 0; i < 8; ++i) p.dbg[(wave >> 2) * 8 + i] = seg[i];
-#endif
 #undef GF_PHASE_END
     if (wr == 0) __builtin_amdgcn_s_barrier();  // pairs with wave row 1's last barrier: everyone is past its LDS reads
 
@@ -799,22 +753,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_ph_kernel(const GemmArgs
 //   * same XOR-swizzled 128-byte-row LDS image, swapped operands and fused epilogues (bias / GELU-tanh / SiLU /
 //     gate*+residual / +residual / *multiply, the reference's bf16 rounding sequence) as the other kernels; the epilogue
 //     transposes each wave's 128 x 128 through a private 32 KiB LDS image and stores whole 256-byte row segments.
-#ifndef GF_A4_ROWMAP
-#define GF_A4_ROWMAP 1         // must match the generated loop's PIECE_STEP (tools/gen_gemm_a4.py): 1 <-> 0x1000
-#endif
-#ifdef GF_A4_LOOP_INC          // A/B builds of other generated schedules (tools/gemm_variants.py)
-#include GF_A4_LOOP_INC
-#else
 #include "gf_gemm_a4_loop.inc"
-#endif
 #include "gf_gemm_a4f8_loop.inc"   // the fp8 K loop (tools/gen_gemm_a4f8.py)
-#ifdef GF_A4_HALFTILE_AB           // A/B builds only (tools/gemm_loop_ab.py): the fp8 loop's half-tile schedule with bf16 MFMAs
-#include GF_A4_HALFTILE_AB         // (A4F8_BF16=1 tools/gen_gemm_a4f8.py) — bit-identical to the k-sub-step loop and equally fast
-#endif                             // (profiles/r03/gemm_loop_ab_halftile.log), so the shipped library carries one bf16 loop
 constexpr int A4_THREADS = 256;
-#ifndef GF_A4_NT
-#define GF_A4_NT 1   // the epilogue streams: C stores and residual loads carry the non-temporal hint (D->D +2.6 %, D->F +1.2 %, F->D -0.5 %; 0 for A/B builds)
-#endif
 
 template <int I>
 __device__ __forceinline__ float a4_acc() {
@@ -845,17 +786,6 @@ __global__ __launch_bounds__(A4_THREADS, 1) void gemm_a4_kernel(const GemmArgs p
     const int wm = wave >> 1, wn = wave & 1;
 
     const int nwg = p.tiles_m * p.tiles_n;
-#if GF_GEMM_STAMP   // diagnostic build: s_memtime at kernel entry / loop entry / loop exit / kernel exit, per workgroup (tools/gemm_a4_stamps.py)
-#define A4STAMP(i)                                                                              \
-    {                                                                                           \
-        unsigned long long t_;                                                                  \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");             \
-        if (p.dbg && threadIdx.x == 0) p.dbg[(long)blockIdx.x * 4 + (i)] = t_;                  \
-    }
-#else
-#define A4STAMP(i)
-#endif
-    A4STAMP(0)
     int v;
     {
         const int pid = blockIdx.x;
@@ -877,12 +807,6 @@ __global__ __launch_bounds__(A4_THREADS, 1) void gemm_a4_kernel(const GemmArgs p
     const int srow = lane >> 3;
     unsigned voffA = (unsigned)srow * (unsigned)p.lda * ESZ + (unsigned)(((lane & 7) ^ srow) << 4);
     unsigned voffB = (unsigned)srow * (unsigned)p.ldw * ESZ + (unsigned)(((lane & 7) ^ srow) << 4);
-#ifdef GF_A4_WHATIF
-    if (!FP8 && p.whatif == 16) {   // timing only: un-permuted source chunks (what a padded, un-swizzled LDS image would fetch)
-        voffA = (unsigned)srow * (unsigned)p.lda * 2u + (unsigned)((lane & 7) << 4);
-        voffB = (unsigned)srow * (unsigned)p.ldw * 2u + (unsigned)((lane & 7) << 4);
-    }
-#endif
     // L2 warm-up loads (one line per lane): lane l = row l of this wave's 64 staging rows
     unsigned pfA = (unsigned)lane * (unsigned)p.lda * ESZ, pfB = (unsigned)lane * (unsigned)p.ldw * ESZ;
     const unsigned long baseA = (unsigned long)((const char*)p.A + (long)m0 * p.lda * ESZ);
@@ -892,16 +816,9 @@ __global__ __launch_bounds__(A4_THREADS, 1) void gemm_a4_kernel(const GemmArgs p
     const unsigned nrA = (unsigned)(((long)(min(p.M - m0, BM) - 1) * p.lda + p.K) * ESZ);   // valid bytes from the tile's first row
     const int wvalid = min(p.wrows - n0, BN);                                                // rows of this W tile that exist
     const unsigned nrB = wvalid > 0 ? (unsigned)(((long)(wvalid - 1) * p.ldw + p.K) * ESZ) : 0u;
-#if GF_A4_ROWMAP   // the waves' pieces interleaved: piece p of wave w = rows 32 p + 8 w .. + 7 (the loop generated with A4_PIECE_STEP=0x1000)
     const unsigned stA = 32u * (unsigned)p.lda * ESZ, stB = 32u * (unsigned)p.ldw * ESZ;
     const unsigned soA = (unsigned)wave * 8u * (unsigned)p.lda * ESZ, soB = (unsigned)wave * 8u * (unsigned)p.ldw * ESZ;
     const unsigned ldsW = (unsigned)(unsigned long)lds + (unsigned)wave * 1024u;
-#else
-    static_assert(!FP8, "the fp8 loop is generated for the interleaved row map");
-    const unsigned stA = 8u * (unsigned)p.lda * 2u, stB = 8u * (unsigned)p.ldw * 2u;
-    const unsigned soA = (unsigned)wave * 8u * stA, soB = (unsigned)wave * 8u * stB;
-    const unsigned ldsW = (unsigned)(unsigned long)lds + (unsigned)wave * 8192u;
-#endif
     const unsigned nk = (unsigned)(p.K * (int)ESZ / 128);       // K tiles of 128 bytes per row
     // Staggered K start: the workgroups of column tile j begin their K loop at K tile (2 j) mod nk and wrap around, so
     // that the ~32 column tiles in flight at any time fetch from different 256-byte blocks of their rows.  All rows of the
@@ -947,40 +864,12 @@ __global__ __launch_bounds__(A4_THREADS, 1) void gemm_a4_kernel(const GemmArgs p
         for (int i = 0; i < 8; ++i) rsc[i] = p.row_scale[min(m0 + wm * 128 + i * 16 + (lane & 15), p.M - 1)];
     }
     if constexpr (FP8) {
-        A4STAMP(1)
-#ifdef GF_A4_WHATIF
-        if (p.whatif == 1) GF_A4F8_LOOP_ASM_W1(voffA, voffB, rdA0, rdA1, rdB0, rdB1, aLo, aHi, nrA, bLo, bHi, nrB, soA, stA, soB, stB, ldsW, nk, k0, kb);
-        else if (p.whatif == 4) GF_A4F8_LOOP_ASM_W4(voffA, voffB, rdA0, rdA1, rdB0, rdB1, aLo, aHi, nrA, bLo, bHi, nrB, soA, stA, soB, stB, ldsW, nk, k0, kb);
-        else
-#endif
         GF_A4F8_LOOP_ASM(voffA, voffB, rdA0, rdA1, rdB0, rdB1, aLo, aHi, nrA, bLo, bHi, nrB, soA, stA, soB, stB, ldsW, nk, k0, kb);
-        A4STAMP(2)
     } else
-#ifdef GF_A4_WHATIF   // timing-only variants of the loop (wrong results), selected per launch
-    if (p.whatif == 1) GF_A4_LOOP_ASM_W1(voffA, voffB, pfA, pfB, rdA0, rdA1, rdB0, rdB1, aLo, aHi, nrA, bLo, bHi, nrB, soA, stA, soB, stB, ldsW, nk, k0, kb);
-    else if (p.whatif == 2) GF_A4_LOOP_ASM_W2(voffA, voffB, pfA, pfB, rdA0, rdA1, rdB0, rdB1, aLo, aHi, nrA, bLo, bHi, nrB, soA, stA, soB, stB, ldsW, nk, k0, kb);
-    else if (p.whatif == 4) GF_A4_LOOP_ASM_W4(voffA, voffB, pfA, pfB, rdA0, rdA1, rdB0, rdB1, aLo, aHi, nrA, bLo, bHi, nrB, soA, stA, soB, stB, ldsW, nk, k0, kb);
-    else if (p.whatif == 5) GF_A4_LOOP_ASM_W5(voffA, voffB, pfA, pfB, rdA0, rdA1, rdB0, rdB1, aLo, aHi, nrA, bLo, bHi, nrB, soA, stA, soB, stB, ldsW, nk, k0, kb);
-    else if (p.whatif == 64) GF_A4_LOOP_ASM_W64(voffA, voffB, pfA, pfB, rdA0, rdA1, rdB0, rdB1, aLo, aHi, nrA, bLo, bHi, nrB, soA, stA, soB, stB, ldsW, nk, k0, kb);
-    else if (p.whatif == 128) GF_A4_LOOP_ASM_W128(voffA, voffB, pfA, pfB, rdA0, rdA1, rdB0, rdB1, aLo, aHi, nrA, bLo, bHi, nrB, soA, stA, soB, stB, ldsW, nk, k0, kb);
-    else
-#endif
-#ifdef GF_A4_HALFTILE_AB
-    if (p.halftile) {
-        A4STAMP(1)
-        GF_A4H_LOOP_ASM(voffA, voffB, rdA0, rdA1, rdB0, rdB1, aLo, aHi, nrA, bLo, bHi, nrB, soA, stA, soB, stB, ldsW, nk, k0, kb);
-        A4STAMP(2)
-    } else
-#endif
     {
-        A4STAMP(1)
         GF_A4_LOOP_ASM(voffA, voffB, pfA, pfB, rdA0, rdA1, rdB0, rdB1, aLo, aHi, nrA, bLo, bHi, nrB, soA, stA, soB, stB, ldsW, nk, k0, kb);
-        A4STAMP(2)
     }
 
-#ifdef GF_A4_WHATIF
-    if (p.whatif == 32) return;   // timing only: no epilogue at all
-#endif
     // ---- epilogue: a[(i*8+j)*4 + r] = C[m0 + wm*128 + 16 i + frow][n0 + wn*128 + 16 j + 4 fq + r]  (the asm ended on a barrier:
     // every wave is past its LDS reads and every LDS-DMA has landed)
     GF_LDS char* ep = lds + wave * 32768;   // private 128 rows x 256 B; 8-byte slot s of row r at slot s ^ ((r & 15) << 1)
@@ -995,11 +884,7 @@ __global__ __launch_bounds__(A4_THREADS, 1) void gemm_a4_kernel(const GemmArgs p
         for (int it = 0; it < 32; ++it) {
             const int mr = m0 + wm * 128 + it * 4 + (lane >> 4);
             if (mr < p.M && nr < p.N) {
-#if GF_A4_NT
                 rres[it] = __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(p.R + (long)mr * p.ldr + nr));
-#else
-                rres[it] = *reinterpret_cast<const u16x8*>(p.R + (long)mr * p.ldr + nr);
-#endif
             } else {
                 rres[it] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
             }
@@ -1095,18 +980,10 @@ __global__ __launch_bounds__(A4_THREADS, 1) void gemm_a4_kernel(const GemmArgs p
                                                         : f2bf(bf2f(r8[e]) + t);      // x + ...
                     }
                 }
-#if GF_A4_NT
                 __builtin_nontemporal_store(o, reinterpret_cast<u16x8*>(p.C + (long)m * p.ldc + n));
-#else
-                *reinterpret_cast<u16x8*>(p.C + (long)m * p.ldc + n) = o;
-#endif
             }
         }
     }
-#if GF_GEMM_STAMP
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have left the CU
-    A4STAMP(3)
-#endif
 }
 
 template <int EPI, bool FP8 = false>
@@ -1117,7 +994,6 @@ int launch_gemm_a4(const GemmArgs& a0, hipStream_t stream) {
         // 12 operand slices per K step; with the long K loop of F->D (K = 13824) 4 x 8 measured +1.6 %, at K = 5120 8 x 4 +1-2 %
         const int g = gf_options().a4_group_m.load(std::memory_order_relaxed);
         a.group_m = g > 0 ? g : (a.K * (FP8 ? 1 : 2) >= 16384 ? 4 : GROUP_M);   // by the K loop's length in bytes per row
-        a.halftile = gf_options().a4_loop_h.load(std::memory_order_relaxed);
     }
     static GfDeviceOnce once;
     hipError_t e = gf_once_per_device(once, [] {
@@ -1133,316 +1009,36 @@ int launch_gemm_a4(const GemmArgs& a0, hipStream_t stream) {
     return GF_OK;
 }
 
-// ================================================================================================================
-// EXPERIMENTAL, NOT THE SHIPPED PATH (GF_GEMM_KERNEL=sl / sl8 select it; parity-tested): measured 1.07 / 1.22 / 1.20 PFLOP/s
-// (sl8, the two-waves-per-SIMD form: 1.07 / 1.18 / 1.17) against the phased kernel's 1.18 / 1.34 / 1.35.  What-if builds: without its DMA instructions the same loop runs at
-// 1.85 PFLOP/s, without its barrier and waits still at 1.22 — with ONE wave per SIMD the LDS-DMA issue back-pressure
-// (misses queue in the vector memory path; tools/issue_probe.py shows the mix at full rate only on cached sources)
-// stalls the wave's MFMAs too, while the phased kernel's second wave per SIMD computes through those stalls.
-// gemm_sl_kernel — slot-scheduled bf16 GEMM: 4 waves per workgroup (ONE per SIMD, up to 512 registers), 256x256 tile,
-// 128x128 per wave on v_mfma_f32_32x32x16_bf16 with the 256 fp32 accumulators in AGPRs.
-// Why: tools/gemm_stamps.py shows the phased kernel issue-bound on its coarse structure (a load segment of 2 DMA pieces
-// + 8-12 ds_read + waits is longer than the MFMA burst it is paired with), while tools/issue_probe.py shows the SAME
-// instruction mix finely interleaved — per 8 MFMAs 4 ds_read_b128 and 2 LDS-DMA pieces — running at 32.5 cycles per
-// 32x32x16 MFMA, i.e. at the matrix pipe's rate.  So here every wave runs one software pipeline:
-//   * K-step 32 per stage, NST = 4 stages of (256 x 64 B of A + 256 x 64 B of W) = 128 KiB; tile t+3 streams in by
-//     LDS-DMA while tile t is multiplied; ONE barrier per K-tile, placed between its two 16-k halves;
-//   * half h of tile t = 16 MFMAs (4 x 4 accumulator tiles) on the fragment set read during the previous half; its 16
-//     slots carry, pinned in order, the 8 fragment reads of the next half (even slots) and 4 of the 8 DMA pieces of
-//     tile t+3 (slots 1, 5, 9, 13);
-//   * LDS image: 64-byte rows, 16-byte chunk index XOR ((row >> 2) & 3) — conflict-free for the 32-row x 2-chunk
-//     fragment read of the 32x32x16 form (16 consecutive lanes cover one 256-byte bank period);
-//   * DMA in the saddr form (SGPR base + 32-bit VGPR offset): advancing K is one scalar add per operand and tile;
-//   * same swapped-operand / whole-tile LDS epilogue and fused epilogues as the phased kernel.
-constexpr int SL_BK = 32;
-constexpr int SL_NST = 4;
-constexpr int SL_STAGE = 2 * 256 * SL_BK * 2;      // 32 KiB: A then W
-constexpr int SL_LDS = SL_NST * SL_STAGE;          // 128 KiB (the epilogue's 256 x 512 B image reuses it)
-
-typedef __attribute__((ext_vector_type(4))) int i32x4;
-__device__ __forceinline__ void sl_dma(const void* base, unsigned off, GF_LDS char* l) {
-    unsigned keep;
-    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)l);
-#if GF_SL_BUFFER_DMA   // experiment: the buffer form of the same LDS-DMA (SRD base + VGPR offset), as the vendor GEMMs issue it
-    const unsigned long b = (unsigned long)base;
-    i32x4 srd;
-    srd[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)b);
-    srd[1] = __builtin_amdgcn_readfirstlane((int)((b >> 32) & 0xffff));
-    srd[2] = -1;            // num_records
-    srd[3] = 0x00020000;    // raw buffer, 32-bit data format
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(off), "s"(srd), "s"(dst)
-                 : "memory");
-    return;
-#endif
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(off), "s"(base), "s"(dst)
-                 : "memory");
-}
-
-// NW = 4: one wave per SIMD, 128x128 per wave (the design described above).  NW = 8: two waves per SIMD, 128x64 per wave (128
-// accumulators, all in AGPRs): the same slot pipeline per wave, and a partner wave whose MFMAs run through this wave's DMA
-// stalls.
-template <int EPI, int NW>
-__global__ __launch_bounds__(64 * NW, NW / 4) void gemm_sl_kernel(const GemmArgs p) {
-    constexpr int NJ = (NW == 4) ? 4 : 2;          // 32-column accumulator tiles per wave
-    constexpr int NPC = 32 / NW;                   // DMA pieces per wave and tile (half A, half W)
-    constexpr int NMF = 4 * NJ;                    // MFMAs per half
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    GF_LDS char* lds = (GF_LDS char*)smem;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = (NW == 4) ? (wave >> 1) : (wave >> 2), wc = (NW == 4) ? (wave & 1) : (wave & 3);
-    const int r = lane & 31, h = lane >> 5;
-
-    const int nwg = p.tiles_m * p.tiles_n;
-    int v;
-    {
-        const int pid = blockIdx.x;
-        const int xcd = pid & 7, local = pid >> 3;
-        const int q = nwg >> 3, rr = nwg & 7;
-        v = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + local;
-    }
-    const int per_group = GROUP_M * p.tiles_n;
-    const int group = v / per_group;
-    const int first_m = group * GROUP_M;
-    const int gsz = min(p.tiles_m - first_m, GROUP_M);
-    const int in_group = v - group * per_group;
-    const int m0 = (first_m + in_group % gsz) * BM, n0 = (in_group / gsz) * BN;
-
-    // ---- DMA: a piece = 16 rows x 64 B; wave w stages pieces (NPC/2) w .. of A and of W.  Lane L fills physical
-    // chunk L&3 of row L>>2, which holds logical chunk (L&3) ^ ((row>>2)&3).
-    unsigned offA[NPC / 2], offB[NPC / 2];
-    {
-        const int prow = lane >> 2;
-#pragma unroll
-        for (int i = 0; i < NPC / 2; ++i) {
-            const int row = ((NPC / 2) * wave + i) * 16 + prow;             // 0..255 inside the tile
-            const int lch = (lane & 3) ^ ((row >> 2) & 3);
-            const long ra = min(m0 + row, p.M - 1), rb = min(n0 + row, p.N - 1);
-            offA[i] = (unsigned)((ra * p.lda + lch * 8) * 2);
-            offB[i] = (unsigned)((rb * p.ldw + lch * 8) * 2);
-        }
-    }
-    const int nk = p.K / SL_BK;
-    // piece < NPC/2: A, else W, of the tile whose operand bases are (ta, tw) and whose stage starts at byte `stage_off`
-    auto dma_piece = [&](const char* ta, const char* tw, int stage_off, int piece) {
-        const bool isw = piece >= NPC / 2;
-        const int pi = isw ? piece - NPC / 2 : piece;
-        GF_LDS char* dst = lds + stage_off + (isw ? SL_STAGE / 2 : 0) + ((NPC / 2) * wave + pi) * 1024;
-        sl_dma(isw ? tw : ta, isw ? offB[pi] : offA[pi], dst);
-    };
-    // ---- fragment addresses (without the stage base): rows wr*128 + 32 i + r (A) / wc*128 + 32 j + r (W), chunk (2 ks + h)
-    const int key = (r >> 2) & 3;
-    int a_rd[2], b_rd[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        a_rd[ks] = (wr * 128 + r) * 64 + (((2 * ks + h) ^ key) << 4);
-        b_rd[ks] = SL_STAGE / 2 + (wc * (32 * NJ) + r) * 64 + (((2 * ks + h) ^ key) << 4);
-    }
-    bf16x8 fa[2][4], fb[2][NJ];                // [fragment set][row tile / column tile]
-    auto read_frag = [&](int set, int idx, int stage_off, int ks) {   // idx < NJ: W column tile, else A row tile idx - NJ
-        if (idx < NJ) fb[set][idx] = *(GF_LDS bf16x8*)(lds + stage_off + b_rd[ks] + idx * 2048);
-        else fa[set][idx - NJ] = *(GF_LDS bf16x8*)(lds + stage_off + a_rd[ks] + (idx - NJ) * 2048);
-    };
-
-    f32x16 acc[4][NJ];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    // one half: 16 MFMAs on fragment set CUR; slot m also carries read m/2 of the next set (even m) and one DMA piece (m = 1,
-    // 5, 9, 13; skipped behind a uniform branch once nothing is left to stream).  sched_barrier(0) after every slot pins
-    // the written order (MFMA and DMA are volatile asms).  ONE loop body for every tile: the accumulators keep their
-    // registers — hipcc does not know the asm MFMAs' latency and must never be given a reason to copy them in the loop.
-    auto half = [&](auto cur_c, int next_stage_off, int next_ks, bool stream, const char* ta, const char* tw, int dma_stage_off,
-                    int dma_piece0) {
-        constexpr int CUR = decltype(cur_c)::value;
-#pragma unroll
-        for (int m = 0; m < NMF; ++m) {
-            const int i = m / NJ, j = m % NJ;
-            // NW = 4: the 256 accumulators would fill the AGPR file to the last register (hipcc then spills, and scratch
-            // traffic counts in the same vmcnt as the DMA): rows 0-2 of the accumulator grid are pinned to AGPRs, row 3 to
-            // VGPRs.  NW = 8: all 128 in AGPRs.
-            if (NW == 8 || i < 3) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fb[CUR][j]), "v"(fa[CUR][i]));
-            else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(fb[CUR][j]), "v"(fa[CUR][i]));
-            // next set, one read per slot from slot 0: the W fragments first (every MFMA needs one of them at once), then the
-            // A fragments (row tile i is first used by MFMA NJ i): the youngest reads are the ones needed last
-            if (NW == 4 ? ((m & 1) == 0) : (m < 4 + NJ)) read_frag(1 - CUR, NW == 4 ? (m >> 1) : m, next_stage_off, next_ks);
-            if ((m % (NMF / (NPC / 2))) == 1 && stream) dma_piece(ta, tw, dma_stage_off, dma_piece0 + m / (NMF / (NPC / 2)));
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    typedef std::integral_constant<int, 0> C0;
-    typedef std::integral_constant<int, 1> C1;
-    auto handoff = [&](int tiles2) {   // allowed in flight: tiles2 half-tiles' worth of this wave's pieces; then the barrier
-        const int outstanding = tiles2 * (NPC / 2);
-        if (outstanding == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else if (outstanding == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else if (outstanding == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (outstanding == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else if (outstanding == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // no lgkmcnt wait: the reads in flight belong to tile t's stage, which is only refilled after the NEXT barrier, and
-        // by then the second half's MFMAs have consumed them
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-    };
-
-    // ---- prologue: tiles 0..2 in flight, tile 0 landed, fragment set 0 = (tile 0, k-half 0)
-    const char* const a0p = (const char*)p.A;
-    const char* const w0p = (const char*)p.W;
-#pragma unroll 1
-    for (int t = 0; t < SL_NST - 1 && t < nk; ++t)
-#pragma unroll
-        for (int pc = 0; pc < NPC; ++pc) dma_piece(a0p + (long)t * (SL_BK * 2), w0p + (long)t * (SL_BK * 2), t * SL_STAGE, pc);
-    handoff(nk >= 3 ? 4 : (nk == 2 ? 2 : 0));
-#pragma unroll
-    for (int idx = 0; idx < 4 + NJ; ++idx) read_frag(0, idx, 0, 0);
-
-    // tile t+3 streams in while tile t is multiplied (its stage was released by the barrier inside tile t-1); past the end
-    // the fragment prefetch reads a stale stage (harmless) and the DMA slots are skipped
-#pragma unroll 1
-    for (int t = 0; t < nk; ++t) {
-        const int st = (t & (SL_NST - 1)) * SL_STAGE, stn = ((t + 1) & (SL_NST - 1)) * SL_STAGE;
-        const int std_ = ((t + 3) & (SL_NST - 1)) * SL_STAGE;
-        const bool stream = t + 3 < nk;
-        const char* ta = a0p + (long)(t + 3) * (SL_BK * 2);
-        const char* tw = w0p + (long)(t + 3) * (SL_BK * 2);
-        half(C0{}, st, 1, stream, ta, tw, std_, 0);     // (t, k 0..15); reads (t, k 16..31); A pieces of t+3
-        handoff(stream ? 3 : (t + 2 < nk ? 2 : 0));     // tile t+1 complete in LDS; nobody reads tile t's first half any more
-        half(C1{}, stn, 0, stream, ta, tw, std_, NPC / 2);   // (t, k 16..31); reads (t+1, k 0..15); W pieces of t+3
-    }
-    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results before anything else reads them
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __syncthreads();   // every wave is past its LDS reads: the stages become the epilogue image
-
-    // ---- epilogue: bf16 tile -> swizzled 256 x 256 LDS image (512-byte rows) -> full-row stores
-    // acc[i][j][4g + q] = C[m0 + wr*128 + 32 i + r][n0 + wc*128 + 32 j + 8 g + 4 h + q]
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int ncol = wc * (32 * NJ) + j * 32 + g * 8 + h * 4;
-            float bv[4] = {0.f, 0.f, 0.f, 0.f};
-            if (p.bias && n0 + ncol < p.N) {
-                const u16x4 b4 = *reinterpret_cast<const u16x4*>(p.bias + n0 + ncol);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) bv[q] = bf2f(b4[q]);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = wr * 128 + i * 32 + r;
-                float y[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    y[q] = rbf(acc[i][j][4 * g + q] + bv[q]);  // the Linear's own bf16 output
-                    if (EPI == GF_EPI_BIAS_GELU_TANH) y[q] = gelu_tanh_f(y[q]);
-                    if (EPI == GF_EPI_BIAS_SILU) y[q] = y[q] / (1.0f + expf(-y[q]));
-                }
-                u32x2 pk;
-                pk[0] = pack2bf(y[0], y[1]);
-                pk[1] = pack2bf(y[2], y[3]);
-                const int slot = (ncol >> 2) ^ ((row & 31) << 1);  // 8-byte slot (64 per row); 16-byte pairs stay together
-                *(GF_LDS u32x2*)(lds + row * 512 + slot * 8) = pk;
-            }
-        }
-    __syncthreads();
-    {
-        const int cc = lane & 31;                 // 16-byte chunk of the row
-        const int n = n0 + cc * 8;
-        const bool n_ok = n < p.N;
-        u16x8 g8;
-        if (EPI == GF_EPI_BIAS_GATE_RESID && n_ok) g8 = *reinterpret_cast<const u16x8*>(p.gate + n);
-#pragma unroll 4
-        for (int it = 0; it < 128 / NW; ++it) {
-            const int row = wave * (256 / NW) + it * 2 + (lane >> 5);
-            const int m = m0 + row;
-            const u16x8 yv = *(GF_LDS u16x8*)(lds + row * 512 + ((cc ^ (row & 31)) << 4));
-            if (m < p.M && n_ok) {
-                u16x8 o = yv;
-                if (EPI == GF_EPI_BIAS_GATE_RESID || EPI == GF_EPI_BIAS_RESID || EPI == GF_EPI_BIAS_MUL) {
-                    const u16x8 r8 = *reinterpret_cast<const u16x8*>(p.R + (long)m * p.ldr + n);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        float t = bf2f(yv[e]);
-                        if (EPI == GF_EPI_BIAS_GATE_RESID) t = rbf(bf2f(g8[e]) * t);  // gate * residual
-                        o[e] = (EPI == GF_EPI_BIAS_MUL) ? f2bf(t * bf2f(r8[e]))       // fc1(x) * gelu(gate(x))
-                                                        : f2bf(bf2f(r8[e]) + t);      // x + ...
-                    }
-                }
-                *reinterpret_cast<u16x8*>(p.C + (long)m * p.ldc + n) = o;
-            }
-        }
-    }
-}
-
-template <int EPI, int NW>
-int launch_gemm_sl(const GemmArgs& a, hipStream_t stream) {
-    static GfDeviceOnce once;
-    hipError_t e = gf_once_per_device(once, [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sl_kernel<EPI, NW>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, SL_LDS);
-    });
-    if (e != hipSuccess) {
-        gf_set_error("gf_gemm: hipFuncSetAttribute(%d B LDS) failed: %s", SL_LDS, hipGetErrorString(e));
-        return GF_ERR_LAUNCH;
-    }
-    hipLaunchKernelGGL((gemm_sl_kernel<EPI, NW>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(64 * NW), SL_LDS, stream, a);
-    GF_CHECK_LAUNCH("gf_gemm_bf16");
-    return GF_OK;
-}
-
 template <int EPI, bool FP8>
 int launch_gemm(const GemmArgs& a, hipStream_t stream) {
+    // the 4-wave kernel for the large shapes (every Linear of a DiT block at S >= 512); `prefer_8wave` (gf_set_option, tests: the
+    // cross-kernel bit-identity checks) sends them to the 8-wave kernel below.  Its 32-bit staging offsets cover 256 rows of either operand.
+    const bool use_a4 = gf_options().prefer_8wave.load(std::memory_order_relaxed) == 0;
     if constexpr (!FP8) {
-        // bf16: GF_GEMM_KERNEL=sl selects the experimental slot-scheduled kernel (A/B); its DMA offsets are 32-bit byte
-        // offsets from the operand base
-        const int gk = gf_options().gemm_kernel.load(std::memory_order_relaxed);
-        const int use_sl = gk == 3 ? 8 : (gk == 2 ? 4 : 0);                                  // "sl8" / "sl"
-        if (use_sl && (long)a.M * a.lda < (1L << 31) && (long)a.N * a.ldw < (1L << 31))
-            return use_sl == 8 ? launch_gemm_sl<EPI, 8>(a, stream) : launch_gemm_sl<EPI, 4>(a, stream);
-        // the 4-wave kernel for the large shapes (every Linear of a DiT block at S >= 512): GF_GEMM_KERNEL=ph selects the
-        // 8-wave phased kernel instead (A/B runs).  Its 32-bit staging offsets cover 256 rows of either operand.
-        const bool use_a4 = gk != 1;                  // A/B runs toggle it inside one process (gf_reload_options)
         if (use_a4 && a.M >= 512 && a.K % 64 == 0 && 256L * a.lda * 2 + a.K * 2L < (1L << 31) &&
             256L * a.ldw * 2 + a.K * 2L < (1L << 31))
             return launch_gemm_a4<EPI>(a, stream);
-    }
-    if constexpr (FP8) {
-        // the 4-wave fp8 kernel for the large shapes (GF_GEMM_KERNEL=ph selects the 8-wave one-barrier kernel below: A/B runs)
-        const bool use_a4 = gf_options().gemm_kernel.load(std::memory_order_relaxed) != 1;
+    } else {
         if (use_a4 && a.M >= 512 && a.K % 128 == 0 && 256L * a.lda + a.K < (1L << 31) && 256L * a.ldw + a.K < (1L << 31))
             return launch_gemm_a4<EPI, true>(a, stream);
     }
-    // bf16 ships the phased kernel (+5..11 % at the DiT shapes); fp8 ships the one-barrier-per-K-tile kernel (at 254
-    // VGPRs the phased fp8 variant measured 10-15 % slower).  GF_GEMM_V1=0/1 overrides for A/B tuning.
-    static const bool use_v1 = [] {     // fixed at the first launch: it selects which kernel gets its LDS attribute set
-        const int v = gf_options().gemm_v1.load(std::memory_order_relaxed);
-        return v < 0 ? FP8 : v == 1;
-    }();
+    // small M: bf16 runs the phased 8-wave kernel, fp8 the one-barrier-per-K-tile 8-wave kernel (at 254 VGPRs the phased fp8
+    // variant measured 10-15 % slower)
     static GfDeviceOnce once;   // per instantiation
     hipError_t e = gf_once_per_device(once, [] {
-        const void* fn = use_v1 ? reinterpret_cast<const void*>(gemm_kernel<EPI, FP8>)
-                                : reinterpret_cast<const void*>(gemm_ph_kernel<EPI, FP8>);
+        const void* fn;
+        if constexpr (FP8) fn = reinterpret_cast<const void*>(gemm_kernel<EPI, true>);
+        else fn = reinterpret_cast<const void*>(gemm_ph_kernel<EPI, false>);
         return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
     });
     if (e != hipSuccess) {
         gf_set_error("gf_gemm: hipFuncSetAttribute(%d B LDS) failed: %s", GEMM_LDS, hipGetErrorString(e));
         return GF_ERR_LAUNCH;
     }
-    if (use_v1)
-        hipLaunchKernelGGL((gemm_kernel<EPI, FP8>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(GEMM_THREADS), GEMM_LDS,
-                           stream, a);
+    if constexpr (FP8)
+        hipLaunchKernelGGL((gemm_kernel<EPI, true>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(GEMM_THREADS), GEMM_LDS, stream, a);
     else
-        hipLaunchKernelGGL((gemm_ph_kernel<EPI, FP8>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(GEMM_THREADS), GEMM_LDS,
+        hipLaunchKernelGGL((gemm_ph_kernel<EPI, false>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(GEMM_THREADS), GEMM_LDS,
                            stream, a);
     GF_CHECK_LAUNCH(FP8 ? "gf_gemm_fp8" : "gf_gemm_bf16");
     return GF_OK;
@@ -1528,20 +1124,11 @@ static int gemm_dispatch(bool fp8, const void* A, int64_t lda, const void* W, in
     a.ldr = ldr;
     a.tiles_m = (int)((M + BM - 1) / BM);
     a.tiles_n = (int)((N + BN - 1) / BN);
-#if GF_GEMM_STAMP
-    a.dbg = g_gemm_dbg;
-#else
-    a.dbg = nullptr;
-#endif
-    a.whatif = 0;
     // K tiles between the K-loop starts of neighbouring column tiles (0 = off).  The rotation changes the ORDER of the sum over k
     // (not the sum): a4 outputs match the unrotated kernels (M < 512: the 8-wave path) to fp32 rounding, not bit for bit.
     a.stagger = gf_options().a4_stagger.load(std::memory_order_relaxed);
     a.wrows = (int)N;
     a.stagger_rows = 0;
-#ifdef GF_A4_WHATIF
-    a.whatif = gf_options().a4_whatif.load(std::memory_order_relaxed);
-#endif
     hipStream_t s = (hipStream_t)stream;
 #define GF_GEMM_CASE(E) case E: return fp8 ? launch_gemm<E, true>(a, s) : launch_gemm<E, false>(a, s);
     switch (epilogue) {
@@ -1602,8 +1189,6 @@ extern "C" GF_API int gf_linear_vt32(const void* x, int64_t ldx, const void* w, 
     a.ldr = 0;
     a.tiles_m = (int)((N + BM - 1) / BM);
     a.tiles_n = (int)((kv_pad + BN - 1) / BN);
-    a.dbg = nullptr;
-    a.whatif = 0;
     a.stagger = gf_options().a4_stagger.load(std::memory_order_relaxed);
     a.wrows = (int)kv_len;
     a.stagger_rows = 1;
@@ -1640,8 +1225,6 @@ extern "C" GF_API int gf_linear_vt32_fp8(const void* x8, int64_t ldx, const floa
     a.ldr = 0;
     a.tiles_m = (int)((N + BM - 1) / BM);
     a.tiles_n = (int)((kv_pad + BN - 1) / BN);
-    a.dbg = nullptr;
-    a.whatif = 0;
     a.stagger = gf_options().a4_stagger.load(std::memory_order_relaxed);
     a.wrows = (int)kv_len;
     a.stagger_rows = 1;
@@ -1686,13 +1269,10 @@ extern "C" GF_API int gf_gemm_bf16_batched(const void* A, int64_t lda, int64_t s
     const bool narrow = N <= 128;
     a.tiles_m = (int)((M + BM - 1) / BM);
     a.tiles_n = narrow ? (int)((N + 127) / 128) : (int)((N + BN - 1) / BN);
-    a.dbg = nullptr;
-    a.whatif = 0;
     a.stagger = 0;
     a.wrows = (int)N;
     a.stagger_rows = 0;
     a.group_m = 0;
-    a.halftile = 0;
     a.cv = ConvGeom{};
     return narrow ? launch_conv<GF_EPI_BIAS, 1, 0>(a, (hipStream_t)stream, (int)batch) : launch_conv<GF_EPI_BIAS, 2, 0>(a, (hipStream_t)stream, (int)batch);
 }
@@ -1750,8 +1330,6 @@ extern "C" GF_API int gf_conv3d_bf16(const void* src, const void* cache, const v
     const bool w192 = !narrow && !force_nb && ((N + 191) / 192) * 192 < ((N + BN - 1) / BN) * BN;
     a.tiles_m = (int)((M + BM - 1) / BM);
     a.tiles_n = narrow ? (int)((N + 127) / 128) : (w192 ? (int)((N + 191) / 192) : (int)((N + BN - 1) / BN));
-    a.dbg = nullptr;
-    a.whatif = 0;
     a.stagger = 0;
     a.wrows = (int)N;
     a.stagger_rows = 0;

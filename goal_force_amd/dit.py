@@ -185,7 +185,8 @@ _FOLD_PAD_KEYS = [_os.environ.get("GF_FOLD_PAD_KEYS", "1") != "0"]      # a list
 
 def pad_run(ctx2: torch.Tensor) -> int:
     """First row index n of the run of identical rows that ends the [L, D] tensor (rows n .. L-1 are all equal): L - 1 when the
-    last two rows differ.  One comparison kernel and one 8-byte read-back per call (once per expert, prompt and block)."""
+    last two rows differ.  One comparison kernel and one 8-byte read-back per call.  The run is a property of the embedded context,
+    so model_fn_wan_video calls this ONCE per embedded context (ContextCache.pad_n) and hands n to every block."""
     L = ctx2.shape[0]
     if L < 2:
         return max(L - 1, 0)
@@ -281,18 +282,20 @@ class CrossAttention(nn.Module):
         self.norm_q, self.norm_k = RMSNorm(dim, eps=eps), RMSNorm(dim, eps=eps)
         self.has_image_input = False
 
-    def context_kv(self, ctx2: torch.Tensor, fold: bool = True):
+    def context_kv(self, ctx2: torch.Tensor, fold: bool = True, pad_n: Optional[int] = None):
         """k = norm_k(Wk ctx), v = Wv ctx — constant per (expert, prompt, block); cacheable over steps.  -> (k, v, m).
 
         `fold`: the prompter zeroes the text-encoder output past the prompt (wan_prompter.py:99-109), so the padded rows of
         `text_embedding(context)` are all the same vector — and so are their K and V rows (every op here acts row by row).
         softmax over [k_0 .. k_{n-1}, k_pad x m] is evaluated on n + 1 keys with the last one counting m times
         (ops.flash_attn(last_key_mult=m)): the same function of q, 41 keys instead of 512 for a 40-token prompt.  The run is
-        DETECTED on the tensor (pad_run), never assumed; a context without such a run is attended in full.  GF_FOLD_PAD_KEYS=0
-        switches the folding off (A/B, and the bit-for-bit cross-check in tests/test_kernels_gpu.py)."""
+        DETECTED on the tensor (pad_run), never assumed; a context without such a run is attended in full.  `pad_n` is that
+        detection's result when the caller already ran it on this very tensor (model_fn does, once per embedded context, instead
+        of one host read-back per block).  GF_FOLD_PAD_KEYS=0 switches the folding off (A/B, and the bit-for-bit cross-check in
+        tests/test_kernels_gpu.py)."""
         m = 1
         if fold and ctx2.is_cuda and _FOLD_PAD_KEYS[0]:
-            n = pad_run(ctx2)
+            n = pad_run(ctx2) if pad_n is None else pad_n
             if ctx2.shape[0] - n >= 2 and n + 1 < ops.VT_MIN_KV:      # (the multiplicity form exists for short key sequences only)
                 m = ctx2.shape[0] - n
                 ctx2 = ctx2[: n + 1]
@@ -346,7 +349,7 @@ class DiTBlock(nn.Module):
         self.gate = GateModule()
 
     def forward(self, x, context, t_mod, freqs, context_kv=None, out=None, sp=None, keep=None, self_attn_memo=None,
-                fold_pad_keys=True):
+                fold_pad_keys=True, pad_n=None):
         """`self_attn_memo` (a dict, optional): x + gate_msa * self_attn(modulate(norm1(x))) — the block's first half — does not
         depend on the text context.  The two forwards of a CFG step run this block on IDENTICAL x, t_mod and freqs (block 0 of the
         DiT and of the ControlNet, model_fn_wan_video), so the first stores that half here and the second takes it: same kernels
@@ -388,7 +391,7 @@ class DiTBlock(nn.Module):
         else:
             ops.layernorm_modulate(x_new, weight=self.norm3.weight, bias=self.norm3.bias, eps=self.eps, out=h)
         if context_kv is None:
-            context_kv = self.cross_attn.context_kv(_tokens2d(context), fold=fold_pad_keys and keep is None)
+            context_kv = self.cross_attn.context_kv(_tokens2d(context), fold=fold_pad_keys and keep is None, pad_n=pad_n)
         a = self.cross_attn.attend(h, context_kv)
         linear(a, self.cross_attn.o, epilogue=ops.EPI_BIAS_RESID, resid=x_new, out=x_new)               # DIT:227
         if keep is not None and keep.get("wide"):

@@ -29,7 +29,7 @@ import torch
 
 from . import ops
 from ._lib import GoalForceError
-from .dit import WanModel
+from .dit import WanModel, pad_run, _FOLD_PAD_KEYS
 
 
 class ContextCache:
@@ -38,6 +38,7 @@ class ContextCache:
 
     def __init__(self):
         self.ctx = None
+        self.pad_n = None       # dit.pad_run(ctx): where the run of identical padded rows starts — detected once, used by every block
         self.dit_kv = {}
         self.cn_kv = {}
 
@@ -108,11 +109,13 @@ def model_fn_wan_video(
 
     # Text embedding (GF:1447)
     if context_cache is not None and context_cache.ctx is not None:
-        ctx = context_cache.ctx
+        ctx, pad_n = context_cache.ctx, context_cache.pad_n
     else:
         ctx = dit.embed_text(context)
+        # ONE read-back per embedded context; the blocks below take n instead of detecting the run again
+        pad_n = pad_run(ctx[0]) if _FOLD_PAD_KEYS[0] else None
         if context_cache is not None:
-            context_cache.ctx = ctx
+            context_cache.ctx, context_cache.pad_n = ctx, pad_n
 
     # Image embedding + patchify (GF:1456-1464) — cat([latents, y]) is folded into the patch gather
     x, (f, h, w) = dit.patchify(latents, extra=y if (y is not None and dit.require_vae_embedding) else None)
@@ -141,7 +144,7 @@ def model_fn_wan_video(
         if context_cache is None:
             return None
         if idx not in cache_dict:
-            cache_dict[idx] = block.cross_attn.context_kv(ctx[0])
+            cache_dict[idx] = block.cross_attn.context_kv(ctx[0], pad_n=pad_n)
         return cache_dict[idx]
 
     # blocks (GF:1503-1570); ControlNet block i is evaluated right before DiT block i
@@ -152,9 +155,9 @@ def model_fn_wan_video(
         if block_id < n_cn:
             cb = controlnet.controlnet_dit.blocks[block_id]
             c = cb(c, ctx, t_mod, rope, context_kv=kv_for(context_cache.cn_kv if context_cache else None, cb, block_id),
-                   sp=sp, self_attn_memo=memo_cn)
+                   sp=sp, self_attn_memo=memo_cn, pad_n=pad_n)
         x = block(x, ctx, t_mod, rope, context_kv=kv_for(context_cache.dit_kv if context_cache else None, block, block_id),
-                  sp=sp, self_attn_memo=memo_dit)
+                  sp=sp, self_attn_memo=memo_dit, pad_n=pad_n)
         if block_id < n_cn:
             # x = x + zero_conv(state)   (GF:1565-1570) — Conv1d(k=1) == Linear, fused residual epilogue
             ops.gemm(c, controlnet.zero_conv_weight(block_id), controlnet.controlnet_zero_convs_after[block_id].bias,

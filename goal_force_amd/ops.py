@@ -7,7 +7,6 @@ There is no CPU path: tensors must live on a HIP device.
 from __future__ import annotations
 
 import math
-import os
 
 import torch
 
@@ -199,41 +198,45 @@ def gemm(a, w, bias=None, epilogue=EPI_BIAS, resid=None, gate=None, out=None):
     return out
 
 
-VT_MIN_KV = int(os.environ.get("GF_ATTN_VT_MIN_KV", "2048"))   # key sequences at least this long go through the pre-transposed-V kernel
-# A/B knobs of this module, read once (like the library's own: gf_reload_options); reload_options() re-reads both sides
-_OPT = {"attn_k3": os.environ.get("GF_ATTN_KERNEL", "3") == "3", "vt_from_gemm": os.environ.get("GF_VT_FROM_GEMM", "1") == "1"}
+VT_MIN_KV = 2048   # key sequences at least this long go through the pre-transposed-V kernel (kernel 3)
+# Dispatch overrides.  Every kernel ships, each for the shapes its launcher sends it; the parity tests cross-check two kernels on
+# the SAME operands, which needs a way to route a shape to the kernel that would not get it by default.  Nothing here (and nothing
+# in the library) reads an environment variable: the defaults are the shipped dispatch and only `options(...)` changes them.
+#   library side (gf_set_option): prefer_8wave, a4_stagger, a4_group_m, conv_nb, conv_gather, conv_direct, vae_rms3
+#   this module: attn_k3 (False: long key sequences on kernel 2), vt_from_gemm (False: V^T by gf_transpose_v32, not by the V projection)
+_LIB_DEFAULTS = {"prefer_8wave": 0, "a4_stagger": 2, "a4_group_m": 0, "conv_nb": 0, "conv_gather": 0, "conv_direct": 1, "vae_rms3": 1}
+_OPT = {"attn_k3": True, "vt_from_gemm": True}
+_LIB_OPT = dict(_LIB_DEFAULTS)
 
 
-def reload_options():
-    """Re-read the A/B / diagnostic environment knobs (GF_GEMM_KERNEL, GF_A4_STAGGER, GF_ATTN_KERNEL, GF_VT_FROM_GEMM, ...): the
-    launch paths read them once per process, so a process that changes os.environ at run time (tests, tools) calls this."""
-    _OPT["attn_k3"] = os.environ.get("GF_ATTN_KERNEL", "3") == "3"
-    _OPT["vt_from_gemm"] = os.environ.get("GF_VT_FROM_GEMM", "1") == "1"
-    _lib.load().gf_reload_options()
-
-
-class env_options:
-    """`with ops.env_options(GF_GEMM_KERNEL="ph"): ...` — set (None: unset) knobs for a block and restore them afterwards."""
+class options:
+    """`with ops.options(prefer_8wave=1): ...` — dispatch overrides for a block, restored afterwards (tests and A/B tools)."""
 
     def __init__(self, **kv):
+        for k in kv:
+            if k not in _OPT and k not in _LIB_DEFAULTS:
+                raise GoalForceError(f"ops.options: unknown option {k!r}")
         self.kv, self.old = kv, {}
 
-    def _apply(self, kv):
+    @staticmethod
+    def _apply(kv):
         for k, v in kv.items():
-            if v is None:
-                os.environ.pop(k, None)
+            if k in _OPT:
+                _OPT[k] = bool(v)
             else:
-                os.environ[k] = str(v)
-        reload_options()
+                _lib.check(_lib.load().gf_set_option(k.encode(), int(v)), f"gf_set_option({k})")
+                _LIB_OPT[k] = int(v)
 
     def __enter__(self):
-        self.old = {k: os.environ.get(k) for k in self.kv}
+        self.old = {k: (_OPT[k] if k in _OPT else _LIB_OPT[k]) for k in self.kv}
         self._apply(self.kv)
         return self
 
     def __exit__(self, *exc):
         self._apply(self.old)
         return False
+
+
 _VT_WS = {}
 
 
@@ -328,7 +331,7 @@ def flash_attn(q, k, v, num_heads, out=None, scale=None, vt=None, last_key_mult=
     if skv >= VT_MIN_KV and head_dim == 128 and num_heads * 128 * kv_pad < 2 ** 31:
         # long key sequences (the DiT self-attention): hand V over pre-transposed — one LDS read per PV MFMA instead of two;
         # the transpose (0.7 % of the attention's time at S=32760) is inside the timed region
-        # GF_ATTN_KERNEL=2 (read per call: A/B runs) selects the 32x32x16-MFMA kernel 2; default = kernel 3 on 16x16x32 MFMAs
+        # kernel 3 (16x16x32 MFMAs); options(attn_k3=False) sends the shape to kernel 2 (32x32x16) for the cross-check tests
         k3 = _OPT["attn_k3"]
         tr, fa = (lib.gf_transpose_v32, lib.gf_flash_attn_fwd_vt32) if k3 else (lib.gf_transpose_v, lib.gf_flash_attn_fwd_vt)
         if vt is None:
@@ -649,7 +652,7 @@ def transpose_pad_batched(x, rpad):
 def gemm_batched(a, w, out=None):
     """out[b] = a[b] @ w[b]^T for b < B in ONE launch (gf_gemm_bf16_batched): a [B, M, K], w [B, N, K], out [B, M, N] — views with any
     batch / row strides and a contiguous last dim (heads of a [L, H*d] tensor: t.view(L, H, d).permute(1, 0, 2)).  No bias / epilogue.
-    The 8-wave kernel: bit-identical to B calls of gemm() under GF_GEMM_KERNEL=ph (for M >= 512 gemm() takes the 4-wave kernel, which sums the
+    The 8-wave kernel: bit-identical to B calls of gemm() under options(prefer_8wave=1) (for M >= 512 gemm() takes the 4-wave kernel, which sums the
     same products from a rotated K tile on: equal up to fp32 summation order)."""
     _req(a, "gemm_batched.a")
     _req(w, "gemm_batched.w")

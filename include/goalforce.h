@@ -48,9 +48,13 @@ typedef enum {
 GF_API const char* gf_version(void);      /* "goalforce-hip <semver> gfx950" */
 GF_API const char* gf_last_error(void);   /* thread-local message of the last failure */
 GF_API int gf_abi_version(void);          /* bumped on any signature change */
-/* The launchers' A/B and diagnostic knobs (GF_GEMM_KERNEL, GF_A4_STAGGER, GF_ATTN_KERNEL, GF_CONV_NB, ...) are read from the
- * environment once per process and validated; a process that changes one of them at run time calls this afterwards. */
-GF_API void gf_reload_options(void);
+/* Dispatch overrides.  Every kernel in the library ships, each for the shapes its launcher sends it; the parity tests cross-check
+ * two kernels on the same operands, which needs a way to route a shape to the one that would not get it by default.  Names:
+ * "prefer_8wave" (0/1), "a4_stagger" (>= 0), "a4_group_m" (0 = by K), "conv_nb" (0 = by Cout, 1, 2), "conv_gather" (0/1),
+ * "conv_direct" (0/1), "vae_rms3" (0/1).  Values are clamped to their range; an unknown name returns GF_ERR_INVALID_ARG.
+ * The library reads NO environment variable: only these calls change the dispatch.  Process-wide, relaxed atomics. */
+GF_API int gf_set_option(const char* name, int value);
+GF_API void gf_reset_options(void);   /* back to the shipped dispatch */
 
 /* ------------------------------------------------------------------------
  * gf_layernorm_modulate — LayerNorm over the last dim (fp32 math, one
@@ -126,7 +130,7 @@ GF_API int gf_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, 
  * elements, and a stride may be smaller than a matrix (heads side by side in one [L, H*d] tensor: strideA = d, lda = H*d).  The small
  * per-head / per-frame products of the umT5 encoder's attention (wan_video_text_encoder.py:61-93: q k^T and attn v per head) and of the
  * VAE AttentionBlock (VAE:304-342, per frame).  K a multiple of 64, N of 8.  Runs on the 8-wave kernel: bit-identical to `batch`
- * gf_gemm_bf16 calls on that kernel (M < 512, or GF_GEMM_KERNEL=ph); the 4-wave kernel gf_gemm_bf16 takes for M >= 512 rotates the K
+ * gf_gemm_bf16 calls on that kernel (M < 512, or gf_set_option("prefer_8wave", 1)); the 4-wave kernel gf_gemm_bf16 takes for M >= 512 rotates the K
  * loop's start per column tile, i.e. sums the same products in another order. */
 GF_API int gf_gemm_bf16_batched(const void* A, int64_t lda, int64_t strideA, const void* W, int64_t ldw, int64_t strideW, void* C,
                                 int64_t ldc, int64_t strideC, int64_t M, int64_t N, int64_t K, int64_t batch, void* stream);

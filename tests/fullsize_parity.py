@@ -178,12 +178,7 @@ def hip_loop(pipe, inp, n_steps, taps=None):
     if taps is not None:
         pipe.scheduler.set_timesteps(n_steps, shift=5.0)
         ts = pipe.scheduler.timesteps[0].unsqueeze(0).to(dtype=torch.bfloat16, device=lat.device)
-        hooks = [pipe.dit.blocks[i].register_forward_hook(lambda m, a, o, i=i: tapped.__setitem__(i, o.detach().clone().reshape(1, -1, o.shape[-1])))
-                 for i in taps if i < len(pipe.dit.blocks)]
-        first = pipe.model_fn(dit=pipe.dit, controlnet=pipe.controlnet, latents=lat, timestep=ts, context=inp["ctx_p"], y=inp["y"],
-                              control_signal_video_latents=inp["control"])
-        for h in hooks:
-            h.remove()
+        first, tapped = hip_forward(pipe, inp, ts, taps)
     out = []
     for i in range(n_steps):
         lat = pipe.denoise(lat, inp["ctx_p"], inp["ctx_n"], inp["y"], inp["control"], num_inference_steps=n_steps, cfg_scale=5.0,
@@ -191,6 +186,84 @@ def hip_loop(pipe, inp, n_steps, taps=None):
         out.append(lat)
     torch.cuda.synchronize()
     return out, first, tapped
+
+
+def hip_forward(pipe, inp, ts, taps):
+    """One cond forward of the product (high-noise expert + ControlNet) with the residual stream kept after the DiT blocks `taps`."""
+    tapped = {}
+    hooks = [pipe.dit.blocks[i].register_forward_hook(lambda m, a, o, i=i: tapped.__setitem__(i, o.detach().clone().reshape(1, -1, o.shape[-1])))
+             for i in taps if i < len(pipe.dit.blocks)]
+    try:
+        first = pipe.model_fn(dit=pipe.dit, controlnet=pipe.controlnet, latents=inp["latents"], timestep=ts, context=inp["ctx_p"],
+                              y=inp["y"], control_signal_video_latents=inp["control"])
+    finally:
+        for h in hooks:
+            h.remove()
+    torch.cuda.synchronize()
+    return first, tapped
+
+
+def run_forward(layers=40, cn_layers=10, grid=(21, 60, 104), fp8=True, taps=(0, 9, 19, 39), q_chunk=2048, log=print, out_path=None):
+    """ONE noise prediction at production size (GF:1503-1570: step 0 of the 50-step schedule, cond branch, high-noise expert with its
+    ControlNet): the product against fp32 math next to the reference's bf16 arithmetic, at the residual stream after the DiT blocks
+    `taps` and at the noise prediction; with `fp8` also the config-5 stack against the live torch._scaled_mm chain.  This is the
+    part of run() that fits a gated test at 40 + 10 blocks and S = 32760 (one fp32 forward instead of 2 x steps of them)."""
+    from goal_force_amd.dit import enable_fp8
+    torch.set_grad_enabled(False)
+    torch.backends.cuda.matmul.allow_tf32 = False
+    dev = torch.device("cuda", torch.cuda.current_device())
+    taps = tuple(t for t in taps if t < layers)
+    t_all = time.time()
+    cfg, pipe = build(layers, cn_layers, dev, need_low=False)
+    inp = inputs(pipe, grid, dev)
+    tokens = grid[0] * (grid[1] // 2) * (grid[2] // 2)
+    pipe.scheduler.set_timesteps(50, shift=5.0)
+    ts = pipe.scheduler.timesteps[0].unsqueeze(0).to(dtype=torch.bfloat16, device=dev)          # GF:707
+    rep = {"config": {"layers": layers, "controlnet_layers": cn_layers, "latent": [1, 16, *grid], "tokens": tokens,
+                      "what": "one cond forward, step 0 of the 50-step shift-5 schedule", "timestep_bf16": float(ts.float()),
+                      "taps_after_dit_block": [t + 1 for t in taps], "weights": "random-init bf16 (bench.py seeds 100/300)",
+                      "device": torch.cuda.get_device_name(0), "fp32_attention_q_chunk": q_chunk}}
+    log(f"  built {layers} + {cn_layers} blocks in {time.time() - t_all:.1f} s")
+    t0 = time.time()
+    hip_first, hip_tap = hip_forward(pipe, inp, ts, taps)
+    log(f"  hip forward: {time.time() - t0:.1f} s")
+
+    def oracle(dtype, chain=False):
+        tap = {}
+        o = OracleRunner(pipe, cfg, dtype, q_chunk, fp8_chain=chain)
+        t0 = time.time()
+        first = o.forward(0, inp["latents"].to(dtype), ts, inp["ctx_p"], inp, tap=lambda i, x: tap.__setitem__(i, x.clone()) if i in taps else None)
+        torch.cuda.synchronize()
+        log(f"  oracle[{o.name()}] forward: {time.time() - t0:.1f} s")
+        return first, tap
+
+    f32_first, f32_tap = oracle(torch.float32)
+    b16_first, b16_tap = oracle(torch.bfloat16)
+
+    def rows(name, tap, first):
+        r = {"after_block": {str(i + 1): rel_l2(tap[i].float(), f32_tap[i]) for i in taps if i in tap},
+             "noise_pred_step0_cond": rel_l2(first.float(), f32_first)}
+        log(f"  {name} vs fp32: blocks {r['after_block']}  noise_pred {r['noise_pred_step0_cond']:.3e}")
+        return r
+
+    rep["hip_bf16_vs_fp32"] = rows("hip-bf16", hip_tap, hip_first)
+    rep["ref_bf16_vs_fp32"] = rows("ref-bf16", b16_tap, b16_first)
+    rep["hip_bf16_vs_ref_bf16"] = {"noise_pred_step0_cond": rel_l2(hip_first.float(), b16_first.float())}
+    _dump(rep, out_path)
+    if fp8:
+        del b16_tap, b16_first
+        for m in (pipe.dit, pipe.controlnet):
+            enable_fp8(m)
+        h8_first, h8_tap = hip_forward(pipe, inp, ts, taps)
+        for m in (pipe.dit, pipe.controlnet):
+            enable_fp8(m, False)
+        c8_first, c8_tap = oracle(torch.bfloat16, chain=True)
+        rep["hip_fp8_vs_fp32"] = rows("hip-fp8", h8_tap, h8_first)
+        rep["scaled_mm_chain_vs_fp32"] = rows("scaled_mm-chain", c8_tap, c8_first)
+        rep["hip_fp8_vs_scaled_mm_chain"] = {"noise_pred_step0_cond": rel_l2(h8_first.float(), c8_first.float())}
+    rep["wall_s"] = time.time() - t_all
+    _dump(rep, out_path)
+    return rep
 
 
 def decode_u8(pipe, lat):
@@ -282,14 +355,17 @@ def main():
     ap.add_argument("--layers", type=int, default=40)
     ap.add_argument("--cn-layers", type=int, default=10)
     ap.add_argument("--grid", type=int, nargs=3, default=[21, 60, 104], help="latent f, H/8, W/8 (default 832x480x81f)")
-    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=4, help="0: one cond forward only (run_forward, what the gated full-size test runs)")
     ap.add_argument("--fp8", action="store_true")
     ap.add_argument("--q-chunk", type=int, default=2048)
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     t0 = time.time()
-    rep = run(a.layers, a.cn_layers, tuple(a.grid), a.steps, a.fp8, q_chunk=a.q_chunk, decode=not a.no_decode, out_path=a.out)
+    if a.steps == 0:
+        rep = run_forward(a.layers, a.cn_layers, tuple(a.grid), a.fp8, q_chunk=a.q_chunk, out_path=a.out)
+    else:
+        rep = run(a.layers, a.cn_layers, tuple(a.grid), a.steps, a.fp8, q_chunk=a.q_chunk, decode=not a.no_decode, out_path=a.out)
     rep["wall_s"] = time.time() - t0
     print(json.dumps(rep))
     _dump(rep, a.out)

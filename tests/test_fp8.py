@@ -185,7 +185,7 @@ def test_hip_fp8_a4_exact_integer_layout(M, N, K):
     assert torch.equal(a8.float().cpu(), a) and torch.equal(w8.float().cpu(), w)
     got = ops.gemm_fp8(a8, rs.cuda(), w8, bias.to(BF).cuda())
     assert torch.equal(got.cpu(), ref), f"{int((got.cpu() != ref).sum())} of {ref.numel()} elements differ"
-    with ops.env_options(GF_GEMM_KERNEL="ph"):           # the 8-wave kernel on the same operands: same exact result
+    with ops.options(prefer_8wave=1):           # the 8-wave kernel on the same operands: same exact result
         assert torch.equal(ops.gemm_fp8(a8, rs.cuda(), w8, bias.to(BF).cuda()).cpu(), ref)
 
 
@@ -207,7 +207,7 @@ def test_hip_fp8_a4_vs_8wave_kernel(M, N, K):
              dict(epilogue=ops.EPI_BIAS_RESID, resid=resid), dict(epilogue=ops.EPI_BIAS_GATE_RESID, resid=resid, gate=gate),
              dict(epilogue=ops.EPI_BIAS_MUL, resid=resid)]
     for kw in cases:
-        with ops.env_options(GF_GEMM_KERNEL="ph"):
+        with ops.options(prefer_8wave=1):
             want = ops.gemm_fp8(x8, s, w8, bias, **kw)
         got = ops.gemm_fp8(x8, s, w8, bias, **kw)
         bad, e = _ulp_stats(got.cpu(), want.cpu())
@@ -309,6 +309,6 @@ def test_hip_fp8_linear_vt32_is_projection_plus_transpose_bit_for_bit(skv, n, k)
         pos = torch.arange(skv, dtype=torch.float32)[:, None] * torch.arange(1, 65, dtype=torch.float32)[None, :] * 1e-3
         rope = RopeTable(torch.polar(torch.ones_like(pos), pos), "cuda")
         a = sa.attend(xa, rope)
-        with ops.env_options(GF_VT_FROM_GEMM="0"):
+        with ops.options(vt_from_gemm=False):
             bb = sa.attend(xa, rope)
         assert torch.equal(a, bb)

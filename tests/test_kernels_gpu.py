@@ -232,7 +232,7 @@ def test_flash_attn_lse_same_on_both_v_paths(ops, monkeypatch):
     sq, skv, heads = 300, 2100, 3
     q, k, v = (dev(torch.randn((n, heads * 128), generator=g).to(BF)) for n in (sq, skv, skv))
     o3, l3 = ops.flash_attn_lse(q, k, v, heads)                 # skv >= VT_MIN_KV: kernel 3
-    with ops.env_options(GF_ATTN_KERNEL="2"):                   # (the knobs are read once per process: env_options reloads them)
+    with ops.options(attn_k3=False):                            # the same shape on kernel 2
         o1, l1 = ops.flash_attn_lse(q, k, v, heads)             # kernel 2, V^T path
         monkeypatch.setattr(ops, "VT_MIN_KV", 1 << 30)
         o2, l2 = ops.flash_attn_lse(q, k, v, heads)             # kernel 2, plain path
@@ -344,7 +344,7 @@ def test_self_attention_same_bits_with_v_transposed_by_the_projection(ops, monke
     rope = RopeTable(torch.polar(torch.ones_like(pos), pos), "cuda")
     assert ops.vt32_ok(s, heads, 128)
     a = sa.attend(x, rope)
-    with ops.env_options(GF_VT_FROM_GEMM="0"):
+    with ops.options(vt_from_gemm=False):
         assert not ops.vt32_ok(s, heads, 128)
         b = sa.attend(x, rope)
     assert torch.equal(a, b)
@@ -509,56 +509,6 @@ def test_abi_error_channel(ops):
         ops.flash_attn(q, q, q, 2)
 
 
-@pytest.mark.parametrize("variant", ["sl", "sl8"])
-def test_gemm_experimental_slot_kernel_in_subprocess(variant):
-    """GF_GEMM_KERNEL=sl / sl8 (read once per process) selects the slot-scheduled kernel with one / two waves per SIMD:
-    keep both correct."""
-    import subprocess
-    import sys
-    code = r'''
-import math, torch
-import torch.nn.functional as F
-from goal_force_amd import ops
-torch.manual_seed(3)
-for (M, N, K) in ((256, 256, 64), (300, 520, 192), (1000, 768, 1024)):
-    a = torch.randn((M, K), device="cuda").to(torch.bfloat16)
-    w = (torch.randn((N, K), device="cuda") / math.sqrt(K)).to(torch.bfloat16)
-    b = torch.randn((N,), device="cuda").to(torch.bfloat16)
-    r = torch.randn((M, N), device="cuda").to(torch.bfloat16)
-    g = torch.randn((N,), device="cuda").to(torch.bfloat16)
-    ref = F.linear(a.float(), w.float(), b.float())
-    def rel(x, y): return float((x.float() - y).norm() / y.norm())
-    assert rel(ops.gemm(a, w, b), ref) < 2e-3
-    assert rel(ops.gemm(a, w, b, epilogue=ops.EPI_BIAS_GELU_TANH), F.gelu(ref.to(torch.bfloat16).float(), approximate="tanh")) < 3e-3
-    assert rel(ops.gemm(a, w, b, epilogue=ops.EPI_BIAS_GATE_RESID, resid=r, gate=g), r.float() + g.float() * ref) < 3e-3
-print("ok")
-'''
-    env = dict(os.environ, GF_GEMM_KERNEL=variant, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
-
-
-def test_flash_attn_kernel1_in_subprocess():
-    """GF_ATTN_KERNEL=1 (read once per process) selects the phase-serial predecessor kept for A/B runs: keep it correct."""
-    import subprocess
-    import sys
-    code = r'''
-import math, torch
-from goal_force_amd import ops
-torch.manual_seed(5)
-for (sq, skv, h) in ((72, 72, 2), (777, 1333, 3), (1000, 512, 4)):
-    q, k, v = (torch.randn((n, h * 128), device="cuda").to(torch.bfloat16) for n in (sq, skv, skv))
-    o = ops.flash_attn(q, k, v, h).float().cpu()
-    qh, kh, vh = (t.float().cpu().view(t.shape[0], h, 128).transpose(0, 1) for t in (q, k, v))
-    ref = (torch.softmax(qh @ kh.transpose(1, 2) / math.sqrt(128), -1) @ vh).transpose(0, 1).reshape(sq, h * 128)
-    assert float((o - ref).norm() / ref.norm()) < 4e-3
-print("ok")
-'''
-    env = dict(os.environ, GF_ATTN_KERNEL="1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
-
-
 A4_SHAPES = [(512, 256, 64), (513, 520, 192), (1000, 768, 1024), (777, 5120, 5120), (2048, 13824, 512), (4096, 264, 13824),
              (2300, 520, 8192)]   # the last two: K >= 8192 -> tile groups of 4 row tiles (9 row tiles: a ragged last group)
 
@@ -567,7 +517,7 @@ A4_SHAPES = [(512, 256, 64), (513, 520, 192), (1000, 768, 1024), (777, 5120, 512
 def test_gemm_a4_vs_phased_kernel(ops, M, N, K):
     """The 4-wave kernel (M >= 512; one wave per SIMD, asm K loop, buffer LDS-DMA with num_records cut-off instead of row
     clamping) against the 8-wave phased kernel on ragged M / N tiles, single-K-tile problems and every fused epilogue.
-    With the staggered K start off (GF_A4_STAGGER=0) both accumulate every C element over k in the same order with the
+    With the staggered K start off (options(a4_stagger=0)) both accumulate every C element over k in the same order with the
     same MFMA: BIT-IDENTICAL.  With it on (shipped) the sum over k is rotated per column tile: equal to fp32 rounding
     (<= 1 bf16 ulp on all but a sliver of the outputs), and a row's bits do not depend on which M tile it falls in."""
     g = torch.Generator().manual_seed(M + 3 * N + K)
@@ -579,12 +529,12 @@ def test_gemm_a4_vs_phased_kernel(ops, M, N, K):
     cases = [dict(), dict(epilogue=ops.EPI_BIAS_GELU_TANH), dict(epilogue=ops.EPI_BIAS_SILU),
              dict(epilogue=ops.EPI_BIAS_RESID, resid=resid), dict(epilogue=ops.EPI_BIAS_GATE_RESID, resid=resid, gate=gate),
              dict(epilogue=ops.EPI_BIAS_MUL, resid=resid)]
-    with ops.env_options(GF_A4_STAGGER="0"):
+    with ops.options(a4_stagger=0):
         want0 = ops.gemm(a, w, bias)
     for kw in cases:
-        with ops.env_options(GF_GEMM_KERNEL="ph"):
+        with ops.options(prefer_8wave=1):
             want = ops.gemm(a, w, bias, **kw)
-        with ops.env_options(GF_GEMM_KERNEL="a4", GF_A4_STAGGER="0"):
+        with ops.options(prefer_8wave=0, a4_stagger=0):
             got = ops.gemm(a, w, bias, **kw)
         assert torch.equal(got, want), f"{kw.get('epilogue')}: {int((got != want).sum())} elements differ"
         rot = ops.gemm(a, w, bias, **kw)
@@ -600,7 +550,7 @@ def test_gemm_a4_vs_phased_kernel(ops, M, N, K):
     assert torch.equal(big[:, 8:8 + N], ops.gemm(wide[:, 64:].contiguous(), w, bias))
     assert float(big[:, :8].abs().sum()) == 0 and float(big[:, 8 + N:].abs().sum()) == 0
     # a negative stagger is clamped to 0 (it used to turn into a huge K offset): same bits as the unrotated kernel
-    with ops.env_options(GF_A4_STAGGER="-3"):
+    with ops.options(a4_stagger=-3):
         assert torch.equal(ops.gemm(a, w, bias), want0)
 
 

@@ -94,7 +94,7 @@ def test_batched_gemm_and_transpose_equal_the_per_problem_loop(B, M, N, K, heads
     """gf_gemm_bf16_batched / gf_transpose_pad_batched (one launch for all heads of the umT5 attention, all frames of the VAE attention)
     against one gf_gemm_bf16 / gf_transpose_pad call per problem: bit for bit, with the operands as strided head views of one
     [rows, B*d] tensor or as separate matrices, ragged M / N included; argument errors.  The per-problem calls are pinned to the 8-wave
-    kernel (GF_GEMM_KERNEL=ph), which the batched launch uses: for M >= 512 gf_gemm_bf16 would take the 4-wave kernel, whose column tiles
+    kernel (options(prefer_8wave=1)), which the batched launch uses: for M >= 512 gf_gemm_bf16 would take the 4-wave kernel, whose column tiles
     start their K loops at rotated K tiles — the same products summed in another order."""
     from goal_force_amd import ops
     from goal_force_amd._lib import GoalForceError
@@ -109,7 +109,7 @@ def test_batched_gemm_and_transpose_equal_the_per_problem_loop(B, M, N, K, heads
         out = None
     got = ops.gemm_batched(a, w, out=out)
     assert tuple(got.shape) == (B, M, N)
-    with ops.env_options(GF_GEMM_KERNEL="ph"):
+    with ops.options(prefer_8wave=1):
         for b in range(B):
             ref = ops.gemm(a[b], w[b])
             assert torch.equal(got[b], ref), (b, int((got[b] != ref).sum()))

@@ -55,11 +55,11 @@ def test_flash_attn_backward(sq, skv, heads):
 
 
 @pytest.mark.parametrize("sq,skv,heads", [(1000, 777, 8), (2085, 1999, 8), (96, 4000, 3)])
-def test_flash_attn_backward_kernels_agree_with_the_first_kernels(sq, skv, heads):
-    """The 16x16x32 kernels (dQ + paired dK/dV, 7 tile products) against the first kernels (GF_ATTN_BWD=v1: 32x32x16, dQ / dV / dK
-    passes): the same per-element arithmetic, another summation order — ragged lengths, the XCD-ordered grid (heads % 8 == 0).
-    And against fp32 autograd the new kernels must be at least as close as the first ones (a -DGF_BWD_QSCALE=1 build, which
-    rebuilds P from the forward's pre-scaled Q', fails this line by 25 % on dQ: why it is not shipped)."""
+def test_flash_attn_backward_ragged_lengths_and_xcd_grid_vs_fp32_autograd(sq, skv, heads):
+    """dQ (32 queries per wave) and the paired dK / dV kernel (48 keys per wave pair) against fp32 autograd of the written-out
+    attention at ragged lengths and on the XCD-ordered grid (heads % 8 == 0).  Bar: 5e-3 rel-L2 per gradient — the bf16 rounding of
+    the outputs alone is ~2e-3; the shipped kernels measured 2.4e-3 on dQ (profiles/r04/attnbwd_ab_qscale.log), and the variant
+    that rebuilt P from the forward's pre-scaled Q' (3.0e-3, tools/patches/attention_bwd_experiments.patch) was dropped for it."""
     from goal_force_amd import ops
     g = torch.Generator().manual_seed(sq + skv)
     q = torch.randn((sq, heads * HD), generator=g).to(BF).cuda()
@@ -68,15 +68,11 @@ def test_flash_attn_backward_kernels_agree_with_the_first_kernels(sq, skv, heads
     dout = torch.randn((sq, heads * HD), generator=g).to(BF).cuda()
     o, lse = ops.flash_attn_lse(q, k, v, heads)
     got = ops.flash_attn_bwd(q, k, v, o, dout, lse, heads)
-    with ops.env_options(GF_ATTN_BWD="v1"):
-        want = ops.flash_attn_bwd(q, k, v, o, dout, lse, heads)
     ref = _ref_attention_grads(q, k, v, dout, heads)[2:]
-    for name, a, b, r in zip(("dq", "dk", "dv"), got, want, ref):
+    for name, a, r in zip(("dq", "dk", "dv"), got, ref):
         assert torch.isfinite(a.float()).all(), name
-        e = rel_l2(a.float().cpu(), b.float().cpu())
-        assert e < 3e-3, f"{name}: rel_l2={e:.3e}"
-        e_new, e_old = rel_l2(a.float().cpu(), r), rel_l2(b.float().cpu(), r)
-        assert e_new < 1e-2 and e_new <= 1.1 * e_old + 2e-4, f"{name}: vs fp32 autograd new {e_new:.3e}, first kernels {e_old:.3e}"
+        e = rel_l2(a.float().cpu(), r)
+        assert e < 5e-3, f"{name}: vs fp32 autograd {e:.3e}"
 
 
 def test_flash_attn_backward_strided_inputs():

@@ -71,7 +71,7 @@ def _unrotated_yardstick_gemm():
     the implicit-GEMM convolution uses (k tiles 0, 1, 2, ...).  The 4-wave GEMM kernel that large dense shapes go through by
     default starts each column tile's K loop at a staggered tile (same sum, rotated order: test_kernels_gpu.py)."""
     from goal_force_amd import ops
-    with ops.env_options(GF_A4_STAGGER="0"):       # the launchers read their knobs once per process: env_options reloads them
+    with ops.options(a4_stagger=0):
         yield
 
 
@@ -193,7 +193,7 @@ def test_hip_conv_history_in_front_bit_identical(T, H, W, C, N, ks):
 def test_hip_direct_conv_c96_equals_implicit_gemm_at_tile_size():
     """The 96-channel level of a production tile's first frames (240 x 416; C = N = 96, 3x3x3, history in front): the direct
     convolution (gf_conv_direct.hip: 6 x 32 pixel patches walking the frames, input halo staged once per frame, three
-    accumulator sets) against the implicit GEMM it replaces (GF_CONV_DIRECT=0) — bit for bit, with and without the residual, over
+    accumulator sets) against the implicit GEMM it replaces (options(conv_direct=0)) — bit for bit, with and without the residual, over
     several frame segments."""
     from goal_force_amd import ops
     g = torch.Generator().manual_seed(96)
@@ -207,7 +207,7 @@ def test_hip_direct_conv_c96_equals_implicit_gemm_at_tile_size():
     w = w.cuda()
     b = torch.randn((C,), generator=g).to(BF).cuda()
     resid = torch.randn((T * H * W, C), generator=g).to(BF).cuda()
-    with ops.env_options(GF_CONV_DIRECT="0"):
+    with ops.options(conv_direct=0):
         ref = ops.vae_conv3d(x, None, w, b, 3, 3, history_in_front=True)
         ref_r = ops.vae_conv3d(x, None, w, b, 3, 3, resid=resid, history_in_front=True)
     got = ops.vae_conv3d(x, None, w, b, 3, 3, history_in_front=True)
@@ -220,14 +220,14 @@ def test_hip_direct_conv_c96_equals_implicit_gemm_at_tile_size():
 @pytest.mark.parametrize("C", [96, 192, 384])
 def test_hip_rmsnorm_silu_three_chunk_kernel_is_bit_identical(C):
     """RMS_norm (+SiLU) at C = 96 / 192 / 384: the all-lanes-live kernel (three chunks per lane, the row sum's two top butterfly stages
-    as in-lane additions) against the power-of-two kernel (GF_VAE_RMS3=0) — bit for bit, ragged row counts included."""
+    as in-lane additions) against the power-of-two kernel (options(vae_rms3=0)) — bit for bit, ragged row counts included."""
     from goal_force_amd import ops
     g = torch.Generator().manual_seed(C)
     for rows in (1, 37, 4099, 120 * 208):
         x = (torch.randn((rows, C), generator=g) * 2.5).to(BF).cuda()
         gam = (1 + 0.1 * torch.randn(C, generator=g)).to(BF).cuda()
         for silu in (True, False):
-            with ops.env_options(GF_VAE_RMS3="0"):
+            with ops.options(vae_rms3=0):
                 ref = ops.vae_rmsnorm_silu(x, gam, silu=silu)
             got = ops.vae_rmsnorm_silu(x, gam, silu=silu)
             assert torch.equal(got, ref), (C, rows, silu, int((got != ref).sum()))
@@ -237,7 +237,7 @@ def test_hip_rmsnorm_silu_three_chunk_kernel_is_bit_identical(C):
 @pytest.mark.parametrize("T,Hs,Ws,t_off", [(3, 12, 16, 0), (5, 8, 48, 1), (2, 120, 208, 0), (9, 20, 32, 2)])
 def test_hip_direct_upsample_conv_equals_implicit_gemm(T, Hs, Ws, t_off):
     """The decoder's full-resolution upsample convolution (nearest 2x + 3x3, 192 -> 96 channels): the direct kernel (8 x 32 output
-    patches, half-resolution halo, 18 weight stages per frame) against the implicit GEMM (GF_CONV_DIRECT=0) and, at the small sizes,
+    patches, half-resolution halo, 18 weight stages per frame) against the implicit GEMM (options(conv_direct=0)) and, at the small sizes,
     the patch matrix + GEMM — bit for bit, with a frame offset and over several frame segments."""
     from goal_force_amd import ops
     g = torch.Generator().manual_seed(T * 1000 + Hs)
@@ -247,7 +247,7 @@ def test_hip_direct_upsample_conv_equals_implicit_gemm(T, Hs, Ws, t_off):
     w = (torch.randn((N, k), generator=g) / k ** 0.5).to(BF).cuda()
     b = torch.randn((N,), generator=g).to(BF).cuda()
     kw = dict(upsample2x=True, t_off=t_off, t_out=T - t_off)
-    with ops.env_options(GF_CONV_DIRECT="0"):
+    with ops.options(conv_direct=0):
         ref = ops.vae_conv3d(x, None, w, b, 1, 3, **kw)
     got = ops.vae_conv3d(x, None, w, b, 1, 3, **kw)
     assert got.shape == ref.shape == ((T - t_off) * 4 * Hs * Ws, N)

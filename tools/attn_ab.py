@@ -9,6 +9,8 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the variants these builds select are not in the product sources: tools/experimental_tree.sh re-creates them (tools/patches/)
+CSRC = os.environ.get("GF_CSRC", os.path.join(ROOT, "build", "experimental", "csrc"))
 OUT = os.path.join(ROOT, "build", "ab")
 
 
@@ -16,11 +18,11 @@ def build(specs):
     os.makedirs(OUT, exist_ok=True)
     for f in glob.glob(os.path.join(OUT, "libgf_*.so")):
         os.remove(f)
-    src = [os.path.join(ROOT, "goal_force_amd", "csrc", f) for f in ("gf_attention.hip", "gf_abi.hip")]
+    src = [os.path.join(CSRC, f) for f in ("gf_attention.hip", "gf_abi.hip")]
     for spec in specs:
         name, _, flags = spec.partition(":")
         subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DGF_BUILD",
-                        "-mllvm", "-amdgpu-mfma-vgpr-form", f"-I{ROOT}/include", f"-I{ROOT}/goal_force_amd/csrc",
+                        "-mllvm", "-amdgpu-mfma-vgpr-form", f"-I{CSRC}/../include", f"-I{CSRC}",
                         "-o", os.path.join(OUT, f"libgf_{name}.so")] + [f for f in flags.split(",") if f] + src, check=True)
         print("built", name, flags, flush=True)
 

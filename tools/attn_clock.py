@@ -14,14 +14,16 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the variants these builds select are not in the product sources: tools/experimental_tree.sh re-creates them (tools/patches/)
+CSRC = os.environ.get("GF_CSRC", os.path.join(ROOT, "build", "experimental", "csrc"))
 OUT = os.path.join(ROOT, "build", "ab", "gfclock.so")
 
 
 def build():
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    src = [os.path.join(ROOT, "goal_force_amd", "csrc", f) for f in ("gf_attention.hip", "gf_abi.hip")]
+    src = [os.path.join(CSRC, f) for f in ("gf_attention.hip", "gf_abi.hip")]
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DGF_BUILD", "-DGF_K3_CLOCK=1",
-                    "-mllvm", "-amdgpu-mfma-vgpr-form", f"-I{ROOT}/include", f"-I{ROOT}/goal_force_amd/csrc", "-o", OUT] + src, check=True)
+                    "-mllvm", "-amdgpu-mfma-vgpr-form", f"-I{CSRC}/../include", f"-I{CSRC}", "-o", OUT] + src, check=True)
     print("built", OUT)
 
 

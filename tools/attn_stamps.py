@@ -8,14 +8,16 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the variants these builds select are not in the product sources: tools/experimental_tree.sh re-creates them (tools/patches/)
+CSRC = os.environ.get("GF_CSRC", os.path.join(ROOT, "build", "experimental", "csrc"))
 sys.path.insert(0, ROOT)
 import torch
 
 out = os.path.join(ROOT, "gpurun_out", "libgf_stamp.so")
 os.makedirs(os.path.dirname(out), exist_ok=True)
-src = [os.path.join(ROOT, "goal_force_amd", "csrc", f) for f in ("gf_attention.hip", "gf_abi.hip")]
+src = [os.path.join(CSRC, f) for f in ("gf_attention.hip", "gf_abi.hip")]
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DGF_BUILD",
-                "-DGF_ATTN_STAMP=1", f"-I{ROOT}/include", f"-I{ROOT}/goal_force_amd/csrc", "-o", out] + src, check=True)
+                "-DGF_ATTN_STAMP=1", f"-I{CSRC}/../include", f"-I{CSRC}", "-o", out] + src, check=True)
 lib = ctypes.CDLL(out)
 S, H, D = 32760, 40, 5120
 q = torch.randn((S, D), device="cuda").to(torch.bfloat16)

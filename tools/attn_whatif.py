@@ -10,6 +10,8 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the variants these builds select are not in the product sources: tools/experimental_tree.sh re-creates them (tools/patches/)
+CSRC = os.environ.get("GF_CSRC", os.path.join(ROOT, "build", "experimental", "csrc"))
 OUT = os.path.join(ROOT, "build", "whatif")
 MASKS = [0, 1, 2, 4, 8, 16, 3, 7, 15, 31, 63, 5, 62, 64, 67, 128, 256, 143, 271]
 NAMES = {1: "no fma/exp/sum/pack", 2: "no max/rescale decision", 4: "no LDS fragment reads", 8: "no wait+barrier",
@@ -23,11 +25,11 @@ def describe(m):
 def build():
     os.makedirs(OUT, exist_ok=True)
     only = [int(a) for a in sys.argv[1:] if a.isdigit()]
-    src = [os.path.join(ROOT, "goal_force_amd", "csrc", f) for f in ("gf_attention.hip", "gf_abi.hip")]
+    src = [os.path.join(CSRC, f) for f in ("gf_attention.hip", "gf_abi.hip")]
     for m in (only or MASKS):
         subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DGF_BUILD",
-                        "-mllvm", "-amdgpu-mfma-vgpr-form", f"-DGF_ATTN_WHATIF={m}", f"-I{ROOT}/include",
-                        f"-I{ROOT}/goal_force_amd/csrc", "-o", os.path.join(OUT, f"libgf_w{m}.so")] + src, check=True)
+                        "-mllvm", "-amdgpu-mfma-vgpr-form", f"-DGF_ATTN_WHATIF={m}", f"-I{CSRC}/../include",
+                        f"-I{CSRC}", "-o", os.path.join(OUT, f"libgf_w{m}.so")] + src, check=True)
         print("built", m, describe(m), flush=True)
 
 

@@ -10,6 +10,8 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the variants these builds select are not in the product sources: tools/experimental_tree.sh re-creates them (tools/patches/)
+CSRC = os.environ.get("GF_CSRC", os.path.join(ROOT, "build", "experimental", "csrc"))
 sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, "build", "ab")
 VARIANTS = {      # KV16_WHATIF bits (32-key kernel only; timing only, wrong results): 1 no DMA in the loop, 4 no P hand-off, 8 no barrier, 16 no counted wait, 32 L2-hot DMA
@@ -24,13 +26,13 @@ for spec in os.environ.get("BWD_AB_EXTRA", "").split(";"):     # name:flag,flag
 
 def build():
     os.makedirs(OUT, exist_ok=True)
-    src = [os.path.join(ROOT, "goal_force_amd", "csrc", f) for f in ("gf_attention_bwd.hip", "gf_abi.hip")]
+    src = [os.path.join(CSRC, f) for f in ("gf_attention_bwd.hip", "gf_abi.hip")]
     for old in os.listdir(OUT):
         if old.startswith("libbwd_"):
             os.remove(os.path.join(OUT, old))
     for name, flags in VARIANTS.items():
         subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DGF_BUILD", "-fno-slp-vectorize",
-                        f"-I{ROOT}/include", f"-I{ROOT}/goal_force_amd/csrc", "-o", os.path.join(OUT, f"libbwd_{name}.so")] + flags + src,
+                        f"-I{CSRC}/../include", f"-I{CSRC}", "-o", os.path.join(OUT, f"libbwd_{name}.so")] + flags + src,
                        check=True)
         print("built", name, flags, flush=True)
 

@@ -1,4 +1,7 @@
 #!/usr/bin/env python3
+# NOTE (round 5): this script drives variants that are no longer in the product library (GF_* environment selectors, v1 / sl
+# kernels, what-if builds).  It runs against a library built from the experimental tree: `bash tools/experimental_tree.sh`, then build
+# build/experimental/csrc as the Makefile builds goal_force_amd/csrc and point GOALFORCE_HIP_LIB at the result.
 """Flash-attention backward against an fp64 autograd reference and against the first kernels (GF_ATTN_BWD=v1) at two mid sizes:
 rel-L2 of dq / dk / dv (what a change of the P arithmetic costs in accuracy; run on the GPU)."""
 import math, os, sys, torch

@@ -27,7 +27,7 @@ def main():
     best = {}
     for rnd in range(3):
         for name, env in (("implicit", "0"), ("direct", "1")):
-            with ops.env_options(GF_CONV_DIRECT=env):
+            with ops.options(conv_direct=int(env)):
                 for kind, kw in (("bias", {}), ("resid", dict(resid=resid))):
                     ops.vae_conv3d(x, None, w, b, 3, 3, history_in_front=True, **kw)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -66,7 +66,7 @@ def main():
     bestu = {}
     for rnd in range(3):
         for name, env in (("implicit", "0"), ("direct", "1")):
-            with ops.env_options(GF_CONV_DIRECT=env):
+            with ops.options(conv_direct=int(env)):
                 ops.vae_conv3d(xs, None, wu, b, 1, 3, upsample2x=True)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()

@@ -9,14 +9,16 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the variants these builds select are not in the product sources: tools/experimental_tree.sh re-creates them (tools/patches/)
+CSRC = os.environ.get("GF_CSRC", os.path.join(ROOT, "build", "experimental", "csrc"))
 LIB = os.path.join(ROOT, "build", "ab", "libstamp_a4.so")
 
 
 def build():
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    src = [os.path.join(ROOT, "goal_force_amd", "csrc", f) for f in ("gf_gemm.hip", "gf_abi.hip")]
+    src = [os.path.join(CSRC, f) for f in ("gf_gemm.hip", "gf_abi.hip")]
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DGF_BUILD", "-DGF_GEMM_STAMP=1",
-                    f"-I{ROOT}/include", f"-I{ROOT}/goal_force_amd/csrc", "-o", LIB] + src, check=True)
+                    f"-I{CSRC}/../include", f"-I{CSRC}", "-o", LIB] + src, check=True)
     print("built", LIB)
 
 

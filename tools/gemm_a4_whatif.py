@@ -8,6 +8,8 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the variants these builds select are not in the product sources: tools/experimental_tree.sh re-creates them (tools/patches/)
+CSRC = os.environ.get("GF_CSRC", os.path.join(ROOT, "build", "experimental", "csrc"))
 LIB = os.path.join(ROOT, "build", "whatif", "libgf_a4w.so")
 NAMES = {0: "shipped loop", 1: "no barriers / vmcnt waits", 2: "K position frozen (all staging hits L2)", 4: "no staging instructions",
          5: "no staging, no barriers", 16: "source chunks not permuted (linear 128-byte rows per 8 lanes)", 32: "no epilogue", 64: "no vmcnt wait (barriers kept)", 128: "no barriers (vmcnt wait kept)"}
@@ -15,9 +17,9 @@ NAMES = {0: "shipped loop", 1: "no barriers / vmcnt waits", 2: "K position froze
 
 def build():
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    src = [os.path.join(ROOT, "goal_force_amd", "csrc", f) for f in ("gf_gemm.hip", "gf_abi.hip")]
+    src = [os.path.join(CSRC, f) for f in ("gf_gemm.hip", "gf_abi.hip")]
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DGF_BUILD",
-                    "-DGF_A4_WHATIF", f"-I{ROOT}/include", f"-I{ROOT}/goal_force_amd/csrc", "-o", LIB] + src, check=True)
+                    "-DGF_A4_WHATIF", f"-I{CSRC}/../include", f"-I{CSRC}", "-o", LIB] + src, check=True)
     print("built", LIB)
 
 

@@ -1,4 +1,7 @@
 #!/usr/bin/env python3
+# NOTE (round 5): this script drives variants that are no longer in the product library (GF_* environment selectors, v1 / sl
+# kernels, what-if builds).  It runs against a library built from the experimental tree: `bash tools/experimental_tree.sh`, then build
+# build/experimental/csrc as the Makefile builds goal_force_amd/csrc and point GOALFORCE_HIP_LIB at the result.
 """A/B of GEMM library builds in ONE process (interleaved rounds, same device): every build/ab/libgemm_*.so, each with
 GF_GEMM_KERNEL = a4 and ph, on the three DiT shapes (+ torch F.linear = hipBLASLt as the yardstick)."""
 import ctypes

@@ -28,8 +28,7 @@ def main():
         best = {v: 1e9 for v in vals}
         for rnd in range(5):
             for v in vals:
-                os.environ["GF_A4_GROUP_M"] = str(v)
-                ops.reload_options()       # the launch paths read the knobs once per process
+                ops.options(a4_group_m=v).__enter__()      # (left set: the next value overwrites it; reset after the sweep)
                 ops.gemm(x, w, b, out=out, **kw)
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -1,3 +1,6 @@
+# NOTE (round 5): this script drives variants that are no longer in the product library (GF_* environment selectors, v1 / sl
+# kernels, what-if builds).  It runs against a library built from the experimental tree: `bash tools/experimental_tree.sh`, then build
+# build/experimental/csrc as the Makefile builds goal_force_amd/csrc and point GOALFORCE_HIP_LIB at the result.
 import os, sys, torch
 sys.path.insert(0, os.getcwd())
 from goal_force_amd import ops

@@ -1,4 +1,7 @@
 #!/usr/bin/env python3
+# NOTE (round 5): this script drives variants that are no longer in the product library (GF_* environment selectors, v1 / sl
+# kernels, what-if builds).  It runs against a library built from the experimental tree: `bash tools/experimental_tree.sh`, then build
+# build/experimental/csrc as the Makefile builds goal_force_amd/csrc and point GOALFORCE_HIP_LIB at the result.
 """A/B of the two bf16 K loops of gemm_a4_kernel in ONE process (interleaved rounds): the k-sub-step loop (three barriers per K
 tile, tools/gen_gemm_a4.py) against the half-tile loop (two barriers, staging by halves: the fp8 loop's schedule with bf16 MFMAs,
 A4F8_BF16=1 tools/gen_gemm_a4f8.py), selected per launch with GF_A4_LOOP.  Checks that both produce the same bits.

@@ -23,8 +23,7 @@ def main():
         best = {v: 1e9 for v in vals}
         for rnd in range(4):
             for v in vals:
-                os.environ["GF_A4_STAGGER"] = str(v)
-                ops.reload_options()       # the launch paths read the knobs once per process
+                ops.options(a4_stagger=v).__enter__()      # (left set: the next value overwrites it)
                 ops.gemm(x, w, b, out=out)
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -8,6 +8,8 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the variants these builds select are not in the product sources: tools/experimental_tree.sh re-creates them (tools/patches/)
+CSRC = os.environ.get("GF_CSRC", os.path.join(ROOT, "build", "experimental", "csrc"))
 OUT = os.path.join(ROOT, "build", "ab")
 
 
@@ -15,7 +17,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     for f in glob.glob(os.path.join(OUT, "libgemm_*.so")):
         os.remove(f)
-    src = [os.path.join(ROOT, "goal_force_amd", "csrc", f) for f in ("gf_gemm.hip", "gf_abi.hip")]
+    src = [os.path.join(CSRC, f) for f in ("gf_gemm.hip", "gf_abi.hip")]
     for spec in sys.argv[1:]:
         name, _, rest = spec.partition(":")
         envs, _, flags = rest.partition(":")
@@ -24,7 +26,7 @@ def main():
         env.update(kv.split("=", 1) for kv in envs.split(",") if kv)
         subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_gemm_a4.py")], env=env, check=True, stdout=subprocess.DEVNULL)
         subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DGF_BUILD",
-                        f"-I{ROOT}/include", f"-I{ROOT}/goal_force_amd/csrc", f'-DGF_A4_LOOP_INC="{inc}"',
+                        f"-I{CSRC}/../include", f"-I{CSRC}", f'-DGF_A4_LOOP_INC="{inc}"',
                         "-o", os.path.join(OUT, f"libgemm_{name}.so")] + [f for f in flags.split(",") if f] + src, check=True)
         print("built", name, envs, flags, flush=True)
 

@@ -79,11 +79,8 @@ def main():
             rounds = {"3": [], "2": []}
             for _ in range(3):
                 for kern in ("3", "2"):
-                    os.environ["GF_ATTN_KERNEL"] = kern
-                    ops.reload_options()       # the launch paths read the knobs once per process
-                    rounds[kern].append(timeit(lambda: ops.flash_attn(q, k, v, H, out=o), a.iters)[0])
-            os.environ.pop("GF_ATTN_KERNEL")
-            ops.reload_options()       # the launch paths read the knobs once per process
+                    with ops.options(attn_k3=(kern == "3")):
+                        rounds[kern].append(timeit(lambda: ops.flash_attn(q, k, v, H, out=o), a.iters)[0])
             for kern, ts in rounds.items():
                 print(f"   A/B kernel {kern}: medians {', '.join(f'{t:.3f}' for t in ts)} ms -> {fl / min(ts) / 1e9:.1f} TFLOP/s best")
         if a.zeros:
@@ -91,12 +88,9 @@ def main():
                              ("random again", lambda t: t)):
                 qq, kk, vv = mk(q), mk(k), mk(v)
                 for kern in ("3", "2"):
-                    os.environ["GF_ATTN_KERNEL"] = kern
-                    ops.reload_options()       # the launch paths read the knobs once per process
-                    med, mn = timeit(lambda: ops.flash_attn(qq, kk, vv, H, out=o), a.iters)
+                    with ops.options(attn_k3=(kern == "3")):
+                        med, mn = timeit(lambda: ops.flash_attn(qq, kk, vv, H, out=o), a.iters)
                     print(f"   {name:13s} kernel {kern}: median {med:.3f} ms ({fl / med / 1e9:.1f} TFLOP/s), min {mn:.3f} ms")
-                os.environ.pop("GF_ATTN_KERNEL")
-                ops.reload_options()       # the launch paths read the knobs once per process
     elif a.what == "attnbwd":
         q = torch.randn((s, D), device="cuda").to(BF)
         k = torch.randn((s, D), device="cuda").to(BF)
@@ -104,8 +98,8 @@ def main():
         do = torch.randn((s, D), device="cuda").to(BF)
         o, lse = ops.flash_attn_lse(q, k, v, H)
         med, mn = timeit(lambda: ops.flash_attn_bwd(q, k, v, o, do, lse, H), a.iters)
-        fl = 10.0 * s * s * D       # the 5 necessary products (executed: dQ 3 + dK/dV 4 = 7; GF_ATTN_BWD=v1: 3 + 2 + 3 = 8)
-        ex = 1.6 if os.environ.get("GF_ATTN_BWD") == "v1" else 1.4
+        fl = 10.0 * s * s * D       # the 5 necessary products (executed: dQ 3 + dK/dV 4 = 7)
+        ex = 1.4
         print(f"flash_attn_bwd S={s} H={H}: median {med:.3f} ms ({fl / med / 1e9:.1f} TFLOP/s algorithmic, "
               f"{ex * fl / med / 1e9:.1f} executed)")
     elif a.what == "gemm" and a.only:
@@ -141,11 +135,8 @@ def main():
                 rounds = {"a4": [], "ph": []}
                 for _ in range(3):
                     for kern in ("a4", "ph"):
-                        os.environ["GF_GEMM_KERNEL"] = kern
-                        ops.reload_options()       # the launch paths read the knobs once per process
-                        rounds[kern].append(timeit(lambda: ops.gemm(inp, w, b, out=out), a.iters)[0])
-                os.environ.pop("GF_GEMM_KERNEL")
-                ops.reload_options()       # the launch paths read the knobs once per process
+                        with ops.options(prefer_8wave=int(kern == "ph")):
+                            rounds[kern].append(timeit(lambda: ops.gemm(inp, w, b, out=out), a.iters)[0])
                 for kern, ts in rounds.items():
                     print(f"   A/B {kern} {name}: medians {', '.join(f'{t:.3f}' for t in ts)} ms -> {fl / min(ts) / 1e9:.1f} TFLOP/s best")
             if n == D:

@@ -9,7 +9,7 @@ for shape in ((40, 240, 416, 96), (40, 120, 208, 192), (20, 60, 104, 384)):
     res = {}
     for rnd in range(3):
         for name, env in (("pow2", "0"), ("three", "1")):
-            with ops.env_options(GF_VAE_RMS3=env):
+            with ops.options(vae_rms3=int(env)):
                 ops.vae_rmsnorm_silu(x, gam, silu=True, out=out)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
