@@ -154,6 +154,85 @@ def cpu_baseline(torch, runs=3):
             "block_seconds": dt, "tflops": tflops}
 
 
+def vae_entries(cprof, top=3):
+    """roofline entries of the tiled VAE decode's dominant convolution launches (BASELINE config 4) from per-launch events
+    (ops.PROFILE_CONV): launches are grouped by shape; per group algorithmic FLOPs = 2 rows Cout (kt ks^2 Cin), algorithmic bytes =
+    input + weights + output (+ residual) in bf16, mean launch time, fraction of the dense bf16 MFMA peak.  The `top` groups by total
+    time are returned with the share of the decode's convolution time each one is."""
+    groups = {}
+    for e0, e1, rows, n, c, kt, ks, mode, has_resid in cprof:
+        groups.setdefault((rows, n, c, kt, ks, mode, has_resid), []).append(e0.elapsed_time(e1))
+    total = sum(sum(v) for v in groups.values()) or 1.0
+    out = []
+    for (rows, n, c, kt, ks, mode, has_resid), ms in sorted(groups.items(), key=lambda kv: -sum(kv[1]))[:top]:
+        taps = kt * ks * ks
+        fl = 2.0 * rows * n * taps * c
+        in_rows = rows // 4 if mode == 1 else (rows * 4 if mode == 2 else rows)      # the nearest-exact 2x upsample / stride-2 read
+        by = in_rows * c * 2 + n * taps * c * 2 + rows * n * 2 * (2 if has_resid else 1)
+        avg = sum(ms) / len(ms)
+        if kt == 3 and ks == 3 and mode == 0 and c == 96 and (n == 96 or n <= 16):
+            kern = "conv3d_c96_kernel (direct 3x3x3, halo staged once per frame, three temporal accumulator sets)"
+        elif kt == 3 and ks == 3 and mode == 0 and c % 64 == 0 and n % 16 == 0 and c >= 192:
+            kern = f"conv3d_wide_kernel<{c}> (direct 3x3x3 at the {c}-channel level)"
+        elif kt == 1 and ks == 3 and mode == 1 and c == 192:
+            kern = "conv2d_up_c192_kernel (direct 3x3 with the nearest-exact 2x upsample folded into the halo)"
+        else:
+            kern = "gemm_ph_kernel<CONV> (implicit GEMM, LDS-DMA gather)"
+        what = f"{kt}x{ks}x{ks} conv {c}->{n} over {rows} output pixels" + (" +residual" if has_resid else "") + \
+               (" (2x upsample folded in)" if mode == 1 else " (stride 2)" if mode == 2 else "")
+        traffic, src = static_traffic(f"vae_conv_c{c}_n{n}_k{kt}{ks}_m{mode}")
+        out.append({"bound": "mfma", "kernel": kern, "launch": what, "achieved": fl / (avg * 1e-3) / 1e12, "peak": PEAK_BF16_TFLOPS,
+                    "unit": "TFLOP/s", "frac": fl / (avg * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_static": True,
+                    "traffic_source": src, "algorithmic_bytes_per_launch": by, "algorithmic_flops_per_launch": fl, "launches": len(ms),
+                    "avg_launch_ms": avg, "share_of_decode_conv_time": sum(ms) / total})
+    return out, total
+
+
+def preloop_seconds(torch, vae, dev):
+    """The units in front of the denoising loop at full size ("text / VAE encode reported separately"): two tiled VAE
+    encodes of an 81-frame 480x832 clip (control video GF:791-805, image conditioning GF:887-917; tile (30,52)/(15,26)) and two
+    umT5-XXL forwards at 512 tokens (positive + negative prompt, wan_video_text_encoder.py:209-255), random-init weights of the
+    real shapes.  1 warm-up + 1 timed each."""
+    from goal_force_amd.text_encoder import WanTextEncoder
+    out = {}
+    video = (torch.rand((3, 81, 480, 832), device=dev) * 2 - 1).to(torch.bfloat16)
+    kw = dict(device=dev, tiled=True, tile_size=(30, 52), tile_stride=(15, 26))
+    vae.encode([video], **kw)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    z = vae.encode([video], **kw)
+    z2 = vae.encode([video], **kw)
+    torch.cuda.synchronize()
+    out["vae_tiled_encode_x2_s"] = time.perf_counter() - t0
+    assert tuple(z.shape) == (1, 16, 21, 60, 104) and bool(torch.isfinite(z.float()).all()) and torch.equal(z, z2)
+    del video, z, z2
+    with torch.device("meta"):
+        te = WanTextEncoder()
+    te = te.to_empty(device=dev).to(torch.bfloat16)
+    g = torch.Generator(device=dev).manual_seed(1)
+    for n, prm in te.named_parameters():
+        if n.endswith("norm.weight") or "norm1" in n or "norm2" in n:
+            prm.data.fill_(1.0)
+        else:
+            prm.data.copy_(torch.randn(prm.shape, generator=g, device=dev, dtype=torch.float32) * 0.02)
+    ids = torch.randint(0, 256384, (1, 512), device=dev)
+    mask = torch.zeros((1, 512), dtype=torch.long, device=dev)
+    mask[:, :40] = 1
+    te(ids, mask)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e1 = te(ids, mask)
+    e2 = te(ids, mask)
+    torch.cuda.synchronize()
+    out["umt5_xxl_512_tokens_x2_s"] = time.perf_counter() - t0
+    assert bool(torch.isfinite(e1.float()).all()) and torch.equal(e1, e2)
+    out["umt5_xxl_params"] = sum(prm.numel() for prm in te.parameters())
+    out["total_s"] = out["vae_tiled_encode_x2_s"] + out["umt5_xxl_512_tokens_x2_s"]
+    out["what"] = ("per video, in front of the loop: 2 tiled VAE encodes of [3,81,480,832] (control video, first-frame conditioning) + "
+                   "2 umT5-XXL forwards at 512 tokens; random-init weights; NOT part of `value` (SURVEY §8d: reported separately)")
+    return out
+
+
 def tensor_digest(torch, t):
     """sha256 of the raw bytes + a few statistics of a device tensor (self-check of the timed run's outputs)."""
     import hashlib
@@ -172,29 +251,55 @@ def self_launch(n):
     import subprocess
     port = os.environ.get("MASTER_PORT")
     if port is None:
+        # a free port now; if another process takes it before rank 0 binds it the ranks fail at rendezvous and the parent exits
+        # non-zero with rank 0's message (set MASTER_PORT to pin one)
         sk = socket.socket()
         sk.bind(("127.0.0.1", 0))
         port = str(sk.getsockname()[1])
         sk.close()
+    import signal
     procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else sys.stderr))
-    rc, alive = 0, list(procs)
-    while alive:
-        for p in list(alive):
-            code = p.poll()
-            if code is None:
-                continue
-            alive.remove(p)
-            if code != 0 and rc == 0:          # one rank failed: the others would wait in a collective forever
-                rc = code
-                print(f"bench.py: rank {procs.index(p)} exited with {code}; stopping the other ranks", file=sys.stderr)
-                for q in alive:
-                    q.terminate()
-        time.sleep(0.2)
+
+    def stop_children(*_):
+        """terminate, then kill, every rank still alive (the parent must never leave ranks holding the GPUs behind)"""
+        live = [p for p in procs if p.poll() is None]
+        for p in live:
+            p.terminate()
+        t_end = time.time() + 10.0
+        for p in live:
+            try:
+                p.wait(timeout=max(0.0, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+
+    def on_signal(signum, _frame):
+        stop_children()
+        sys.exit(128 + signum)
+
+    signal.signal(signal.SIGTERM, on_signal)
+    signal.signal(signal.SIGINT, on_signal)
+    rc = 0
+    try:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=None if r == 0 else sys.stderr))
+        alive = list(procs)
+        while alive:
+            for p in list(alive):
+                code = p.poll()
+                if code is None:
+                    continue
+                alive.remove(p)
+                if code != 0 and rc == 0:          # one rank failed: the others would wait in a collective forever
+                    rc = code
+                    print(f"bench.py: rank {procs.index(p)} exited with {code}; stopping the other ranks", file=sys.stderr)
+                    for q in alive:
+                        q.terminate()
+            time.sleep(0.2)
+    finally:
+        stop_children()          # also reached when a Popen raised half-way or the poll loop was interrupted
     sys.exit(rc if rc >= 0 else 1)
 
 
@@ -213,7 +318,11 @@ def main():
                          "encodings of the real first frame and of the rendered goal-force map (the kernels' speed depends on the data)")
     ap.add_argument("--peaky", type=float, default=1.0, help="multiply every self-attention norm_q weight by this factor (8: attention "
                     "logits x 8, near-one-hot softmax rows) — data-sensitivity runs only")
-    ap.add_argument("--config5-steps", type=int, default=4, help="N = 1, bf16 run: after the bf16 timed region, switch the SAME modules to "
+    ap.add_argument("--peaky-steps", type=int, default=2, help="N = 1, bf16 run: after the timed region, time this many steps (1 warm-up first) with "
+                    "every self-attention's logits x 8 (norm_q weights x 8: near-one-hot softmax rows, what trained attention looks like); "
+                    "reported as `data_sensitivity`; 0 = skip")
+    ap.add_argument("--no-preloop", action="store_true", help="skip the pre-loop timing (2 tiled VAE encodes + 2 umT5-XXL forwards)")
+    ap.add_argument("--config5-steps", type=int, default=2, help="N = 1, bf16 run: after the bf16 timed region, switch the SAME modules to "
                     "the fp8_linear contract (BASELINE config 5) and time this many steps (1 warm-up first); reported as `config5` in the "
                     "JSON line; 0 = skip")
     ap.add_argument("--no-launch-events", action="store_true", help="do not record the per-launch HIP events behind `roofline` / "
@@ -313,6 +422,16 @@ def main():
                             controlnet=True, step_ids=ids, cfg_parallel=cfgp, record_step_times=record,
                             sequence_parallel=seqp)
 
+    # N > 1: every collective of the run once at its production size, content-checked, BEFORE anything is timed — a transport
+    # problem surfaces here with the backend's own message, not as a hang or a wrong number in the timed region
+    pre = None
+    if cfgp is not None:
+        from goal_force_amd.distributed import preflight
+        pre = preflight(cfgp, dev, log=(lambda m: print(m, file=sys.stderr, flush=True)) if rank == 0 else None)
+        if rank == 0:
+            print(f"bench.py pre-flight: backend {pre['backend']}, rccl_ranks {pre['rccl_ranks']}, min free HBM {pre['min_hbm_free_gb']:.1f} GB; "
+                  + "; ".join(f"rank {r['rank']} -> {r['device']} (video {r['sample']}, branch {r['branch']}, sp {r['sp_rank']})"
+                              for r in pre["ranks"]), file=sys.stderr, flush=True)
     if warm_ids:
         run(warm_ids)
     if world > 1:
@@ -348,6 +467,14 @@ def main():
     assert tuple(frames.shape) == (1, 3, 81, 480, 832)
     if not bool(torch.isfinite(frames.float()).all()):
         raise SystemExit(f"rank {rank}: non-finite decoded frames")
+    # per-launch events of the decode's convolutions (config 4's roofline entries): a third decode, outside `vae_s`
+    vae_roofline, vae_conv_ms = None, None
+    if world == 1 and not args.no_launch_events:
+        ops.PROFILE_CONV = []
+        vae.decode(final, tiled=True, tile_size=(30, 52), tile_stride=(15, 26))
+        torch.cuda.synchronize()
+        cprof, ops.PROFILE_CONV = ops.PROFILE_CONV, None
+        vae_roofline, vae_conv_ms = vae_entries(cprof)
     u8 = pipe.frames_uint8(frames)                      # [81,480,832,3] uint8, 97 MB (what the reference saves, GF:735)
     frames_digest = tensor_digest(torch, u8)
     # end-of-run all-gather of every sample's frames among the samples' lead ranks (one contributor per sample, the
@@ -383,47 +510,107 @@ def main():
     config5 = None
     if world == 1 and not args.fp8 and args.config5_steps > 0:
         from goal_force_amd.dit import enable_fp8
-        for m in (dit, dit2, cn, cn2):
-            enable_fp8(m)
-        k5 = args.config5_steps
-        ids5 = sorted({min(n_sched - 1, ((2 * i + 1) * n_sched) // (2 * k5)) for i in range(k5)}) if k5 > 1 else [0]
-        run([ids5[0]])
-        torch.cuda.synchronize()
-        ops.PROFILE_ATTN, ops.PROFILE_GEMM = (None, None) if args.no_launch_events else ([], [])
-        t5 = time.perf_counter()
-        final5 = run(ids5, record=True)
-        torch.cuda.synchronize()
-        el5 = time.perf_counter() - t5
-        prof5, ops.PROFILE_ATTN = ops.PROFILE_ATTN or [], None
-        gprof5, ops.PROFILE_GEMM = ops.PROFILE_GEMM or [], None
-        if not bool(torch.isfinite(final5.float()).all()):
-            raise SystemExit("config 5: non-finite latents after the timed fp8 steps")
-        hi5 = [ms for ms, low in pipe.last_step_ms if not low]
-        lo5 = [ms for ms, low in pipe.last_step_ms if low]
-        att5 = [a.elapsed_time(b) for a, b, sq, skv, _ in prof5 if sq == skv == S_TOK]
-        sps5 = el5 / len(ids5)
-        config5 = {"what": "BASELINE config 5: the same run with every nn.Linear of the DiT / ControlNet blocks on the fp8_linear contract "
-                           "(per-row dynamic activation scale, unit weight scale, OCP e4m3; diffsynth/vram_management/layers.py:115-151)",
-                   "dtype": "fp8-e4m3 block Linears (bf16 elsewhere, fp32 accumulate)", "steps": len(ids5), "warmup": 1, "step_ids": ids5,
-                   "ms_per_step": sps5 * 1e3, "denoise_step_ms_high_noise": sum(hi5) / len(hi5) if hi5 else None,
-                   "denoise_step_ms_low_noise": sum(lo5) / len(lo5) if lo5 else None,
-                   "frames_per_sec": 81.0 / (n_sched * sps5 + vae_s),
-                   "frames_per_sec_schedule_weighted": (81.0 / ((21 * sum(hi5) / len(hi5) + 29 * sum(lo5) / len(lo5)) / 1e3 + vae_s)
-                                                        if hi5 and lo5 else None),
-                   "self_attention_avg_launch_ms": sum(att5) / len(att5) if att5 else None,
-                   "latents": tensor_digest(torch, final5),
-                   "roofline_gemm": gemm_entries(gprof5, S_TOK, True)}
-        for m in (dit, dit2, cn, cn2):
-            enable_fp8(m, False)
+        try:
+            for m in (dit, dit2, cn, cn2):
+                enable_fp8(m)
+            k5 = args.config5_steps
+            ids5 = sorted({min(n_sched - 1, ((2 * i + 1) * n_sched) // (2 * k5)) for i in range(k5)}) if k5 > 1 else [0]
+            run([ids5[0]])
+            torch.cuda.synchronize()
+            ops.PROFILE_ATTN, ops.PROFILE_GEMM = (None, None) if args.no_launch_events else ([], [])
+            t5 = time.perf_counter()
+            final5 = run(ids5, record=True)
+            torch.cuda.synchronize()
+            el5 = time.perf_counter() - t5
+            prof5, ops.PROFILE_ATTN = ops.PROFILE_ATTN or [], None
+            gprof5, ops.PROFILE_GEMM = ops.PROFILE_GEMM or [], None
+            if not bool(torch.isfinite(final5.float()).all()):
+                raise RuntimeError("non-finite latents after the timed fp8 steps")
+            hi5 = [ms for ms, low in pipe.last_step_ms if not low]
+            lo5 = [ms for ms, low in pipe.last_step_ms if low]
+            att5 = [a.elapsed_time(b) for a, b, sq, skv, _ in prof5 if sq == skv == S_TOK]
+            sps5 = el5 / len(ids5)
+            w5 = (21 * sum(hi5) / len(hi5) + 29 * sum(lo5) / len(lo5)) / 1e3 if hi5 and lo5 else n_sched * sps5
+            config5 = {"what": "BASELINE config 5: the same run with every nn.Linear of the DiT / ControlNet blocks on the fp8_linear contract "
+                               "(per-row dynamic activation scale, unit weight scale, OCP e4m3; diffsynth/vram_management/layers.py:115-151)",
+                       "dtype": "fp8-e4m3 block Linears (bf16 elsewhere, fp32 accumulate)", "steps": len(ids5), "warmup": 1, "step_ids": ids5,
+                       "ms_per_step": sps5 * 1e3, "denoise_step_ms_high_noise": sum(hi5) / len(hi5) if hi5 else None,
+                       "denoise_step_ms_low_noise": sum(lo5) / len(lo5) if lo5 else None,
+                       "frames_per_sec": 81.0 / (w5 + vae_s),
+                       "frames_per_sec_definition": "81 / (21 high-noise + 29 low-noise step times + VAE decode): the schedule's own mix",
+                       "self_attention_avg_launch_ms": sum(att5) / len(att5) if att5 else None,
+                       "latents": tensor_digest(torch, final5),
+                       "roofline_gemm": gemm_entries(gprof5, S_TOK, True)}
+        except Exception as e:      # noqa: BLE001 — the bf16 measurement above must reach the JSON line whatever happens here
+            config5 = {"error": f"{type(e).__name__}: {e}"}
+            print(f"bench.py: the config-5 leg failed ({config5['error']}); the bf16 line is printed without it", file=sys.stderr)
+        finally:
+            ops.PROFILE_ATTN, ops.PROFILE_GEMM = None, None
+            for m in (dit, dit2, cn, cn2):
+                enable_fp8(m, False)
+
+    # ---- data sensitivity (N = 1, bf16): the same steps with every self-attention's logits x 8 — random-init attention is
+    # near-uniform (the friendliest data for the lazy-rescale softmax); trained attention is peaky
+    sensitivity = None
+    if world == 1 and not args.fp8 and args.peaky == 1.0 and args.peaky_steps > 0:
+        qn = [blk.self_attn.norm_q.weight for m in (dit, dit2, cn, cn2) for blk in m.modules()
+              if hasattr(blk, "self_attn") and hasattr(blk.self_attn, "norm_q")]
+        try:
+            for w in qn:
+                w.data.mul_(8.0)               # exact in bf16 (a power of two): undone exactly below
+            kp = args.peaky_steps
+            idsp = sorted({min(n_sched - 1, ((2 * i + 1) * n_sched) // (2 * kp)) for i in range(kp)}) if kp > 1 else [0]
+            run([idsp[0]])
+            torch.cuda.synchronize()
+            ops.PROFILE_ATTN = None if args.no_launch_events else []
+            finalp = run(idsp, record=True)
+            torch.cuda.synchronize()
+            profp, ops.PROFILE_ATTN = ops.PROFILE_ATTN or [], None
+            hip_ = [ms for ms, low in pipe.last_step_ms if not low]
+            lop_ = [ms for ms, low in pipe.last_step_ms if low]
+            attp = [a.elapsed_time(b) for a, b, sq, skv, _ in profp if sq == skv == S_TOK]
+            if not bool(torch.isfinite(finalp.float()).all()):
+                raise RuntimeError("non-finite latents with the logits x 8")
+            wp = (21 * sum(hip_) / len(hip_) + 29 * sum(lop_) / len(lop_)) / 1e3 if hip_ and lop_ else None
+            sensitivity = {"what": "the same bf16 steps with every self-attention's logits x 8 (norm_q weights x 8): near-one-hot softmax rows, "
+                                   "the rescale path of the attention kernel is taken as often as trained weights would take it",
+                           "steps": len(idsp), "warmup": 1, "step_ids": idsp,
+                           "denoise_step_ms_high_noise": sum(hip_) / len(hip_) if hip_ else None,
+                           "denoise_step_ms_low_noise": sum(lop_) / len(lop_) if lop_ else None,
+                           "frames_per_sec": 81.0 / (wp + vae_s) if wp else None,
+                           "self_attention_avg_launch_ms": sum(attp) / len(attp) if attp else None}
+        except Exception as e:      # noqa: BLE001
+            sensitivity = {"error": f"{type(e).__name__}: {e}"}
+            print(f"bench.py: the data-sensitivity leg failed ({sensitivity['error']})", file=sys.stderr)
+        finally:
+            ops.PROFILE_ATTN = None
+            for w in qn:
+                w.data.mul_(0.125)
+
+    # ---- pre-loop units at full size (N = 1): reported separately, never part of `value`
+    preloop = None
+    if world == 1 and not args.no_preloop:
+        try:
+            preloop = preloop_seconds(torch, vae, dev)
+        except Exception as e:      # noqa: BLE001
+            preloop = {"error": f"{type(e).__name__}: {e}"}
+            print(f"bench.py: the pre-loop leg failed ({preloop['error']})", file=sys.stderr)
 
     if rank == 0:
         attn_traffic, attn_traffic_src = static_traffic("attn_self")
         sec_per_step = elapsed / k
         videos = 1 if world == 1 else world // (2 * args.sp)
-        loop_s = n_sched * sec_per_step
-        value = videos * 81.0 / (loop_s + vae_s + gather_s)
         hi = [ms for ms, low in step_ms if not low]
         lo = [ms for ms, low in step_ms if low]
+        # the 50-step loop: 21 high-noise + 29 low-noise steps (boundary 0.875 on the shift-5 schedule), each at its measured mean —
+        # the K timed steps cannot hold that ratio exactly (K = 20: 8 + 12), so the headline weights them instead of scaling their sum
+        if hi and lo and k < n_sched:
+            loop_s = (21 * sum(hi) / len(hi) + 29 * sum(lo) / len(lo)) / 1e3
+            loop_how = "21 x mean high-noise step + 29 x mean low-noise step (HIP events around each step on the launch stream)"
+        else:
+            loop_s = n_sched * sec_per_step
+            loop_how = "all 50 steps timed" if k >= n_sched else "50 x the mean timed step (one kind of step timed only)"
+        value = videos * 81.0 / (loop_s + vae_s + gather_s)
         # dominant kernel: self-attention flash-attention launches (q_len == kv_len == S)
         self_att = [(a.elapsed_time(b)) for a, b, sq, skv, _ in prof if sq == skv == S_TOK]
         att_ms = sum(self_att) / max(1, len(self_att))
@@ -455,8 +642,9 @@ def main():
                                           if os.environ.get("GF_FOLD_PAD_KEYS", "1") != "0" else "all 512 context keys attended",
                        "parallelism": "1 GPU: sequential CFG (block 0's context-independent half shared by the two branches)" if world == 1 else f"{videos} video(s) x CFG pair, RCCL all-gather of noise_pred per step"
                                       + (f"; head-parallel attention degree {args.sp} (RCCL all-to-all over xGMI)" if args.sp > 1 else ""),
+                       "value_definition": "frames/s = videos * 81 / (50-step loop + tiled VAE decode + frame all-gather); 50-step loop = " + loop_how,
                        "vae_decode": "tiled (30,52)/(15,26) decode of [1,16,21,60,104] on the HIP kernels, measured after the "
-                                     "timed steps and included in value: frames/s = videos*81 / (50*s_per_step + vae_s)"
+                                     "timed steps and included in value"
                                      + ("" if world == 1 else "; tiles split over the two ranks of each CFG pair")},
             "vae_decode_s": vae_s, "denoise_loop_s_50_steps": loop_s,
             "frame_allgather_s": gather_s, "samples_gathered": n_gathered,
@@ -473,8 +661,7 @@ def main():
             "denoise_step_ms_high_noise": sum(hi) / len(hi) if hi else None,
             "denoise_step_ms_low_noise": sum(lo) / len(lo) if lo else None,
             "step_mfma_frac": (sum(step_flops) / elapsed / 1e12) / PEAK_BF16_TFLOPS,
-            "frames_per_sec_schedule_weighted": (videos * 81.0 / ((21 * sum(hi) / len(hi) + 29 * sum(lo) / len(lo)) / 1e3 + vae_s)
-                                                 if hi and lo else None),
+            "frames_per_sec_unweighted": videos * 81.0 / (n_sched * sec_per_step + vae_s + gather_s),
             "roofline": {"bound": "mfma", "kernel": "flash_attn_fwd_kernel3<2> (self-attention, S=32760, 40 heads, d=128; V^T is written by the V projection GEMM, gf_linear_vt32)",
                          "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "peak_note": "dense bf16 MFMA peak = 256 CU x 4096 FLOP/clk x 2.4 GHz (MI355X_MICROARCH.md); under this "
@@ -494,8 +681,18 @@ def main():
         # second entry: the FFN GEMMs (D->F with the GELU epilogue, F->D with gate*+residual) — with the four D->D
         # projections the GEMMs are the other ~45 % of a step
         out["roofline_gemm"] = gemm_entries(gprof, S_TOK // args.sp, args.fp8)
+        if vae_roofline is not None:
+            out["roofline_vae"] = vae_roofline
+            out["vae_decode_conv_ms"] = vae_conv_ms
         if config5 is not None:
             out["config5"] = config5
+        if sensitivity is not None:
+            out["data_sensitivity"] = sensitivity
+        if preloop is not None:
+            out["preloop"] = preloop
+        if pre is not None:
+            out["preflight"] = {"steps": pre["steps"], "rccl_ranks": pre["rccl_ranks"], "min_hbm_free_gb": pre["min_hbm_free_gb"],
+                                "ranks": [{k_: r[k_] for k_ in ("rank", "sample", "branch", "sp_rank", "device", "hbm_free_gb")} for r in pre["ranks"]]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(torch)
         print(json.dumps(out))

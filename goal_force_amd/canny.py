@@ -102,16 +102,29 @@ def _identity_tables(n: int):
     return np.arange(n + 1, dtype=np.int32), np.arange(n, dtype=np.int32), np.ones(n, np.float32)
 
 
+def _integer_ratio(ssize: int, dsize: int) -> bool:
+    ratio = ssize / dsize
+    return abs(ratio - round(ratio)) < 2.220446049250313e-16
+
+
 def _area_or_identity(ssize: int, dsize: int):
     if ssize == dsize:
         return _identity_tables(ssize)         # cv2.resize to the same size is a copy
     if dsize > ssize:
         raise NotImplementedError("INTER_AREA enlarging (OpenCV switches to a bilinear variant) is not on the Canny path")
-    ratio = ssize / dsize
-    if abs(ratio - round(ratio)) < 2.220446049250313e-16:
-        raise NotImplementedError(f"INTER_AREA by the integer ratio {ratio:g}: OpenCV takes its integer fast path (ResizeAreaFast), "
-                                  "which is not restated here")
     return area_tables(ssize, dsize)
+
+
+def area_tables_2d(W: int, Wd: int, H: int, Hd: int):
+    """The four table triples of one INTER_AREA shrink, chosen PER IMAGE as resize.cpp does: OpenCV takes its integer fast path
+    (ResizeAreaFast: integer block sums, one rounding division) only when BOTH scale_x and scale_y are integers; a mixed case — an
+    integer ratio on one axis, a fractional one on the other — runs the general overlap tables on both axes, which area_tables
+    produces for any ratio.  Refused (not restated here): both ratios integral and at least one > 1, i.e. inputs whose short side
+    is an integer multiple of the detect resolution AND whose long side divides evenly too (1024 x 1024, 1024 x 2048, ... at 512)."""
+    if (W, H) != (Wd, Hd) and Wd <= W and Hd <= H and _integer_ratio(W, Wd) and _integer_ratio(H, Hd):
+        raise NotImplementedError(f"INTER_AREA {W}x{H} -> {Wd}x{Hd}: both ratios are integers ({W // Wd}, {H // Hd}) — OpenCV takes its "
+                                  "integer fast path (ResizeAreaFast), which is not restated here")
+    return (*_area_or_identity(W, Wd), *_area_or_identity(H, Hd))
 
 
 def _dev(a: np.ndarray, device):
@@ -164,7 +177,7 @@ class CannyDetector:
             _lib.check(lib.gf_resize_lanczos4_u8(x.data_ptr(), img.data_ptr(), *(t.data_ptr() for t in tabs), T, H, W, Hd, Wd, st),
                        "gf_resize_lanczos4_u8")
         else:
-            tabs = [_dev(a, x.device) for a in (*_area_or_identity(W, Wd), *_area_or_identity(H, Hd))]
+            tabs = [_dev(a, x.device) for a in area_tables_2d(W, Wd, H, Hd)]
             _lib.check(lib.gf_resize_area_u8(x.data_ptr(), img.data_ptr(), *(t.data_ptr() for t in tabs), T, H, W, Hd, Wd, 0, st),
                        "gf_resize_area_u8")
         return img
@@ -234,7 +247,7 @@ class ControlSignalDataset_CannyEdge(torch.utils.data.Dataset):
         x = _u8_frames(processed_video, det.device)
         T, H, W, _ = x.shape
         state, (Hd, Wd) = det.edge_state(x)
-        tabs = [_dev(a, x.device) for a in (*_area_or_identity(Wd, W), *_area_or_identity(Hd, H))]
+        tabs = [_dev(a, x.device) for a in area_tables_2d(Wd, W, Hd, H)]
         out = torch.empty((T, H, W, 3), dtype=torch.bfloat16, device=x.device)
         st = torch.cuda.current_stream(x.device).cuda_stream
         _lib.check(_lib.load().gf_resize_area_u8(state.data_ptr(), out.data_ptr(), *(t.data_ptr() for t in tabs), T, Hd, Wd, H, W, 1, st),

@@ -121,6 +121,95 @@ class CfgPairParallel:
         return out
 
 
+def preflight(cfgp: CfgPairParallel, device, latent_shape=(1, 16, 21, 60, 104), frames_shape=(81, 480, 832, 3),
+              tile_shape=(81, 240, 416, 8), log=None) -> dict:
+    """First-contact check of an N > 1 run, BEFORE anything is timed: every collective of the sampling path once at its production
+    size — the per-step all-gather of the noise prediction inside the CFG pair (4.19 MB), one VAE-tile broadcast inside the pair
+    (129 MB), the end-of-run all-gather of the uint8 frames among the samples' lead ranks (97 MB per sample), and the head
+    all-to-all of the sequence-parallel group when P > 1 — each timed, each checked for CONTENT (a rank-dependent fill pattern), so
+    that a transport problem (IPC mode, a missing xGMI link, two ranks on one device) surfaces here with the backend's own error
+    text instead of as a hang or a wrong number in the timed region.  Also reports the rank -> device map, the backend, and the
+    free HBM of every rank.  Returns the report (identical on every rank); raises GoalForceError naming the step that failed."""
+    import time
+    rep = {"world": cfgp.world_size, "backend": dist.get_backend(), "samples": cfgp.num_samples, "sp_size": cfgp.sp_size, "steps": {}}
+    dev = torch.device(device)
+    on_gpu = dev.type == "cuda"
+
+    def sync():
+        if on_gpu:
+            torch.cuda.synchronize(dev)
+
+    def step(name, fn):
+        try:
+            sync()
+            dist.barrier()
+            t0 = time.perf_counter()
+            nbytes = fn()
+            sync()
+            dt = time.perf_counter() - t0
+        except Exception as e:      # noqa: BLE001 — the backend's message is the diagnosis
+            raise GoalForceError(f"multi-GPU pre-flight: `{name}` failed on rank {cfgp.rank} (sample {cfgp.sample}, branch "
+                                 f"{cfgp.branch}, sp_rank {cfgp.sp_rank}, device {dev}) over backend {rep['backend']}: "
+                                 f"{type(e).__name__}: {e}") from e
+        rep["steps"][name] = {"bytes": int(nbytes), "seconds": dt}
+        if log:
+            log(f"  pre-flight rank {cfgp.rank}: {name}: {nbytes / 1e6:.1f} MB in {dt * 1e3:.2f} ms")
+
+    def check(ok, name):
+        if not bool(ok):
+            raise GoalForceError(f"multi-GPU pre-flight: `{name}` delivered wrong CONTENT on rank {cfgp.rank} (device {dev}, backend "
+                                 f"{rep['backend']}): the transport is not moving the peers' data")
+
+    def noise_pair():
+        x = torch.full(latent_shape, float(cfgp.branch + 1), dtype=torch.bfloat16, device=dev)
+        posi, nega = cfgp.exchange(x)
+        check(float(posi.flatten()[0]) == 1.0 and float(nega.flatten()[-1]) == 2.0, "noise-prediction all-gather (CFG pair)")
+        return 2 * x.numel() * 2
+
+    def tile_bcast():
+        t = torch.full(tile_shape, float(cfgp.sample + 1) if cfgp.branch == 0 else 0.0, dtype=torch.bfloat16, device=dev)
+        src = dist.get_global_rank(cfgp.pair_group, 0)
+        dist.broadcast(t, src=src, group=cfgp.pair_group)
+        check(float(t.flatten()[-1]) == cfgp.sample + 1, "VAE tile broadcast (CFG pair)")
+        return t.numel() * 2
+
+    def frames_gather():
+        f = torch.full(frames_shape, cfgp.sample + 1, dtype=torch.uint8, device=dev) if cfgp.is_lead else None
+        out = cfgp.gather_frames(f, frames_shape, torch.uint8, dev)
+        if cfgp.is_lead:
+            check(all(int(t.flatten()[-1]) == i + 1 for i, t in enumerate(out)), "frame all-gather (lead ranks)")
+            return len(out) * out[0].numel()
+        return 0
+
+    step("noise_pred_allgather_pair", noise_pair)
+    step("vae_tile_broadcast_pair", tile_bcast)
+    step("frames_allgather_leads", frames_gather)
+    if cfgp.sp_size > 1:
+        sp = cfgp.sequence_parallel()
+
+        def heads_a2a():
+            return sp.preflight(dev)
+        step("head_all_to_all_sp_group", heads_a2a)
+    # rank -> device map and HBM headroom of every rank
+    free, total = (torch.cuda.mem_get_info(dev) if on_gpu else (0, 0))
+    mine = {"rank": cfgp.rank, "sample": cfgp.sample, "branch": cfgp.branch, "sp_rank": cfgp.sp_rank, "device": str(dev),
+            "device_name": torch.cuda.get_device_name(dev) if on_gpu else "cpu", "hbm_free_gb": free / 2 ** 30, "hbm_total_gb": total / 2 ** 30,
+            "seconds": {k: v["seconds"] for k, v in rep["steps"].items()}}
+    allr = [None] * cfgp.world_size
+    dist.all_gather_object(allr, mine)
+    rep["ranks"] = allr
+    for name in rep["steps"]:          # the slowest rank's time is the step's time
+        rep["steps"][name]["seconds"] = max(r["seconds"][name] for r in allr)
+        rep["steps"][name]["bytes"] = max(rep["steps"][name]["bytes"], 0)
+    if on_gpu and rep["backend"] == "nccl":
+        devs = [r["device"] for r in allr]
+        if len(set(devs)) != len(devs):
+            raise GoalForceError(f"multi-GPU pre-flight: two ranks share a device under RCCL: {devs}")
+    rep["rccl_ranks"] = cfgp.world_size if rep["backend"] == "nccl" else 0
+    rep["min_hbm_free_gb"] = min(r["hbm_free_gb"] for r in allr)
+    return rep
+
+
 def init_from_env(backend: Optional[str] = None):
     """torchrun / torch.distributed.run environment -> (rank, local_rank, world_size); initialises the
     default process group when WORLD_SIZE > 1.  Under RCCL ("nccl") every rank needs a GPU of its own: LOCAL_RANK beyond the

@@ -236,6 +236,17 @@ class SelfAttention(nn.Module):
         keep["wide"] also the three projections ("qp", "kp" before their norm, "v")."""
         fp8 = getattr(self.q, "_gf_w8", None) is not None
         xin = (x2 if isinstance(x2, QuantizedInput) else QuantizedInput(x2)) if fp8 else x2
+        if sp is not None and keep is None:
+            # head-parallel: every projection's tokens-for-heads exchange starts as soon as the projection is ready and flies under
+            # the next one (same kernels on the same values as below: bit-identical, another issue order)
+            k = linear(xin, self.k)
+            ops.rmsnorm_rope(k, self.norm_k.weight, rope.cos, rope.sin, self.head_dim, self.norm_k.eps)
+            hk = sp.heads_start(k)
+            hv = sp.heads_start(linear(xin, self.v))
+            q = linear(xin, self.q)
+            ops.rmsnorm_rope(q, self.norm_q.weight, rope.cos, rope.sin, self.head_dim, self.norm_q.eps)
+            hq = sp.heads_start(q)
+            return sp.attention_started(hq, hk, hv, self.num_heads, tuple(q.shape))
         q, k = linear(xin, self.q), linear(xin, self.k)
         if keep is not None and keep.get("wide"):      # training with room to spare: the pre-norm projections stay for the backward
             keep["qp"], keep["kp"] = q, k

@@ -28,6 +28,8 @@ _BF16 = torch.bfloat16
 PROFILE_ATTN = None
 # Same for the GEMM (bench.py's second roofline entry): a list collects (start, end, M, N, K, epilogue) per launch.
 PROFILE_GEMM = None
+# the same for the VAE convolutions (bench.py's `roofline_vae`): (ev0, ev1, rows, N, C, kt, ks, mode, with_resid) per gf_conv3d_bf16 launch
+PROFILE_CONV = None
 
 
 def _stream(t: torch.Tensor):
@@ -573,10 +575,17 @@ def vae_conv3d(src, cache, w, bias, kt, ks, upsample2x=False, downsample2=False,
         if resid.dim() != 2 or resid.shape[0] != t_out * px or resid.stride(1) != 1:
             raise GoalForceError("vae_conv3d.resid must be [T_out*Ho*Wo, >=N] with contiguous rows")
         ldr = resid.stride(0)
+    prof = PROFILE_CONV
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.check(_lib.load().gf_conv3d_bf16(_ptr(src), _ptr(cache), _ptr(w), w.stride(0), _ptr(bias), _ptr(out), out.stride(0),
                                           T, t_out, H, W, C, kt, ks, mode, t_stride, t_off, n, k,
                                           EPI_BIAS if resid is None else EPI_BIAS_RESID, _ptr(resid), ldr, _stream(src)),
                "gf_conv3d_bf16")
+    if prof is not None:
+        e1.record()
+        prof.append((e0, e1, t_out * px, n, C, kt, ks, mode, resid is not None))
     return out
 
 

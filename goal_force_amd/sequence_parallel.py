@@ -9,9 +9,15 @@ chunked `x` (GF:1489-1522 vs 1565-1570) — so here the ControlNet tokens are sh
 sharding"): ControlNet block i and DiT block i see the same token chunk and the zero-conv injection stays local.
 
 Per self-attention (q, k, v local [S/P, NH*DH]):
-    all-to-all      [S/P, P, (NH/P)*DH] -> [P, S/P, (NH/P)*DH] = all S tokens of this rank's NH/P heads     (x3: q, k, v)
-    flash-attention over NH/P heads, S x S                                                               (HIP kernel)
-    all-to-all back [P, S/P, (NH/P)*DH] -> [S/P, NH*DH]
+    all-to-all      [S/P, P, (NH/P)*DH] -> [P, S/P, (NH/P)*DH] = all S tokens of this rank's NH/P heads     (x3: k, v, q)
+    flash-attention over NH/P heads, S x S, in two halves of the head group                              (HIP kernel)
+    all-to-all back [P, S/P, (NH/P)*DH] -> [S/P, NH*DH]                                                    (x2: one per half)
+The exchanges are asynchronous and ordered so that they hide under compute (SelfAttention.attend): K's exchange starts as soon as K
+is normed and rotated and flies under the V projection, V's under the Q projection and its norm; the first half's way back flies
+under the second half's attention.  Exposed per attention: Q's exchange and the second half's way back (2 of 5 transfers).
+The V-by-GEMM shortcut of the one-GPU path (gf_linear_vt32: the V projection writes the attention kernel's V^T operand) does not
+carry over: the projection mixes all channels of a rank's OWN tokens, the attention needs ALL tokens of the rank's heads, so V must
+cross the fabric between the two — the received V goes through gf_transpose_v32 (0.7 % of the attention's time).
 Full-width RMSNorm and RoPE act per token and run before the exchange on the local chunk; cross-attention keeps all heads
 local (its K/V are the 512 replicated text tokens): no communication.  Every head is computed by the same kernel on the same
 values in the same key order as on one GPU and every other op is row-wise, so the sharded forward is bit-identical to the
@@ -92,28 +98,68 @@ class SequenceParallel:
         return out if total is None or total == out.shape[0] else out[:total]
 
     # ---- attention ------------------------------------------------------------------------------------------------
-    def attention(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: int) -> torch.Tensor:
-        """q, k, v: this rank's tokens [S/P, NH*DH] (already normed and rotated) -> attention output [S/P, NH*DH]."""
+    def heads_start(self, t: torch.Tensor):
+        """Start the tokens-for-heads exchange of ONE projection: t = this rank's tokens [S/P, NH*DH] -> (work, recv) with
+        recv [S, (NH/P)*DH] = all S tokens of this rank's head group once `work.wait()` has returned.  The collective is
+        asynchronous (RCCL runs it on the process group's own stream, ordered after the kernels already queued on the current one):
+        SelfAttention.attend starts K's exchange, then computes the V projection while it flies, and so on — only the last
+        exchange (Q) is exposed."""
         p = self.size
-        if p == 1:
-            return ops.flash_attn(q, k, v, num_heads)
+        sl, d = t.shape
+        dh = d // p
+        send = torch.empty((p, sl, dh), dtype=t.dtype, device=t.device)
+        send.copy_(t.reshape(sl, p, dh).transpose(0, 1))      # [S/P, P, dh] -> [P, S/P, dh]: block j goes to rank j
+        recv = torch.empty((p * sl, dh), dtype=t.dtype, device=t.device)
+        work = dist.all_to_all_single(recv, send, group=self.group, async_op=True)
+        return work, recv, send                                # (send is kept alive until the wait)
+
+    def attention_started(self, hq, hk, hv, num_heads: int, out_shape) -> torch.Tensor:
+        """The attention over this rank's head group from three started exchanges (heads_start), and the heads-for-tokens exchange
+        back.  The head group is computed in two halves: the first half's way back flies under the second half's attention."""
+        p = self.size
         if num_heads % p:
             raise GoalForceError(f"sequence parallel: {num_heads} heads do not divide by {p} ranks")
-        sl, d = q.shape
-        dh = d // p                                   # columns of this rank's head group
-        send = torch.empty((3, p, sl, dh), dtype=q.dtype, device=q.device)
-        for i, t in enumerate((q, k, v)):             # [S/P, P, dh] -> [P, S/P, dh]: block j goes to rank j
-            send[i].copy_(t.reshape(sl, p, dh).transpose(0, 1))
-        recv = torch.empty((3, p * sl, dh), dtype=q.dtype, device=q.device)
-        works = [dist.all_to_all_single(recv[i], send[i], group=self.group, async_op=True) for i in range(3)]
-        for w in works:
-            w.wait()
-        o_heads = ops.flash_attn(recv[0], recv[1], recv[2], num_heads // p)      # [S, dh]: rows already in token order
-        back = torch.empty((p, sl, dh), dtype=q.dtype, device=q.device)
-        dist.all_to_all_single(back, o_heads.reshape(p, sl, dh), group=self.group)   # block j = head group j of my tokens
+        sl, d = out_shape
+        hl = num_heads // p                            # heads of this rank
+        hd = d // num_heads
+        for h in (hk, hv, hq):
+            h[0].wait()
+        q, k, v = hq[1], hk[1], hv[1]                  # [S, hl * hd], rows in token order
+        parts = [(0, hl)] if hl < 2 else [(0, (hl + 1) // 2), ((hl + 1) // 2, hl)]
+        backs = []
+        for h0, h1 in parts:
+            c0, c1 = h0 * hd, h1 * hd
+            o = ops.flash_attn(q[:, c0:c1], k[:, c0:c1], v[:, c0:c1], h1 - h0)            # [S, (h1 - h0) * hd]
+            back = torch.empty((p, sl, c1 - c0), dtype=o.dtype, device=o.device)
+            backs.append((dist.all_to_all_single(back, o.reshape(p, sl, c1 - c0), group=self.group, async_op=True), back, o, c0, c1))
         out = torch.empty((sl, d), dtype=q.dtype, device=q.device)
-        out.view(sl, p, dh).copy_(back.transpose(0, 1))
+        ov = out.view(sl, p, hl * hd)                  # column j * (hl hd) + c = head group j (from rank j), its column c
+        for w, back, _, c0, c1 in backs:
+            w.wait()
+            ov[:, :, c0:c1].copy_(back.transpose(0, 1))
         return out
+
+    def attention(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: int) -> torch.Tensor:
+        """q, k, v: this rank's tokens [S/P, NH*DH] (already normed and rotated) -> attention output [S/P, NH*DH]."""
+        if self.size == 1:
+            return ops.flash_attn(q, k, v, num_heads)
+        if num_heads % self.size:
+            raise GoalForceError(f"sequence parallel: {num_heads} heads do not divide by {self.size} ranks")
+        hk, hv, hq = self.heads_start(k), self.heads_start(v), self.heads_start(q)
+        return self.attention_started(hq, hk, hv, num_heads, tuple(q.shape))
+
+    def preflight(self, device) -> int:
+        """One head all-to-all at production size (S = 32760 tokens, D = 5120: [S/P, D] bf16 per rank) with a content check;
+        returns the bytes this rank sent (distributed.preflight)."""
+        p = self.size
+        sl, d = -(-32760 // p), 5120
+        t = torch.full((sl, d), float(self.rank + 1), dtype=torch.bfloat16, device=device)
+        w, recv, _ = self.heads_start(t)
+        w.wait()
+        want = torch.arange(1, p + 1, dtype=torch.float32, device=recv.device).repeat_interleave(sl)
+        if not torch.equal(recv[:, 0].float(), want):
+            raise GoalForceError("sequence-parallel pre-flight: the head all-to-all delivered the wrong blocks")
+        return t.numel() * 2 * (p - 1) // p
 
 
 def attention(sp: Optional[SequenceParallel], q, k, v, num_heads: int):

@@ -70,11 +70,13 @@ def resize_lanczos4_u8(img, hd, wd):
 
 # ------------------------------------------------------------------ INTER_AREA (shrinking, non-integer ratio), 8-bit
 def _area_axis(ssize, dsize):
-    """dense [dsize, ssize] float32 weight matrix + per-row ordered entry lists (the order matters for the float sums)."""
+    """per-row ordered entry lists (source index, fp32 weight) of resize.cpp computeResizeAreaTab (the order matters for the float
+    sums).  Valid for any shrink ratio; whether OpenCV USES these tables is decided per image (resize_area_u8): only when both
+    ratios are integers does it take ResizeAreaFast instead, which is not restated."""
     if ssize == dsize:
         return [[(i, np.float32(1.0))] for i in range(ssize)]
     scale = float(ssize) / float(dsize)
-    assert scale > 1 and abs(scale - round(scale)) > 1e-12, "only OpenCV's general area path is restated"
+    assert scale > 1, "only shrinking is on the Canny path"
     rows = []
     for d in range(dsize):
         f1 = d * scale
@@ -96,6 +98,8 @@ def _area_axis(ssize, dsize):
 def resize_area_u8(img, hd, wd):
     """img uint8 [H,W,C] -> uint8 [hd,wd,C]: horizontal float sums per source row, then the vertical combination, cvRound."""
     h, w, c = img.shape
+    integral = lambda a, b: abs(a / b - round(a / b)) < 2.220446049250313e-16       # noqa: E731
+    assert (h, w) == (hd, wd) or not (integral(w, wd) and integral(h, hd)), "both ratios integral: OpenCV's ResizeAreaFast is not restated"
     xr, yr = _area_axis(w, wd), _area_axis(h, hd)
     src = img.astype(np.float32)
     hor = np.zeros((h, wd, c), np.float32)

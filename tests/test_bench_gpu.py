@@ -17,7 +17,8 @@ import pytest
 from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
-ARGS = ["--layers", "2", "--steps", "2", "--warmup", "0", "--no-cpu-baseline"]
+# the sharding tests time two layers; the extra legs of the N = 1 line (config 5, data sensitivity, pre-loop) have their own test below
+ARGS = ["--layers", "2", "--steps", "2", "--warmup", "0", "--no-cpu-baseline", "--config5-steps", "0", "--peaky-steps", "0", "--no-preloop"]
 
 
 def _free_port():
@@ -58,6 +59,12 @@ def test_bench_two_ranks_bit_identical_to_one():
     assert two["distributed"] == {**two["distributed"], "world": 2, "backend": "gloo", "rccl_ranks": 0}
     assert one["distributed"]["world"] == 1 and one["frame_allgather_s"] == 0.0
     assert two["frame_allgather_s"] > 0 and two["samples_gathered"] == 1
+    # the N > 1 pre-flight ran every collective of the path once before the timed region and reports the layout
+    pf = two["preflight"]
+    assert set(pf["steps"]) == {"noise_pred_allgather_pair", "vae_tile_broadcast_pair", "frames_allgather_leads"} and pf["rccl_ranks"] == 0
+    assert pf["steps"]["noise_pred_allgather_pair"]["bytes"] == 2 * 16 * 21 * 60 * 104 * 2 and pf["steps"]["frames_allgather_leads"]["bytes"] == 81 * 480 * 832 * 3
+    assert [(r["rank"], r["sample"], r["branch"]) for r in pf["ranks"]] == [(0, 0, 0), (1, 0, 1)] and pf["min_hbm_free_gb"] > 1
+    assert "preflight" not in one
     assert two["self_check"]["latents"]["sha256"] == one["self_check"]["latents"]["sha256"]
     assert two["self_check"]["frames_uint8"]["sha256"] == one["self_check"]["frames_uint8"]["sha256"]
     assert "cpu_baseline" not in two
@@ -121,3 +128,37 @@ def test_bench_self_launch_eight_ranks_and_failure_exit_code():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--sp", "3"] + ARGS, env=_clean_env(),
                          capture_output=True, text=True, timeout=600)
     assert bad.returncode != 0 and not any(l.startswith("{") for l in bad.stdout.splitlines())
+
+
+def test_bench_line_is_schedule_weighted_and_carries_preloop_vae_roofline_and_data_sensitivity():
+    """What SURVEY §8(d) asks of the driver-visible line, on a 2-layer model so that it runs in a minute:
+    `value` is the 21 : 29 schedule-weighted figure; `preloop` = two tiled VAE encodes + two umT5-XXL forwards at full size, reported
+    beside it and not inside it; `roofline_vae` = the decode's three dominant convolution launches; `data_sensitivity` = the same
+    steps with the attention logits x 8; `config5` without an error."""
+    j = _launch(1, ["--config5-steps", "2", "--peaky-steps", "2"] )          # (ARGS switches the legs off; argparse keeps the LAST value)
+    assert "error" not in j["config5"] and j["config5"]["steps"] == 2 and j["config5"]["ms_per_step"] > 0
+    hi, lo, vs = j["denoise_step_ms_high_noise"], j["denoise_step_ms_low_noise"], j["vae_decode_s"]
+    assert hi > lo > 0, "a high-noise step runs the ControlNet on top of the DiT"
+    want = 81.0 / ((21 * hi + 29 * lo) / 1e3 + vs)
+    assert abs(j["value"] - want) <= 1e-9 * want, (j["value"], want)
+    assert abs(j["denoise_loop_s_50_steps"] - (21 * hi + 29 * lo) / 1e3) < 1e-9 and "21 x mean high-noise" in j["config"]["value_definition"]
+    assert j["ms_per_step"] > 0 and j["frames_per_sec_unweighted"] > 0
+    ds = j["data_sensitivity"]
+    assert "error" not in ds and ds["steps"] == 2 and ds["denoise_step_ms_high_noise"] > 0 and ds["self_attention_avg_launch_ms"] > 0
+    rv = j["roofline_vae"]
+    assert len(rv) == 3 and all(0 < e["frac"] < 1 and e["bound"] == "mfma" and e["launches"] > 0 and e["algorithmic_flops_per_launch"] > 1e11
+                                for e in rv)
+    assert sum(e["share_of_decode_conv_time"] for e in rv) > 0.5, "the three entries are the bulk of the decode's convolution time"
+    assert 0.5 * vs * 1e3 < j["vae_decode_conv_ms"] < 1.05 * vs * 1e3, "the convolutions are most of the tiled decode"
+
+
+def test_bench_preloop_leg_at_full_size():
+    """`preloop` (on by default in the driver's command): 2 tiled VAE encodes of an 81-frame 480x832 clip + 2 umT5-XXL forwards."""
+    args = [a for a in ARGS if a != "--no-preloop"]
+    port_env = _clean_env()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + args, env=port_env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    pl = _one_json(r.stdout)["preloop"]
+    assert "error" not in pl, pl
+    assert 0.05 < pl["vae_tiled_encode_x2_s"] < 10 and 0.005 < pl["umt5_xxl_512_tokens_x2_s"] < 10 and pl["umt5_xxl_params"] > 5e9
+    assert abs(pl["total_s"] - pl["vae_tiled_encode_x2_s"] - pl["umt5_xxl_512_tokens_x2_s"]) < 1e-9

@@ -87,8 +87,14 @@ def test_product_tables_equal_the_oracles_independent_restatement():
         assert [e[0] for e in flat] == src.tolist() and np.array([e[1] for e in flat], np.float32).tobytes() == al.tobytes()
         assert st[0] == 0 and st[-1] == len(src)
     assert cn.resized_shape(480, 832) == co.resize_target(480, 832)
+    # OpenCV chooses its integer fast path PER IMAGE (both ratios integral); a mixed case runs the general tables on both axes
     with pytest.raises(NotImplementedError):
-        cn._area_or_identity(1024, 512)
+        cn.area_tables_2d(1024, 512, 2048, 512)
+    st, src, al = cn.area_tables_2d(1024, 512, 600, 500)[:3]            # ratio 2 on x beside 1.2 on y: general tables, uniform 1/2 weights
+    assert st.tolist() == list(range(0, 1025, 2)) and src.tolist() == list(range(1024)) and set(al.tolist()) == {0.5}
+    flat = [e for r in co._area_axis(1024, 512) for e in r]
+    assert [e[0] for e in flat] == src.tolist() and np.array([e[1] for e in flat], np.float32).tobytes() == al.tobytes()
+    assert len(cn.area_tables_2d(512, 512, 600, 500)) == 6               # one axis untouched
 
 
 def test_dataset_host_logic(tmp_path, monkeypatch):

@@ -96,3 +96,46 @@ def test_contiguous_csv_sharding_matches_reference_rule():
 def test_cfg_pair_needs_even_world():
     with pytest.raises(ValueError):
         CfgPairParallel(0, 3)
+
+
+def _preflight_worker(rank, world, port, out, sp_size, sabotage):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from goal_force_amd import distributed as gd
+        cp = CfgPairParallel(rank, world, sp_size=sp_size)
+        if sabotage and rank == 1:
+            # a transport that "succeeds" without moving the peer's data: the content check must catch it
+            cp.exchange = lambda x: (x, x)
+        try:
+            rep = gd.preflight(cp, "cpu", latent_shape=(1, 16, 3, 4, 6), frames_shape=(5, 8, 8, 3), tile_shape=(5, 8, 8, 8))
+            torch.save({"rep": rep, "error": None}, os.path.join(out, f"r{rank}.pt"))
+        except Exception as e:      # noqa: BLE001
+            torch.save({"rep": None, "error": f"{type(e).__name__}: {e}"}, os.path.join(out, f"r{rank}.pt"))
+            if not sabotage:
+                raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,sp_size", [(2, 1), (4, 1), (8, 1), (4, 2)])
+def test_multi_gpu_preflight_runs_every_collective_and_reports_the_layout(world, sp_size, tmp_path):
+    """bench.py --gpus N runs distributed.preflight before its timed region: every collective of the path once,
+    content-checked, with the rank -> device map and per-rank memory head-room in the report (identical on all ranks)."""
+    mp.spawn(_preflight_worker, args=(world, _free_port(), str(tmp_path), sp_size, False), nprocs=world, join=True)
+    reps = [torch.load(os.path.join(tmp_path, f"r{r}.pt"))["rep"] for r in range(world)]
+    want = {"noise_pred_allgather_pair", "vae_tile_broadcast_pair", "frames_allgather_leads"} | ({"head_all_to_all_sp_group"} if sp_size > 1 else set())
+    for r, rep in enumerate(reps):
+        assert set(rep["steps"]) == want and rep["world"] == world and rep["backend"] == "gloo" and rep["rccl_ranks"] == 0
+        assert rep["samples"] == world // (2 * sp_size)
+        assert [x["rank"] for x in rep["ranks"]] == list(range(world))
+        assert [(x["sample"], x["branch"], x["sp_rank"]) for x in rep["ranks"]] == \
+            [(q // (2 * sp_size), (q // sp_size) % 2, q % sp_size) for q in range(world)]
+        assert rep["steps"]["noise_pred_allgather_pair"]["bytes"] == 2 * 16 * 3 * 4 * 6 * 2
+        assert all(v["seconds"] >= 0 for v in rep["steps"].values())
+
+
+def test_multi_gpu_preflight_fails_loudly_on_a_transport_that_moves_nothing(tmp_path):
+    mp.spawn(_preflight_worker, args=(2, _free_port(), str(tmp_path), 1, True), nprocs=2, join=True)
+    err = torch.load(os.path.join(tmp_path, "r1.pt"))["error"]
+    assert err and "pre-flight" in err and "noise-prediction all-gather" in err and "rank 1" in err, err
