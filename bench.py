@@ -154,6 +154,15 @@ def cpu_baseline(torch, runs=3):
             "block_seconds": dt, "tflops": tflops}
 
 
+def conv_kernel_name(kt, ks, mode, c, n):
+    """Which kernel gf_conv3d_bf16 sends a shape to (gf_gemm.hip::gf_conv3d_bf16, the same rules)."""
+    if kt == 3 and ks == 3 and mode == 0 and c == 96 and (n == 96 or n <= 16):
+        return "conv3d_c96_kernel (direct 3x3x3, halo staged once per frame, three temporal accumulator sets)"
+    if kt == 1 and ks == 3 and mode == 1 and c == 192 and n == 96:
+        return "conv2d_up_c192_kernel (direct 3x3 with the nearest-exact 2x upsample folded into the halo)"
+    return "gemm_ph_kernel<CONV> (8-wave implicit GEMM, LDS-DMA gather, 256 x 192 tile at Cout = 192 / 384)"
+
+
 def vae_entries(cprof, top=3):
     """roofline entries of the tiled VAE decode's dominant convolution launches (BASELINE config 4) from per-launch events
     (ops.PROFILE_CONV): launches are grouped by shape; per group algorithmic FLOPs = 2 rows Cout (kt ks^2 Cin), algorithmic bytes =
@@ -170,14 +179,7 @@ def vae_entries(cprof, top=3):
         in_rows = rows // 4 if mode == 1 else (rows * 4 if mode == 2 else rows)      # the nearest-exact 2x upsample / stride-2 read
         by = in_rows * c * 2 + n * taps * c * 2 + rows * n * 2 * (2 if has_resid else 1)
         avg = sum(ms) / len(ms)
-        if kt == 3 and ks == 3 and mode == 0 and c == 96 and (n == 96 or n <= 16):
-            kern = "conv3d_c96_kernel (direct 3x3x3, halo staged once per frame, three temporal accumulator sets)"
-        elif kt == 3 and ks == 3 and mode == 0 and c % 64 == 0 and n % 16 == 0 and c >= 192:
-            kern = f"conv3d_wide_kernel<{c}> (direct 3x3x3 at the {c}-channel level)"
-        elif kt == 1 and ks == 3 and mode == 1 and c == 192:
-            kern = "conv2d_up_c192_kernel (direct 3x3 with the nearest-exact 2x upsample folded into the halo)"
-        else:
-            kern = "gemm_ph_kernel<CONV> (implicit GEMM, LDS-DMA gather)"
+        kern = conv_kernel_name(kt, ks, mode, c, n)
         what = f"{kt}x{ks}x{ks} conv {c}->{n} over {rows} output pixels" + (" +residual" if has_resid else "") + \
                (" (2x upsample folded in)" if mode == 1 else " (stride 2)" if mode == 2 else "")
         traffic, src = static_traffic(f"vae_conv_c{c}_n{n}_k{kt}{ks}_m{mode}")
