@@ -26,14 +26,14 @@ SYMBOLS = (
     "gf_flash_attn_fwd_lse", "gf_flash_attn_bwd", "gf_flash_attn_bwd_workspace_bytes",
     "gf_layernorm_bwd", "gf_rmsnorm_rope_bwd", "gf_colsum", "gf_act_bwd", "gf_mse_loss", "gf_adamw_step", "gf_f32_to_bf16", "gf_sumsq",
     "gf_transpose_v", "gf_flash_attn_fwd_vt", "gf_transpose_v32", "gf_flash_attn_fwd_vt32", "gf_linear_vt32",
-    "gf_conv3d_bf16", "gf_gemm_bf16_batched", "gf_transpose_pad_batched",
+    "gf_conv3d_bf16", "gf_conv3d_padded_bf16", "gf_vae_rmsnorm_silu_padded", "gf_gemm_bf16_batched", "gf_transpose_pad_batched",
     "gf_resize_lanczos4_u8", "gf_resize_area_u8", "gf_canny_u8", "gf_flash_attn_fwd_lastmult",
 )
 
 # the C ABI revision these bindings were written against (csrc/gf_abi.hip: GF_ABI_VERSION).  A stale or foreign .so whose entry
 # points take differently sized buffers (gf_flash_attn_bwd's workspace grew 3x between revisions 7 and 10 under an unchanged
 # signature) is refused at load time instead of overrunning memory.
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 EPI_BIAS, EPI_BIAS_GELU_TANH, EPI_BIAS_GATE_RESID, EPI_BIAS_RESID, EPI_BIAS_SILU, EPI_BIAS_MUL = range(6)
 
@@ -93,6 +93,8 @@ def _declare(lib):
                            _i64, _i64, _int, _vp, _i64, _vp],
         "gf_vae_finish_latent": [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp],
         "gf_vae_rmsnorm_silu": [_vp, _vp, _vp, _i64, _i64, _int, _vp],
+        "gf_vae_rmsnorm_silu_padded": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp],
+        "gf_conv3d_padded_bf16": [_vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _int, _vp, _i64, _vp],
         "gf_softmax_rows": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _f32, _vp],
         "gf_transpose_pad": [_vp, _i64, _vp, _i64, _i64, _i64, _vp],
         "gf_transpose_pad_batched": [_vp, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _vp],

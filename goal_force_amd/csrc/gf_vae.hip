@@ -196,9 +196,11 @@ __global__ __launch_bounds__(VT) void rmsnorm_silu_kernel(const u16* __restrict_
 // ~4.9 TB/s): LP lanes per pixel with THREE 16-byte chunks each (sub, sub + LP, sub + 2 LP), every lane live.  The row sum is the same
 // tree as above — its two top butterfly stages pair chunk c with c ^ 2 LP and c ^ LP, which are now additions inside the lane
 // ((p[sub] + p[sub + 2 LP]) + (p[sub + LP] + 0)) — so the results are bit-identical to rmsnorm_silu_kernel<4 LP>.
-template <int LP>
+// PAD: the output is the interior of a zero-bordered buffer [T][H + 2][W + 2][C] (gf_conv_a4.hip): pixel (t, y, x) of the contiguous
+// input goes to row (t (H + 2) + y) (W + 2) + x behind `out` (which points at the interior's first pixel); hw = H W, w = W.
+template <int LP, bool PAD = false>
 __global__ __launch_bounds__(VT) void rmsnorm_silu3_kernel(const u16* __restrict__ x, const u16* __restrict__ gamma,
-                                                           u16* __restrict__ out, long rows, float scale, int silu) {
+                                                           u16* __restrict__ out, long rows, float scale, int silu, int hw = 0, int w = 0) {
     constexpr int RPW = 64 / LP, C = 24 * LP;
     const int lane = threadIdx.x & 63;
     const int sub = lane & (LP - 1);
@@ -240,6 +242,12 @@ __global__ __launch_bounds__(VT) void rmsnorm_silu3_kernel(const u16* __restrict
             const float nrm = fmaxf(rbf(sqrtf(s)), 1e-12f);
             const float rinv = 1.0f / nrm;
             if (rowi[u] < rows) {
+                long orow = rowi[u];
+                if constexpr (PAD) {
+                    const int t = (int)(rowi[u] / hw), rem = (int)(rowi[u] - (long)t * hw);
+                    const int y = rem / w, xx = rem - y * w;
+                    orow = ((long)t * (hw / w + 2) + y) * (w + 2) + xx;
+                }
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     u32x4 o;
@@ -261,7 +269,7 @@ __global__ __launch_bounds__(VT) void rmsnorm_silu3_kernel(const u16* __restrict
                         }
                         o[p] = r;
                     }
-                    *reinterpret_cast<u32x4*>(out + rowi[u] * C + ((sub + k * LP) << 3)) = o;
+                    *reinterpret_cast<u32x4*>(out + orow * C + ((sub + k * LP) << 3)) = o;
                 }
             }
         }
@@ -458,6 +466,30 @@ extern "C" GF_API int gf_vae_rmsnorm_silu(const void* x, const void* gamma, void
 #undef GF_RMS_LAUNCH
 #undef GF_RMS3_LAUNCH
     GF_CHECK_LAUNCH("gf_vae_rmsnorm_silu");
+    return GF_OK;
+}
+
+// RMS_norm (+SiLU) of a contiguous [T, H, W, C] activation written into the INTERIOR of a zero-bordered buffer [T][H + 2][W + 2][C]:
+// `out_interior` = the address of padded pixel (frame 0, y = 1, x = 1), i.e. of the first real pixel.  Same arithmetic, same kernel
+// as gf_vae_rmsnorm_silu (C = 192 / 384: the three-chunk kernel); the borders are the caller's (zero them once).
+extern "C" GF_API int gf_vae_rmsnorm_silu_padded(const void* x, const void* gamma, void* out_interior, int64_t T, int64_t H, int64_t W,
+                                                 int64_t C, int silu, void* stream) {
+    GF_CHECK_ARG(x && gamma && out_interior && T >= 0 && H > 0 && W > 0, "gf_vae_rmsnorm_silu_padded: bad arguments");
+    if (!(C == 192 || C == 384)) {
+        gf_set_error("gf_vae_rmsnorm_silu_padded: C=%ld (192 or 384: the levels whose convolutions read the padded layout)", (long)C);
+        return GF_ERR_UNSUPPORTED;
+    }
+    GF_CHECK_ARG(gf_aligned16(x) && gf_aligned16(out_interior) && gf_aligned16(gamma), "gf_vae_rmsnorm_silu_padded: alignment");
+    GF_CHECK_ARG(T * H * W < (1LL << 31) && H * W < (1LL << 30), "gf_vae_rmsnorm_silu_padded: too many pixels");
+    const long rows = T * H * W;
+    if (rows == 0) return GF_OK;
+    if (C == 192)
+        hipLaunchKernelGGL((rmsnorm_silu3_kernel<8, true>), dim3(vgrid(rows * 8)), dim3(VT), 0, (hipStream_t)stream, (const u16*)x,
+                           (const u16*)gamma, (u16*)out_interior, rows, sqrtf((float)C), silu ? 1 : 0, (int)(H * W), (int)W);
+    else
+        hipLaunchKernelGGL((rmsnorm_silu3_kernel<16, true>), dim3(vgrid(rows * 16)), dim3(VT), 0, (hipStream_t)stream, (const u16*)x,
+                           (const u16*)gamma, (u16*)out_interior, rows, sqrtf((float)C), silu ? 1 : 0, (int)(H * W), (int)W);
+    GF_CHECK_LAUNCH("gf_vae_rmsnorm_silu_padded");
     return GF_OK;
 }
 

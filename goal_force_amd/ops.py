@@ -205,9 +205,10 @@ VT_MIN_KV = 2048   # key sequences at least this long go through the pre-transpo
 # the SAME operands, which needs a way to route a shape to the kernel that would not get it by default.  Nothing here (and nothing
 # in the library) reads an environment variable: the defaults are the shipped dispatch and only `options(...)` changes them.
 #   library side (gf_set_option): prefer_8wave, a4_stagger, a4_group_m, conv_nb, conv_gather, conv_direct, vae_rms3
-#   this module: attn_k3 (False: long key sequences on kernel 2), vt_from_gemm (False: V^T by gf_transpose_v32, not by the V projection)
+#   this module: attn_k3 (False: long key sequences on kernel 2), vt_from_gemm (False: V^T by gf_transpose_v32, not by the V projection),
+#                conv_padded (False: the VAE's 192 / 384-channel 3x3x3 convolutions on gf_conv3d_bf16 instead of the padded-layout kernel)
 _LIB_DEFAULTS = {"prefer_8wave": 0, "a4_stagger": 2, "a4_group_m": 0, "conv_nb": 0, "conv_gather": 0, "conv_direct": 1, "vae_rms3": 1}
-_OPT = {"attn_k3": True, "vt_from_gemm": True}
+_OPT = {"attn_k3": True, "vt_from_gemm": True, "conv_padded": True}
 _LIB_OPT = dict(_LIB_DEFAULTS)
 
 
@@ -586,6 +587,66 @@ def vae_conv3d(src, cache, w, bias, kt, ks, upsample2x=False, downsample2=False,
     if prof is not None:
         e1.record()
         prof.append((e0, e1, t_out * px, n, C, kt, ks, mode, resid is not None))
+    return out
+
+
+PADDED_CONV_CHANNELS = (192, 384)     # the levels whose 3x3x3 convolutions run on gf_conv3d_padded_bf16
+
+
+def padded_activation(T, H, W, C, device):
+    """A zero-bordered conv input [2 + T, H + 2, W + 2, C] (gf_conv3d_padded_bf16) and two views of it: the two history frames'
+    interior [2, H, W, C] and the T frames' interior [T, H, W, C].  Zeroed once here; producers only ever write the interiors."""
+    buf = torch.zeros((T + 2, H + 2, W + 2, C), dtype=_BF16, device=device)
+    return buf, buf[:2, 1:H + 1, 1:W + 1], buf[2:, 1:H + 1, 1:W + 1]
+
+
+def vae_rmsnorm_silu_padded(x, gamma, buf, silu=True):
+    """RMS_norm(+SiLU) of the contiguous x [T, H, W, C] into frames [2:] of the zero-bordered buffer `buf` [2 + T, H + 2, W + 2, C]."""
+    _req(x, "vae_rmsnorm_silu_padded.x")
+    _req(gamma, "vae_rmsnorm_silu_padded.gamma")
+    _req(buf, "vae_rmsnorm_silu_padded.buf")
+    T, H, W, C = x.shape
+    if not x.is_contiguous() or not buf.is_contiguous() or tuple(buf.shape) != (T + 2, H + 2, W + 2, C) or gamma.numel() != C:
+        raise GoalForceError("vae_rmsnorm_silu_padded: x [T,H,W,C] contiguous, buf [T+2,H+2,W+2,C] contiguous")
+    interior = buf[2, 1, 1]
+    _lib.check(_lib.load().gf_vae_rmsnorm_silu_padded(_ptr(x), _ptr(gamma), interior.data_ptr(), T, H, W, C, 1 if silu else 0, _stream(x)),
+               "gf_vae_rmsnorm_silu_padded")
+    return buf[2:, 1:H + 1, 1:W + 1]
+
+
+def vae_conv3d_padded(buf, w, bias, n_out=None, resid=None, out=None):
+    """CausalConv3d 3x3x3 on the zero-bordered activation `buf` [2 + T, H + 2, W + 2, C] (frames 0, 1 = history) x w [N, >= 27 C]
+    -> [T*H*W, N]; resid [T*H*W, >= N] is added after the bf16 rounding of conv + bias.  Bit-identical to vae_conv3d."""
+    _req(buf, "vae_conv3d_padded.buf")
+    _req(w, "vae_conv3d_padded.w")
+    if buf.dim() != 4 or not buf.is_contiguous():
+        raise GoalForceError("vae_conv3d_padded.buf must be contiguous [2+T, H+2, W+2, C]")
+    T, H, W, C = buf.shape[0] - 2, buf.shape[1] - 2, buf.shape[2] - 2, buf.shape[3]
+    n = w.shape[0]
+    if w.dim() != 2 or w.stride(1) != 1 or w.shape[1] < 27 * C:
+        raise GoalForceError("vae_conv3d_padded.w must be [N, >= 27 C] with contiguous rows")
+    if out is None:
+        out = torch.empty((T * H * W, n), dtype=_BF16, device=buf.device)
+    elif out.dim() != 2 or out.shape != (T * H * W, n) or out.stride(1) != 1:
+        raise GoalForceError("vae_conv3d_padded.out must be [T*H*W, N] with contiguous rows")
+    ldr = 0
+    if bias is not None:
+        _req(bias, "vae_conv3d_padded.bias")
+    if resid is not None:
+        _req(resid, "vae_conv3d_padded.resid")
+        if resid.dim() != 2 or resid.shape[0] != T * H * W or resid.stride(1) != 1:
+            raise GoalForceError("vae_conv3d_padded.resid must be [T*H*W, >= N] with contiguous rows")
+        ldr = resid.stride(0)
+    prof = PROFILE_CONV
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.check(_lib.load().gf_conv3d_padded_bf16(_ptr(buf), _ptr(w), w.stride(0), _ptr(bias), _ptr(out), out.stride(0), T, H, W, C, n,
+                                                 EPI_BIAS if resid is None else EPI_BIAS_RESID, _ptr(resid), ldr, _stream(buf)),
+               "gf_conv3d_padded_bf16")
+    if prof is not None:
+        e1.record()
+        prof.append((e0, e1, T * H * W, n, C, 3, 3, 3, resid is not None))      # mode 3 = the padded-layout direct kernel
     return out
 
 

@@ -226,6 +226,7 @@ class WanVideoVAE(nn.Module):
         self.z_dim = z_dim
         self._prepared = None     # GEMM-ready weights (built lazily, invalidated on load)
         self._cache: Dict[str, torch.Tensor] = {}
+        self._pad_pool: Dict[tuple, list] = {}    # zero-bordered conv inputs by shape (_padded_buffer)
         # latent frames per decoder call / 4-frame chunks per encoder call after the first frame (1 = the reference's streaming
         # granularity; any value gives the same bits).  20 = the whole 81-frame clip of a tile: ~10 GB of activations.
         self.frames_per_chunk = int(os.environ.get("GF_VAE_FRAMES_PER_CHUNK", "20"))
@@ -315,9 +316,47 @@ class WanVideoVAE(nn.Module):
                             epilogue=ops.EPI_BIAS if resid is None else ops.EPI_BIAS_RESID, resid=r2).view(T, H, W, -1)
         return _conv(x, cache, c, resid=r2).view(T, H, W, -1)
 
+    def _padded_conv(self, P, name, x, gamma, resid=None):
+        """RMS_norm + SiLU + CausalConv3d 3x3x3 of a 192- / 384-channel level (VAE:267-301, 33-52) through the zero-bordered layout of
+        gf_conv3d_padded_bf16: the norm writes the interior of the padded buffer, the two cached history frames are copied into the
+        interior of its first two frames (zeros without a history), the convolution reads taps as constant row shifts.  Same values,
+        same sums as _causal_conv: bit-identical."""
+        c = P[name]
+        T, H, W, C = x.shape
+        buf, hist, _ = self._padded_buffer(T, H, W, C, x.device)
+        cur = ops.vae_rmsnorm_silu_padded(x, gamma, buf, silu=True)
+        cache = self._cache.get(name)
+        if cache is None:
+            hist.zero_()
+            cache = torch.zeros((CACHE_T, H, W, C), dtype=x.dtype, device=x.device)
+        else:
+            hist.copy_(cache)
+        # the feature cache after the chunk: the last two frames of [cache, x] (VAE:283-294), as a contiguous copy
+        if T >= CACHE_T:
+            nxt = torch.empty((CACHE_T, H, W, C), dtype=x.dtype, device=x.device)
+            nxt.copy_(cur[-CACHE_T:])
+        else:
+            nxt = torch.cat([cache[T - CACHE_T:], cur.contiguous()], dim=0)
+        self._cache[name] = nxt
+        r2 = None if resid is None else resid.reshape(T * H * W, -1)
+        return ops.vae_conv3d_padded(buf, c["w"], c["b"], resid=r2).view(T, H, W, -1)
+
+    def _padded_buffer(self, T, H, W, C, device):
+        """One zero-bordered buffer per shape: zeroed when created, afterwards only its interior is written.  One is enough — every
+        producer and consumer of it runs on the same stream, and a residual block's second conv input is built after the first
+        convolution has read the buffer.  decode() / encode() drop the pool when they return."""
+        key = (T, H, W, C, str(device))
+        if key not in self._pad_pool:
+            self._pad_pool[key] = ops.padded_activation(T, H, W, C, device)
+        return self._pad_pool[key]
+
     def _res_block(self, P, name, x, cin, cout):
         """ResidualBlock (VAE:267-301)."""
         h = x if cin == cout else self._causal_conv(P, name + ".shortcut", x)
+        if IMPLICIT_CONV and ops._OPT["conv_padded"] and cin in ops.PADDED_CONV_CHANNELS and cout in ops.PADDED_CONV_CHANNELS \
+                and x.is_contiguous():
+            y = self._padded_conv(P, name + ".residual.2", x, P[name + ".residual.0.gamma"])
+            return self._padded_conv(P, name + ".residual.6", y, P[name + ".residual.3.gamma"], resid=h)
         front, y = _with_history(x.shape, x)
         ops.vae_rmsnorm_silu(x, P[name + ".residual.0.gamma"], silu=True, out=y)
         y = self._causal_conv(P, name + ".residual.2", y, front=front)
@@ -524,6 +563,7 @@ class WanVideoVAE(nn.Module):
             else:
                 z = self.single_encode(v, device)
             outs.append(z.squeeze(0))
+        self._pad_pool = {}
         return torch.stack(outs)
 
     # ---------------------------------------------------------------- public API (VAE:1103-1152, 1211-1247)
@@ -593,5 +633,6 @@ class WanVideoVAE(nn.Module):
             v = (self.tiled_decode(hs, device, tile_size, tile_stride, tile_group=tile_group) if tiled
                  else self.single_decode(hs, device))
             videos.append(v.squeeze(0))
+        self._pad_pool = {}
         return torch.stack(videos)
 

@@ -445,6 +445,20 @@ GF_API int gf_gemm_fp8(const void* A8, int64_t lda, const void* W8, int64_t ldw,
                        const void* bias, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                        int epilogue, const void* resid, int64_t ldr, const void* gate, void* stream);
 
+/* ------------------------------------------------------------------------
+ * gf_conv3d_padded_bf16 — CausalConv3d 3x3x3, stride 1 (VAE:33-52) of the 192- and 384-channel levels of Decoder3d / Encoder3d
+ * (VAE:736-838, 517-617) as a direct convolution on the 4-wave GEMM loop (gf_conv_a4.hip).
+ *   xp   : zero-bordered activation [2 + T][H + 2][W + 2][C] bf16 — frames 0, 1 = the two cached history frames (zeros = no
+ *          history), one pixel of zeros around every frame; real pixel (t, y, x) at [2 + t][1 + y][1 + x]
+ *   Wm   : [N, ldw] bf16, K order (dt, dy, dx, cin), ldw >= 27 C
+ *   out  : [T H W, ldo] bf16 = conv + bias (GF_EPI_BIAS) or resid + bf16(conv + bias) (GF_EPI_BIAS_RESID, resid [T H W, ldr])
+ * C = 192 or 384; results bit-identical to gf_conv3d_bf16 on the same values.  The caller owns every buffer; no workspace.
+ * gf_vae_rmsnorm_silu_padded — gf_vae_rmsnorm_silu writing into the interior of such a buffer: out_interior = &xp[f][1][1][0]. */
+GF_API int gf_conv3d_padded_bf16(const void* xp, const void* Wm, int64_t ldw, const void* bias, void* out, int64_t ldo, int64_t T,
+                                 int64_t H, int64_t W, int64_t C, int64_t N, int epilogue, const void* resid, int64_t ldr, void* stream);
+GF_API int gf_vae_rmsnorm_silu_padded(const void* x, const void* gamma, void* out_interior, int64_t T, int64_t H, int64_t W, int64_t C,
+                                      int silu, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -217,6 +217,78 @@ def test_hip_direct_conv_c96_equals_implicit_gemm_at_tile_size():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("T,H,W,C,N", [(1, 4, 6, 192, 192), (3, 10, 14, 192, 384), (2, 30, 52, 384, 384), (5, 17, 23, 384, 384),
+                                       (3, 60, 104, 192, 192), (2, 120, 208, 192, 192)])
+def test_hip_padded_layout_conv_equals_implicit_gemm(T, H, W, C, N):
+    """The 3x3x3 causal convolutions of the 192- / 384-channel levels on the padded-layout kernel (gf_conv_a4.hip: the activation in a
+    zero-bordered buffer, taps as constant row shifts, the 4-wave GEMM loop on a 256 x 192 tile) against the implicit GEMM
+    (gf_conv3d_bf16) on the same values — bit for bit, with a non-zero two-frame history, with and without the residual; sizes
+    from one ragged row tile to a production tile's frames (120 x 208: 26 k padded rows per frame, rows of the border dropped)."""
+    from goal_force_amd import ops
+    g = torch.Generator().manual_seed(T * 100 + H + C + N)
+    k = 27 * C
+    hist_and_x = (torch.randn((T + 2, H, W, C), generator=g) * 0.7).to(BF).cuda()
+    w = (torch.randn((N, k), generator=g) / k ** 0.5).to(BF).cuda()
+    b = torch.randn((N,), generator=g).to(BF).cuda()
+    resid = torch.randn((T * H * W, N), generator=g).to(BF).cuda()
+    with ops.options(conv_direct=0):
+        ref = ops.vae_conv3d(hist_and_x[2:], None, w, b, 3, 3, history_in_front=True)
+        ref_r = ops.vae_conv3d(hist_and_x[2:], None, w, b, 3, 3, resid=resid, history_in_front=True)
+    buf, hist, cur = ops.padded_activation(T, H, W, C, "cuda")
+    hist.copy_(hist_and_x[:2])
+    cur.copy_(hist_and_x[2:])
+    got = ops.vae_conv3d_padded(buf, w, b)
+    assert got.shape == ref.shape == (T * H * W, N)
+    assert torch.equal(got, ref), f"{int((got != ref).sum())} of {ref.numel()} differ"
+    assert torch.equal(ops.vae_conv3d_padded(buf, w, b, resid=resid), ref_r)
+    assert float(ref.float().abs().max()) > 0.5
+    # the borders are the zero padding: a buffer whose border was scribbled on gives other values (the test would be vacuous otherwise)
+    if H * W <= 400:
+        buf[:, 0].fill_(1.0)
+        assert not torch.equal(ops.vae_conv3d_padded(buf, w, b), ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C", [192, 384])
+def test_hip_rmsnorm_silu_into_the_padded_layout(C):
+    """gf_vae_rmsnorm_silu_padded writes exactly gf_vae_rmsnorm_silu's values into the interior of the zero-bordered buffer and
+    leaves the border and the history frames alone."""
+    from goal_force_amd import ops
+    g = torch.Generator().manual_seed(C + 1)
+    T, H, W = 3, 9, 13
+    x = (torch.randn((T, H, W, C), generator=g) * 2.5).to(BF).cuda()
+    gam = (1 + 0.1 * torch.randn(C, generator=g)).to(BF).cuda()
+    buf, hist, cur = ops.padded_activation(T, H, W, C, "cuda")
+    hist.fill_(3.0)
+    for silu in (True, False):
+        view = ops.vae_rmsnorm_silu_padded(x, gam, buf, silu=silu)
+        assert torch.equal(view, ops.vae_rmsnorm_silu(x, gam, silu=silu)) and view.data_ptr() == cur.data_ptr()
+        assert float(buf[:, 0].abs().sum()) == 0 and float(buf[:, -1].abs().sum()) == 0
+        assert float(buf[:, :, 0].abs().sum()) == 0 and float(buf[:, :, -1].abs().sum()) == 0 and bool((hist == 3.0).all())
+
+
+@pytest.mark.gpu
+def test_hip_decoder_tile_same_bits_on_both_conv_paths():
+    """One whole decoder tile (all levels, the feature caches across chunks) with the 192- / 384-channel convolutions on the
+    padded-layout kernel and on the implicit GEMM (options(conv_padded=False)): the same frames, bit for bit; likewise the encoder."""
+    from goal_force_amd import ops
+    from goal_force_amd.vae import WanVideoVAE
+    torch.manual_seed(11)
+    vae = WanVideoVAE().to(BF).cuda()
+    vae.frames_per_chunk = 2
+    z = torch.randn((16, 5, 8, 12)).to(BF).cuda()
+    got = vae.decode_tile_channels_last(z)
+    with ops.options(conv_padded=False):
+        ref = vae.decode_tile_channels_last(z)
+    assert torch.equal(got, ref) and tuple(got.shape) == (17, 64, 96, 8)
+    video = (torch.rand((3, 9, 64, 96)) * 2 - 1).to(BF).cuda()
+    e = vae.encode_tile_channels_last(video)
+    with ops.options(conv_padded=False):
+        e_ref = vae.encode_tile_channels_last(video)
+    assert torch.equal(e, e_ref)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("C", [96, 192, 384])
 def test_hip_rmsnorm_silu_three_chunk_kernel_is_bit_identical(C):
     """RMS_norm (+SiLU) at C = 96 / 192 / 384: the all-lanes-live kernel (three chunks per lane, the row sum's two top butterfly stages
