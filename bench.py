@@ -67,7 +67,7 @@ def static_traffic(key):
     now = source_sha256(e["sources"])
     if now != e["sources_sha256"]:
         msg = (f"STALE: {', '.join(e['sources'])} changed since the PMC pass {e['from']} (sha256 {e['sources_sha256'][:12]} -> "
-               f"{now[:12]}): re-run tools/profile_r04.sh + tools/pmc_static.py")
+               f"{now[:12]}): re-run tools/profile_r05.sh + tools/pmc_static.py")
         print(f"bench.py: roofline traffic for {key} withheld — {msg}", file=sys.stderr)
         return None, msg
     return int(e["bytes_per_launch"]), f"{e['from']} (kernel sources sha256 {now[:12]}, library {tab.get('gf_version', '?')})"
@@ -156,6 +156,8 @@ def cpu_baseline(torch, runs=3):
 
 def conv_kernel_name(kt, ks, mode, c, n):
     """Which kernel gf_conv3d_bf16 sends a shape to (gf_gemm.hip::gf_conv3d_bf16, the same rules)."""
+    if mode == 3:
+        return "conv_a4_kernel (direct 3x3x3 on the 4-wave GEMM loop: zero-bordered activation, taps as row shifts, 256 x 192 tile)"
     if kt == 3 and ks == 3 and mode == 0 and c == 96 and (n == 96 or n <= 16):
         return "conv3d_c96_kernel (direct 3x3x3, halo staged once per frame, three temporal accumulator sets)"
     if kt == 1 and ks == 3 and mode == 1 and c == 192 and n == 96:
@@ -181,7 +183,7 @@ def vae_entries(cprof, top=3):
         avg = sum(ms) / len(ms)
         kern = conv_kernel_name(kt, ks, mode, c, n)
         what = f"{kt}x{ks}x{ks} conv {c}->{n} over {rows} output pixels" + (" +residual" if has_resid else "") + \
-               (" (2x upsample folded in)" if mode == 1 else " (stride 2)" if mode == 2 else "")
+               (" (2x upsample folded in)" if mode == 1 else " (stride 2)" if mode == 2 else "")      # (mode 3 = the padded layout: a few per cent more rows are read; the figures stay the algorithmic ones)
         traffic, src = static_traffic(f"vae_conv_c{c}_n{n}_k{kt}{ks}_m{mode}")
         out.append({"bound": "mfma", "kernel": kern, "launch": what, "achieved": fl / (avg * 1e-3) / 1e12, "peak": PEAK_BF16_TFLOPS,
                     "unit": "TFLOP/s", "frac": fl / (avg * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_static": True,

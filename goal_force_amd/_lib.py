@@ -26,7 +26,7 @@ SYMBOLS = (
     "gf_flash_attn_fwd_lse", "gf_flash_attn_bwd", "gf_flash_attn_bwd_workspace_bytes",
     "gf_layernorm_bwd", "gf_rmsnorm_rope_bwd", "gf_colsum", "gf_act_bwd", "gf_mse_loss", "gf_adamw_step", "gf_f32_to_bf16", "gf_sumsq",
     "gf_transpose_v", "gf_flash_attn_fwd_vt", "gf_transpose_v32", "gf_flash_attn_fwd_vt32", "gf_linear_vt32",
-    "gf_conv3d_bf16", "gf_conv3d_padded_bf16", "gf_vae_rmsnorm_silu_padded", "gf_gemm_bf16_batched", "gf_transpose_pad_batched",
+    "gf_conv3d_bf16", "gf_conv3d_padded_bf16", "gf_vae_rmsnorm_silu_padded", "gf_vae_upsample2x_padded", "gf_gemm_bf16_batched", "gf_transpose_pad_batched",
     "gf_resize_lanczos4_u8", "gf_resize_area_u8", "gf_canny_u8", "gf_flash_attn_fwd_lastmult",
 )
 
@@ -94,7 +94,8 @@ def _declare(lib):
         "gf_vae_finish_latent": [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp],
         "gf_vae_rmsnorm_silu": [_vp, _vp, _vp, _i64, _i64, _int, _vp],
         "gf_vae_rmsnorm_silu_padded": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp],
-        "gf_conv3d_padded_bf16": [_vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _int, _vp, _i64, _vp],
+        "gf_conv3d_padded_bf16": [_vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _int, _vp, _i64, _vp],
+        "gf_vae_upsample2x_padded": [_vp, _vp, _i64, _i64, _i64, _i64, _vp],
         "gf_softmax_rows": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _f32, _vp],
         "gf_transpose_pad": [_vp, _i64, _vp, _i64, _i64, _i64, _vp],
         "gf_transpose_pad_batched": [_vp, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _vp],

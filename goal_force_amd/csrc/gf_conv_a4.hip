@@ -31,8 +31,9 @@ struct ConvA4Args {
     u16* out;           // [T H W, ldo]
     const u16* resid;   // [T H W, ldr] (GF_EPI_BIAS_RESID)
     int T, H, W, C, N;
+    int kt;             // temporal taps: 3 (causal 3x3x3, two history frames in front of xp) or 1 (3x3 per frame, no history frames)
     long ldw, ldo, ldr;
-    long xp_rows;       // rows of xp = (2 + T)(H + 2)(W + 2)
+    long xp_rows;       // rows of xp = (kt - 1 + T)(H + 2)(W + 2)
     int tiles_m, tiles_n;
 };
 
@@ -87,11 +88,11 @@ __global__ __launch_bounds__(CA_THREADS, 1) void conv_a4_kernel(const ConvA4Args
     const long left = (p.xp_rows - m0) * (long)rowA;
     const unsigned nrA = left > 0 ? (unsigned)(left < 0xffffffffL ? left : 0xffffffffL) : 0u;
     const int wvalid = min(p.N - n0, CA_BN);
-    const unsigned nrB = wvalid > 0 ? (unsigned)(((long)(wvalid - 1) * p.ldw + 27L * p.C) * 2) : 0u;
+    const unsigned nrB = wvalid > 0 ? (unsigned)(((long)(wvalid - 1) * p.ldw + 9L * p.kt * p.C) * 2) : 0u;
     const unsigned stA = 32u * rowA, stB = 32u * rowB;
     const unsigned soA = (unsigned)wave * 8u * rowA, soB = (unsigned)wave * 8u * rowB;
     const unsigned ldsW = (unsigned)(unsigned long)lds + (unsigned)wave * 1024u;
-    const unsigned nk = 27u * (unsigned)p.C / 64u;
+    const unsigned nk = 9u * (unsigned)p.kt * (unsigned)p.C / 64u;
     const unsigned run = 3u * (unsigned)p.C / 64u;                                  // K tiles of a pixel row's three taps
     const unsigned jr = (unsigned)Wp * rowA - 3u * rowA + 128u;                    // last tile of a run -> first tile of the next pixel row
     const unsigned jf = (unsigned)Hp * (unsigned)Wp * rowA - 2u * (unsigned)Wp * rowA - 3u * rowA + 128u;   // ... -> first row of the next frame
@@ -116,6 +117,35 @@ __global__ __launch_bounds__(CA_THREADS, 1) void conv_a4_kernel(const ConvA4Args
 
     // ---- epilogue: a[(i*8+j)*4 + r] = C[m0 + wm*128 + 16 i + frow][n0 + wn*96 + 16 j + 4 fq + r]  (the asm ended on a barrier)
     GF_LDS char* ep = lds + wave * 32768;   // private 128 rows x 256 B (192 used); 8-byte slot s of row r at slot s ^ ((r & 15) << 1)
+    // output rows of this lane's 8 store passes (a lane stores three 16-byte chunks = 48 B of one row: 4 lanes per row, 16 rows per
+    // pass) and, with a residual, its 24 pieces — requested FIRST (96 VGPRs: the fragment registers are free now), so that their HBM
+    // latency passes under the accumulator conversion below (inside the store loop they cost 0.39 of 3.3 ms at the 192-channel level)
+    const int rl = lane >> 2, c3 = (lane & 3) * 3;
+    const int ncol = n0 + wn * 96 + c3 * 8;
+    int orow[8];            // T H W < 2^31 (checked by the launcher)
+    {
+        const int frame = Hp * Wp;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int m = m0 + wm * 128 + it * 16 + rl;        // padded position
+            const int t = m / frame, rem = m - t * frame;
+            const int y = rem / Wp, x = rem - y * Wp;
+            orow[it] = (t < p.T && y < p.H && x < p.W) ? (t * p.H + y) * p.W + x : -1;
+        }
+    }
+    constexpr bool HAS_R = EPI == GF_EPI_BIAS_RESID;
+    u16x8 rres[HAS_R ? 24 : 1];
+    if constexpr (HAS_R) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int nn = ncol + c * 8;
+                rres[it * 3 + c] = (orow[it] >= 0 && nn < p.N)
+                                       ? __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(p.resid + (long)orow[it] * p.ldr + nn))
+                                       : u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+    }
     ca_static_for<0, 6>([&](auto j_c) {
         constexpr int j = decltype(j_c)::value;
         const float bv[4] = {bf2f(bpre[j][0]), bf2f(bpre[j][1]), bf2f(bpre[j][2]), bf2f(bpre[j][3])};
@@ -132,31 +162,22 @@ __global__ __launch_bounds__(CA_THREADS, 1) void conv_a4_kernel(const ConvA4Args
     });
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private image: LDS is in order, no barrier needed
     {
-        // a lane stores three 16-byte chunks (48 B) of one row: 4 lanes per row, 16 rows per pass, 8 passes
-        const int rl = lane >> 2, c3 = (lane & 3) * 3;
-        const int n = n0 + wn * 96 + c3 * 8;
-        const int frame = Hp * Wp;
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int row = it * 16 + rl;
-            const int m = m0 + wm * 128 + row;                 // padded position
-            const int t = m / frame, rem = m - t * frame;
-            const int y = rem / Wp, x = rem - y * Wp;
-            const bool ok = t < p.T && y < p.H && x < p.W;
-            const long orow = ((long)t * p.H + y) * p.W + x;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const int cc = c3 + c;
                 const u16x8 yv = *(GF_LDS u16x8*)(ep + row * 256 + ((cc ^ (row & 15)) << 4));
-                const int nn = n + c * 8;
-                if (ok && nn < p.N) {
+                const int nn = ncol + c * 8;
+                if (orow[it] >= 0 && nn < p.N) {
                     u16x8 o = yv;
-                    if constexpr (EPI == GF_EPI_BIAS_RESID) {
-                        const u16x8 r8 = __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(p.resid + orow * p.ldr + nn));
+                    if constexpr (HAS_R) {
+                        const u16x8 r8 = rres[it * 3 + c];
 #pragma unroll
                         for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(r8[e]) + bf2f(yv[e]));
                     }
-                    *reinterpret_cast<u16x8*>(p.out + orow * p.ldo + nn) = o;
+                    __builtin_nontemporal_store(o, reinterpret_cast<u16x8*>(p.out + (long)orow[it] * p.ldo + nn));
                 }
             }
         }
@@ -180,23 +201,23 @@ int launch_conv_a4(const ConvA4Args& a, hipStream_t stream) {
 
 }  // namespace
 
-// See include/goalforce.h.  xp = the zero-bordered activation [2 + T, H + 2, W + 2, C] (frames 0, 1 = the causal history).
+// See include/goalforce.h.  xp = the zero-bordered activation [kt - 1 + T, H + 2, W + 2, C] (kt = 3: frames 0, 1 = the causal history).
 extern "C" GF_API int gf_conv3d_padded_bf16(const void* xp, const void* Wm, int64_t ldw, const void* bias, void* out, int64_t ldo,
-                                            int64_t T, int64_t H, int64_t W, int64_t C, int64_t N, int epilogue, const void* resid,
-                                            int64_t ldr, void* stream) {
-    GF_CHECK_ARG(xp && Wm && out && T > 0 && H > 0 && W > 0, "gf_conv3d_padded_bf16: bad arguments");
+                                            int64_t T, int64_t H, int64_t W, int64_t C, int64_t N, int64_t kt, int epilogue,
+                                            const void* resid, int64_t ldr, void* stream) {
+    GF_CHECK_ARG(xp && Wm && out && T > 0 && H > 0 && W > 0 && (kt == 1 || kt == 3), "gf_conv3d_padded_bf16: bad arguments (kt = 1 or 3)");
     if (!(C == 192 || C == 384) || N % 8 != 0 || N <= 0) {
         gf_set_error("gf_conv3d_padded_bf16: C=%ld / N=%ld outside the kernel's shapes (C = 192 or 384, N a multiple of 8)", (long)C, (long)N);
         return GF_ERR_UNSUPPORTED;
     }
     GF_CHECK_ARG(epilogue == GF_EPI_BIAS || (epilogue == GF_EPI_BIAS_RESID && resid && ldr >= N && ldr % 8 == 0),
                  "gf_conv3d_padded_bf16: epilogue must be BIAS or BIAS_RESID (with a residual of row stride >= N)");
-    GF_CHECK_ARG(ldw >= 27 * C && ldw % 8 == 0 && ldo >= N && ldo % 8 == 0, "gf_conv3d_padded_bf16: bad leading dimensions");
+    GF_CHECK_ARG(ldw >= 9 * kt * C && ldw % 8 == 0 && ldo >= N && ldo % 8 == 0, "gf_conv3d_padded_bf16: bad leading dimensions");
     GF_CHECK_ARG(gf_aligned16(xp) && gf_aligned16(Wm) && gf_aligned16(out) && (!resid || gf_aligned16(resid)) && (!bias || (((uintptr_t)bias) & 7u) == 0),
                  "gf_conv3d_padded_bf16: 16-byte alignment required (bias: 8)");
     const int64_t Hp = H + 2, Wp = W + 2;
-    const int64_t rows = (T + 2) * Hp * Wp;
-    GF_CHECK_ARG(rows * C * 2 < (1LL << 32) && N * ldw * 2 < (1LL << 32) && T * Hp * Wp < (1LL << 31),
+    const int64_t rows = (T + kt - 1) * Hp * Wp;
+    GF_CHECK_ARG(rows * C * 2 < (1LL << 32) && N * ldw * 2 < (1LL << 32) && T * Hp * Wp < (1LL << 31) && T * H * W < (1LL << 31),
                  "gf_conv3d_padded_bf16: the padded activation and the weights must each stay below 4 GiB");
     ConvA4Args a;
     a.xp = (const u16*)xp;
@@ -209,6 +230,7 @@ extern "C" GF_API int gf_conv3d_padded_bf16(const void* xp, const void* Wm, int6
     a.W = (int)W;
     a.C = (int)C;
     a.N = (int)N;
+    a.kt = (int)kt;
     a.ldw = ldw;
     a.ldo = ldo;
     a.ldr = ldr;

@@ -360,6 +360,29 @@ __global__ __launch_bounds__(VT) void transpose_pad64_kernel(const u16* __restri
     }
 }
 
+// nn.Upsample(scale_factor=(2, 2), mode="nearest-exact") (VAE:82-96) of a contiguous [T, H, W, C] activation, written into the
+// INTERIOR of a zero-bordered buffer [T][2 H + 2][2 W + 2][C] (the input layout of gf_conv3d_padded_bf16 with kt = 1): source pixel
+// (t, y, x) goes to the four pixels (2 y + a, 2 x + b).  One thread per 16-byte chunk of a source pixel.
+__global__ __launch_bounds__(VT) void upsample2x_padded_kernel(const u16* __restrict__ x, u16* __restrict__ out, long pixels, int H, int W,
+                                                               int cpp /* 16-byte chunks per pixel */) {
+    const long total = pixels * cpp;
+    const long stride = (long)gridDim.x * VT;
+    const int Wp = 2 * W + 2, Hp = 2 * H + 2;
+    for (long i = (long)blockIdx.x * VT + threadIdx.x; i < total; i += stride) {
+        const long pix = i / cpp;
+        const int ch = (int)(i - pix * cpp);
+        const int xx = (int)(pix % W);
+        const int y = (int)((pix / W) % H);
+        const long t = pix / ((long)W * H);
+        const u16x8 v = *reinterpret_cast<const u16x8*>(x + pix * (cpp * 8L) + ch * 8);
+        u16* o = out + ((t * Hp + 2 * y) * Wp + 2 * xx) * (cpp * 8L) + ch * 8;
+        *reinterpret_cast<u16x8*>(o) = v;
+        *reinterpret_cast<u16x8*>(o + cpp * 8L) = v;
+        *reinterpret_cast<u16x8*>(o + (long)Wp * cpp * 8L) = v;
+        *reinterpret_cast<u16x8*>(o + (long)(Wp + 1) * cpp * 8L) = v;
+    }
+}
+
 // Tile blend accumulate (WanVideoVAE.tiled_decode VAE:1128-1150, bf16 accumulators):
 //   values[c,t,Y,X] += tile[t,y,x,c] * mask(y,x);  weight[Y,X] += mask(y,x)
 // mask = min(ramp_h(y), ramp_w(x)) with ramps (i+1)/border on non-boundary sides (build_mask VAE:1081-1100).
@@ -490,6 +513,18 @@ extern "C" GF_API int gf_vae_rmsnorm_silu_padded(const void* x, const void* gamm
         hipLaunchKernelGGL((rmsnorm_silu3_kernel<16, true>), dim3(vgrid(rows * 16)), dim3(VT), 0, (hipStream_t)stream, (const u16*)x,
                            (const u16*)gamma, (u16*)out_interior, rows, sqrtf((float)C), silu ? 1 : 0, (int)(H * W), (int)W);
     GF_CHECK_LAUNCH("gf_vae_rmsnorm_silu_padded");
+    return GF_OK;
+}
+
+// out_interior = &xp[0][1][1][0] of the zero-bordered [T][2 H + 2][2 W + 2][C] buffer (borders: the caller zeroes them once)
+extern "C" GF_API int gf_vae_upsample2x_padded(const void* x, void* out_interior, int64_t T, int64_t H, int64_t W, int64_t C, void* stream) {
+    GF_CHECK_ARG(x && out_interior && T >= 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "gf_vae_upsample2x_padded: bad arguments (C a multiple of 8)");
+    GF_CHECK_ARG(gf_aligned16(x) && gf_aligned16(out_interior), "gf_vae_upsample2x_padded: alignment");
+    const long pixels = T * H * W;
+    if (pixels == 0) return GF_OK;
+    hipLaunchKernelGGL(upsample2x_padded_kernel, dim3(vgrid(pixels * (C / 8))), dim3(VT), 0, (hipStream_t)stream, (const u16*)x,
+                       (u16*)out_interior, pixels, (int)H, (int)W, (int)(C / 8));
+    GF_CHECK_LAUNCH("gf_vae_upsample2x_padded");
     return GF_OK;
 }
 

@@ -593,11 +593,24 @@ def vae_conv3d(src, cache, w, bias, kt, ks, upsample2x=False, downsample2=False,
 PADDED_CONV_CHANNELS = (192, 384)     # the levels whose 3x3x3 convolutions run on gf_conv3d_padded_bf16
 
 
-def padded_activation(T, H, W, C, device):
+def padded_activation(T, H, W, C, device, history=True):
     """A zero-bordered conv input [2 + T, H + 2, W + 2, C] (gf_conv3d_padded_bf16) and two views of it: the two history frames'
-    interior [2, H, W, C] and the T frames' interior [T, H, W, C].  Zeroed once here; producers only ever write the interiors."""
-    buf = torch.zeros((T + 2, H + 2, W + 2, C), dtype=_BF16, device=device)
-    return buf, buf[:2, 1:H + 1, 1:W + 1], buf[2:, 1:H + 1, 1:W + 1]
+    interior [2, H, W, C] and the T frames' interior [T, H, W, C].  history=False (a per-frame 3x3 convolution, kt = 1):
+    [T, H + 2, W + 2, C] and (buf, None, interior).  Zeroed once here; producers only ever write the interiors."""
+    h = 2 if history else 0
+    buf = torch.zeros((T + h, H + 2, W + 2, C), dtype=_BF16, device=device)
+    return buf, (buf[:2, 1:H + 1, 1:W + 1] if history else None), buf[h:, 1:H + 1, 1:W + 1]
+
+
+def vae_upsample2x_padded(x, buf):
+    """nearest-exact 2x upsample of the contiguous x [T, H, W, C] into the interior of the zero-bordered `buf` [T, 2H + 2, 2W + 2, C]."""
+    _req(x, "vae_upsample2x_padded.x")
+    _req(buf, "vae_upsample2x_padded.buf")
+    T, H, W, C = x.shape
+    if not x.is_contiguous() or not buf.is_contiguous() or tuple(buf.shape) != (T, 2 * H + 2, 2 * W + 2, C):
+        raise GoalForceError("vae_upsample2x_padded: x [T,H,W,C] contiguous, buf [T,2H+2,2W+2,C] contiguous")
+    _lib.check(_lib.load().gf_vae_upsample2x_padded(_ptr(x), buf[0, 1, 1].data_ptr(), T, H, W, C, _stream(x)), "gf_vae_upsample2x_padded")
+    return buf[:, 1:2 * H + 1, 1:2 * W + 1]
 
 
 def vae_rmsnorm_silu_padded(x, gamma, buf, silu=True):
@@ -614,17 +627,18 @@ def vae_rmsnorm_silu_padded(x, gamma, buf, silu=True):
     return buf[2:, 1:H + 1, 1:W + 1]
 
 
-def vae_conv3d_padded(buf, w, bias, n_out=None, resid=None, out=None):
-    """CausalConv3d 3x3x3 on the zero-bordered activation `buf` [2 + T, H + 2, W + 2, C] (frames 0, 1 = history) x w [N, >= 27 C]
-    -> [T*H*W, N]; resid [T*H*W, >= N] is added after the bf16 rounding of conv + bias.  Bit-identical to vae_conv3d."""
+def vae_conv3d_padded(buf, w, bias, resid=None, out=None, kt=3):
+    """kt = 3: CausalConv3d 3x3x3 on the zero-bordered activation `buf` [2 + T, H + 2, W + 2, C] (frames 0, 1 = history); kt = 1: a
+    3x3 convolution per frame on `buf` [T, H + 2, W + 2, C].  x w [N, >= 9 kt C] -> [T*H*W, N]; resid [T*H*W, >= N] is added after
+    the bf16 rounding of conv + bias.  Bit-identical to vae_conv3d."""
     _req(buf, "vae_conv3d_padded.buf")
     _req(w, "vae_conv3d_padded.w")
-    if buf.dim() != 4 or not buf.is_contiguous():
-        raise GoalForceError("vae_conv3d_padded.buf must be contiguous [2+T, H+2, W+2, C]")
-    T, H, W, C = buf.shape[0] - 2, buf.shape[1] - 2, buf.shape[2] - 2, buf.shape[3]
+    if buf.dim() != 4 or not buf.is_contiguous() or kt not in (1, 3):
+        raise GoalForceError("vae_conv3d_padded.buf must be contiguous [kt-1+T, H+2, W+2, C], kt = 1 or 3")
+    T, H, W, C = buf.shape[0] - (kt - 1), buf.shape[1] - 2, buf.shape[2] - 2, buf.shape[3]
     n = w.shape[0]
-    if w.dim() != 2 or w.stride(1) != 1 or w.shape[1] < 27 * C:
-        raise GoalForceError("vae_conv3d_padded.w must be [N, >= 27 C] with contiguous rows")
+    if w.dim() != 2 or w.stride(1) != 1 or w.shape[1] < 9 * kt * C:
+        raise GoalForceError("vae_conv3d_padded.w must be [N, >= 9 kt C] with contiguous rows")
     if out is None:
         out = torch.empty((T * H * W, n), dtype=_BF16, device=buf.device)
     elif out.dim() != 2 or out.shape != (T * H * W, n) or out.stride(1) != 1:
@@ -641,12 +655,12 @@ def vae_conv3d_padded(buf, w, bias, n_out=None, resid=None, out=None):
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.check(_lib.load().gf_conv3d_padded_bf16(_ptr(buf), _ptr(w), w.stride(0), _ptr(bias), _ptr(out), out.stride(0), T, H, W, C, n,
+    _lib.check(_lib.load().gf_conv3d_padded_bf16(_ptr(buf), _ptr(w), w.stride(0), _ptr(bias), _ptr(out), out.stride(0), T, H, W, C, n, kt,
                                                  EPI_BIAS if resid is None else EPI_BIAS_RESID, _ptr(resid), ldr, _stream(buf)),
                "gf_conv3d_padded_bf16")
     if prof is not None:
         e1.record()
-        prof.append((e0, e1, T * H * W, n, C, 3, 3, 3, resid is not None))      # mode 3 = the padded-layout direct kernel
+        prof.append((e0, e1, T * H * W, n, C, kt, 3, 3, resid is not None))      # mode 3 = the padded-layout direct kernel
     return out
 
 

@@ -411,7 +411,16 @@ class WanVideoVAE(nn.Module):
                 out[n0:].view(Tr, 2, H * W, C).copy_(y2.view(Tr, H * W, 2, C).transpose(1, 2))
                 x = out
                 T = n0 + 2 * Tr
-        return _conv(x, None, P[name + ".resample.1"], upsample2x=True).view(T, 2 * H, 2 * W, -1)
+        rc = P[name + ".resample.1"]
+        if IMPLICIT_CONV and ops._OPT["conv_padded"] and C in ops.PADDED_CONV_CHANNELS and rc["w"].shape[0] >= 192 and x.is_contiguous():
+            # 384 -> 192: the upsampled frames go into the zero-bordered layout once (4 x the source, one pass) and the 3x3
+            # convolution reads its taps as row shifts (gf_conv3d_padded_bf16, kt = 1) — same values, same sums as the folded gather
+            key = ("up", T, 2 * H, 2 * W, C, str(x.device))
+            if key not in self._pad_pool:
+                self._pad_pool[key] = ops.padded_activation(T, 2 * H, 2 * W, C, x.device, history=False)
+            ops.vae_upsample2x_padded(x, self._pad_pool[key][0])
+            return ops.vae_conv3d_padded(self._pad_pool[key][0], rc["w"], rc["b"], kt=1).view(T, 2 * H, 2 * W, -1)
+        return _conv(x, None, rc, upsample2x=True).view(T, 2 * H, 2 * W, -1)
 
     def _decode_chunk(self, P, x, first):
         """Decoder3d.forward on one latent frame (VAE:788-838).  x [1,h,w,16] -> [1 or 4, 8h, 8w, 8]."""

@@ -448,16 +448,20 @@ GF_API int gf_gemm_fp8(const void* A8, int64_t lda, const void* W8, int64_t ldw,
 /* ------------------------------------------------------------------------
  * gf_conv3d_padded_bf16 — CausalConv3d 3x3x3, stride 1 (VAE:33-52) of the 192- and 384-channel levels of Decoder3d / Encoder3d
  * (VAE:736-838, 517-617) as a direct convolution on the 4-wave GEMM loop (gf_conv_a4.hip).
- *   xp   : zero-bordered activation [2 + T][H + 2][W + 2][C] bf16 — frames 0, 1 = the two cached history frames (zeros = no
- *          history), one pixel of zeros around every frame; real pixel (t, y, x) at [2 + t][1 + y][1 + x]
- *   Wm   : [N, ldw] bf16, K order (dt, dy, dx, cin), ldw >= 27 C
+ *   xp   : zero-bordered activation [kt - 1 + T][H + 2][W + 2][C] bf16 — kt = 3: frames 0, 1 = the two cached history frames (zeros =
+ *          no history), real pixel (t, y, x) at [2 + t][1 + y][1 + x]; kt = 1 (a 3x3 convolution per frame, e.g. the resample
+ *          convolution behind the nearest-exact 2x upsample, VAE:82-96): no history frames; one pixel of zeros around every frame
+ *   Wm   : [N, ldw] bf16, K order (dt, dy, dx, cin), ldw >= 9 kt C
  *   out  : [T H W, ldo] bf16 = conv + bias (GF_EPI_BIAS) or resid + bf16(conv + bias) (GF_EPI_BIAS_RESID, resid [T H W, ldr])
  * C = 192 or 384; results bit-identical to gf_conv3d_bf16 on the same values.  The caller owns every buffer; no workspace.
- * gf_vae_rmsnorm_silu_padded — gf_vae_rmsnorm_silu writing into the interior of such a buffer: out_interior = &xp[f][1][1][0]. */
+ * gf_vae_rmsnorm_silu_padded — gf_vae_rmsnorm_silu writing into the interior of such a buffer: out_interior = &xp[f][1][1][0].
+ * gf_vae_upsample2x_padded — nearest-exact 2x upsample of [T, H, W, C] into the interior of a [T][2 H + 2][2 W + 2][C] buffer. */
 GF_API int gf_conv3d_padded_bf16(const void* xp, const void* Wm, int64_t ldw, const void* bias, void* out, int64_t ldo, int64_t T,
-                                 int64_t H, int64_t W, int64_t C, int64_t N, int epilogue, const void* resid, int64_t ldr, void* stream);
+                                 int64_t H, int64_t W, int64_t C, int64_t N, int64_t kt, int epilogue, const void* resid, int64_t ldr,
+                                 void* stream);
 GF_API int gf_vae_rmsnorm_silu_padded(const void* x, const void* gamma, void* out_interior, int64_t T, int64_t H, int64_t W, int64_t C,
                                       int silu, void* stream);
+GF_API int gf_vae_upsample2x_padded(const void* x, void* out_interior, int64_t T, int64_t H, int64_t W, int64_t C, void* stream);
 
 #ifdef __cplusplus
 }

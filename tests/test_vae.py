@@ -249,6 +249,30 @@ def test_hip_padded_layout_conv_equals_implicit_gemm(T, H, W, C, N):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("T,Hs,Ws", [(1, 3, 5), (3, 12, 16), (2, 60, 104)])
+def test_hip_padded_layout_upsample_conv_equals_implicit_gemm(T, Hs, Ws):
+    """The decoder's 384 -> 192 resample convolution behind the nearest-exact 2x upsample (VAE:82-96): the upsampled frames written
+    once into the zero-bordered layout (gf_vae_upsample2x_padded) + gf_conv3d_padded_bf16 with kt = 1, against the implicit GEMM
+    that folds the upsample into its gather — bit for bit."""
+    from goal_force_amd import ops
+    g = torch.Generator().manual_seed(T * 1000 + Hs)
+    C, N = 384, 192
+    k = 9 * C
+    x = (torch.randn((T, Hs, Ws, C), generator=g) * 0.7).to(BF).cuda()
+    w = (torch.randn((N, k), generator=g) / k ** 0.5).to(BF).cuda()
+    b = torch.randn((N,), generator=g).to(BF).cuda()
+    ref = ops.vae_conv3d(x, None, w, b, 1, 3, upsample2x=True)
+    buf, none, interior = ops.padded_activation(T, 2 * Hs, 2 * Ws, C, "cuda", history=False)
+    assert none is None
+    up = ops.vae_upsample2x_padded(x, buf)
+    assert torch.equal(up, x.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)) and up.data_ptr() == interior.data_ptr()
+    assert float(buf[:, 0].abs().sum()) == 0 and float(buf[:, :, -1].abs().sum()) == 0
+    got = ops.vae_conv3d_padded(buf, w, b, kt=1)
+    assert got.shape == ref.shape == (T * 4 * Hs * Ws, N)
+    assert torch.equal(got, ref), f"{int((got != ref).sum())} of {ref.numel()} differ"
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("C", [192, 384])
 def test_hip_rmsnorm_silu_into_the_padded_layout(C):
     """gf_vae_rmsnorm_silu_padded writes exactly gf_vae_rmsnorm_silu's values into the interior of the zero-bordered buffer and
