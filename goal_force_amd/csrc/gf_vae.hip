@@ -374,12 +374,12 @@ __global__ __launch_bounds__(VT) void upsample2x_padded_kernel(const u16* __rest
         const int xx = (int)(pix % W);
         const int y = (int)((pix / W) % H);
         const long t = pix / ((long)W * H);
-        const u16x8 v = *reinterpret_cast<const u16x8*>(x + pix * (cpp * 8L) + ch * 8);
+        const u16x8 v = __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(x + pix * (cpp * 8L) + ch * 8));
         u16* o = out + ((t * Hp + 2 * y) * Wp + 2 * xx) * (cpp * 8L) + ch * 8;
-        *reinterpret_cast<u16x8*>(o) = v;
-        *reinterpret_cast<u16x8*>(o + cpp * 8L) = v;
-        *reinterpret_cast<u16x8*>(o + (long)Wp * cpp * 8L) = v;
-        *reinterpret_cast<u16x8*>(o + (long)(Wp + 1) * cpp * 8L) = v;
+        __builtin_nontemporal_store(v, reinterpret_cast<u16x8*>(o));
+        __builtin_nontemporal_store(v, reinterpret_cast<u16x8*>(o + cpp * 8L));
+        __builtin_nontemporal_store(v, reinterpret_cast<u16x8*>(o + (long)Wp * cpp * 8L));
+        __builtin_nontemporal_store(v, reinterpret_cast<u16x8*>(o + (long)(Wp + 1) * cpp * 8L));
     }
 }
 
