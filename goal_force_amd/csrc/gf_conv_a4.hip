@@ -177,7 +177,9 @@ __global__ __launch_bounds__(CA_THREADS, 1) void conv_a4_kernel(const ConvA4Args
 #pragma unroll
                         for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(r8[e]) + bf2f(yv[e]));
                     }
-                    __builtin_nontemporal_store(o, reinterpret_cast<u16x8*>(p.out + (long)orow[it] * p.ldo + nn));
+                    // plain stores: a row's two 192-byte halves come from two waves, and the 128-byte line they share is merged in L2
+                    // (non-temporal stores sent it to the fabric twice: 2.2 GB written per 0.78 GB of output)
+                    *reinterpret_cast<u16x8*>(p.out + (long)orow[it] * p.ldo + nn) = o;
                 }
             }
         }

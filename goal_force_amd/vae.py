@@ -353,13 +353,16 @@ class WanVideoVAE(nn.Module):
     def _res_block(self, P, name, x, cin, cout):
         """ResidualBlock (VAE:267-301)."""
         h = x if cin == cout else self._causal_conv(P, name + ".shortcut", x)
-        if IMPLICIT_CONV and ops._OPT["conv_padded"] and cin in ops.PADDED_CONV_CHANNELS and cout in ops.PADDED_CONV_CHANNELS \
-                and x.is_contiguous():
+        # per convolution: the padded-layout kernel where the INPUT has 192 / 384 channels (conv 1: cin, conv 2: cout)
+        pad_ok = IMPLICIT_CONV and ops._OPT["conv_padded"] and x.is_contiguous()
+        if pad_ok and cin in ops.PADDED_CONV_CHANNELS:
             y = self._padded_conv(P, name + ".residual.2", x, P[name + ".residual.0.gamma"])
+        else:
+            front, y = _with_history(x.shape, x)
+            ops.vae_rmsnorm_silu(x, P[name + ".residual.0.gamma"], silu=True, out=y)
+            y = self._causal_conv(P, name + ".residual.2", y, front=front)
+        if pad_ok and cout in ops.PADDED_CONV_CHANNELS:
             return self._padded_conv(P, name + ".residual.6", y, P[name + ".residual.3.gamma"], resid=h)
-        front, y = _with_history(x.shape, x)
-        ops.vae_rmsnorm_silu(x, P[name + ".residual.0.gamma"], silu=True, out=y)
-        y = self._causal_conv(P, name + ".residual.2", y, front=front)
         front, y2 = _with_history(y.shape, y)
         ops.vae_rmsnorm_silu(y, P[name + ".residual.3.gamma"], silu=True, out=y2)
         return self._causal_conv(P, name + ".residual.6", y2, resid=h, front=front)
