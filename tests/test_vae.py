@@ -218,12 +218,13 @@ def test_hip_direct_conv_c96_equals_implicit_gemm_at_tile_size():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("T,H,W,C,N", [(1, 4, 6, 192, 192), (3, 10, 14, 192, 384), (2, 30, 52, 384, 384), (5, 17, 23, 384, 384),
-                                       (3, 60, 104, 192, 192), (2, 120, 208, 192, 192)])
+                                       (3, 60, 104, 192, 192), (2, 120, 208, 192, 192), (2, 6, 10, 192, 96), (1, 5, 7, 384, 200)])
 def test_hip_padded_layout_conv_equals_implicit_gemm(T, H, W, C, N):
     """The 3x3x3 causal convolutions of the 192- / 384-channel levels on the padded-layout kernel (gf_conv_a4.hip: the activation in a
     zero-bordered buffer, taps as constant row shifts, the 4-wave GEMM loop on a 256 x 192 tile) against the implicit GEMM
     (gf_conv3d_bf16) on the same values — bit for bit, with a non-zero two-frame history, with and without the residual; sizes
-    from one ragged row tile to a production tile's frames (120 x 208: 26 k padded rows per frame, rows of the border dropped)."""
+    from one ragged row tile to a production tile's frames (120 x 208: 26 k padded rows per frame, rows of the border dropped);
+    Cout = 96 and 200: a partly filled and a ragged second column tile (not shapes of the VAE; the kernel's edges)."""
     from goal_force_amd import ops
     g = torch.Generator().manual_seed(T * 100 + H + C + N)
     k = 27 * C

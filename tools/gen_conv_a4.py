@@ -45,8 +45,10 @@ CLOBBER_S = list(range(36, 60)) + list(range(60, 73))
 V_FIRST = 128                                         # v[128:255] are the loop's fragment registers
 PIECE_STEP = 0x1000                                   # LDS bytes between a wave's consecutive pieces (the four waves interleaved)
 FRAG_STEP = 2048                                      # LDS bytes between the fragments of consecutive 16-row blocks
-DS = 4                                                # MFMA slots between staging pieces
-WAIT_SLOT = 64
+# schedule parameters (the shipped values are the defaults; tools/conv_a4_variants.sh sweeps them into build/variants/)
+DS = int(os.environ.get("CONV_A4_DS", "4"))           # MFMA slots between staging pieces
+WAIT_SLOT = int(os.environ.get("CONV_A4_WAIT", "64")) # slot of the counted wait for tile t+1
+RD_STEP = int(os.environ.get("CONV_A4_RDSTEP", "2"))  # slots between the sub-step-0 fragment reads behind it
 
 
 def advance_a():
@@ -151,7 +153,7 @@ def gen():
     at(b1 - 1, "s_waitcnt lgkmcnt(0)")
     at(b1, "s_barrier")
     a_slots = [b1 + 1 + DS * p for p in range(PA)]
-    b2 = a_slots[-1] + 6                                   # B2: behind the last sub-step-1 read of B
+    b2 = max(a_slots[-1] + 3, a_slots[NJ - 1] + 4) if DS != 4 else a_slots[-1] + 6     # B2: behind the last A piece and the last sub-step-1 read of B
     b_slots = [b2 + 1 + DS * p for p in range(PB)]
     b_slots = [x + 2 if x in (WAIT_SLOT, WAIT_SLOT + 1) else x for x in b_slots]    # not between the counted wait and its barrier
     for p in range(PA):
@@ -160,10 +162,13 @@ def gen():
             at(a_slots[p] + 1, rd(B_K1, p, "%[rdB1]"))
         if p < PA - 1:
             at(a_slots[p] + 1, dma(0, p)[1])              # the M0 step: one MFMA behind the piece that still has to read M0
-    assert a_slots[NJ - 1] + 1 < b2 - 1 and b2 < NI * NJ, "the sub-step-1 reads of B must land before the second half starts"
+    assert a_slots[NJ - 1] + 1 < b2 - 1 and a_slots[NJ - 1] + 1 < NI * NJ - 2, "the sub-step-1 reads of B must land before the second half starts"
+    assert b2 - 2 > a_slots[-1], "M0 moves to the W region only behind the last A piece"
     at(b2 - 2, f"s_add_u32 m0, s{S_WR}, {B_TILE}")
     at(b2 - 1, "s_waitcnt lgkmcnt(0)")
     at(b2, "s_barrier")
+    if b2 - 1 >= NI * NJ:                                  # the barrier sits in the second half: its MFMAs need the fragments earlier
+        at(NI * NJ - 2, "s_waitcnt lgkmcnt(0)")
     for p in range(PB):
         at(b_slots[p], dma(1, p)[0])
         if p < PB - 1:
@@ -177,10 +182,10 @@ def gen():
     at(WAIT_SLOT, f"s_waitcnt vmcnt({n_before})")
     at(WAIT_SLOT + 1, "s_barrier")
     for i in range(NI):
-        at(WAIT_SLOT + 2 + 2 * i, rd(A_K0, i, "%[rdA0]"))
+        at(WAIT_SLOT + 2 + RD_STEP * i, rd(A_K0, i, "%[rdA0]"))
     for j in range(NJ):
-        at(WAIT_SLOT + 2 + 2 * NI + 2 * j, rd(B_K0, j, "%[rdB0]"))
-    assert WAIT_SLOT + 2 + 2 * NI + 2 * (NJ - 1) <= NS - 3
+        at(WAIT_SLOT + 2 + RD_STEP * NI + RD_STEP * j, rd(B_K0, j, "%[rdB0]"))
+    assert WAIT_SLOT + 2 + RD_STEP * NI + RD_STEP * (NJ - 1) <= NS - 3
     adv = last_piece + 1                                   # the staging position moves on only behind the iteration's last piece
     at(adv, f"s_xor_b32 s{S_WR}, s{S_WR}, {STAGE}", *advance_a()[:3])
     at(adv + 1, *advance_a()[3:7])
