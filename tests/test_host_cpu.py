@@ -243,3 +243,38 @@ def test_pad_run_finds_the_run_of_identical_rows_that_ends_a_context():
     z = torch.zeros(512, 16, dtype=BF)
     z[:40] = torch.randn(40, 16, generator=g).to(BF)
     assert pad_run(z) == 40                        # the prompter's layout: 40 real rows, 472 zero rows
+
+
+def test_generated_k_loops_are_what_their_generators_emit(tmp_path):
+    """The three asm K loops under goal_force_amd/csrc/*.inc are committed generator output (the build does not run the generators):
+    regenerating them must reproduce the committed files byte for byte — a hand edit or a stale file fails here, and each generator's
+    own schedule replay (register lifetimes, SCC chains, counted waits) runs as part of it."""
+    import subprocess
+    import sys
+    for gen, env_key, inc in (("gen_gemm_a4.py", "A4_OUT", "gf_gemm_a4_loop.inc"), ("gen_gemm_a4f8.py", "A4F8_OUT", "gf_gemm_a4f8_loop.inc"),
+                              ("gen_conv_a4.py", "CONV_A4_OUT", "gf_conv_a4_loop.inc")):
+        out = tmp_path / inc
+        env = {k: v for k, v in os.environ.items() if not k.startswith(("A4", "CONV_A4"))}
+        env[env_key] = str(out)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", gen)], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert out.read_bytes() == open(os.path.join(ROOT, "goal_force_amd", "csrc", inc), "rb").read(), f"{inc} is not what tools/{gen} emits"
+
+
+def test_experiment_patches_still_apply_to_the_product_sources():
+    """tools/patches/*_experiments.patch hold the kernels and diagnostic builds that left the product sources (attention kernel 1, the
+    sl GEMMs, the first backward kernels, the env-variable selectors).  They are diffs against the CURRENT product files: an edit to
+    one of those files without `tools/patches/make_patches.sh` would silently orphan the experimental tree — so it is re-created here."""
+    import shutil
+    import subprocess
+    if shutil.which("patch") is None:
+        pytest.skip("no `patch` tool on this host")
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "experimental_tree.sh")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "FAILED" not in r.stdout + r.stderr, (r.stdout + r.stderr)[-2000:]
+    x = os.path.join(ROOT, "build", "experimental", "csrc")
+    assert "void flash_attn_fwd_kernel(const AttnArgs p)" in open(os.path.join(x, "gf_attention.hip")).read()
+    assert "gemm_sl_kernel" in open(os.path.join(x, "gf_gemm.hip")).read() and "getenv" in open(os.path.join(x, "gf_abi.hip")).read()
+    assert "getenv" not in open(os.path.join(ROOT, "goal_force_amd", "csrc", "gf_abi.hip")).read(), "the product library reads no environment variable"
+    for f in os.listdir(os.path.join(ROOT, "goal_force_amd", "csrc")):
+        if f.endswith((".hip", ".h")):
+            assert "getenv" not in open(os.path.join(ROOT, "goal_force_amd", "csrc", f)).read(), f

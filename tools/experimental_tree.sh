@@ -17,4 +17,5 @@ cp -r include build/experimental/include
   patch -s -p0 gf_gemm.hip < ../../../tools/patches/gemm_experiments.patch
   patch -s -p0 < ../../../tools/patches/abi_experiments.patch )
 ( cd build/experimental && patch -s -p0 include/goalforce.h < ../../tools/patches/header_experiments.patch )
+A4_WHATIF_VARIANTS=1 A4_OUT=build/experimental/csrc/gf_gemm_a4_loop.inc python3 tools/gen_gemm_a4.py > /dev/null      # + the what-if loops
 echo "build/experimental/{csrc,include}: the experimental tree (kernel 1, sl GEMMs, v1 backward, GF_K3_* / GF_*_WHATIF / *_STAMP builds)"

@@ -319,8 +319,10 @@ def emit(name, lines):
 
 def main():
     text = emit("GF_A4_LOOP_ASM", gen())
-    # timing-only variants behind -DGF_A4_WHATIF (tools/gemm_a4_whatif.py); never in the shipped library
-    text += "#ifdef GF_A4_WHATIF\n" + "".join(emit(f"GF_A4_LOOP_ASM_W{w}", gen(w)) for w in (1, 2, 4, 5, 64, 128)) + "#endif\n"
+    if os.environ.get("A4_WHATIF_VARIANTS", "0") == "1":
+        # timing-only variants behind -DGF_A4_WHATIF (tools/gemm_a4_whatif.py): generated for the experimental tree only
+        # (tools/experimental_tree.sh); the product's .inc holds the one loop that ships
+        text += "#ifdef GF_A4_WHATIF\n" + "".join(emit(f"GF_A4_LOOP_ASM_W{w}", gen(w)) for w in (1, 2, 4, 5, 64, 128)) + "#endif\n"
     out = os.environ.get("A4_OUT", OUT)
     with open(out, "w") as f:
         f.write(text)
