@@ -593,6 +593,14 @@ def vae_conv3d(src, cache, w, bias, kt, ks, upsample2x=False, downsample2=False,
 PADDED_CONV_CHANNELS = (192, 384)     # the levels whose 3x3x3 convolutions run on gf_conv3d_padded_bf16
 
 
+def padded_conv_fits(T, H, W, C, history=True):
+    """Whether gf_conv3d_padded_bf16 can take this shape: the zero-bordered buffer is addressed with 32-bit byte offsets (< 4 GiB) and
+    its rows with 31-bit indices.  A production tile is far below (0.82 GB at the 192-channel level); an UNTILED 480 x 832 decode
+    exceeds it at the 384 -> 192 resample convolution (6.3 GB) — such shapes stay on the implicit GEMM."""
+    rows = (T + (2 if history else 0)) * (H + 2) * (W + 2)
+    return C in PADDED_CONV_CHANNELS and rows * C * 2 < (1 << 32) and rows < (1 << 31)
+
+
 def padded_activation(T, H, W, C, device, history=True):
     """A zero-bordered conv input [2 + T, H + 2, W + 2, C] (gf_conv3d_padded_bf16) and two views of it: the two history frames'
     interior [2, H, W, C] and the T frames' interior [T, H, W, C].  history=False (a per-frame 3x3 convolution, kt = 1):

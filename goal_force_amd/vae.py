@@ -355,13 +355,13 @@ class WanVideoVAE(nn.Module):
         h = x if cin == cout else self._causal_conv(P, name + ".shortcut", x)
         # per convolution: the padded-layout kernel where the INPUT has 192 / 384 channels (conv 1: cin, conv 2: cout)
         pad_ok = IMPLICIT_CONV and ops._OPT["conv_padded"] and x.is_contiguous()
-        if pad_ok and cin in ops.PADDED_CONV_CHANNELS:
+        if pad_ok and ops.padded_conv_fits(*x.shape[:3], cin):
             y = self._padded_conv(P, name + ".residual.2", x, P[name + ".residual.0.gamma"])
         else:
             front, y = _with_history(x.shape, x)
             ops.vae_rmsnorm_silu(x, P[name + ".residual.0.gamma"], silu=True, out=y)
             y = self._causal_conv(P, name + ".residual.2", y, front=front)
-        if pad_ok and cout in ops.PADDED_CONV_CHANNELS:
+        if pad_ok and ops.padded_conv_fits(*y.shape[:3], cout):
             return self._padded_conv(P, name + ".residual.6", y, P[name + ".residual.3.gamma"], resid=h)
         front, y2 = _with_history(y.shape, y)
         ops.vae_rmsnorm_silu(y, P[name + ".residual.3.gamma"], silu=True, out=y2)
@@ -415,7 +415,8 @@ class WanVideoVAE(nn.Module):
                 x = out
                 T = n0 + 2 * Tr
         rc = P[name + ".resample.1"]
-        if IMPLICIT_CONV and ops._OPT["conv_padded"] and C in ops.PADDED_CONV_CHANNELS and rc["w"].shape[0] >= 192 and x.is_contiguous():
+        if IMPLICIT_CONV and ops._OPT["conv_padded"] and rc["w"].shape[0] >= 192 and x.is_contiguous() \
+                and ops.padded_conv_fits(T, 2 * H, 2 * W, C, history=False):
             # 384 -> 192: the upsampled frames go into the zero-bordered layout once (4 x the source, one pass) and the 3x3
             # convolution reads its taps as row shifts (gf_conv3d_padded_bf16, kt = 1) — same values, same sums as the folded gather
             key = ("up", T, 2 * H, 2 * W, C, str(x.device))

@@ -278,3 +278,14 @@ def test_experiment_patches_still_apply_to_the_product_sources():
     for f in os.listdir(os.path.join(ROOT, "goal_force_amd", "csrc")):
         if f.endswith((".hip", ".h")):
             assert "getenv" not in open(os.path.join(ROOT, "goal_force_amd", "csrc", f)).read(), f
+
+
+def test_padded_conv_path_is_refused_for_shapes_beyond_its_32_bit_offsets():
+    """vae.py sends a convolution to the padded-layout kernel only when its zero-bordered input stays below 4 GiB: a production tile
+    does at every level; the untiled 480 x 832 decode does not at the 384 -> 192 resample convolution and stays on the implicit GEMM."""
+    from goal_force_amd import ops
+    assert ops.padded_conv_fits(81, 120, 208, 192) and ops.padded_conv_fits(41, 60, 104, 384) and ops.padded_conv_fits(21, 30, 52, 384)
+    assert ops.padded_conv_fits(81, 120, 208, 384, history=False)            # the tile's resample convolution (1.6 GB)
+    assert ops.padded_conv_fits(81, 240, 416, 192)                           # untiled level 2: 3.2 GB
+    assert not ops.padded_conv_fits(81, 240, 416, 384, history=False)        # untiled resample convolution: 6.3 GB
+    assert not ops.padded_conv_fits(81, 120, 208, 96)                        # 96 channels: not this kernel's level
