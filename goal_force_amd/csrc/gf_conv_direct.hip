@@ -29,12 +29,6 @@
 
 namespace {
 
-#ifndef CD_WHATIF
-#define CD_WHATIF 0
-#endif
-#ifndef CD_SHARE_A
-#define CD_SHARE_A 1       // 0: the first stage order (dt outermost, every stage reads its own A fragments), for A/B builds
-#endif
 constexpr int CD_C = 96;
 constexpr int CD_TH = 8, CD_TW = 32, CD_HH = CD_TH + 2, CD_HW = CD_TW + 2;
 constexpr int CD_WAVES = 8, CD_THREADS = 64 * CD_WAVES;
@@ -156,87 +150,6 @@ __global__ __launch_bounds__(CD_THREADS, 2) void conv3d_c96_kernel(const CdArgs 
     // workgroup's MFMA time — so a tap's weights are requested TWO taps ahead and the counted wait at a tap's start leaves the
     // newest request in flight (with a 2-stage ring and vmcnt(0) every tap waited ~1 us: 5.6 ms per convolution, measured).
     int st_cur = 0, st_nxt = CD_W_BYTES, st_free = 2 * CD_W_BYTES;     // byte offsets of the stages holding tap t, t + 1 and the free one
-#if CD_SHARE_A == 0
-    int tap_next2 = 2;                                                  // the tap (0..26, wrapping into the next frame) two ahead
-    // one temporal tap dt of input frame g into accumulator set dt (= output frame g - dt): nine spatial taps
-    auto tap_group = [&](auto set_c, bool valid, bool first) __attribute__((always_inline)) {
-        constexpr int SET = decltype(set_c)::value;
-#pragma unroll 1
-        for (int s = 0; s < 9; ++s) {
-            if (!(first && s == 0)) {                      // (the frame's first tap: the halo wait did this already)
-                // weights of this tap landed (the newest request, 3 or 2 instructions of this wave, stays in flight); every wave is
-                // past the previous tap
-#if CD_WHATIF & 1       // timing-only builds (wrong results): 1 = no counted wait, 2 = no barrier, 4 = no weight requests
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#elif CD_WHATIF & 2
-                asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-#else
-                if constexpr (NCB == 6) {
-                    if (more) CD_WAIT_BARRIER(3);
-                    else CD_WAIT_BARRIER(2);
-                } else {
-                    if (more) CD_WAIT_BARRIER(1);
-                    else CD_WAIT_BARRIER(0);
-                }
-#endif
-            }
-#if !(CD_WHATIF & 4)
-            issue_w(tap_next2, st_free);                   // the stage the previous tap has just been read out of
-#endif
-            tap_next2 = tap_next2 == 26 ? 0 : tap_next2 + 1;
-            if (valid) {
-                const int dy = (s * 11) >> 5, dx = s - 3 * dy;
-                GF_LDS char* const aaddr = a_base + (dy * CD_HW + dx) * CD_PITCH;
-                GF_LDS char* const baddr = b_base + st_cur;
-                // fragments of k step ks + 1 are requested before the 12 MFMAs of k step ks (two register sets; the scheduling
-                // barriers keep hipcc from sinking each read next to its use behind an lgkmcnt(0))
-                bf16x8 af[2][PB], bfr[2][CB];
-                auto load = [&](int ks, int set) __attribute__((always_inline)) {
-#pragma unroll
-                    for (int b = 0; b < PB; ++b) af[set][b] = *(GF_LDS bf16x8*)(aaddr + blk_off(b) + ks * 64);
-#pragma unroll
-                    for (int cb = 0; cb < CB; ++cb) bfr[set][cb] = *(GF_LDS bf16x8*)(baddr + cb * 16 * CD_PITCH + ks * 64);
-                };
-#if CD_WHATIF & 8       // 8 = no fragment reads (the MFMAs run on whatever the registers hold)
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-#pragma unroll
-                    for (int b = 0; b < PB; ++b) asm volatile("" : "=v"(af[q][b]));
-#pragma unroll
-                    for (int cb = 0; cb < CB; ++cb) asm volatile("" : "=v"(bfr[q][cb]));
-                }
-#else
-                load(0, 0);
-#endif
-#pragma unroll
-                for (int ks = 0; ks < 3; ++ks) {
-#if !(CD_WHATIF & 8)
-                    if (ks < 2) load(ks + 1, (ks + 1) & 1);
-#endif
-                    __builtin_amdgcn_sched_barrier(0);
-#if CD_WHATIF & 16      // 16 = no MFMAs (the fragment reads stay)
-#pragma unroll
-                    for (int b = 0; b < PB; ++b) asm volatile("" ::"v"(af[ks & 1][b]));
-#pragma unroll
-                    for (int cb = 0; cb < CB; ++cb) asm volatile("" ::"v"(bfr[ks & 1][cb]));
-#else
-#pragma unroll
-                    for (int b = 0; b < PB; ++b)
-#pragma unroll
-                        for (int cb = 0; cb < CB; ++cb)
-                            acc[SET][b][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks & 1][cb], af[ks & 1][b], acc[SET][b][cb], 0, 0, 0);
-#endif
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            const int t = st_cur;
-            st_cur = st_nxt;
-            st_nxt = st_free;
-            st_free = t;
-        }
-    };
-#endif
-#if CD_SHARE_A
     // The same 27 stages in the order (dy, dx) x dt: the three temporal taps of one spatial tap read the SAME pixels of the halo, so the A
     // fragments of a position (3 k steps x PB blocks) are read once and serve three stages — 12 + 27 fragment reads per position instead
     // of 36 + 27 (3.72 against 3.84 ms interleaved in one process, profiles/r03/conv_bench_pipe2.log; a further version with the barrier one
@@ -252,11 +165,6 @@ __global__ __launch_bounds__(CD_THREADS, 2) void conv3d_c96_kernel(const CdArgs 
             auto stage = [&](auto set_c, bool valid) __attribute__((always_inline)) {
                 constexpr int SET = decltype(set_c)::value;
                 if (!(SET == 0 && s == 0)) {               // (the frame's first stage: the halo wait did this already)
-#if CD_WHATIF & 1       // timing-only builds (wrong results): 1 = no counted wait, 2 = no barrier, 4 = no weight requests
-                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#elif CD_WHATIF & 2
-                    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-#else
                     if constexpr (NCB == 6) {
                         if (more) CD_WAIT_BARRIER(3);
                         else CD_WAIT_BARRIER(2);
@@ -264,11 +172,8 @@ __global__ __launch_bounds__(CD_THREADS, 2) void conv3d_c96_kernel(const CdArgs 
                         if (more) CD_WAIT_BARRIER(1);
                         else CD_WAIT_BARRIER(0);
                     }
-#endif
                 }
-#if !(CD_WHATIF & 4)
                 issue_w(dt_next2 * 9 + s2_next2, st_free);
-#endif
                 if (++dt_next2 == 3) {
                     dt_next2 = 0;
                     s2_next2 = s2_next2 == 8 ? 0 : s2_next2 + 1;
@@ -282,39 +187,17 @@ __global__ __launch_bounds__(CD_THREADS, 2) void conv3d_c96_kernel(const CdArgs 
 #pragma unroll
                     for (int cb = 0; cb < CB; ++cb) bfr[set][cb] = *(GF_LDS bf16x8*)(baddr + cb * 16 * CD_PITCH + ks * 64);
                 };
-#if CD_WHATIF & 8       // 8 = no fragment reads (the MFMAs run on whatever the registers hold), 16 = no MFMAs
-                if constexpr (SET == 0) {
-#pragma unroll
-                    for (int q = 0; q < 3; ++q)
-#pragma unroll
-                        for (int b = 0; b < PB; ++b) asm volatile("" : "=v"(af[q][b]));
-                }
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-#pragma unroll
-                    for (int cb = 0; cb < CB; ++cb) asm volatile("" : "=v"(bfr[q][cb]));
-#else
                 load(0, 0);
-#endif
 #pragma unroll
                 for (int ks = 0; ks < 3; ++ks) {
-#if !(CD_WHATIF & 8)
                     if (ks < 2) load(ks + 1, (ks + 1) & 1);
-#endif
                     __builtin_amdgcn_sched_barrier(0);
                     if (valid) {
-#if CD_WHATIF & 16
-#pragma unroll
-                        for (int b = 0; b < PB; ++b) asm volatile("" ::"v"(af[ks][b]));
-#pragma unroll
-                        for (int cb = 0; cb < CB; ++cb) asm volatile("" ::"v"(bfr[ks & 1][cb]));
-#else
 #pragma unroll
                         for (int b = 0; b < PB; ++b)
 #pragma unroll
                             for (int cb = 0; cb < CB; ++cb)
                                 acc[SET][b][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks & 1][cb], af[ks][b], acc[SET][b][cb], 0, 0, 0);
-#endif
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -328,7 +211,6 @@ __global__ __launch_bounds__(CD_THREADS, 2) void conv3d_c96_kernel(const CdArgs 
             stage(std::integral_constant<int, 2>{}, v2);
         }
     };
-#endif
     // this lane's bias values: channels (CB wc + cb) * 16 + 4 kc .. + 3
     u16x4 bias4[CB];
 #pragma unroll
@@ -435,29 +317,17 @@ __global__ __launch_bounds__(CD_THREADS, 2) void conv3d_c96_kernel(const CdArgs 
             }
     };
     issue_w(0, 0);
-    issue_w(CD_SHARE_A ? 9 : 1, CD_W_BYTES);
+    issue_w(9, CD_W_BYTES);      // (the stage order is (dy, dx) x dt: the second stage is tap dt = 1 of position 0)
 #pragma unroll 1
     for (int g = j0; g < j1 + 2; ++g) {                    // input frame g of the walk: output j reads g = j, j + 1, j + 2
         CD_WAIT_BARRIER(0);                                // every wave is done with the previous frame's halo (and its last tap)
         int lane_v = lane;
         asm volatile("" : "+v"(lane_v));                   // opaque: see issue_halo
-#if CD_WHATIF & 32      // 32 = no halo DMA, 64 = no epilogue (timing only)
-        if (g - 3 >= j0) epilogue(g - 3, []() {});
-#elif CD_WHATIF & 64
-        issue_halo(g, lane_v);
-#else
         if (g - 3 >= j0) epilogue(g - 3, [&]() __attribute__((always_inline)) { issue_halo(g, lane_v); });   // completed a frame ago, stored under the DMA
         else issue_halo(g, lane_v);
-#endif
         rotate();
         CD_WAIT_BARRIER(0);                                // halo g (and the weights of its first two taps) landed
-#if CD_SHARE_A
         frame_taps(g >= j0 && g < j1, g - 1 >= j0 && g - 1 < j1, g - 2 >= j0 && g - 2 < j1);
-#else
-        tap_group(std::integral_constant<int, 0>{}, g >= j0 && g < j1, true);
-        tap_group(std::integral_constant<int, 1>{}, g - 1 >= j0 && g - 1 < j1, false);
-        tap_group(std::integral_constant<int, 2>{}, g - 2 >= j0 && g - 2 < j1, false);
-#endif
     }
     CD_WAIT_BARRIER(0);                                    // the ring's last prefetches (never read) must not outlive the workgroup's LDS
     epilogue(j1 - 1, []() {});                             // the segment's last output frame finished with input j1 + 1 (set 2)

@@ -198,41 +198,17 @@ __global__ __launch_bounds__(64 * WROWS) void layernorm_modulate_wave_kernel(
 //   MODE 2: modulate(LayerNorm, b, a)      (a = 1 + scale, b = shift: norm1 / norm2 / head, the reference's three bf16 roundings)
 //   FP8: the result is quantised in registers for an fp8_linear consumer (layernorm_modulate_fp8_wave_kernel's contract).
 __device__ __forceinline__ gf_f32x2 unpack2bf(unsigned u) { return gf_f32x2{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)}; }
-#ifndef GF_LN2_PK
-#define GF_LN2_PK 1     // 0 (diagnostic builds): the pair arithmetic as scalar instructions pinned by inline asm instead of v_pk_*_f32
-#endif
 __device__ __forceinline__ gf_f32x2 ln2_fma(gf_f32x2 a, gf_f32x2 b, gf_f32x2 c) {
-#if GF_LN2_PK
     return __builtin_elementwise_fma(a, b, c);
-#else
-    gf_f32x2 r;
-    asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r[0]) : "v"(a[0]), "v"(b[0]), "v"(c[0]));
-    asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r[1]) : "v"(a[1]), "v"(b[1]), "v"(c[1]));
-    return r;
-#endif
 }
 // (contract off: a product must stay a product — the roundings of the reference's separate ops are the point)
 __device__ __forceinline__ gf_f32x2 ln2_mul(gf_f32x2 a, gf_f32x2 b) {
 #pragma clang fp contract(off)
-#if GF_LN2_PK
     return a * b;
-#else
-    gf_f32x2 r;
-    asm volatile("v_mul_f32 %0, %1, %2" : "=v"(r[0]) : "v"(a[0]), "v"(b[0]));
-    asm volatile("v_mul_f32 %0, %1, %2" : "=v"(r[1]) : "v"(a[1]), "v"(b[1]));
-    return r;
-#endif
 }
 __device__ __forceinline__ gf_f32x2 ln2_add(gf_f32x2 a, gf_f32x2 b) {
 #pragma clang fp contract(off)
-#if GF_LN2_PK
     return a + b;
-#else
-    gf_f32x2 r;
-    asm volatile("v_add_f32 %0, %1, %2" : "=v"(r[0]) : "v"(a[0]), "v"(b[0]));
-    asm volatile("v_add_f32 %0, %1, %2" : "=v"(r[1]) : "v"(a[1]), "v"(b[1]));
-    return r;
-#endif
 }
 
 template <int NCH, int MODE, bool FP8>

@@ -1,4 +1,6 @@
 #!/usr/bin/env python3
+# NOTE (round 5): the -DCD_WHATIF builds this script can drive are built from the experimental tree (`bash tools/experimental_tree.sh`:
+# build/experimental/csrc); the product sources no longer carry those branches.
 """The 96-channel 3x3x3 convolution of one production VAE tile (80 frames of 240 x 416, history in front): direct kernel
 (gf_conv_direct.hip) against the implicit GEMM (GF_CONV_DIRECT=0), interleaved in one process; 3.97 TFLOP per launch."""
 import os

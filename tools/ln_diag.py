@@ -1,4 +1,6 @@
 #!/usr/bin/env python3
+# NOTE (round 5): the -DGF_LN2_PK=0 build this script can drive are built from the experimental tree (`bash tools/experimental_tree.sh`:
+# build/experimental/csrc); the product sources no longer carry those branches.
 """Diagnostic: layernorm_wave2_kernel (pairs, packed fp32 math) against the per-element kernel — where do the two differ, and does
 the difference go away when the pair arithmetic is issued as scalar instructions (build/ab/libln_scalar.so, -DGF_LN2_PK=0)?"""
 import ctypes

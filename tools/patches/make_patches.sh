@@ -18,4 +18,6 @@ mk attention_bwd_experiments.patch goal_force_amd/csrc/gf_attention_bwd.hip
 mk gemm_experiments.patch goal_force_amd/csrc/gf_gemm.hip
 mk abi_experiments.patch goal_force_amd/csrc/gf_abi.hip goal_force_amd/csrc/gf_common.h
 mk header_experiments.patch include/goalforce.h
+mk conv_direct_experiments.patch goal_force_amd/csrc/gf_conv_direct.hip
+mk rowops_experiments.patch goal_force_amd/csrc/gf_rowops.hip
 wc -l tools/patches/*_experiments.patch
