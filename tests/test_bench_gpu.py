@@ -162,3 +162,16 @@ def test_bench_preloop_leg_at_full_size():
     assert "error" not in pl, pl
     assert 0.05 < pl["vae_tiled_encode_x2_s"] < 10 and 0.005 < pl["umt5_xxl_512_tokens_x2_s"] < 10 and pl["umt5_xxl_params"] > 5e9
     assert abs(pl["total_s"] - pl["vae_tiled_encode_x2_s"] - pl["umt5_xxl_512_tokens_x2_s"]) < 1e-9
+
+
+def test_bench_head_parallel_pair_bit_identical_to_one_gpu():
+    """`bench.py --gpus 4 --sp 2`: one video, its CFG pair, every forward head-parallel over two ranks (Ulysses exchanges started
+    as soon as each projection is ready, the head group in two halves; sequence_parallel.py) — the pre-flight runs the head
+    all-to-all at production size, and latents and frames equal the one-GPU run bit for bit."""
+    one = _launch(1)
+    sp = _launch(4, ["--sp", "2"])
+    assert sp["n_gpus"] == 4 and sp["samples_gathered"] == 1 and "head-parallel attention degree 2" in sp["config"]["parallelism"]
+    assert set(sp["preflight"]["steps"]) == {"noise_pred_allgather_pair", "vae_tile_broadcast_pair", "frames_allgather_leads", "head_all_to_all_sp_group"}
+    assert [(r["sample"], r["branch"], r["sp_rank"]) for r in sp["preflight"]["ranks"]] == [(0, 0, 0), (0, 0, 1), (0, 1, 0), (0, 1, 1)]
+    assert sp["self_check"]["latents"]["sha256"] == one["self_check"]["latents"]["sha256"]
+    assert sp["self_check"]["frames_uint8"]["sha256"] == one["self_check"]["frames_uint8"]["sha256"]
