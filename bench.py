@@ -642,8 +642,8 @@ def main():
                                    f"({n_hi} high-noise with ControlNet, {k - n_hi} low-noise with the all-zero ControlNet2 elided)",
                        "layers": args.layers,
                        "cross_attention": "the context's padded rows (identical: the prompter zeroes past the 40-token prompt) are attended as "
-                                          "ONE key with multiplicity 472 (41 keys instead of 512; GF_FOLD_PAD_KEYS=0 attends all 512)"
-                                          if os.environ.get("GF_FOLD_PAD_KEYS", "1") != "0" else "all 512 context keys attended",
+                                          "ONE key with multiplicity 472 (41 keys instead of 512; ops.options(fold_pad_keys=False) attends all 512)"
+                                          if ops._OPT["fold_pad_keys"] else "all 512 context keys attended",
                        "parallelism": "1 GPU: sequential CFG (block 0's context-independent half shared by the two branches)" if world == 1 else f"{videos} video(s) x CFG pair, RCCL all-gather of noise_pred per step"
                                       + (f"; head-parallel attention degree {args.sp} (RCCL all-to-all over xGMI)" if args.sp > 1 else ""),
                        "value_definition": "frames/s = videos * 81 / (50-step loop + tiled VAE decode + frame all-gather); 50-step loop = " + loop_how,

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("GOALFORCE_HIP_LIB", LIB_PATH)
 
 # every symbol include/goalforce.h declares (tests check the .so exports exactly these)
 SYMBOLS = (
-    "gf_version", "gf_last_error", "gf_abi_version", "gf_set_option", "gf_reset_options",
+    "gf_version", "gf_last_error", "gf_abi_version", "gf_set_option", "gf_get_option", "gf_reset_options",
     "gf_modulation", "gf_layernorm_modulate", "gf_rmsnorm_rope", "gf_gemm_bf16", "gf_flash_attn_fwd",
     "gf_patchify_im2col", "gf_unpatchify", "gf_cfg_euler_step", "gf_act", "gf_add_bf16",
     "gf_force_map",
@@ -33,7 +33,7 @@ SYMBOLS = (
 # the C ABI revision these bindings were written against (csrc/gf_abi.hip: GF_ABI_VERSION).  A stale or foreign .so whose entry
 # points take differently sized buffers (gf_flash_attn_bwd's workspace grew 3x between revisions 7 and 10 under an unchanged
 # signature) is refused at load time instead of overrunning memory.
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 EPI_BIAS, EPI_BIAS_GELU_TANH, EPI_BIAS_GATE_RESID, EPI_BIAS_RESID, EPI_BIAS_SILU, EPI_BIAS_MUL = range(6)
 
@@ -57,6 +57,8 @@ def _declare(lib):
     lib.gf_abi_version.argtypes = []
     lib.gf_set_option.restype = _int
     lib.gf_set_option.argtypes = [ctypes.c_char_p, _int]
+    lib.gf_get_option.restype = _int
+    lib.gf_get_option.argtypes = [ctypes.c_char_p, ctypes.POINTER(_int)]
     lib.gf_reset_options.restype = None
     lib.gf_reset_options.argtypes = []
     sigs = {

@@ -5,7 +5,7 @@
 #include <cstdlib>
 #include <cstring>
 
-#define GF_ABI_VERSION 16
+#define GF_ABI_VERSION 17
 
 static thread_local char g_err[512] = "";
 
@@ -48,6 +48,17 @@ extern "C" GF_API int gf_set_option(const char* name, int value) {
             return GF_OK;
         }
     gf_set_error("gf_set_option: unknown option '%s'", name);
+    return GF_ERR_INVALID_ARG;
+}
+
+extern "C" GF_API int gf_get_option(const char* name, int* value) {
+    GF_CHECK_ARG(name && value, "gf_get_option: null argument");
+    for (const OptionSlot& s : kSlots)
+        if (strcmp(name, s.name) == 0) {
+            *value = (g_options.*(s.field)).load(std::memory_order_relaxed);
+            return GF_OK;
+        }
+    gf_set_error("gf_get_option: unknown option '%s'", name);
     return GF_ERR_INVALID_ARG;
 }
 

@@ -140,6 +140,10 @@ def preflight(cfgp: CfgPairParallel, device, latent_shape=(1, 16, 21, 60, 104), 
             torch.cuda.synchronize(dev)
 
     def step(name, fn):
+        """One collective: run it, then agree on the outcome — every rank all-reduces an ok flag (MIN) after the step, so that a
+        content check (or a backend error) on ONE rank raises the same named error on ALL of them, instead of leaving the peers
+        in the next step's barrier until the backend's 10-30 minute timeout."""
+        err, nbytes, dt = None, 0, 0.0
         try:
             sync()
             dist.barrier()
@@ -148,9 +152,21 @@ def preflight(cfgp: CfgPairParallel, device, latent_shape=(1, 16, 21, 60, 104), 
             sync()
             dt = time.perf_counter() - t0
         except Exception as e:      # noqa: BLE001 — the backend's message is the diagnosis
-            raise GoalForceError(f"multi-GPU pre-flight: `{name}` failed on rank {cfgp.rank} (sample {cfgp.sample}, branch "
-                                 f"{cfgp.branch}, sp_rank {cfgp.sp_rank}, device {dev}) over backend {rep['backend']}: "
-                                 f"{type(e).__name__}: {e}") from e
+            err = e
+        ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=dev if rep["backend"] == "nccl" else "cpu")
+        try:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        except Exception:           # noqa: BLE001 — the transport is gone: the local error (if any) is what there is to report
+            pass
+        where = (f"rank {cfgp.rank} (sample {cfgp.sample}, branch {cfgp.branch}, sp_rank {cfgp.sp_rank}, device {dev}) over backend "
+                 f"{rep['backend']}")
+        if err is not None:
+            if isinstance(err, GoalForceError):
+                raise err
+            raise GoalForceError(f"multi-GPU pre-flight: `{name}` failed on {where}: {type(err).__name__}: {err}") from err
+        if int(ok.item()) == 0:
+            raise GoalForceError(f"multi-GPU pre-flight: `{name}` failed on another rank (this is {where}; the failing rank's "
+                                 f"message names the cause)")
         rep["steps"][name] = {"bytes": int(nbytes), "seconds": dt}
         if log:
             log(f"  pre-flight rank {cfgp.rank}: {name}: {nbytes / 1e6:.1f} MB in {dt * 1e3:.2f} ms")
@@ -181,6 +197,17 @@ def preflight(cfgp: CfgPairParallel, device, latent_shape=(1, 16, 21, 60, 104), 
             return len(out) * out[0].numel()
         return 0
 
+    # rank -> device map and HBM headroom of every rank FIRST: two ranks on one device under RCCL would fail or hang inside the first
+    # collective below, so the duplicate is named here (every rank sees the same list and raises the same error)
+    free, total = (torch.cuda.mem_get_info(dev) if on_gpu else (0, 0))
+    mine = {"rank": cfgp.rank, "sample": cfgp.sample, "branch": cfgp.branch, "sp_rank": cfgp.sp_rank, "device": str(dev),
+            "device_name": torch.cuda.get_device_name(dev) if on_gpu else "cpu", "hbm_free_gb": free / 2 ** 30, "hbm_total_gb": total / 2 ** 30}
+    allr = [None] * cfgp.world_size
+    dist.all_gather_object(allr, mine)
+    if on_gpu and rep["backend"] == "nccl":
+        devs = [r["device"] for r in allr]
+        if len(set(devs)) != len(devs):
+            raise GoalForceError(f"multi-GPU pre-flight: two ranks share a device under RCCL: {devs}")
     step("noise_pred_allgather_pair", noise_pair)
     step("vae_tile_broadcast_pair", tile_bcast)
     step("frames_allgather_leads", frames_gather)
@@ -190,21 +217,14 @@ def preflight(cfgp: CfgPairParallel, device, latent_shape=(1, 16, 21, 60, 104), 
         def heads_a2a():
             return sp.preflight(dev)
         step("head_all_to_all_sp_group", heads_a2a)
-    # rank -> device map and HBM headroom of every rank
-    free, total = (torch.cuda.mem_get_info(dev) if on_gpu else (0, 0))
-    mine = {"rank": cfgp.rank, "sample": cfgp.sample, "branch": cfgp.branch, "sp_rank": cfgp.sp_rank, "device": str(dev),
-            "device_name": torch.cuda.get_device_name(dev) if on_gpu else "cpu", "hbm_free_gb": free / 2 ** 30, "hbm_total_gb": total / 2 ** 30,
-            "seconds": {k: v["seconds"] for k, v in rep["steps"].items()}}
-    allr = [None] * cfgp.world_size
-    dist.all_gather_object(allr, mine)
+    secs = [None] * cfgp.world_size
+    dist.all_gather_object(secs, {k: v["seconds"] for k, v in rep["steps"].items()})
+    for r, sc in zip(allr, secs):
+        r["seconds"] = sc
     rep["ranks"] = allr
     for name in rep["steps"]:          # the slowest rank's time is the step's time
         rep["steps"][name]["seconds"] = max(r["seconds"][name] for r in allr)
         rep["steps"][name]["bytes"] = max(rep["steps"][name]["bytes"], 0)
-    if on_gpu and rep["backend"] == "nccl":
-        devs = [r["device"] for r in allr]
-        if len(set(devs)) != len(devs):
-            raise GoalForceError(f"multi-GPU pre-flight: two ranks share a device under RCCL: {devs}")
     rep["rccl_ranks"] = cfgp.world_size if rep["backend"] == "nccl" else 0
     rep["min_hbm_free_gb"] = min(r["hbm_free_gb"] for r in allr)
     return rep

@@ -178,10 +178,6 @@ def enable_fp8(module: nn.Module, enabled=True):
     return module
 
 
-import os as _os
-
-_FOLD_PAD_KEYS = [_os.environ.get("GF_FOLD_PAD_KEYS", "1") != "0"]      # a list: tests flip it without re-importing
-
 
 def pad_run(ctx2: torch.Tensor) -> int:
     """First row index n of the run of identical rows that ends the [L, D] tensor (rows n .. L-1 are all equal): L - 1 when the
@@ -241,11 +237,11 @@ class SelfAttention(nn.Module):
             # the next one (same kernels on the same values as below: bit-identical, another issue order)
             k = linear(xin, self.k)
             ops.rmsnorm_rope(k, self.norm_k.weight, rope.cos, rope.sin, self.head_dim, self.norm_k.eps)
-            hk = sp.heads_start(k)
-            hv = sp.heads_start(linear(xin, self.v))
+            hk = sp.heads_start(k, self.num_heads)
+            hv = sp.heads_start(linear(xin, self.v), self.num_heads)
             q = linear(xin, self.q)
             ops.rmsnorm_rope(q, self.norm_q.weight, rope.cos, rope.sin, self.head_dim, self.norm_q.eps)
-            hq = sp.heads_start(q)
+            hq = sp.heads_start(q, self.num_heads)
             return sp.attention_started(hq, hk, hv, self.num_heads, tuple(q.shape))
         q, k = linear(xin, self.q), linear(xin, self.k)
         if keep is not None and keep.get("wide"):      # training with room to spare: the pre-norm projections stay for the backward
@@ -302,10 +298,10 @@ class CrossAttention(nn.Module):
         (ops.flash_attn(last_key_mult=m)): the same function of q, 41 keys instead of 512 for a 40-token prompt.  The run is
         DETECTED on the tensor (pad_run), never assumed; a context without such a run is attended in full.  `pad_n` is that
         detection's result when the caller already ran it on this very tensor (model_fn does, once per embedded context, instead
-        of one host read-back per block).  GF_FOLD_PAD_KEYS=0 switches the folding off (A/B, and the bit-for-bit cross-check in
+        of one host read-back per block).  `ops.options(fold_pad_keys=False)` switches the folding off (A/B, and the cross-check in
         tests/test_kernels_gpu.py)."""
         m = 1
-        if fold and ctx2.is_cuda and _FOLD_PAD_KEYS[0]:
+        if fold and ctx2.is_cuda and ops._OPT["fold_pad_keys"]:
             n = pad_run(ctx2) if pad_n is None else pad_n
             if ctx2.shape[0] - n >= 2 and n + 1 < ops.VT_MIN_KV:      # (the multiplicity form exists for short key sequences only)
                 m = ctx2.shape[0] - n

@@ -29,7 +29,7 @@ import torch
 
 from . import ops
 from ._lib import GoalForceError
-from .dit import WanModel, pad_run, _FOLD_PAD_KEYS
+from .dit import WanModel, pad_run
 
 
 class ContextCache:
@@ -113,7 +113,7 @@ def model_fn_wan_video(
     else:
         ctx = dit.embed_text(context)
         # ONE read-back per embedded context; the blocks below take n instead of detecting the run again
-        pad_n = pad_run(ctx[0]) if _FOLD_PAD_KEYS[0] else None
+        pad_n = pad_run(ctx[0]) if ops._OPT["fold_pad_keys"] else None
         if context_cache is not None:
             context_cache.ctx, context_cache.pad_n = ctx, pad_n
 

@@ -206,14 +206,25 @@ VT_MIN_KV = 2048   # key sequences at least this long go through the pre-transpo
 # in the library) reads an environment variable: the defaults are the shipped dispatch and only `options(...)` changes them.
 #   library side (gf_set_option): prefer_8wave, a4_stagger, a4_group_m, conv_nb, conv_gather, conv_direct, vae_rms3
 #   this module: attn_k3 (False: long key sequences on kernel 2), vt_from_gemm (False: V^T by gf_transpose_v32, not by the V projection),
-#                conv_padded (False: the VAE's 192 / 384-channel 3x3x3 convolutions on gf_conv3d_bf16 instead of the padded-layout kernel)
+#                conv_padded (False: the VAE's 192 / 384-channel 3x3x3 convolutions on gf_conv3d_bf16 instead of the padded-layout kernel),
+#                fold_pad_keys (False: cross-attention over all 512 context keys instead of the prompt + ONE key of multiplicity, dit.py)
 _LIB_DEFAULTS = {"prefer_8wave": 0, "a4_stagger": 2, "a4_group_m": 0, "conv_nb": 0, "conv_gather": 0, "conv_direct": 1, "vae_rms3": 1}
-_OPT = {"attn_k3": True, "vt_from_gemm": True, "conv_padded": True}
-_LIB_OPT = dict(_LIB_DEFAULTS)
+_OPT = {"attn_k3": True, "vt_from_gemm": True, "conv_padded": True, "fold_pad_keys": True}
+
+
+def lib_option(name: str) -> int:
+    """The value of a library-side dispatch option as the LIBRARY holds it (gf_get_option) — not a Python mirror: a caller that
+    used gf_set_option / gf_reset_options directly is seen."""
+    import ctypes
+    v = ctypes.c_int(0)
+    _lib.check(_lib.load().gf_get_option(name.encode(), ctypes.byref(v)), f"gf_get_option({name})")
+    return int(v.value)
 
 
 class options:
-    """`with ops.options(prefer_8wave=1): ...` — dispatch overrides for a block, restored afterwards (tests and A/B tools)."""
+    """`with ops.options(prefer_8wave=1): ...` — dispatch overrides for a block, restored afterwards (tests and A/B tools).  The
+    restore values are read from the library when the block is entered; an override that fails half-way rolls back the ones
+    already applied before the error propagates."""
 
     def __init__(self, **kv):
         for k in kv:
@@ -222,21 +233,28 @@ class options:
         self.kv, self.old = kv, {}
 
     @staticmethod
-    def _apply(kv):
-        for k, v in kv.items():
-            if k in _OPT:
-                _OPT[k] = bool(v)
-            else:
-                _lib.check(_lib.load().gf_set_option(k.encode(), int(v)), f"gf_set_option({k})")
-                _LIB_OPT[k] = int(v)
+    def _apply_one(k, v):
+        if k in _OPT:
+            _OPT[k] = bool(v)
+        else:
+            _lib.check(_lib.load().gf_set_option(k.encode(), int(v)), f"gf_set_option({k})")
 
     def __enter__(self):
-        self.old = {k: (_OPT[k] if k in _OPT else _LIB_OPT[k]) for k in self.kv}
-        self._apply(self.kv)
+        self.old = {}
+        try:
+            for k, v in self.kv.items():
+                old = _OPT[k] if k in _OPT else lib_option(k)
+                self._apply_one(k, v)
+                self.old[k] = old
+        except BaseException:
+            self.__exit__(None, None, None)
+            raise
         return self
 
     def __exit__(self, *exc):
-        self._apply(self.old)
+        for k, v in reversed(list(self.old.items())):
+            self._apply_one(k, v)
+        self.old = {}
         return False
 
 

@@ -14,7 +14,6 @@ the models are attached; it can also be supplied pre-computed: `context_posi`, `
 from __future__ import annotations
 
 import copy
-import os
 from typing import Optional
 
 import numpy as np
@@ -52,8 +51,8 @@ class WanVideoPipeline:
         self.model_fn = model_fn_wan_video  # GF:161 — the reference's own swap point
         self.share_cfg_prefix = True        # denoise(): block 0's self-attention half once per CFG step (bit-identical)
         # denoise(): the uncond forward of a CFG step on a second HIP stream, concurrent with the cond forward (same kernels, same
-        # bits).  Measured (3 % slower at full size) and left off: GF_CFG_STREAMS=1 switches it on for A/Bs.
-        self.cfg_streams = os.environ.get("GF_CFG_STREAMS", "0") == "1"
+        # bits).  Measured (3 % slower at full size) and left off; a plain attribute, set by whoever wants the A/B.
+        self.cfg_streams = False
         self._cfg_side_stream = None
         self.vram_management_enabled = False
         self.elide_zero_controlnet = True

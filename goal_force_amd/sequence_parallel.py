@@ -98,14 +98,17 @@ class SequenceParallel:
         return out if total is None or total == out.shape[0] else out[:total]
 
     # ---- attention ------------------------------------------------------------------------------------------------
-    def heads_start(self, t: torch.Tensor):
+    def heads_start(self, t: torch.Tensor, num_heads: Optional[int] = None):
         """Start the tokens-for-heads exchange of ONE projection: t = this rank's tokens [S/P, NH*DH] -> (work, recv) with
         recv [S, (NH/P)*DH] = all S tokens of this rank's head group once `work.wait()` has returned.  The collective is
         asynchronous (RCCL runs it on the process group's own stream, ordered after the kernels already queued on the current one):
         SelfAttention.attend starts K's exchange, then computes the V projection while it flies, and so on — only the last
-        exchange (Q) is exposed."""
+        exchange (Q) is exposed.  `num_heads`: checked against the group size HERE, before any fabric traffic is issued."""
         p = self.size
         sl, d = t.shape
+        if d % p or (num_heads is not None and (num_heads % p or d % num_heads)):
+            raise GoalForceError(f"sequence parallel: {num_heads if num_heads is not None else '?'} heads of total width {d} do not "
+                                 f"divide over {p} ranks")
         dh = d // p
         send = torch.empty((p, sl, dh), dtype=t.dtype, device=t.device)
         send.copy_(t.reshape(sl, p, dh).transpose(0, 1))      # [S/P, P, dh] -> [P, S/P, dh]: block j goes to rank j
@@ -145,7 +148,7 @@ class SequenceParallel:
             return ops.flash_attn(q, k, v, num_heads)
         if num_heads % self.size:
             raise GoalForceError(f"sequence parallel: {num_heads} heads do not divide by {self.size} ranks")
-        hk, hv, hq = self.heads_start(k), self.heads_start(v), self.heads_start(q)
+        hk, hv, hq = self.heads_start(k, num_heads), self.heads_start(v, num_heads), self.heads_start(q, num_heads)
         return self.attention_started(hq, hk, hv, num_heads, tuple(q.shape))
 
     def preflight(self, device) -> int:

@@ -21,7 +21,6 @@ Design (MI355X-first, not a port of torch autograd):
 from __future__ import annotations
 
 import math
-import os
 from typing import Optional
 
 import torch
@@ -200,8 +199,8 @@ _PARAM_NAMES = (
 )
 
 
-# What a block's forward keeps for its backward besides its inputs (GF_TRAIN_KEEP):
-#   "none": nothing — the backward recomputes the whole block (GF_TRAIN_KEEP_ATTN=0 is the same switch under its first name);
+# What a block's forward keeps for its backward besides its inputs (set_keep_level):
+#   "none": nothing — the backward recomputes the whole block;
 #   "attn": the self-attention output + log-sum-exp (0.34 GB per block at 32760 tokens; 17 GB at A14B size, 0.9 s less per step);
 #   "wide": also the three self-attention projections (pre-norm q, k; v) and the block's state after the self- and the
 #           cross-attention branch: 2.0 GB per block, 100 GB at A14B size — a training step then peaks near 190 GB of the 288 GB and
@@ -210,14 +209,20 @@ _PARAM_NAMES = (
 #   "auto" (default): "wide" for a block whose forward finds the device with room for it (free memory, torch's cached blocks
 #           included, >= WIDE_HEADROOM x the five tensors it would keep), else "attn" — a process that also holds the second
 #           expert, a longer sequence or a smaller part degrades to the 17 GB setting instead of running out of memory.
-_KEEP = os.environ.get("GF_TRAIN_KEEP", "auto")
-if os.environ.get("GF_TRAIN_KEEP_ATTN", "1") == "0":
-    _KEEP = "none"
-if _KEEP not in ("none", "attn", "wide", "auto"):
-    raise GoalForceError(f"GF_TRAIN_KEEP={_KEEP!r}: expected none, attn, wide or auto")
-KEEP_ATTENTION = _KEEP != "none"
-KEEP_WIDE = _KEEP == "wide"
-KEEP_AUTO = _KEEP == "auto"
+KEEP_ATTENTION, KEEP_WIDE, KEEP_AUTO = True, False, True
+
+
+def set_keep_level(level: str = "auto") -> str:
+    """Choose what the blocks' forwards keep ("none" / "attn" / "wide" / "auto", above); returns the level that was in force.
+    A call, not an environment variable: nothing in this package reads the environment to pick a code path."""
+    global KEEP_ATTENTION, KEEP_WIDE, KEEP_AUTO
+    if level not in ("none", "attn", "wide", "auto"):
+        raise GoalForceError(f"set_keep_level({level!r}): expected none, attn, wide or auto")
+    old = "none" if not KEEP_ATTENTION else "wide" if KEEP_WIDE else "auto" if KEEP_AUTO else "attn"
+    KEEP_ATTENTION, KEEP_WIDE, KEEP_AUTO = level != "none", level == "wide", level == "auto"
+    return old
+
+
 WIDE_HEADROOM = 24      # blocks' worth of wide tensors that must still fit (the blocks ahead of this one + the backward's ~6 GB working set)
 
 

@@ -21,8 +21,8 @@ How the reference's algorithm maps here
 """
 from __future__ import annotations
 
+import contextlib
 import math
-import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -38,17 +38,11 @@ VAE_STD = [2.8184, 1.4541, 2.3275, 2.6558, 1.2196, 1.7708, 2.6052, 2.0743,
            3.2687, 2.1526, 2.8652, 1.5579, 1.6382, 1.1253, 2.8251, 1.9160]        # VAE:1067-1070
 
 
-# Convolutions run as ONE implicit GEMM (gf_conv3d_bf16: no patch matrix in HBM).  GF_VAE_CONV=im2col selects the first
-# version (gf_vae_im2col + gf_gemm_bf16, bit-identical results) for A/B timing and for the parity test of the two.
-IMPLICIT_CONV = os.environ.get("GF_VAE_CONV", "implicit") != "im2col"
-
-
 def _conv(x, cache, c, resid=None, **gather):
-    """One prepared conv `c` (dict of _prep_conv) on x [T,H,W,C] (+ 2-frame cache) -> [T_out*Ho*Wo, N]."""
-    if IMPLICIT_CONV:
-        return ops.vae_conv3d(x, cache, c["w"], c["b"], c["kt"], c["ks"], resid=resid, **gather)
-    cols = ops.vae_im2col(x, cache, c["kt"], c["ks"], c["kpad"], **gather)
-    return ops.gemm(cols, c["w"], c["b"], epilogue=ops.EPI_BIAS if resid is None else ops.EPI_BIAS_RESID, resid=resid)
+    """One prepared conv `c` (dict of _prep_conv) on x [T,H,W,C] (+ 2-frame cache) -> [T_out*Ho*Wo, N]: ONE implicit GEMM
+    (gf_conv3d_bf16: no patch matrix in HBM).  The patch-matrix form (gf_vae_im2col + gf_gemm_bf16) is the tests' cross-check of
+    it (tests/test_vae.py), not a product path."""
+    return ops.vae_conv3d(x, cache, c["w"], c["b"], c["kt"], c["ks"], resid=resid, **gather)
 
 
 def _with_history(shape, like):
@@ -226,12 +220,14 @@ class WanVideoVAE(nn.Module):
         self.z_dim = z_dim
         self._prepared = None     # GEMM-ready weights (built lazily, invalidated on load)
         self._cache: Dict[str, torch.Tensor] = {}
-        self._pad_pool: Dict[tuple, list] = {}    # zero-bordered conv inputs by shape (_padded_buffer)
+        self._pad_pool: Dict[tuple, list] = {}    # zero-bordered conv inputs by shape (_padded_buffer); lives inside a _pool_scope
+        self._pool_depth, self._pool_sig, self._pool_stream = 0, None, None
         # latent frames per decoder call / 4-frame chunks per encoder call after the first frame (1 = the reference's streaming
         # granularity; any value gives the same bits).  20 = the whole 81-frame clip of a tile: ~10 GB of activations.
-        self.frames_per_chunk = int(os.environ.get("GF_VAE_FRAMES_PER_CHUNK", "20"))
-        # the clip's first frame in one chunk with the first group of frames (0: a chunk of its own, as the reference streams it; A/B)
-        self.merge_first = os.environ.get("GF_VAE_MERGE_FIRST", "1") != "0"
+        # Plain attributes (no environment variable reads them): tests and tools assign them.
+        self.frames_per_chunk = 20
+        # the clip's first frame in one chunk with the first group of frames (False: a chunk of its own, as the reference streams it)
+        self.merge_first = True
 
     # ---------------------------------------------------------------- state dict
     def load_state_dict(self, state_dict, strict=True, **kw):
@@ -298,7 +294,7 @@ class WanVideoVAE(nn.Module):
         cache = None
         if c["kt"] == 3:
             cache = self._cache.get(name)
-            if front is not None and IMPLICIT_CONV:
+            if front is not None:
                 if x.data_ptr() != front[CACHE_T:].data_ptr() or front.shape[1:] != x.shape[1:]:
                     raise GoalForceError("_causal_conv: x must be frames [2:] of `front`")
                 if cache is None:
@@ -341,20 +337,46 @@ class WanVideoVAE(nn.Module):
         r2 = None if resid is None else resid.reshape(T * H * W, -1)
         return ops.vae_conv3d_padded(buf, c["w"], c["b"], resid=r2).view(T, H, W, -1)
 
-    def _padded_buffer(self, T, H, W, C, device):
+    def _padded_buffer(self, T, H, W, C, device, history=True):
         """One zero-bordered buffer per shape: zeroed when created, afterwards only its interior is written.  One is enough — every
-        producer and consumer of it runs on the same stream, and a residual block's second conv input is built after the first
-        convolution has read the buffer.  decode() / encode() drop the pool when they return."""
-        key = (T, H, W, C, str(device))
+        producer and consumer of it runs on the same stream (checked), and a residual block's second conv input is built after the
+        first convolution has read the buffer.  The pool lives for one _pool_scope (a decode / encode call, or one tile when the
+        tile-level entry points are called directly) and holds the buffers of ONE tile shape at a time (~3 GB at the production tile)."""
+        if self._pool_depth <= 0:
+            raise GoalForceError("_padded_buffer outside a _pool_scope: the padded-layout buffers would never be released")
+        stream = torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == "cuda" else None
+        if self._pool_stream is None:
+            self._pool_stream = stream
+        elif stream != self._pool_stream:
+            raise GoalForceError("the VAE's padded-layout buffers are shared by every convolution of a tile: run a decode / encode on "
+                                 "ONE stream (the pool was created on another stream than the current one)")
+        key = (T, H, W, C, str(device), bool(history))
         if key not in self._pad_pool:
-            self._pad_pool[key] = ops.padded_activation(T, H, W, C, device)
+            self._pad_pool[key] = ops.padded_activation(T, H, W, C, device) if history else \
+                ops.padded_activation(T, H, W, C, device, history=False)
         return self._pad_pool[key]
+
+    @contextlib.contextmanager
+    def _pool_scope(self, tile_sig=None):
+        """The lifetime of the padded-layout pool: the OUTERMOST scope drops it on the way out — also when an exception passes
+        through (callers of the tile-level entry points never released it).  `tile_sig` (a tile-level entry): a tile
+        of another shape than the previous one drops the previous shape's buffers first, so that a decode with ragged edge tiles
+        holds one shape's set, not one set per distinct shape."""
+        if tile_sig is not None and tile_sig != self._pool_sig:
+            self._pad_pool, self._pool_sig = {}, tile_sig
+        self._pool_depth += 1
+        try:
+            yield
+        finally:
+            self._pool_depth -= 1
+            if self._pool_depth == 0:
+                self._pad_pool, self._pool_sig, self._pool_stream = {}, None, None
 
     def _res_block(self, P, name, x, cin, cout):
         """ResidualBlock (VAE:267-301)."""
         h = x if cin == cout else self._causal_conv(P, name + ".shortcut", x)
         # per convolution: the padded-layout kernel where the INPUT has 192 / 384 channels (conv 1: cin, conv 2: cout)
-        pad_ok = IMPLICIT_CONV and ops._OPT["conv_padded"] and x.is_contiguous()
+        pad_ok = ops._OPT["conv_padded"] and x.is_contiguous()
         if pad_ok and ops.padded_conv_fits(*x.shape[:3], cin):
             y = self._padded_conv(P, name + ".residual.2", x, P[name + ".residual.0.gamma"])
         else:
@@ -415,15 +437,13 @@ class WanVideoVAE(nn.Module):
                 x = out
                 T = n0 + 2 * Tr
         rc = P[name + ".resample.1"]
-        if IMPLICIT_CONV and ops._OPT["conv_padded"] and rc["w"].shape[0] >= 192 and x.is_contiguous() \
+        if ops._OPT["conv_padded"] and rc["w"].shape[0] >= 192 and x.is_contiguous() \
                 and ops.padded_conv_fits(T, 2 * H, 2 * W, C, history=False):
             # 384 -> 192: the upsampled frames go into the zero-bordered layout once (4 x the source, one pass) and the 3x3
             # convolution reads its taps as row shifts (gf_conv3d_padded_bf16, kt = 1) — same values, same sums as the folded gather
-            key = ("up", T, 2 * H, 2 * W, C, str(x.device))
-            if key not in self._pad_pool:
-                self._pad_pool[key] = ops.padded_activation(T, 2 * H, 2 * W, C, x.device, history=False)
-            ops.vae_upsample2x_padded(x, self._pad_pool[key][0])
-            return ops.vae_conv3d_padded(self._pad_pool[key][0], rc["w"], rc["b"], kt=1).view(T, 2 * H, 2 * W, -1)
+            up = self._padded_buffer(T, 2 * H, 2 * W, C, x.device, history=False)[0]
+            ops.vae_upsample2x_padded(x, up)
+            return ops.vae_conv3d_padded(up, rc["w"], rc["b"], kt=1).view(T, 2 * H, 2 * W, -1)
         return _conv(x, None, rc, upsample2x=True).view(T, 2 * H, 2 * W, -1)
 
     def _decode_chunk(self, P, x, first):
@@ -446,6 +466,13 @@ class WanVideoVAE(nn.Module):
 
     def decode_tile_channels_last(self, z_slice: torch.Tensor) -> torch.Tensor:
         """VideoVAE_.decode (VAE:1011-1034) for one [16,T,h,w] latent slice -> [4T-3, 8h, 8w, 8] (RGB in 0..2)."""
+        with self._pool_scope(("dec",) + tuple(z_slice.shape)):
+            try:
+                return self._decode_tile(z_slice)
+            finally:
+                self._cache = {}          # the feature caches never outlive a tile, whatever happened inside it
+
+    def _decode_tile(self, z_slice):
         P = self._prepare()
         self._cache = {}
         zc = ops.vae_prep_latent(z_slice, P["mean"], P["inv_std"], cpad=64)         # z / (1/std) + mean
@@ -507,6 +534,13 @@ class WanVideoVAE(nn.Module):
 
     def encode_tile_channels_last(self, video_slice: torch.Tensor) -> torch.Tensor:
         """VideoVAE_.encode (VAE:988-1010) for one [3,T,H,W] slice (any strides) -> normalised mu [T', H/8, W/8, 16]."""
+        with self._pool_scope(("enc",) + tuple(video_slice.shape)):
+            try:
+                return self._encode_tile(video_slice)
+            finally:
+                self._cache = {}
+
+    def _encode_tile(self, video_slice):
         P = self._prepare()
         self._cache = {}
         T = video_slice.shape[1]
@@ -567,16 +601,16 @@ class WanVideoVAE(nn.Module):
         (VAE:1218-1232).  Tile sizes are given in latent units like the reference and scaled by 8 here."""
         u = self.upsampling_factor
         outs = []
-        for v in videos:
-            v = v.unsqueeze(0)
-            if not v.is_cuda:
-                v = v.to(device or "cuda")
-            if tiled:
-                z = self.tiled_encode(v, device, (tile_size[0] * u, tile_size[1] * u), (tile_stride[0] * u, tile_stride[1] * u))
-            else:
-                z = self.single_encode(v, device)
-            outs.append(z.squeeze(0))
-        self._pad_pool = {}
+        with self._pool_scope():
+            for v in videos:
+                v = v.unsqueeze(0)
+                if not v.is_cuda:
+                    v = v.to(device or "cuda")
+                if tiled:
+                    z = self.tiled_encode(v, device, (tile_size[0] * u, tile_size[1] * u), (tile_stride[0] * u, tile_stride[1] * u))
+                else:
+                    z = self.single_encode(v, device)
+                outs.append(z.squeeze(0))
         return torch.stack(outs)
 
     # ---------------------------------------------------------------- public API (VAE:1103-1152, 1211-1247)
@@ -639,13 +673,13 @@ class WanVideoVAE(nn.Module):
     def decode(self, hidden_states, device=None, tiled=False, tile_size=(34, 34), tile_stride=(18, 16), tile_group=None):
         """[B,16,T,h,w] bf16 latents -> [B,3,4T-3,8h,8w] bf16 in [-1,1] (device tensor).  tile_group: see tiled_decode."""
         videos = []
-        for hs in hidden_states:
-            hs = hs.unsqueeze(0)
-            if not hs.is_cuda:
-                hs = hs.to(device or "cuda")
-            v = (self.tiled_decode(hs, device, tile_size, tile_stride, tile_group=tile_group) if tiled
-                 else self.single_decode(hs, device))
-            videos.append(v.squeeze(0))
-        self._pad_pool = {}
+        with self._pool_scope():
+            for hs in hidden_states:
+                hs = hs.unsqueeze(0)
+                if not hs.is_cuda:
+                    hs = hs.to(device or "cuda")
+                v = (self.tiled_decode(hs, device, tile_size, tile_stride, tile_group=tile_group) if tiled
+                     else self.single_decode(hs, device))
+                videos.append(v.squeeze(0))
         return torch.stack(videos)
 

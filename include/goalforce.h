@@ -54,6 +54,7 @@ GF_API int gf_abi_version(void);          /* bumped on any signature change */
  * "conv_direct" (0/1), "vae_rms3" (0/1).  Values are clamped to their range; an unknown name returns GF_ERR_INVALID_ARG.
  * The library reads NO environment variable: only these calls change the dispatch.  Process-wide, relaxed atomics. */
 GF_API int gf_set_option(const char* name, int value);
+GF_API int gf_get_option(const char* name, int* value);   /* the value in force (after clamping); a caller that overrides one reads it first to restore it */
 GF_API void gf_reset_options(void);   /* back to the shipped dispatch */
 
 /* ------------------------------------------------------------------------

@@ -105,8 +105,10 @@ def _preflight_worker(rank, world, port, out, sp_size, sabotage):
         from goal_force_amd import distributed as gd
         cp = CfgPairParallel(rank, world, sp_size=sp_size)
         if sabotage and rank == 1:
-            # a transport that "succeeds" without moving the peer's data: the content check must catch it
-            cp.exchange = lambda x: (x, x)
+            # a transport that "succeeds" without moving the peer's data (the collective is entered, what it delivers is this rank's
+            # own buffer twice): the content check must catch it
+            real = cp.exchange
+            cp.exchange = lambda x: (real(x), (x, x))[1]
         try:
             rep = gd.preflight(cp, "cpu", latent_shape=(1, 16, 3, 4, 6), frames_shape=(5, 8, 8, 3), tile_shape=(5, 8, 8, 8))
             torch.save({"rep": rep, "error": None}, os.path.join(out, f"r{rank}.pt"))
@@ -139,3 +141,6 @@ def test_multi_gpu_preflight_fails_loudly_on_a_transport_that_moves_nothing(tmp_
     mp.spawn(_preflight_worker, args=(2, _free_port(), str(tmp_path), 1, True), nprocs=2, join=True)
     err = torch.load(os.path.join(tmp_path, "r1.pt"))["error"]
     assert err and "pre-flight" in err and "noise-prediction all-gather" in err and "rank 1" in err, err
+    # ... and the peer raises too, at the same step, instead of waiting in the next barrier for the backend's timeout
+    err0 = torch.load(os.path.join(tmp_path, "r0.pt"))["error"]
+    assert err0 and "`noise_pred_allgather_pair` failed on another rank" in err0 and "this is rank 0" in err0, err0

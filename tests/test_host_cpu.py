@@ -167,21 +167,55 @@ def test_attention_backward_workspace_size_is_host_arithmetic():
         assert n == want and n % 256 == 0, (q, kv, h, n, want)
 
 
-def test_training_keep_level_is_validated(monkeypatch):
-    import importlib
+def test_training_keep_level_is_validated():
     import goal_force_amd.training as tr
     from goal_force_amd._lib import GoalForceError
-    monkeypatch.setenv("GF_TRAIN_KEEP", "everything")
+    assert tr.KEEP_AUTO and tr.KEEP_ATTENTION and not tr.KEEP_WIDE      # default: wide only where the device has room for it
+    assert not tr._wide_fits(torch.zeros(4, 8))                         # host tensor: no device to ask -> the 17 GB setting
     with pytest.raises(GoalForceError):
-        importlib.reload(tr)
-    monkeypatch.setenv("GF_TRAIN_KEEP", "attn")
-    assert importlib.reload(tr).KEEP_ATTENTION and not tr.KEEP_WIDE
-    monkeypatch.setenv("GF_TRAIN_KEEP", "wide")
-    assert importlib.reload(tr).KEEP_WIDE and tr._wide_fits(torch.zeros(4, 8))
-    monkeypatch.delenv("GF_TRAIN_KEEP")
-    tr = importlib.reload(tr)                      # default: wide only where the device has room for it
-    assert tr.KEEP_AUTO and tr.KEEP_ATTENTION and not tr.KEEP_WIDE
-    assert not tr._wide_fits(torch.zeros(4, 8))    # host tensor: no device to ask -> the 17 GB setting
+        tr.set_keep_level("everything")
+    try:
+        assert tr.set_keep_level("attn") == "auto" and tr.KEEP_ATTENTION and not tr.KEEP_WIDE and not tr.KEEP_AUTO
+        assert tr.set_keep_level("wide") == "attn" and tr.KEEP_WIDE and tr._wide_fits(torch.zeros(4, 8))
+        assert tr.set_keep_level("none") == "wide" and not tr.KEEP_ATTENTION
+    finally:
+        tr.set_keep_level("auto")
+
+
+# environment variables the package may read: where the library is, and the launcher's rendezvous (torch.distributed.run's own names)
+ENV_WHITELIST = {"GOALFORCE_HIP_LIB", "GF_DIST_BACKEND", "WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                 "HSA_ENABLE_IPC_MODE_LEGACY"}
+
+
+def test_package_reads_no_environment_variable_outside_the_whitelist():
+    """no Python-level env selector of a code path.  Every `os.environ` / `getenv` use in goal_force_amd/*.py
+    names a whitelisted variable (library location, the launcher's rendezvous, the transport) — found on the AST, not by grep."""
+    import ast
+    pkg = os.path.join(ROOT, "goal_force_amd")
+    seen = set()
+    for f in sorted(os.listdir(pkg)):
+        if not f.endswith(".py"):
+            continue
+        tree = ast.parse(open(os.path.join(pkg, f)).read(), f)
+        parents = {c: n for n in ast.walk(tree) for c in ast.iter_child_nodes(n)}
+        for node in ast.walk(tree):
+            is_env = isinstance(node, ast.Attribute) and node.attr in ("environ", "getenv", "putenv") and \
+                isinstance(node.value, ast.Name) and node.value.id in ("os", "_os")
+            if not is_env:
+                continue
+            # the use must be os.environ.get("X") / .setdefault("X", ..) / os.environ["X"] / os.getenv("X") with a literal name
+            cur, name = node, None
+            for _ in range(3):
+                cur = parents.get(cur)
+                if isinstance(cur, ast.Call) and cur.args and isinstance(cur.args[0], ast.Constant):
+                    name = cur.args[0].value
+                    break
+                if isinstance(cur, ast.Subscript) and isinstance(cur.slice, ast.Constant):
+                    name = cur.slice.value
+                    break
+            assert name in ENV_WHITELIST, f"{f}:{node.lineno}: environment use outside the whitelist ({name!r})"
+            seen.add(name)
+    assert "GOALFORCE_HIP_LIB" in seen and "WORLD_SIZE" in seen, seen
 
 
 def test_bindings_refuse_a_library_of_another_abi_revision(monkeypatch):

@@ -267,7 +267,7 @@ def test_flash_attn_last_key_multiplicity_equals_repeated_keys(ops):
 
 def test_cross_attention_folds_the_padded_context_rows(ops):
     """CrossAttention.context_kv detects the run of identical rows that ends a prompter-padded context (wan_prompter.py:99-109) and
-    attends n + 1 keys with multiplicity instead of 512: same result as the unfolded module (GF_FOLD_PAD_KEYS = 0) within bf16
+    attends n + 1 keys with multiplicity instead of 512: same result as the unfolded module (ops.options(fold_pad_keys=False)) within bf16
     rounding; a context without such a run, and the training forward, are attended in full."""
     from goal_force_amd import dit
     g = torch.Generator().manual_seed(5)
@@ -284,13 +284,11 @@ def test_cross_attention_folds_the_padded_context_rows(ops):
     k, v, m = ca.context_kv(ctx[0])
     assert m == 472 and k.shape[0] == 41
     folded = ca(x, ctx)
-    dit._FOLD_PAD_KEYS[0] = False
-    try:
+    with ops.options(fold_pad_keys=False):
         k2, v2, m2 = ca.context_kv(ctx[0])
         assert m2 == 1 and k2.shape[0] == 512 and torch.equal(k2[:41], k) and torch.equal(v2[40], v2[511])
         full = ca(x, ctx)
-    finally:
-        dit._FOLD_PAD_KEYS[0] = True
+    assert ca.context_kv(ctx[0])[2] == 472, "the option is restored on leaving the block"
     assert rel_l2(folded.float().cpu(), full.float().cpu()) < 6e-3      # two bf16 evaluations of the same function
     rnd = torch.randn(1, 64, 256, generator=g).to(BF).cuda()
     assert ca.context_kv(rnd[0])[2] == 1 and ca.context_kv(ctx[0], fold=False)[2] == 1

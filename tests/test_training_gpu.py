@@ -274,7 +274,7 @@ def test_dit_block_backward_mid_size_vs_oracle():
 
 
 def test_dit_block_backward_is_the_same_whatever_the_forward_kept(monkeypatch):
-    """GF_TRAIN_KEEP = none / attn / wide: kept tensors are the forward's own values, so the gradients agree to rounding (the fused
+    """training.set_keep_level none / attn / wide: kept tensors are the forward's own values, so the gradients agree to rounding (the fused
     forward rounds x1 / x2b once where the un-fused recompute rounds per op), for a trainable and for a frozen block."""
     import gen_inputs as gi
     from goal_force_amd import training
@@ -292,8 +292,10 @@ def test_dit_block_backward_is_the_same_whatever_the_forward_kept(monkeypatch):
         for p_ in blk.parameters():
             p_.requires_grad_(not frozen)
         for level in ("none", "attn", "wide"):
-            monkeypatch.setattr(training, "KEEP_ATTENTION", level != "none")
-            monkeypatch.setattr(training, "KEEP_WIDE", level == "wide")
+            monkeypatch.setattr(training, "KEEP_ATTENTION", True)      # (restores the module state after the test)
+            monkeypatch.setattr(training, "KEEP_WIDE", False)
+            monkeypatch.setattr(training, "KEEP_AUTO", True)
+            training.set_keep_level(level)
             for p_ in blk.parameters():
                 p_.grad = None
             xc = x[0].cuda().requires_grad_(True)

@@ -314,6 +314,52 @@ def test_hip_decoder_tile_same_bits_on_both_conv_paths():
 
 
 @pytest.mark.gpu
+def test_hip_padded_pool_is_released_by_every_entry_point_and_on_errors():
+    """the zero-bordered conv inputs (~3 GB at a production tile) live for one decode / encode call — or one tile when
+    the tile-level entry points are called directly — and are dropped when an exception passes through; the feature caches too.  A
+    second stream inside one scope is refused (the buffers are shared by every convolution of the tile)."""
+    from goal_force_amd._lib import GoalForceError
+    from goal_force_amd.vae import WanVideoVAE
+    torch.manual_seed(12)
+    vae = WanVideoVAE().to(BF).cuda()
+    z = torch.randn((16, 3, 8, 12)).to(BF).cuda()
+    seen = []
+    real = vae._decode_chunk
+
+    def spy(P, x, first):
+        out = real(P, x, first)
+        seen.append(len(vae._pad_pool))
+        return out
+    vae._decode_chunk = spy
+    ref = vae.decode_tile_channels_last(z)
+    assert max(seen) > 0, "the tile went through the padded-layout kernel"
+    assert vae._pad_pool == {} and vae._cache == {} and vae._pool_depth == 0
+    got = vae.decode(z[None], tiled=False)
+    assert vae._pad_pool == {} and vae._pool_depth == 0 and got.shape == (1, 3, 9, 64, 96)
+    video = (torch.rand((3, 5, 64, 96)) * 2 - 1).to(BF).cuda()
+    vae.encode_tile_channels_last(video)
+    assert vae._pad_pool == {} and vae._cache == {}
+
+    def boom(P, x, first):
+        real(P, x, first)
+        raise RuntimeError("boom")
+    vae._decode_chunk = boom
+    with pytest.raises(RuntimeError, match="boom"):
+        vae.decode(z[None], tiled=True, tile_size=(8, 8), tile_stride=(4, 4))
+    assert vae._pad_pool == {} and vae._cache == {} and vae._pool_depth == 0 and vae._pool_stream is None
+    vae._decode_chunk = real
+    assert torch.equal(vae.decode_tile_channels_last(z), ref), "and the next call is unaffected"
+    with pytest.raises(GoalForceError, match="_pool_scope"):
+        vae._padded_buffer(3, 8, 12, 192, z.device)
+    side = torch.cuda.Stream()
+    with vae._pool_scope():
+        vae._padded_buffer(3, 8, 12, 192, z.device)
+        with torch.cuda.stream(side), pytest.raises(GoalForceError, match="ONE stream"):
+            vae._padded_buffer(3, 8, 12, 192, z.device)
+    assert vae._pad_pool == {}
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("C", [96, 192, 384])
 def test_hip_rmsnorm_silu_three_chunk_kernel_is_bit_identical(C):
     """RMS_norm (+SiLU) at C = 96 / 192 / 384: the all-lanes-live kernel (three chunks per lane, the row sum's two top butterfly stages
