@@ -207,6 +207,94 @@ class CannyDetector:
         return ((state == 2).to(torch.uint8) * 255).unsqueeze(-1).expand(-1, -1, -1, 3).contiguous()
 
 
+class VideoOperator:
+    """`ControlSignalDataset_CannyEdge.default_video_operator(...)` (DS:441-461): path (relative to base_path) -> list of PIL frames,
+    each through ImageCropAndResize (DS:136-170: scale = max(W'/W, H'/H), bilinear resize to (round(H*scale), round(W*scale)), centre
+    crop).  torchvision's PIL path is `img.resize((w, h), BILINEAR)` and a crop at int(round((size - crop) / 2.0)) — restated on PIL
+    alone (torchvision is not in this image).  Frame count: LoadVideo.get_num_frames (DS:188-194): `num_frames`, or for a shorter clip
+    the largest count <= its length with count % time_division_factor == time_division_remainder.
+    Containers: still images (one frame), GIF (PIL), a DIRECTORY of frame images (sorted by name), `.npy` / `.npz` holding uint8
+    [T,H,W,3]; mp4 / avi / mov / ... go through `imageio` exactly as DS:199-207 when it is importable and are refused by name when
+    it is not (decoding is host I/O outside the path).  A clip that fails to load returns None, as DS:209-212 does."""
+
+    IMAGE_EXT = ("jpg", "jpeg", "png", "webp")
+    VIDEO_EXT = ("mp4", "avi", "mov", "wmv", "mkv", "flv", "webm")
+
+    def __init__(self, base_path="", max_pixels=1920 * 1080, height=None, width=None, height_division_factor=16,
+                 width_division_factor=16, num_frames=81, time_division_factor=4, time_division_remainder=1):
+        self.base_path, self.max_pixels, self.height, self.width = base_path, max_pixels, height, width
+        self.hdiv, self.wdiv = height_division_factor, width_division_factor
+        self.num_frames, self.tdiv, self.trem = num_frames, time_division_factor, time_division_remainder
+
+    def target_size(self, image):
+        """DS:155-165."""
+        if self.height is not None and self.width is not None:
+            return self.height, self.width
+        width, height = image.size
+        if width * height > self.max_pixels:
+            scale = (width * height / self.max_pixels) ** 0.5
+            height, width = int(height / scale), int(width / scale)
+        return height // self.hdiv * self.hdiv, width // self.wdiv * self.wdiv
+
+    def crop_and_resize(self, image):
+        """DS:144-153."""
+        from PIL import Image
+        th, tw = self.target_size(image)
+        width, height = image.size
+        scale = max(tw / width, th / height)
+        image = image.resize((round(width * scale), round(height * scale)), Image.BILINEAR)
+        w, h = image.size
+        top, left = int(round((h - th) / 2.0)), int(round((w - tw) / 2.0))
+        return image.crop((left, top, left + tw, top + th))
+
+    def count(self, available):
+        """DS:188-194."""
+        n = self.num_frames
+        if int(available) < n:
+            n = int(available)
+            while n > 1 and n % self.tdiv != self.trem:
+                n -= 1
+        return n
+
+    def __call__(self, data: str):
+        from PIL import Image
+        path = os.path.join(self.base_path, data)                              # ToAbsolutePath (DS:92-97)
+        ext = path.rsplit(".", 1)[-1].lower() if "." in os.path.basename(path) else ""
+        try:
+            if os.path.isdir(path):
+                names = sorted(f for f in os.listdir(path) if f.rsplit(".", 1)[-1].lower() in self.IMAGE_EXT)
+                frames = [Image.open(os.path.join(path, f)).convert("RGB") for f in names[: self.count(len(names))]]
+            elif ext in ("npy", "npz"):
+                arr = np.load(path)
+                arr = arr[arr.files[0]] if hasattr(arr, "files") else arr
+                frames = [Image.fromarray(np.ascontiguousarray(a)) for a in arr[: self.count(len(arr))]]
+            elif ext in self.IMAGE_EXT:
+                return [self.crop_and_resize(Image.open(path).convert("RGB"))]
+            elif ext == "gif":
+                gif = Image.open(path)
+                frames = []
+                for i in range(self.count(getattr(gif, "n_frames", 1))):
+                    gif.seek(i)
+                    frames.append(gif.convert("RGB"))
+            elif ext in self.VIDEO_EXT:
+                try:
+                    import imageio
+                except ImportError as e:
+                    raise GoalForceError(f"{path}: decoding .{ext} needs `imageio` (as the reference's LoadVideo, DS:199), which is not "
+                                         "installed here: pass a directory of frame images or a .npy / .npz of uint8 [T,H,W,3]") from e
+                reader = imageio.get_reader(path)
+                frames = [Image.fromarray(reader.get_data(i)) for i in range(self.count(reader.count_frames()))]
+                reader.close()
+            else:
+                raise GoalForceError(f"{path}: not a frame directory, image, gif, video or .npy / .npz clip")
+        except GoalForceError:
+            raise
+        except Exception as e:      # noqa: BLE001 — DS:209-212: log and mark the sample invalid
+            print(f"WARNING: Skipping corrupted or unreadable video file: {path}. Error: {e}")
+            return None
+        return [self.crop_and_resize(f) for f in frames]
+
+
 class ControlSignalDataset_CannyEdge(torch.utils.data.Dataset):
     """DS:406-613 — same constructor arguments, `process_for_validation(video_path, prompt)`, `_generate_control_video(frames)`,
     `__getitem__` / `__len__`.  Metadata: `.json` / `.jsonl` lists of dicts, or a CSV (the reference's OpenVid-1M listing) filtered
@@ -223,6 +311,13 @@ class ControlSignalDataset_CannyEdge(torch.utils.data.Dataset):
         self.load_from_cache = metadata_path is None
         self.load_metadata(metadata_path)
         self.canny_detector = CannyDetector(device)
+
+    @staticmethod
+    def default_video_operator(base_path="", max_pixels=1920 * 1080, height=None, width=None, height_division_factor=16,
+                               width_division_factor=16, num_frames=81, time_division_factor=4, time_division_remainder=1):
+        """DS:441-461 — the operator the Canny launcher builds per row (scripts/inference/inference_canny_edge_control.py:141-152)."""
+        return VideoOperator(base_path, max_pixels, height, width, height_division_factor, width_division_factor, num_frames,
+                             time_division_factor, time_division_remainder)
 
     def load_metadata(self, metadata_path: Optional[str]):
         if metadata_path is None:

@@ -299,12 +299,19 @@ class WanVideoPipeline:
         length = (num_frames - 1) // 4 + 1
         noise = self.generate_noise((1, 16, length, height // 8, width // 8), seed=seed, rand_device=rand_device)
         if context_posi is None or (cfg_scale != 1.0 and context_nega is None):
-            if self.text_encoder is None or self.prompter.tokenizer is None:
-                raise GoalForceError("no text encoder / tokenizer loaded: attach pipe.text_encoder (WanTextEncoder) and "
-                                     "pipe.prompter.fetch_tokenizer(path), or pass context_posi/context_nega")
-            self.prompter.fetch_models(self.text_encoder)
-            context_posi = self.prompter.encode_prompt(prompt, positive=True, device=self.device)      # GF:808-822
-            context_nega = self.prompter.encode_prompt(negative_prompt, positive=False, device=self.device)
+            from .text_encoder import WanPrompter
+            if isinstance(self.prompter, WanPrompter):
+                if self.text_encoder is None or self.prompter.tokenizer is None:
+                    raise GoalForceError("no text encoder / tokenizer loaded: attach pipe.text_encoder (WanTextEncoder) and "
+                                         "pipe.prompter.fetch_tokenizer(path), or pass context_posi/context_nega")
+                self.prompter.fetch_models(self.text_encoder)
+            # WanVideoUnit_PromptEmbedder (GF:808-822) through the unit runner: any object with the reference's
+            # `encode_prompt(prompt, positive=, device=)` works as pipe.prompter.  `positive` arrives as None for BOTH prompts in the
+            # reference — the unit maps it from inputs_posi / inputs_nega, which never hold it (GF:812-813; pinned by g13) — and only
+            # feeds prompt refiners, of which Goal Force loads none.
+            context_posi = self.prompter.encode_prompt(prompt, positive=None, device=self.device)
+            if cfg_scale != 1.0:                          # UTIL:262-271: the negative side is only computed under CFG
+                context_nega = self.prompter.encode_prompt(negative_prompt, positive=None, device=self.device)
         if y is None and input_image is not None:
             y = self.embed_image(input_image, num_frames, height, width, tiled, tile_size, tile_stride)
         if y is None and self.dit is not None and self.dit.require_vae_embedding and self.dit.in_dim > noise.shape[1]:

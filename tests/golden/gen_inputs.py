@@ -219,6 +219,12 @@ def preloop_inputs(seed=91):
     return Image.fromarray(img), control
 
 
+# g13: the keyword arguments of the whole-pipeline call (the reference's own names, GF:599-661) and its two prompts
+PIPELINE_PROMPTS = ("the pendulum swings", "static, blurry")
+PIPELINE_CALL_KWARGS = dict(seed=0, height=64, width=96, num_frames=9, num_inference_steps=3, cfg_scale=5.0, tiled=True,
+                            tile_size=(6, 8), tile_stride=(3, 4), controlnet=True)
+
+
 def preloop_decoded_video(seed=92):
     """A [1,3,2,8,8] 'decoded video' slightly outside [-1,1] (the clip must act) for the frames-to-uint8 conversion."""
     return (torch.rand((1, 3, 2, 8, 8), generator=torch.Generator().manual_seed(seed)) * 2.4 - 1.2).to(torch.bfloat16)

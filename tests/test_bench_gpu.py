@@ -29,7 +29,22 @@ def _free_port():
     return p
 
 
-def _launch(world, extra=()):
+_RUNS = {}
+
+
+def _launch(world, extra=(), args=None):
+    """One bench.py run (its JSON line); identical invocations are launched ONCE per test session and shared (the N = 1 two-layer
+    run is the yardstick of three tests)."""
+    extra = tuple(a for a in extra)
+    if extra == ("--sample-offset", "0"):
+        extra = ()                                  # the default
+    key = (world, extra, None if args is None else tuple(args))
+    if key not in _RUNS:
+        _RUNS[key] = _launch_now(world, extra, ARGS if args is None else list(args))
+    return _RUNS[key]
+
+
+def _launch_now(world, extra, args):
     port = _free_port()
     procs = []
     for r in range(world):
@@ -38,7 +53,7 @@ def _launch(world, extra=()):
         if world == 1:
             for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
                 env.pop(k)
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world)] + ARGS + list(extra),
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world)] + args + list(extra),
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=1500) for p in procs]
     for p, (so, se) in zip(procs, outs):
@@ -68,6 +83,38 @@ def test_bench_two_ranks_bit_identical_to_one():
     assert two["self_check"]["latents"]["sha256"] == one["self_check"]["latents"]["sha256"]
     assert two["self_check"]["frames_uint8"]["sha256"] == one["self_check"]["frames_uint8"]["sha256"]
     assert "cpu_baseline" not in two
+
+
+# BASELINE config 3's WORKLOAD: the production model — 40 DiT + 10 ControlNet blocks, both experts, S = 32760 — not a
+# two-layer stand-in.  K = 2 puts one timed step on each side of the expert switch (step ids 12 and 37).
+FULL = ["--steps", "2", "--warmup", "0", "--no-cpu-baseline", "--config5-steps", "0", "--peaky-steps", "0", "--no-preloop"]
+
+
+def test_bench_cfg_pair_at_production_size_bit_identical_to_one_gpu():
+    """`bench.py --gpus 2 --steps 2 --warmup 0` at FULL size over gloo on the box's one GPU (2 ranks x 71 GB of weights): the
+    pre-flight moves every collective of the path at its production byte count, the CFG pair exchanges the 4.19 MB noise prediction
+    per step, the VAE tiles are split over the pair, the leads gather the frames — and latents and uint8 frames equal the N = 1 run of
+    the same step ids bit for bit.  (RCCL between two devices is the one thing a one-GPU box cannot show: SCALE run)"""
+    two = _launch(2, args=FULL)
+    one = _launch(1, args=FULL)
+    for j, n in ((one, 1), (two, 2)):
+        assert j["n_gpus"] == n and j["steps"] == 2 and j["config"]["layers"] == 40 and "[12, 37]" in j["config"]["schedule"]
+        assert j["denoise_step_ms_high_noise"] > j["denoise_step_ms_low_noise"] > 0
+    pf = two["preflight"]
+    assert {k: v["bytes"] for k, v in pf["steps"].items()} == {"noise_pred_allgather_pair": 8386560, "vae_tile_broadcast_pair": 129392640,
+                                                               "frames_allgather_leads": 97044480}
+    assert [(r["rank"], r["sample"], r["branch"]) for r in pf["ranks"]] == [(0, 0, 0), (1, 0, 1)]
+    assert pf["min_hbm_free_gb"] > 20, "two full-size ranks on one 288 GB device leave room for the activations"
+    assert two["distributed"]["world"] == 2 and two["distributed"]["backend"] == "gloo" and two["samples_gathered"] == 1
+    assert two["self_check"]["latents"]["sha256"] == one["self_check"]["latents"]["sha256"]
+    assert two["self_check"]["frames_uint8"]["sha256"] == one["self_check"]["frames_uint8"]["sha256"]
+    # a rank of the pair runs ONE forward per step: with both ranks time-sharing one device the pair's step costs what the N = 1 step costs
+    # plus the lost sharing of block 0 — a gross error in the sharding (both ranks computing both branches) would double it
+    assert two["denoise_step_ms_high_noise"] < 1.5 * one["denoise_step_ms_high_noise"]
+    out = os.path.join(ROOT, "gpurun_out", "r06")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "bench_n2_fullsize_in_suite.json"), "w") as f:
+        json.dump({"n2": two, "n1": one}, f, indent=1)
 
 
 def test_bench_four_ranks_two_videos_bit_identical_to_single_runs():
@@ -135,7 +182,7 @@ def test_bench_line_is_schedule_weighted_and_carries_preloop_vae_roofline_and_da
     `value` is the 21 : 29 schedule-weighted figure; `preloop` = two tiled VAE encodes + two umT5-XXL forwards at full size, reported
     beside it and not inside it; `roofline_vae` = the decode's three dominant convolution launches; `data_sensitivity` = the same
     steps with the attention logits x 8; `config5` without an error."""
-    j = _launch(1, ["--config5-steps", "2", "--peaky-steps", "2"] )          # (ARGS switches the legs off; argparse keeps the LAST value)
+    j = _launch(1, args=[a for a in ARGS if a != "--no-preloop"] + ["--config5-steps", "2", "--peaky-steps", "2"])   # (argparse keeps the LAST value)
     assert "error" not in j["config5"] and j["config5"]["steps"] == 2 and j["config5"]["ms_per_step"] > 0
     hi, lo, vs = j["denoise_step_ms_high_noise"], j["denoise_step_ms_low_noise"], j["vae_decode_s"]
     assert hi > lo > 0, "a high-noise step runs the ControlNet on top of the DiT"
@@ -150,15 +197,8 @@ def test_bench_line_is_schedule_weighted_and_carries_preloop_vae_roofline_and_da
                                 for e in rv)
     assert sum(e["share_of_decode_conv_time"] for e in rv) > 0.5, "the three entries are the bulk of the decode's convolution time"
     assert 0.5 * vs * 1e3 < j["vae_decode_conv_ms"] < 1.05 * vs * 1e3, "the convolutions are most of the tiled decode"
-
-
-def test_bench_preloop_leg_at_full_size():
-    """`preloop` (on by default in the driver's command): 2 tiled VAE encodes of an 81-frame 480x832 clip + 2 umT5-XXL forwards."""
-    args = [a for a in ARGS if a != "--no-preloop"]
-    port_env = _clean_env()
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + args, env=port_env, capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    pl = _one_json(r.stdout)["preloop"]
+    # `preloop` (on by default in the driver's command): 2 tiled VAE encodes of an 81-frame 480x832 clip + 2 umT5-XXL forwards, full size
+    pl = j["preloop"]
     assert "error" not in pl, pl
     assert 0.05 < pl["vae_tiled_encode_x2_s"] < 10 and 0.005 < pl["umt5_xxl_512_tokens_x2_s"] < 10 and pl["umt5_xxl_params"] > 5e9
     assert abs(pl["total_s"] - pl["vae_tiled_encode_x2_s"] - pl["umt5_xxl_512_tokens_x2_s"]) < 1e-9

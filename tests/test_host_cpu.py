@@ -323,3 +323,62 @@ def test_padded_conv_path_is_refused_for_shapes_beyond_its_32_bit_offsets():
     assert ops.padded_conv_fits(81, 240, 416, 192)                           # untiled level 2: 3.2 GB
     assert not ops.padded_conv_fits(81, 240, 416, 384, history=False)        # untiled resample convolution: 6.3 GB
     assert not ops.padded_conv_fits(81, 120, 208, 96)                        # 96 channels: not this kernel's level
+
+
+def test_launcher_takes_the_reference_launchers_arguments():
+    """scripts/inference_goal_force.py parses exactly what scripts/inference/inference_goal_force.sh / inference_canny_edge_control.sh
+    pass (INF:38-56), derives the output directory and the file-name root as INF:73-76, 178-186, and defaults the model paths to the
+    ones the reference hard-codes (INF:81-106)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gf_launcher", os.path.join(ROOT, "scripts", "inference_goal_force.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    a = m.parse_args(["--device_id", "3", "--world_size", "8", "--seed", "5", "--control_signal_type", "canny_edge",
+                      "--model_ckpt_path", "checkpoints/wan2.2_controlnet_canny_edge/step-500.safetensors", "--example_paths", "a.csv", "b.csv"])
+    assert (a.device_id, a.world_size, a.seed, a.control_signal_type, a.example_paths) == (3, 8, 5, "canny_edge", ["a.csv", "b.csv"])
+    assert m.output_location(a) == ("checkpoints/wan2.2_controlnet_canny_edge/step-500-videos", "500")
+    assert len(a.dit_high) == 6 and a.dit_high[5].endswith("high_noise_model/diffusion_pytorch_model-00006-of-00006.safetensors")
+    assert a.vae == "./models/Wan-AI/Wan2.1-T2V-1.3B/Wan2.1_VAE.pth" and a.tokenizer.endswith("google/umt5-xxl")
+    assert m.parse_args(["--controlnet_checkpoint", "x/step-7.safetensors", "--example_paths", "a.csv"]).model_ckpt_path == "x/step-7.safetensors"
+    with pytest.raises(SystemExit):
+        m.parse_args(["--example_paths", "a.csv"])                       # --model_ckpt_path is required (INF:51) unless --synthetic
+    with pytest.raises(SystemExit):
+        m.parse_args(["--control_signal_type", "depth", "--synthetic", "--example_paths", "a.csv"])
+    data = dict(file_id="scene", x_pos=0.4423, y_pos=0.225, target_x_pos=0.655, target_y_pos=0.2375, masses={"projectile": -1, "target": 2.0},
+                force=-1.0, angle=-1.0, target_indirect_force=350.0, target_indirect_angle=0.0)
+    assert m.goal_force_name("500", data, 3) == ("step-500_scene__prj_coords_0.44_0.23__tgt_coords_0.66_0.24__prj_mass_-1.0__tgt_mass_2.0"
+                                                  "__prj_force_-1.0__prj_angle_-1.0__tgt_indirect_force_350.0__tgt_indirect_angle_0.0__seed_3")
+    assert (m.NUM_FRAMES, m.NUM_FRAMES_CANNY, m.CONTROLNET_NUM_LAYERS) == (81, 49, 10)
+
+
+def test_canny_video_operator_crops_resizes_and_counts_frames_like_the_reference(tmp_path):
+    """ControlSignalDataset_CannyEdge.default_video_operator (DS:441-461): ImageCropAndResize (DS:136-170) and LoadVideo's frame count
+    (DS:188-194) restated on PIL; containers readable here (frame directory, .npy, image); mp4 refused by name without imageio."""
+    from PIL import Image
+    from goal_force_amd._lib import GoalForceError
+    from goal_force_amd.canny import ControlSignalDataset_CannyEdge
+    rng = np.random.default_rng(0)
+    clip = rng.integers(0, 255, (15, 50, 90, 3), dtype=np.uint8)
+    np.save(tmp_path / "c.npy", clip)
+    op = ControlSignalDataset_CannyEdge.default_video_operator(base_path=str(tmp_path), max_pixels=921600, height=48, width=80,
+                                                               num_frames=49, time_division_factor=4, time_division_remainder=1)
+    frames = op("c.npy")
+    assert len(frames) == 13 and frames[0].size == (80, 48)              # 15 available -> 13 = 4k + 1
+    # one frame by hand: scale = max(80/90, 48/50) = 0.96 -> resize to (round(90*.96), round(50*.96)) = (86, 48), crop 3 columns left
+    want = Image.fromarray(clip[0]).resize((86, 48), Image.BILINEAR).crop((3, 0, 83, 48))
+    assert np.array_equal(np.array(frames[0]), np.array(want))
+    assert [op.count(n) for n in (100, 49, 48, 6, 5, 1)] == [49, 49, 45, 5, 5, 1]
+    d = tmp_path / "dir"
+    d.mkdir()
+    for i in range(5):
+        Image.fromarray(clip[i]).save(d / f"{i:03d}.png")
+    got = op("dir")
+    assert len(got) == 5 and np.array_equal(np.array(got[4]), np.array(Image.fromarray(clip[4]).resize((86, 48), Image.BILINEAR).crop((3, 0, 83, 48))))
+    free = ControlSignalDataset_CannyEdge.default_video_operator(base_path=str(tmp_path), max_pixels=40 * 40)
+    assert free("dir/000.png")[0].size == (48, 16)                        # 90x50 > 1600 px: scale 1.677 -> 53x29 -> multiples of 16
+    try:
+        import imageio  # noqa: F401
+    except ImportError:
+        (tmp_path / "v.mp4").write_bytes(b"")
+        with pytest.raises(GoalForceError, match="imageio"):
+            op("v.mp4")

@@ -141,3 +141,54 @@ def test_model_fn_and_loop_match_reference(mode):
                           dtype=dt)
     assert [bool(v) for v in g["loop3_switched"]] == [False, False, True]  # 1000, 909.1, 714.3 vs 875
     assert rel_l2(lat, ref(f"loop3_{mode}")) < (2e-2 if dt == BF else 2e-5)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_oracle_pipeline_call_vs_reference_call(mode):
+    """oracle/pipeline_oracle.py::pipeline_call against g13 = the outputs of the reference's OWN `WanVideoPipeline.__call__`
+    (GF:598-737, executed by make_goldens.py::g13_pipeline_call): unit order, noise, both embedders, the 3-step loop with the
+    expert switch and CFG, the tiled decode, the uint8 frames.  fp32: the same arithmetic in another op order (1e-4, frames within
+    one level); bf16: the bar of the other bf16 loop golden (g5 loop3: 2e-2 ... the loop amplifies, so 2 x that here with the VAE
+    encodes in front) — and the post-loop chain alone, fed the reference's latents, bit for bit."""
+    from oracle import pipeline_oracle as plo
+    g = np.load(os.path.join(GOLDEN, "g13_pipeline_call.npz"))
+    g6 = np.load(os.path.join(GOLDEN, "g6_vae.npz"))
+    dt = torch.float32 if mode == "f32" else BF
+    vsd = {k: v.to(dt) for k, v in gi.vae_decoder_sd(list(g6["names"]), g6["shapes"], seed=61).items()}
+    image, control = gi.preloop_inputs()
+    inp = gi.tiny_inputs()
+    assert gi.same_checksum(gi.checksum([torch.from_numpy(np.array(image)).float(), control, inp["ctx_posi"], inp["ctx_nega"]]), g["ck_inputs"])
+    c = lambda sd: {k: v.to(dt) for k, v in sd.items()}
+    cfg = dict(gi.TINY)
+    nl = gi.TINY_CONTROLNET_LAYERS
+    experts = [(c(gi.dit_sd(cfg, seed=41)), cfg, c(gi.controlnet_sd(cfg, nl, seed=42)), nl),
+               (c(gi.dit_sd(cfg, seed=43)), cfg, c(gi.controlnet_sd(cfg, nl, seed=42, zero_convs_zero=True)), nl)]
+    asked = []
+
+    def encode_prompt(p):
+        asked.append(p)
+        return inp["ctx_posi"] if p == gi.PIPELINE_PROMPTS[0] else inp["ctx_nega"]
+    kw = {k: v for k, v in gi.PIPELINE_CALL_KWARGS.items() if k != "controlnet"}
+    lat, video, u8 = plo.pipeline_call(experts, vsd, encode_prompt, gi.PIPELINE_PROMPTS[0], gi.PIPELINE_PROMPTS[1], image, control,
+                                       dtype=dt, **kw)
+    assert asked == list(gi.PIPELINE_PROMPTS)
+    ref_lat = torch.from_numpy(g["latents_f32"]) if mode == "f32" else gi.from_u16(g["latents_bf16"])
+    ref_u8 = g[f"frames_u8_{mode}"]
+    e = rel_l2(lat.float(), ref_lat.float())
+    d = np.abs(u8.numpy().astype(np.int32) - ref_u8.astype(np.int32))
+    if mode == "f32":
+        assert e < 1e-4, e
+        assert int(d.max()) <= 1 and float((d == 0).mean()) > 0.995, (int(d.max()), float((d == 0).mean()))
+    else:
+        assert e < 4e-2, e
+        # the post-loop chain alone on the reference's own final latents: same torch ops, same bytes
+        z = gi.from_u16(g["latents_bf16"])
+        v2 = vo_tiled(z, vsd, kw["tile_size"], kw["tile_stride"])
+        assert torch.equal(v2, gi.from_u16(g["video_bf16"]))
+        assert np.array_equal(plo.frames_uint8(v2).numpy(), g["frames_u8_bf16"])
+    assert u8.shape == (9, 64, 96, 3) and tuple(video.shape) == (1, 3, 9, 64, 96)
+
+
+def vo_tiled(z, sd, tile_size, tile_stride):
+    from oracle import vae_oracle as vo
+    return vo.tiled_decode(z, sd, tile_size, tile_stride)
