@@ -237,6 +237,58 @@ def preloop_seconds(torch, vae, dev):
     return out
 
 
+def gpu_eager_yardstick(torch, pipe, cfg, inp, log):
+    """The SAME full-size step through torch-ROCm's own kernels — hipBLASLt GEMMs (F.linear), F.scaled_dot_product_attention (the
+    reference's attention backend on this stack: flash_attn / sageattention are absent, DIT:55-60), eager LayerNorm / RMSNorm / RoPE /
+    GELU (DIT:92-111, 206-210) — i.e. the arithmetic the reference itself would run on this very GPU, as the checker's bf16 graph
+    (tests/fullsize_parity.py::OracleRunner over oracle/wan_oracle.py, pinned to the reference by the goldens).  A yardstick beside
+    `cpu_baseline`, never part of `value`: 1 untimed warm-up step (library initialisation, autotuning), then one high-noise step
+    (cond + uncond forward with the 10-block ControlNet, CFG, Euler), one low-noise step as the reference runs it (its all-zero
+    ControlNet2 computed) and one with ControlNet2 elided as the product does (bit-identical)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from fullsize_parity import LazySD, OracleRunner
+    run = OracleRunner(pipe, cfg, torch.bfloat16)
+    wo = run.wo
+    sigmas, timesteps = wo.flow_match_sigmas(50, 5.0)
+    with_cn2 = (LazySD(pipe.dit2, torch.bfloat16), LazySD(pipe.controlnet2, torch.bfloat16), pipe.controlnet2.num_layers)
+
+    def step(i, expert):
+        old = run.experts[1]
+        run.experts[1] = expert if expert is not None else old
+        try:
+            which = 0 if float(timesteps[i]) >= 875.0 else 1
+            tsb = timesteps[i].unsqueeze(0).to(torch.bfloat16).to(inp["latents"].device)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            posi = run.forward(which, inp["latents"], tsb, inp["ctx_p"], inp)
+            nega = run.forward(which, inp["latents"], tsb, inp["ctx_n"], inp)
+            lat = wo.euler_step(wo.cfg_combine(posi, nega, 5.0), i, inp["latents"], sigmas)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        finally:
+            run.experts[1] = old
+        if not bool(torch.isfinite(lat.float()).all()):
+            raise RuntimeError("non-finite latents in the eager yardstick")
+        return dt * 1e3
+
+    warm = step(12, None)
+    hi = step(12, None)
+    lo_ref = step(37, with_cn2)
+    lo_elided = step(37, None)
+    log(f"bench.py: eager yardstick (torch-ROCm kernels): warm-up {warm:.0f} ms, high-noise {hi:.0f} ms, low-noise {lo_ref:.0f} ms "
+        f"(ControlNet2 run) / {lo_elided:.0f} ms (elided)")
+    loop = (21 * hi + 29 * lo_ref) / 1e3
+    return {"what": "one full-size denoise step of the same model, inputs and bf16 arithmetic through torch-ROCm's own kernels (hipBLASLt "
+                    "F.linear, F.scaled_dot_product_attention, eager norms / RoPE / GELU): what the reference's code path runs on this GPU; "
+                    "1 warm-up + 1 timed step of each kind; the denoising loop only (no VAE decode on either side of the ratio)",
+            "denoise_step_ms_high_noise": hi, "denoise_step_ms_low_noise": lo_ref,
+            "denoise_step_ms_low_noise_controlnet2_elided": lo_elided, "warmup_step_ms": warm,
+            "ms_per_step": (21 * hi + 29 * lo_ref) / 50.0, "denoise_loop_s_50_steps": loop, "frames_per_sec": 81.0 / loop,
+            "frames_per_sec_definition": "81 / (21 x high-noise + 29 x low-noise step as the reference runs it), denoise only",
+            "torch": torch.__version__}
+
+
 def tensor_digest(torch, t):
     """sha256 of the raw bytes + a few statistics of a device tensor (self-check of the timed run's outputs)."""
     import hashlib
@@ -329,6 +381,8 @@ def main():
     ap.add_argument("--config5-steps", type=int, default=2, help="N = 1, bf16 run: after the bf16 timed region, switch the SAME modules to "
                     "the fp8_linear contract (BASELINE config 5) and time this many steps (1 warm-up first); reported as `config5` in the "
                     "JSON line; 0 = skip")
+    ap.add_argument("--no-yardstick", action="store_true", help="skip the same-GPU eager yardstick (N = 1, bf16 run: the same step through "
+                    "torch-ROCm's own kernels after the timed region, ~35 s; reported as `gpu_eager_yardstick`)")
     ap.add_argument("--no-launch-events", action="store_true", help="do not record the per-launch HIP events behind `roofline` / "
                     "`roofline_gemm` in the timed region (they are then null): measures what those ~900 event pairs per forward cost "
                     "(profiles/r03/README.md: below 0.1 %)")
@@ -338,6 +392,13 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args.gpus)                  # never returns
 
+    t_start = time.perf_counter()
+
+    def phase(name):
+        """wall-clock phases of the run on rank 0's stderr (never in the JSON line): where a launch spends its time outside the timed region"""
+        if os.environ.get("RANK", "0") == "0":
+            print(f"bench.py [{time.perf_counter() - t_start:7.2f} s] {name}", file=sys.stderr, flush=True)
+
     import torch
     import torch.distributed as dist
     from goal_force_amd import ops
@@ -346,7 +407,9 @@ def main():
     from goal_force_amd.pipeline import WanVideoPipeline, build_random_controlnet, build_random_expert
 
     torch.set_grad_enabled(False)
+    phase("torch imported")
     rank, local, world = init_from_env()
+    phase("process group ready")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node and --gpus must agree")
     torch.cuda.set_device(local)
@@ -372,6 +435,8 @@ def main():
     torch.manual_seed(7)
     vae = WanVideoVAE().to(torch.bfloat16).to(dev)   # real Wan VAE architecture, random-init decoder weights
     pipe = WanVideoPipeline.from_modules(dit, dit2, cn, cn2, vae=vae, device=dev)
+    torch.cuda.synchronize()
+    phase("experts, ControlNets and VAE resident")
 
     # synthetic conditioning, per-video seed
     g = torch.Generator().manual_seed(1000 + sample)
@@ -436,11 +501,13 @@ def main():
             print(f"bench.py pre-flight: backend {pre['backend']}, rccl_ranks {pre['rccl_ranks']}, min free HBM {pre['min_hbm_free_gb']:.1f} GB; "
                   + "; ".join(f"rank {r['rank']} -> {r['device']} (video {r['sample']}, branch {r['branch']}, sp {r['sp_rank']})"
                               for r in pre["ranks"]), file=sys.stderr, flush=True)
+    phase("inputs built" + ("" if pre is None else ", pre-flight done"))
     if warm_ids:
         run(warm_ids)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    phase("warm-up done, timed region starts")
     ops.PROFILE_ATTN, ops.PROFILE_GEMM = (None, None) if args.no_launch_events else ([], [])
     t0 = time.perf_counter()
     final = run(step_ids, record=True)
@@ -448,6 +515,7 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    phase("timed region done")
     prof, ops.PROFILE_ATTN = ops.PROFILE_ATTN or [], None
     gprof, ops.PROFILE_GEMM = ops.PROFILE_GEMM or [], None
     step_ms = list(pipe.last_step_ms)           # (ms, is_low_noise) of the timed steps (the config-5 leg below records its own)
@@ -481,6 +549,7 @@ def main():
         vae_roofline, vae_conv_ms = vae_entries(cprof)
     u8 = pipe.frames_uint8(frames)                      # [81,480,832,3] uint8, 97 MB (what the reference saves, GF:735)
     frames_digest = tensor_digest(torch, u8)
+    phase("VAE decodes and digests done")
     # end-of-run all-gather of every sample's frames among the samples' lead ranks (one contributor per sample, the
     # other ranks send nothing): 1 warm-up + 1 timed.  Rank 0 is a lead and ends up with every video's frames.
     gather_s, n_gathered = 0.0, 1
@@ -504,6 +573,7 @@ def main():
             lat_by_sample = {sm: h for sm, lead, h in lat_all if lead}
             sample_digests = [{"sample": args.sample_offset + i, "latents_sha256": lat_by_sample[args.sample_offset + i],
                                "frames_uint8_sha256": tensor_digest(torch, f)["sha256"]} for i, f in enumerate(allf)]
+    phase("frame all-gather done")
     if world > 1:
         t = torch.tensor([elapsed, vae_s, gather_s], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -600,6 +670,18 @@ def main():
             preloop = {"error": f"{type(e).__name__}: {e}"}
             print(f"bench.py: the pre-loop leg failed ({preloop['error']})", file=sys.stderr)
 
+    # ---- same-GPU yardstick (N = 1, bf16, full depth): the step through torch-ROCm's own kernels, reported beside cpu_baseline
+    yardstick = None
+    if world == 1 and not args.fp8 and not args.no_yardstick and args.peaky == 1.0:
+        try:
+            yardstick = gpu_eager_yardstick(torch, pipe, cfg, dict(latents=latents, y=y, control=control, ctx_p=ctx_p, ctx_n=ctx_n),
+                                            lambda m: print(m, file=sys.stderr, flush=True))
+        except Exception as e:      # noqa: BLE001 — the measurement above must reach the JSON line whatever happens here
+            yardstick = {"error": f"{type(e).__name__}: {e}"}
+            print(f"bench.py: the eager-yardstick leg failed ({yardstick['error']})", file=sys.stderr)
+        torch.cuda.empty_cache()
+
+    phase("extra legs done")
     if rank == 0:
         attn_traffic, attn_traffic_src = static_traffic("attn_self")
         sec_per_step = elapsed / k
@@ -694,6 +776,13 @@ def main():
             out["data_sensitivity"] = sensitivity
         if preloop is not None:
             out["preloop"] = preloop
+        if yardstick is not None:
+            if "error" not in yardstick:
+                hi_ms, lo_ms = out["denoise_step_ms_high_noise"], out["denoise_step_ms_low_noise"]
+                yardstick["speedup_denoise_loop"] = yardstick["denoise_loop_s_50_steps"] / loop_s
+                yardstick["speedup_high_noise_step"] = yardstick["denoise_step_ms_high_noise"] / hi_ms if hi_ms else None
+                yardstick["speedup_low_noise_step"] = yardstick["denoise_step_ms_low_noise"] / lo_ms if lo_ms else None
+            out["gpu_eager_yardstick"] = yardstick
         if pre is not None:
             out["preflight"] = {"steps": pre["steps"], "rccl_ranks": pre["rccl_ranks"], "min_hbm_free_gb": pre["min_hbm_free_gb"],
                                 "ranks": [{k_: r[k_] for k_ in ("rank", "sample", "branch", "sp_rank", "device", "hbm_free_gb")} for r in pre["ranks"]]}

@@ -75,7 +75,39 @@ def psnr_u8(a, b):
     return float("inf") if mse == 0 else 10.0 * torch.log10(torch.tensor(255.0 ** 2 / mse)).item()
 
 
+PRETRAINED = None      # {"models_dir": ..., "ckpt": ...} when main() found trained weights to load (--models-dir / --model-ckpt-path)
+
+
+def pretrained_paths(models_dir):
+    """The files the reference launcher loads (INF:81-106), or None when any expert shard or the VAE is missing under models_dir."""
+    hi = [os.path.join(models_dir, "Wan2.2-I2V-A14B", "high_noise_model", f"diffusion_pytorch_model-0000{i}-of-00006.safetensors") for i in range(1, 7)]
+    lo = [p.replace("high_noise_model", "low_noise_model") for p in hi]
+    vae = os.path.join(models_dir, "Wan2.1-T2V-1.3B", "Wan2.1_VAE.pth")
+    return (hi, lo, vae) if all(os.path.exists(p) for p in hi + lo + [vae]) else None
+
+
+def build_pretrained(models_dir, ckpt, cn_layers, dev):
+    """TRAINED weights through the product's own `from_pretrained` (the reference's call, INF:81-111) — the run the build image cannot
+    make (no checkpoints, no network): `python tests/fullsize_parity.py --steps 50 --models-dir ./models/Wan-AI --model-ckpt-path
+    checkpoints/.../step-N.safetensors`.  The text encoder is not loaded: the conditioning tensors stay the seeded synthetic ones."""
+    from goal_force_amd.pipeline import ModelConfig, WanVideoPipeline
+    hi, lo, vae = pretrained_paths(models_dir)
+    pipe = WanVideoPipeline.from_pretrained(torch_dtype=torch.bfloat16, device=dev, controlnet=True, controlnet_num_layers=cn_layers,
+                                            model_configs=[ModelConfig(path=hi), ModelConfig(path=lo), ModelConfig(path=vae)])
+    if ckpt:
+        pipe.load_controlnet_weights(pipe.controlnet, ckpt, torch_dtype=torch.bfloat16)        # INF:108
+    return config_of(pipe.dit), pipe
+
+
+def config_of(dit):
+    """The oracle's cfg dict of a built WanModel."""
+    return dict(dim=dit.dim, in_dim=dit.in_dim, ffn_dim=dit.blocks[0].ffn_dim, out_dim=dit.out_dim, text_dim=dit.text_embedding[0].in_features,
+                freq_dim=dit.freq_dim, eps=dit.eps, patch_size=dit.patch_size, num_heads=dit.num_heads, num_layers=len(dit.blocks))
+
+
 def build(layers, cn_layers, dev, need_low=True):
+    if PRETRAINED is not None:
+        return build_pretrained(PRETRAINED["models_dir"], PRETRAINED["ckpt"], cn_layers, dev)
     from goal_force_amd.dit import A14B_CONFIG
     from goal_force_amd.pipeline import WanVideoPipeline, build_random_controlnet, build_random_expert
     from goal_force_amd.vae import WanVideoVAE
@@ -99,7 +131,8 @@ def inputs(pipe, grid, dev, sample=0):
     y[:, :4] = 0
     y[:, :4, 0] = 1
     control = torch.randn((1, 16, f, hh, ww), generator=g)
-    ctx_p, ctx_n = torch.randn((1, 512, 4096), generator=g), torch.randn((1, 512, 4096), generator=g)
+    td = pipe.dit.text_embedding[0].in_features               # 4096 at A14B size
+    ctx_p, ctx_n = torch.randn((1, 512, td), generator=g), torch.randn((1, 512, td), generator=g)
     ctx_p[:, 40:] = 0
     ctx_n[:, 40:] = 0
     bf = torch.bfloat16
@@ -290,7 +323,7 @@ def run(layers=40, cn_layers=10, grid=(21, 60, 104), steps=4, fp8=False, taps=(0
     inp = inputs(pipe, grid, dev)
     tokens = grid[0] * (grid[1] // 2) * (grid[2] // 2)
     rep = {"config": {"layers": layers, "controlnet_layers": cn_layers, "latent": [1, 16, *grid], "tokens": tokens, "steps": steps,
-                      "taps_after_dit_block": [t + 1 for t in taps], "weights": "random-init bf16 (bench.py seeds 100/200/300/400)",
+                      "taps_after_dit_block": [t + 1 for t in taps], "weights": "random-init bf16 (bench.py seeds 100/200/300/400)" if PRETRAINED is None else f"TRAINED: {PRETRAINED}",
                       "device": torch.cuda.get_device_name(0), "fp32_attention_q_chunk": q_chunk}}
 
     # ---- the product
@@ -360,7 +393,17 @@ def main():
     ap.add_argument("--q-chunk", type=int, default=2048)
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--models-dir", default="./models/Wan-AI", help="where the reference keeps its checkpoints (INF:81-106): when both experts' "
+                    "shards and Wan2.1_VAE.pth are there the run uses TRAINED weights through from_pretrained, else random-init ones")
+    ap.add_argument("--model-ckpt-path", default=None, help="ControlNet checkpoint step-N.safetensors (INF:51, 108); only with trained weights")
     a = ap.parse_args()
+    global PRETRAINED
+    if pretrained_paths(a.models_dir) is not None:
+        PRETRAINED = {"models_dir": a.models_dir, "ckpt": a.model_ckpt_path}
+        print(f"fullsize_parity: TRAINED weights from {a.models_dir}" + (f" + ControlNet {a.model_ckpt_path}" if a.model_ckpt_path else
+              " (ControlNet = copies of DiT blocks 0..N-1, zero zero-convs: GF:559-568)"), file=sys.stderr)
+    else:
+        print(f"fullsize_parity: no checkpoints under {a.models_dir}: random-init weights (trained-weight parity stays unpinned)", file=sys.stderr)
     t0 = time.time()
     if a.steps == 0:
         rep = run_forward(a.layers, a.cn_layers, tuple(a.grid), a.fp8, q_chunk=a.q_chunk, out_path=a.out)

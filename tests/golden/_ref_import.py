@@ -80,14 +80,23 @@ def load_reference(with_pipeline=True, with_dataset=True):
         spec.loader.exec_module(mod)
         out.gf = mod
     if with_dataset:
+        out.real = {}
         for n in ("torchvision", "imageio", "controlnet_aux", "cv2"):
             if n not in sys.modules:
-                _stub(n)
-        tv = sys.modules["torchvision"]
-        tv.transforms = _stub("torchvision.transforms", ToTensor=_Anything, ToPILImage=_Anything, Compose=_Anything,
-                              Resize=_Anything, CenterCrop=_Anything, Normalize=_Anything)
-        sys.modules["imageio"].v3 = _stub("imageio.v3")
-        sys.modules["controlnet_aux"].CannyDetector = _Anything
+                try:                                   # the real package when the image has it (g14 needs the real cv2 + controlnet_aux)
+                    importlib.import_module(n)
+                    out.real[n] = True
+                except Exception:                      # noqa: BLE001 — absent (or broken) here: an empty stub, uses are at call time
+                    _stub(n)
+                    out.real[n] = False
+        if not out.real.get("torchvision", True):
+            tv = sys.modules["torchvision"]
+            tv.transforms = _stub("torchvision.transforms", ToTensor=_Anything, ToPILImage=_Anything, Compose=_Anything,
+                                  Resize=_Anything, CenterCrop=_Anything, Normalize=_Anything)
+        if not out.real.get("imageio", True):
+            sys.modules["imageio"].v3 = _stub("imageio.v3")
+        if not out.real.get("controlnet_aux", True):
+            sys.modules["controlnet_aux"].CannyDetector = _Anything
         spec = importlib.util.spec_from_file_location("gf_ref_unified_dataset",
                                                       os.path.join(REF, "src/goal_force/unified_dataset.py"))
         mod = importlib.util.module_from_spec(spec)

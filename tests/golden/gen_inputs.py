@@ -257,3 +257,23 @@ def fp8_case(M, N, K):
     w = (torch.randn((N, K), generator=g) / math.sqrt(K)).to(torch.bfloat16)
     b = (0.1 * torch.randn(N, generator=g)).to(torch.bfloat16)
     return x, w, b
+
+
+def canny_inputs(seed=141):
+    """g14: seeded uint8 clips for the Canny control video (DS:559-578): piecewise-constant random fields (16-pixel cells, lightly
+    blurred: step edges of every height and both thresholds' sides) at the production frame size 480 x 832 and at 240 x 416 — both
+    below the detector's 512 resolution, as every frame the dataset produces is (enlarged by Lanczos, edges reduced back by area)."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    out = {}
+    for tag, (h, w), n in (("240x416", (240, 416), 3), ("480x832", (480, 832), 2)):
+        frames = []
+        for _ in range(n):
+            low = rng.random((h // 16 + 1, w // 16 + 1, 3))
+            big = np.kron(low, np.ones((16, 16, 1)))[:h, :w]
+            k = np.array([0.25, 0.5, 0.25])
+            for ax in (0, 1):
+                big = np.apply_along_axis(lambda v: np.convolve(v, k, mode="same"), ax, big)
+            frames.append((big * 255).clip(0, 255).astype(np.uint8))
+        out[tag] = np.stack(frames)
+    return out

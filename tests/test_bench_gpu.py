@@ -18,7 +18,7 @@ from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
 # the sharding tests time two layers; the extra legs of the N = 1 line (config 5, data sensitivity, pre-loop) have their own test below
-ARGS = ["--layers", "2", "--steps", "2", "--warmup", "0", "--no-cpu-baseline", "--config5-steps", "0", "--peaky-steps", "0", "--no-preloop"]
+ARGS = ["--layers", "2", "--steps", "2", "--warmup", "0", "--no-cpu-baseline", "--config5-steps", "0", "--peaky-steps", "0", "--no-preloop", "--no-yardstick"]
 
 
 def _free_port():
@@ -87,7 +87,7 @@ def test_bench_two_ranks_bit_identical_to_one():
 
 # BASELINE config 3's WORKLOAD: the production model — 40 DiT + 10 ControlNet blocks, both experts, S = 32760 — not a
 # two-layer stand-in.  K = 2 puts one timed step on each side of the expert switch (step ids 12 and 37).
-FULL = ["--steps", "2", "--warmup", "0", "--no-cpu-baseline", "--config5-steps", "0", "--peaky-steps", "0", "--no-preloop"]
+FULL = ["--steps", "2", "--warmup", "0", "--no-cpu-baseline", "--config5-steps", "0", "--peaky-steps", "0", "--no-preloop", "--no-yardstick"]
 
 
 def test_bench_cfg_pair_at_production_size_bit_identical_to_one_gpu():
@@ -182,7 +182,7 @@ def test_bench_line_is_schedule_weighted_and_carries_preloop_vae_roofline_and_da
     `value` is the 21 : 29 schedule-weighted figure; `preloop` = two tiled VAE encodes + two umT5-XXL forwards at full size, reported
     beside it and not inside it; `roofline_vae` = the decode's three dominant convolution launches; `data_sensitivity` = the same
     steps with the attention logits x 8; `config5` without an error."""
-    j = _launch(1, args=[a for a in ARGS if a != "--no-preloop"] + ["--config5-steps", "2", "--peaky-steps", "2"])   # (argparse keeps the LAST value)
+    j = _launch(1, args=[a for a in ARGS if a not in ("--no-preloop", "--no-yardstick")] + ["--config5-steps", "2", "--peaky-steps", "2"])   # (argparse keeps the LAST value)
     assert "error" not in j["config5"] and j["config5"]["steps"] == 2 and j["config5"]["ms_per_step"] > 0
     hi, lo, vs = j["denoise_step_ms_high_noise"], j["denoise_step_ms_low_noise"], j["vae_decode_s"]
     assert hi > lo > 0, "a high-noise step runs the ControlNet on top of the DiT"
@@ -197,6 +197,13 @@ def test_bench_line_is_schedule_weighted_and_carries_preloop_vae_roofline_and_da
                                 for e in rv)
     assert sum(e["share_of_decode_conv_time"] for e in rv) > 0.5, "the three entries are the bulk of the decode's convolution time"
     assert 0.5 * vs * 1e3 < j["vae_decode_conv_ms"] < 1.05 * vs * 1e3, "the convolutions are most of the tiled decode"
+    # `gpu_eager_yardstick`: the same step through torch-ROCm's own kernels, beside the line and never inside `value`
+    ys = j["gpu_eager_yardstick"]
+    assert "error" not in ys, ys
+    assert ys["denoise_step_ms_high_noise"] > 0 and ys["denoise_step_ms_low_noise"] >= ys["denoise_step_ms_low_noise_controlnet2_elided"] * 0.9
+    assert abs(ys["denoise_loop_s_50_steps"] - (21 * ys["denoise_step_ms_high_noise"] + 29 * ys["denoise_step_ms_low_noise"]) / 1e3) < 1e-9
+    assert abs(ys["speedup_denoise_loop"] - ys["denoise_loop_s_50_steps"] / j["denoise_loop_s_50_steps"]) < 1e-9
+    assert ys["speedup_denoise_loop"] > 1.0, "the HIP path is faster than the eager stack on the same GPU"
     # `preloop` (on by default in the driver's command): 2 tiled VAE encodes of an 81-frame 480x832 clip + 2 umT5-XXL forwards, full size
     pl = j["preloop"]
     assert "error" not in pl, pl
