@@ -299,6 +299,10 @@ def tensor_digest(torch, t):
             "absmax": float(f.abs().max())}
 
 
+def host_threads_per_rank(n):
+    return max(1, min(8, (os.cpu_count() or 8) // max(1, n)))
+
+
 def self_launch(n):
     """`python bench.py --gpus N` with no launcher: N child processes of this file, one per GPU, torch.distributed.run's
     environment.  Runs in a parent that has imported neither torch nor anything else that initialises HIP (a process that has
@@ -339,6 +343,10 @@ def self_launch(n):
         for r in range(n):
             env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                        MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+            # N ranks x (all host cores) OpenMP threads each thrash the host: 8 ranks spent 70 s building a VAE that one rank builds in
+            # 0.5 s (profiles/r06/bench_n8_phases.*).  torch.distributed.run sets OMP_NUM_THREADS=1 for the same reason; host work here is
+            # weight initialisation and checksums only, so a few threads per rank are plenty.  The caller's own setting wins.
+            env.setdefault("OMP_NUM_THREADS", str(host_threads_per_rank(n)))
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                           stdout=None if r == 0 else sys.stderr))
         alive = list(procs)
@@ -408,6 +416,9 @@ def main():
 
     torch.set_grad_enabled(False)
     phase("torch imported")
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and "OMP_NUM_THREADS" not in os.environ:
+        # ranks started by hand (tests) without a thread budget: the same budget self_launch() gives its children
+        torch.set_num_threads(host_threads_per_rank(int(os.environ["WORLD_SIZE"])))
     rank, local, world = init_from_env()
     phase("process group ready")
     if world != args.gpus:
@@ -427,13 +438,17 @@ def main():
     dit2 = build_random_expert(cfg, seed=200, device=dev)
     cn = build_random_controlnet(n_cn, cfg, seed=300, device=dev)
     cn2 = build_random_controlnet(n_cn, cfg, seed=400, device=dev, zero_convs_zero=True)
+    torch.cuda.synchronize()
+    phase("experts and ControlNets built on the device")
     if args.fp8:
         from goal_force_amd.dit import enable_fp8
         for m in (dit, dit2, cn, cn2):
             enable_fp8(m)
     from goal_force_amd.vae import WanVideoVAE
     torch.manual_seed(7)
-    vae = WanVideoVAE().to(torch.bfloat16).to(dev)   # real Wan VAE architecture, random-init decoder weights
+    vae = WanVideoVAE()                              # real Wan VAE architecture, random-init weights (CPU generator: the same on every rank)
+    phase("VAE constructed on the host")
+    vae = vae.to(torch.bfloat16).to(dev)
     pipe = WanVideoPipeline.from_modules(dit, dit2, cn, cn2, vae=vae, device=dev)
     torch.cuda.synchronize()
     phase("experts, ControlNets and VAE resident")

@@ -99,6 +99,10 @@ def main(argv=None):
     from goal_force_amd.vae import WanVideoVAE
 
     torch.set_grad_enabled(False)
+    if a.world_size > 1 and "OMP_NUM_THREADS" not in os.environ:
+        # one process per device, started side by side by the shell script: without a budget each would run its host work (checkpoint
+        # casts, VAE / tokenizer set-up) on ALL cores and the processes thrash each other (measured: 70 s instead of 0.5 s at 8 ranks)
+        torch.set_num_threads(max(1, min(16, (os.cpu_count() or 8) // a.world_size)))
     # INF:62-67: with HIP_/CUDA_VISIBLE_DEVICES set the isolated GPU appears as cuda:0, otherwise this process takes
     # cuda:{device_id}.  The C-ABI launches go to the CURRENT HIP device, so it is selected before anything is built.
     isolated = any(v in os.environ for v in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"))
