@@ -564,6 +564,32 @@ def main():
         vae_roofline, vae_conv_ms = vae_entries(cprof)
     u8 = pipe.frames_uint8(frames)                      # [81,480,832,3] uint8, 97 MB (what the reference saves, GF:735)
     frames_digest = tensor_digest(torch, u8)
+    # ---- the host side of the B1 boundary (N = 1): `pipe(...)` is handed a host control-signal video ([81,480,832,3] bf16, 194 MB; the
+    # reference's dataset builds it on the CPU) and an image, and returns 81 PIL frames (97 MB device -> host + the PIL wrapping, UTIL:85-91).
+    # `value` is measured with inputs resident in HBM; this is what the PCIe crossings and the PIL conversion add per video.
+    host_boundary = None
+    if world == 1:
+        try:
+            hc = torch.zeros((81, 480, 832, 3), dtype=torch.bfloat16).pin_memory()
+            hc.to(dev)
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            hc.to(dev)
+            torch.cuda.synchronize()
+            h2d = time.perf_counter() - tb
+            tb = time.perf_counter()
+            host_u8 = u8.cpu()
+            d2h = time.perf_counter() - tb
+            tb = time.perf_counter()
+            pil = pipe.vae_output_to_video(frames)
+            pil_s = time.perf_counter() - tb
+            assert len(pil) == 81 and pil[0].size == (832, 480) and tuple(host_u8.shape) == (81, 480, 832, 3)
+            host_boundary = {"h2d_control_video_s": h2d, "h2d_bytes": hc.numel() * 2, "d2h_frames_s": d2h, "d2h_bytes": host_u8.numel(),
+                             "frames_to_pil_s": pil_s, "what": "per video, outside `value`: pinned-host -> HBM copy of the control-signal video, HBM -> host "
+                             "copy of the uint8 frames, and vae_output_to_video (uint8 conversion + D2H + 81 PIL images) as pipe(...) returns them"}
+            del hc, host_u8, pil
+        except Exception as e:      # noqa: BLE001
+            host_boundary = {"error": f"{type(e).__name__}: {e}"}
     phase("VAE decodes and digests done")
     # end-of-run all-gather of every sample's frames among the samples' lead ranks (one contributor per sample, the
     # other ranks send nothing): 1 warm-up + 1 timed.  Rank 0 is a lead and ends up with every video's frames.
@@ -791,6 +817,11 @@ def main():
             out["data_sensitivity"] = sensitivity
         if preloop is not None:
             out["preloop"] = preloop
+        if host_boundary is not None:
+            if "error" not in host_boundary:
+                extra_s = host_boundary["h2d_control_video_s"] + host_boundary["frames_to_pil_s"]
+                host_boundary["frames_per_sec_pcie_inclusive"] = videos * 81.0 / (loop_s + vae_s + gather_s + extra_s)
+            out["host_boundary"] = host_boundary
         if yardstick is not None:
             if "error" not in yardstick:
                 hi_ms, lo_ms = out["denoise_step_ms_high_noise"], out["denoise_step_ms_low_noise"]

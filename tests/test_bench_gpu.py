@@ -197,6 +197,9 @@ def test_bench_line_is_schedule_weighted_and_carries_preloop_vae_roofline_and_da
                                 for e in rv)
     assert sum(e["share_of_decode_conv_time"] for e in rv) > 0.5, "the three entries are the bulk of the decode's convolution time"
     assert 0.5 * vs * 1e3 < j["vae_decode_conv_ms"] < 1.05 * vs * 1e3, "the convolutions are most of the tiled decode"
+    hb = j["host_boundary"]                      # the PCIe crossings + PIL wrapping of the B1 boundary, beside `value`
+    assert "error" not in hb and hb["h2d_bytes"] == 81 * 480 * 832 * 3 * 2 and hb["d2h_bytes"] == 81 * 480 * 832 * 3
+    assert 0 < hb["frames_per_sec_pcie_inclusive"] < j["value"] and hb["frames_per_sec_pcie_inclusive"] > 0.7 * j["value"]
     # `gpu_eager_yardstick`: the same step through torch-ROCm's own kernels, beside the line and never inside `value`
     ys = j["gpu_eager_yardstick"]
     assert "error" not in ys, ys
