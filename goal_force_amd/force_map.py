@@ -196,3 +196,76 @@ class ControlSignalDataset_Balls(torch.utils.data.Dataset):
                 "target_indirect_force": b["target_indirect_force"], "target_indirect_angle": b["target_indirect_angle"],
                 "target_x_pos": b["target_x_pos"], "target_y_pos": b["target_y_pos"], "file_id": b["file_id"],
                 "masses": b["masses"], "coords": b["coords"]}
+
+
+class ControlSignalDataset_Dominos(ControlSignalDataset_Balls):
+    """DS:1099-1555.  The reference's dominos dataset is its balls dataset line for line: the same constructor, CSV columns,
+    `get_batch`, `_generate_control_video` (DS:1253-1367 == DS:775-889), `get_blob_for_mass` and `get_gaussian_blob` — only the
+    training-mode video slicing differs (DS:1462-1464), which is outside the sampling path like every training-mode (video)
+    loader.  `scripts/train/train.py:167-181` muxes it with the balls and plants sets; here it is the same renderer under the
+    reference's name (pinned separately: tests/golden/g15 runs the reference's Dominos class itself)."""
+
+
+class ControlSignalDataset_Plants(torch.utils.data.Dataset):
+    """Inference-mode (is_validation_dataset=True) mirror of DS:1557-1894: the plants scenes carry ONE poke — CSV columns image,
+    force, angle, coordx, coordy, width, height, caption (DS:1739-1760) — rendered as the moving direct-force blob in channel 0;
+    channels 1 and 2 (goal force, masses) stay zero and nothing is clamped (DS:1667-1698).  `min_force` / `max_force` are 0 / 1 until
+    the caller sets them (DS:1663-1664), as with the balls set."""
+
+    def __init__(self, base_path=None, metadata_path=None, repeat=1, data_file_keys=tuple(), main_data_operator=lambda x: x,
+                 special_operator_map=None, is_validation_dataset=False, num_frames=None, height=None, width=None, device="cuda"):
+        if not is_validation_dataset:
+            raise NotImplementedError("training-mode (video) datasets are outside the sampling path (SURVEY §2 #7)")
+        self.base_path, self.metadata_path, self.repeat = base_path, metadata_path, repeat
+        self.is_validation_dataset = True
+        self.num_frames, self.height, self.width = num_frames, height, width
+        self.media_type = "image"
+        self.device = device
+        self.load_metadata()
+
+    def load_metadata(self):
+        """DS:1638-1664 (validation branch)."""
+        import pandas
+        img_dir = os.path.join(self.base_path, "images")
+        names = set(os.listdir(img_dir)) if os.path.isdir(img_dir) else set()
+        df = pandas.read_csv(self.metadata_path)
+        self.df = df[df[self.media_type].map(lambda x: x in names)]
+        self.min_force, self.max_force = 0.0, 1.0
+
+    def __len__(self):
+        return len(self.df) * self.repeat
+
+    def get_batch(self, idx):
+        """DS:1739-1760 (image branch)."""
+        from PIL import Image
+        item = self.df.iloc[idx]
+        image = Image.open(os.path.join(self.base_path, "images", item[self.media_type]))
+        if image.size != (self.width, self.height):
+            image = image.resize((self.width, self.height), resample=Image.Resampling.LANCZOS)
+        return dict(image=image, caption=item["caption"], force=item["force"], angle=item["angle"],
+                    x_pos=item["coordx"] / item["width"], y_pos=item["coordy"] / item["height"],
+                    file_id=str(item[self.media_type]).split(".png")[0])
+
+    def plan(self, force, angle, x_pos, y_pos, num_frames, height, width) -> BlobPlan:
+        """DS:1667-1698: one moving blob of radius 20 in channel 0 — the direct-force geometry of DS:1671-1690, which is that of
+        the balls set (plan_control_video's STEP 2) with nothing else drawn and no clamp."""
+        if force == -1:
+            raise GoalForceError("the plants set has no goal-force mode: `force` must be given (DS:1677)")
+        plan = plan_control_video(force, angle, x_pos, y_pos, -1, -1, 0.0, 0.0, num_frames, height, width,
+                                  {"projectile": -1, "target": -1, "distractors": []}, {"projectile": [0, 0], "target": [0, 0], "distractors": []},
+                                  self.min_force, self.max_force, 0.0, 1.0, 0.0, 1.0)
+        plan.clamp01 = False             # (a single blob of amplitude 1 never exceeds 1: the clamp would be a no-op; kept off as DS:1696)
+        return plan
+
+    def _generate_control_video(self, force, angle, x_pos, y_pos, num_frames=49, num_channels=3, height=480, width=720):
+        """DS:1667 signature; returns bf16 [num_frames, height, width, 3] on self.device."""
+        if num_channels != 3:
+            raise GoalForceError("control videos have 3 channels")
+        return render_control_video(self.plan(force, angle, x_pos, y_pos, num_frames, height, width), self.device)
+
+    def __getitem__(self, data_id):
+        b = self.get_batch(data_id % len(self.df))
+        cv = self._generate_control_video(b["force"], b["angle"], b["x_pos"], b["y_pos"], num_frames=self.num_frames, num_channels=3,
+                                          height=self.height, width=self.width)
+        return {"video": [b["image"]], "prompt": b["caption"], "control_video": cv, "force": b["force"], "angle": b["angle"],
+                "x_pos": b["x_pos"], "y_pos": b["y_pos"], "file_id": b["file_id"]}

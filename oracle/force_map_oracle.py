@@ -1,7 +1,9 @@
 """CPU ORACLE — TEST INFRASTRUCTURE ONLY.  Torch-CPU restatement of the Goal-Force control-signal video
 (src/goal_force/unified_dataset.py:775-940: _generate_control_video / get_gaussian_blob /
 get_blob_for_mass), pinned bit-exactly (sha256) against tests/golden/g7_force_maps.npz which the
-reference's own class produced for all 12 example CSV rows + 2 synthetic direct-force rows."""
+reference's own class produced for all 12 example CSV rows + 2 synthetic direct-force rows.
+`plants_control_video` restates the plants variant (DS:1667-1698), pinned the same way against tests/golden/g15_dataset_variants.npz
+(the reference's ControlSignalDataset_Plants / _Dominos classes run on seeded rows)."""
 import math
 
 import numpy as np
@@ -47,3 +49,18 @@ def control_video(force, angle, x_pos, y_pos, tforce, tangle, tx, ty, masses, co
     if masses["target"] > -1:
         sig[..., 2] += mass(coords["target"][0], height - coords["target"][1], masses["target"])
     return torch.clamp(sig, min=0.0, max=1.0).to(torch.bfloat16)
+
+
+def plants_control_video(force, angle, x_pos, y_pos, num_frames=49, height=480, width=720, min_force=30.0, max_force=400.0):
+    """DS:1667-1698: the direct-force blob alone, written to all three channels and then channels 1, 2 zeroed; no clamp.  bf16 [F,H,W,3]."""
+    sig = torch.zeros((num_frames, 3, height, width))
+    x0, y0 = x_pos * width, (1 - y_pos) * height
+    disp = width / 8 + (width / 2 - width / 8) * ((force - min_force) / (max_force - min_force))
+    x1 = x0 + disp * math.cos(angle * torch.pi / 180.0)
+    y1 = y0 - disp * math.sin(angle * torch.pi / 180.0)
+    for fr in range(num_frames):
+        t = fr / (num_frames - 1)
+        sig[fr] += gaussian_blob(x0 * (1 - t) + x1 * t, y0 * (1 - t) + y1 * t, 20, height, width)[None]
+    sig = sig.permute(0, 2, 3, 1).contiguous()
+    sig[..., 1:3] = 0
+    return sig.to(torch.bfloat16)

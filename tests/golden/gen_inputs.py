@@ -277,3 +277,10 @@ def canny_inputs(seed=141):
             frames.append((big * 255).clip(0, 255).astype(np.uint8))
         out[tag] = np.stack(frames)
     return out
+
+
+# g15: rows for the dominos / plants dataset variants (DS:1099-1894).  Dominos rows = g7's two synthetic rows (the reference's classes are
+# line-for-line copies: the goldens must coincide); plants rows (force, angle, x_pos, y_pos, frames, height, width), the last at the
+# signature's own defaults (49 frames, 480 x 720, DS:1667)
+PLANTS_ROWS = [(200.0, 45.0, 0.25, 0.25, 81, 480, 832), (390.0, 200.0, 0.84, 0.83, 81, 480, 832), (35.0, -90.0, 0.5, 0.9, 81, 480, 832),
+               (120.0, 10.0, 0.3, 0.6, 49, 480, 720)]

@@ -82,3 +82,95 @@ def test_hip_force_map_vs_reference_golden(k):
     assert np.allclose(cs, g[f"chan_sum_{k}"], rtol=2e-4, atol=1.0)
     if hashlib.sha256(raw.tobytes()).digest() == bytes(g[f"sha256_{k}"]):
         print(f"row {k}: bit-exact with the reference")
+
+
+# ------------------------------------------------------------------ the dominos / plants dataset variants (DS:1099-1894; g15)
+def _g15():
+    return np.load(os.path.join(GOLDEN, "g15_dataset_variants.npz"))
+
+
+def test_dominos_golden_is_the_balls_golden():
+    """The reference's ControlSignalDataset_Dominos._generate_control_video (DS:1253-1367) is a copy of the balls one: run on g7's
+    synthetic rows by make_goldens.py::g15 it produced g7's bytes — which is why the product's Dominos class is the Balls renderer."""
+    from goal_force_amd.force_map import ControlSignalDataset_Balls, ControlSignalDataset_Dominos
+    g, g7 = _g15(), np.load(os.path.join(GOLDEN, "g7_force_maps.npz"))
+    for k in (12, 13):
+        assert bytes(g[f"dominos_sha256_{k}"]) == bytes(g7[f"sha256_{k}"])
+    assert issubclass(ControlSignalDataset_Dominos, ControlSignalDataset_Balls)
+    assert ControlSignalDataset_Dominos._generate_control_video is ControlSignalDataset_Balls._generate_control_video
+
+
+@pytest.mark.parametrize("k", range(len(gi.PLANTS_ROWS)))
+def test_plants_oracle_matches_reference_sha256(k):
+    g = _g15()
+    f, a, x, y, nf, h, w = gi.PLANTS_ROWS[k]
+    raw = gi.to_u16(fo.plants_control_video(f, a, x, y, num_frames=nf, height=h, width=w))
+    assert hashlib.sha256(raw.tobytes()).digest() == bytes(g[f"plants_sha256_{k}"])
+    assert np.array_equal(raw[::8, ::8, ::8, :], g[f"plants_down_{k}"])
+
+
+def test_plants_plan_is_one_unclamped_direct_force_blob():
+    from goal_force_amd._lib import GoalForceError
+    from goal_force_amd.force_map import ControlSignalDataset_Plants
+    ds = object.__new__(ControlSignalDataset_Plants)
+    ds.min_force, ds.max_force = 30.0, 400.0
+    f, a, x, y, nf, h, w = gi.PLANTS_ROWS[3]
+    plan = ds.plan(f, a, x, y, nf, h, w)
+    ch, pr, ce = plan.arrays()
+    assert list(ch) == [0] and not plan.clamp01 and pr.shape == (1, 2) and float(pr[0, 0]) == 800.0 and ce.shape == (1, 49, 2)
+    disp = w / 8 + (w / 2 - w / 8) * ((f - 30.0) / 370.0)
+    assert np.allclose(ce[0, 0], [x * w, (1 - y) * h]) and np.allclose(ce[0, -1, 0], x * w + disp * np.cos(np.deg2rad(a)), atol=1e-3)
+    with pytest.raises(GoalForceError):
+        ds.plan(-1, a, x, y, nf, h, w)
+    with pytest.raises(NotImplementedError):
+        ControlSignalDataset_Plants(is_validation_dataset=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", range(len(gi.PLANTS_ROWS)))
+def test_hip_plants_force_map_vs_reference_golden(k):
+    from goal_force_amd.force_map import ControlSignalDataset_Plants
+    g = _g15()
+    ds = object.__new__(ControlSignalDataset_Plants)
+    ds.min_force, ds.max_force, ds.device = 30.0, 400.0, "cuda"
+    f, a, x, y, nf, h, w = gi.PLANTS_ROWS[k]
+    got = ds._generate_control_video(f, a, x, y, num_frames=nf, num_channels=3, height=h, width=w).cpu()
+    assert got.shape == (nf, h, w, 3) and got.dtype == torch.bfloat16 and float(got[..., 1:].abs().max()) == 0
+    raw = gi.to_u16(got)
+    for name, sl in (("down", raw[::8, ::8, ::8, :]), ("frame", raw[nf // 2, ::2, ::4, :])):
+        d = np.abs(sl.astype(np.int32) - g[f"plants_{name}_{k}"].astype(np.int32))
+        assert d.max() <= 1 and (d > 0).mean() < 2e-3, f"{name}: max ulp diff {d.max()}, {(d > 0).mean():.2e} differ"
+    assert np.allclose(got.float().sum(dim=(0, 1, 2)).numpy(), g[f"plants_chan_sum_{k}"], rtol=2e-4, atol=1.0)
+
+
+@pytest.mark.gpu
+def test_hip_plants_and_dominos_datasets_read_their_csv_rows(tmp_path):
+    """Validation-mode datasets end to end: CSV row + PNG -> the dict the drivers consume (DS:1488-1539, 1842-1878)."""
+    from PIL import Image
+    from goal_force_amd.force_map import ControlSignalDataset_Dominos, ControlSignalDataset_Plants
+    (tmp_path / "images").mkdir()
+    Image.fromarray(np.zeros((480, 832, 3), np.uint8)).save(tmp_path / "images" / "fern.png")
+    (tmp_path / "plants.csv").write_text('image,force,angle,coordx,coordy,width,height,caption\nfern.png,200.0,45.0,208,120,832,480,"The fern sways."\n'
+                                         'missing.png,1,1,1,1,832,480,"dropped: no such image"\n')
+    ds = ControlSignalDataset_Plants(base_path=str(tmp_path), metadata_path=str(tmp_path / "plants.csv"), is_validation_dataset=True,
+                                     num_frames=81, height=480, width=832)
+    assert len(ds) == 1 and (ds.min_force, ds.max_force) == (0.0, 1.0)
+    ds.min_force, ds.max_force = 30.0, 400.0
+    d = ds[0]
+    assert d["prompt"] == "The fern sways." and d["file_id"] == "fern" and len(d["video"]) == 1 and d["x_pos"] == 0.25 and d["y_pos"] == 0.25
+    g = _g15()          # PLANTS_ROWS[0] is this row
+    raw = gi.to_u16(d["control_video"].cpu())
+    dd = np.abs(raw[::8, ::8, ::8, :].astype(np.int32) - g["plants_down_0"].astype(np.int32))
+    assert dd.max() <= 1
+    (tmp_path / "dom.csv").write_text("image,projectile_force_angle,projectile_force_magnitude,projectile_coordx,projectile_coordy,projectile_mass,"
+                                      "target_indirect_force_angle,target_indirect_force_magnitude,target_coordx,target_coordy,target_mass,width,height,caption\n"
+                                      'fern.png,45.0,200.0,208,120,2.0,-1.0,-1.0,600,300,-1.0,832,480,"The domino falls."\n')
+    dm = ControlSignalDataset_Dominos(base_path=str(tmp_path), metadata_path=str(tmp_path / "dom.csv"), is_validation_dataset=True,
+                                      num_frames=81, height=480, width=832)
+    dm.min_mass, dm.max_mass, dm.min_force, dm.max_force = 1.0, 4.0, 30.0, 400.0
+    dm.min_indirect_force, dm.max_indirect_force = 30.0, 400.0
+    e = dm[0]
+    g7 = np.load(os.path.join(GOLDEN, "g7_force_maps.npz"))          # its synthetic row 12 is this row
+    raw = gi.to_u16(e["control_video"].cpu())
+    dd = np.abs(raw[::8, ::8, ::8, :].astype(np.int32) - g7["down_12"].astype(np.int32))
+    assert dd.max() <= 1 and e["prompt"] == "The domino falls."
