@@ -352,6 +352,19 @@ class WanVideoPipeline:
         t = t * ((max_value - min_value) / 255) + min_value
         return t.permute(2, 0, 1).unsqueeze(0)
 
+    def preprocess_video(self, video, min_value=-1, max_value=1):
+        """UTIL:69-73 — list of PIL frames -> bf16 [1,3,T,H,W] in [-1,1] (each frame through preprocess_image, stacked along T)."""
+        return torch.stack([self.preprocess_image(f, min_value, max_value) for f in video], dim=2)
+
+    def embed_input_video(self, input_video, tiled, tile_size, tile_stride):
+        """WanVideoUnit_InputVideoEmbedder (GF:767-789), the `input_video is not None` branch up to its VAE encode: the latents of
+        the clip.  In training mode (scheduler.training) the unit returns them as `input_latents` next to `latents = noise`; in
+        sampling mode it noises them to the first timestep (video-to-video, a branch Goal Force never takes)."""
+        if self.vae is None:
+            raise GoalForceError("embed_input_video needs pipe.vae")
+        v = self.preprocess_video(input_video)[0]
+        return self.vae.encode([v], device=self.device, tiled=tiled, tile_size=tile_size, tile_stride=tile_stride)
+
     def embed_image(self, input_image, num_frames, height, width, tiled, tile_size, tile_stride):
         """WanVideoUnit_ImageEmbedderVAE, `end_image is None` branch (GF:887-917): y = [mask(4) ; vae.encode(video)(16)]
         where video = the image followed by num_frames-1 zero frames.  The reference builds the mask by repeating pixel

@@ -438,6 +438,43 @@ def training_loss(pipe, *, input_latents, noise, context, y, control_signal_vide
     return MseLossFn.apply(pred[0], target[0].contiguous(), float(sch.training_weight(timestep)))
 
 
+def forward_preprocess(pipe, data, extra_inputs=("input_image",), tiled=False, tile_size=(30, 52), tile_stride=(15, 26)):
+    """`WanTrainingModule.forward_preprocess` (scripts/train/train.py:76-118): one dataset item — {"video": list of PIL frames,
+    "prompt": str, "control_video": [F,H,W,3] tensor} — through the pipeline's units in TRAINING mode, i.e. what the reference's
+    loop `for unit in self.pipe.units: ...` produces for the inputs Goal Force trains on (cfg_scale 1: no negative prompt, UTIL:262-271;
+    tiled False; extra_inputs "input_image" = the clip's first frame, train.py:104-106):
+        ShapeChecker GF:741-747 · NoiseInitializer GF:751-763 (unseeded: `rand_device = pipe.device`, train.py:93) ·
+        PromptEmbedder GF:808-820 · InputVideoEmbedder GF:767-789 (training branch: latents = noise, input_latents = vae.encode(video)) ·
+        ControlVideoEmbedder GF:791-805 · ImageEmbedderVAE GF:887-917.
+    Returns the keyword arguments of training_loss: input_latents, noise, context, y, control_signal_video_latents."""
+    if not pipe.scheduler.training:
+        raise GoalForceError("forward_preprocess: put the scheduler in training mode first (set_timesteps(1000, training=True), utils.py:560)")
+    video = data["video"]
+    width, height = video[0].size
+    num_frames = len(video)
+    h2, w2, f2 = pipe.check_resize_height_width(height, width, num_frames)
+    if (h2, w2, f2) != (height, width, num_frames):
+        raise GoalForceError(f"forward_preprocess: a clip of {num_frames} frames of {width}x{height} does not fit the model's grid "
+                             f"({f2} x {w2}x{h2}): the reference would encode the clip as it is and fail in the patch embedding")
+    noise = pipe.generate_noise((1, 16, (num_frames - 1) // 4 + 1, height // 8, width // 8), seed=None, rand_device=pipe.device)
+    pr = pipe.prompter
+    from .text_encoder import WanPrompter
+    if isinstance(pr, WanPrompter):
+        if pipe.text_encoder is None or pr.tokenizer is None:
+            raise GoalForceError("forward_preprocess: no text encoder / tokenizer loaded")
+        pr.fetch_models(pipe.text_encoder)
+    context = pr.encode_prompt(data["prompt"], positive=None, device=pipe.device)          # GF:812-813: `positive` is never in the inputs
+    input_latents = pipe.embed_input_video(video, tiled, tile_size, tile_stride).to(dtype=pipe.torch_dtype)
+    control = pipe.embed_control_video(data["control_video"], tiled, tile_size, tile_stride)
+    y = None
+    if "input_image" in extra_inputs:
+        y = pipe.embed_image(video[0], num_frames, height, width, tiled, tile_size, tile_stride)
+    unknown = [e for e in extra_inputs if e != "input_image"]
+    if unknown:
+        raise NotImplementedError(f"extra_inputs {unknown}: pipeline branches Goal Force never trains (train.py:107-112)")
+    return dict(input_latents=input_latents, noise=noise, context=context, y=y, control_signal_video_latents=control)
+
+
 class AdamW:
     """torch.optim.AdamW(params, lr, weight_decay) of launch_training_task (utils.py:755) on the HIP kernel: bf16
     parameters, fp32 moments (the reference's moments inherit the parameters' bf16; fp32 is strictly more precise)."""

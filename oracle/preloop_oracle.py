@@ -5,6 +5,9 @@ pipeline (src/goal_force/wan_video_new.py "GF") on torch-CPU, over oracle/vae_or
   * control_latents  WanVideoUnit_ControlVideoEmbedder GF:791-805
   * image_y          WanVideoUnit_ImageEmbedderVAE GF:887-917 (the `end_image is None` branch; preprocess_image UTIL:60-66)
   * shape_check      WanVideoUnit_ShapeChecker GF:740-747 -> check_resize_height_width UTIL:41-57
+  * input_latents    WanVideoUnit_InputVideoEmbedder GF:767-789 up to its VAE encode (preprocess_video UTIL:69-73): the training
+                     branch's `input_latents`; pinned bit-exactly (bf16) against tests/golden/g16_forward_preprocess.npz = the
+                     reference's own units run in training mode as scripts/train/train.py:76-118 runs them
 
 Pinned bit-exactly (bf16) against tests/golden/g10_preloop.npz, which tests/golden/make_goldens.py::g10_preloop made by
 running the REFERENCE's unit classes on the reference's BasePipeline and WanVideoVAE (tests/test_preloop.py).
@@ -57,3 +60,11 @@ def image_y(image, num_frames, height, width, sd, dtype=torch.bfloat16, tiled=Tr
     mask[:, 0] = 1
     lat = _encode(video, sd, tiled, tile_size, tile_stride)[0]
     return torch.cat([mask, lat.to(dtype)]).unsqueeze(0)
+
+
+def input_latents(frames, sd, dtype=torch.bfloat16, tiled=False, tile_size=(30, 52), tile_stride=(15, 26)):
+    """list of PIL frames -> latents [1,16,f,H/8,W/8] of the clip (GF:774-776): every frame `x * (2 / 255) - 1` in `dtype`
+    (UTIL:60-66), stacked along T (UTIL:69-73), through vae.encode."""
+    px = [torch.from_numpy(np.array(f, dtype=np.float32)).to(dtype) * (2 / 255) + (-1) for f in frames]
+    video = torch.stack([p.permute(2, 0, 1) for p in px], dim=1).unsqueeze(0)                 # [1,3,T,H,W]
+    return _encode(video, sd, tiled, tile_size, tile_stride).to(dtype)

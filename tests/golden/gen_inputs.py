@@ -284,3 +284,12 @@ def canny_inputs(seed=141):
 # signature's own defaults (49 frames, 480 x 720, DS:1667)
 PLANTS_ROWS = [(200.0, 45.0, 0.25, 0.25, 81, 480, 832), (390.0, 200.0, 0.84, 0.83, 81, 480, 832), (35.0, -90.0, 0.5, 0.9, 81, 480, 832),
                (120.0, 10.0, 0.3, 0.6, 49, 480, 720)]
+
+
+def training_clip(seed=161, frames=9, height=64, width=96):
+    """g16: a 9-frame 96x64 RGB clip (list of PIL images) — a smooth random field drifting two pixels per frame."""
+    import numpy as np
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    base = np.kron(rng.random((height // 8 + 4, width // 8 + 4, 3)), np.ones((8, 8, 1)))
+    return [Image.fromarray((base[8:8 + height, 2 * i:2 * i + width] * 255).astype(np.uint8)) for i in range(frames)]

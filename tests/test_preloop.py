@@ -135,3 +135,60 @@ def test_frames_to_uint8_matches_reference_bytes():
     assert not np.array_equal(g["frames_u8_bf16"], g["frames_u8_f32"])      # the dtype of the arithmetic matters
     ims = pipe.vae_output_to_video(vid)
     assert len(ims) == 2 and ims[0].size == (8, 8) and np.array_equal(np.array(ims[1]), g["frames_u8_bf16"][1])
+
+
+# ------------------------------------------------------------------ training-side caller: forward_preprocess (train.py:76-118; g16)
+def _g16():
+    g = np.load(os.path.join(GOLDEN, "g16_forward_preprocess.npz"))
+    g6 = np.load(os.path.join(GOLDEN, "g6_vae.npz"))
+    sd = gi.vae_decoder_sd(list(g6["names"]), g6["shapes"], seed=61)
+    clip, (_, control), inp = gi.training_clip(), gi.preloop_inputs(), gi.tiny_inputs()
+    assert gi.same_checksum(gi.checksum([torch.from_numpy(np.stack([np.array(f) for f in clip])).float(), control, inp["ctx_posi"]]), g["ck_inputs"])
+    return g, sd, clip, control, inp
+
+
+def test_oracle_training_inputs_match_the_reference_units_in_training_mode():
+    """The reference's units, run in training mode the way WanTrainingModule.forward_preprocess runs them (g16): the clip's latents
+    (InputVideoEmbedder), the control latents and y — oracle bit-exact in bf16; the tensors forward_preprocess hands to training_loss."""
+    g, sd, clip, control, inp = _g16()
+    # every tensor the reference's units left in the inputs (control_signal_video = the raw clip that went in; latents IS noise in training mode)
+    assert [str(k) for k in g["keys"]] == ["context", "control_signal_video", "control_signal_video_latents", "input_latents", "latents", "noise", "y"]
+    assert torch.equal(po.input_latents(clip, sd), gi.from_u16(g["input_latents_bf16"]))
+    assert torch.equal(po.control_latents(control, sd, tiled=False), gi.from_u16(g["control_signal_video_latents_bf16"]))
+    assert torch.equal(po.image_y(clip[0], F, H, W, sd, tiled=False), gi.from_u16(g["y_bf16"]))
+    assert torch.equal(inp["ctx_posi"], gi.from_u16(g["context_bf16"]))
+    sd32 = {k: v.float() for k, v in sd.items()}
+    assert rel_l2(po.input_latents(clip, sd32, dtype=torch.float32), torch.from_numpy(g["input_latents_f32"])) < 1e-5
+
+
+@pytest.mark.gpu
+def test_hip_forward_preprocess_vs_reference_golden():
+    """training.forward_preprocess(pipe, item) -> the keyword arguments of training_loss, against g16."""
+    from goal_force_amd import training as tr
+    from goal_force_amd._lib import GoalForceError
+    g, sd, clip, control, inp = _g16()
+    pipe = _gpu_pipe(sd)
+
+    class Prompter:
+        calls = []
+
+        def encode_prompt(self, prompt, positive=True, device="cuda"):
+            self.calls.append((prompt, positive))
+            return inp["ctx_posi"].to(device)
+    pipe.prompter = Prompter()
+    item = {"video": clip, "prompt": gi.PIPELINE_PROMPTS[0], "control_video": control}
+    with pytest.raises(GoalForceError, match="training mode"):
+        tr.forward_preprocess(pipe, item)
+    pipe.scheduler.set_timesteps(1000, training=True)
+    out = tr.forward_preprocess(pipe, item)
+    assert sorted(out) == ["context", "control_signal_video_latents", "input_latents", "noise", "y"]
+    assert Prompter.calls == [(gi.PIPELINE_PROMPTS[0], None)]
+    assert tuple(out["noise"].shape) == (1, 16, 3, 8, 12) and out["noise"].dtype == BF and out["noise"].is_cuda
+    assert torch.equal(out["context"].cpu(), gi.from_u16(g["context_bf16"]))
+    assert torch.equal(out["y"][:, :4].cpu(), gi.from_u16(g["y_bf16"])[:, :4])
+    for k, got in (("input_latents", out["input_latents"]), ("control_signal_video_latents", out["control_signal_video_latents"]), ("y", out["y"])):
+        ref_bf, ref32 = gi.from_u16(g[f"{k}_bf16"]).float(), torch.from_numpy(g[f"{k}_f32"])
+        sl = slice(4, None) if k == "y" else slice(None)
+        e, e_ref = rel_l2(got.cpu().float()[:, sl], ref32[:, sl]), rel_l2(ref_bf[:, sl], ref32[:, sl])
+        assert got.dtype == BF and tuple(got.shape) == tuple(ref32.shape)
+        assert e < max(1.5e-2, 1.5 * e_ref), f"{k}: vs fp32 {e:.3e} (reference bf16 {e_ref:.3e})"
