@@ -21,6 +21,7 @@ Design (MI355X-first, not a port of torch autograd):
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import torch
@@ -497,12 +498,13 @@ class AdamW:
         return math.sqrt(float(sq[0]))
 
     @torch.no_grad()
-    def step(self, max_grad_norm: Optional[float] = None):
-        """One update; `max_grad_norm` > 0 applies accelerator.clip_grad_norm_ (utils.py:806-808) as a gradient scale."""
+    def step(self, max_grad_norm: Optional[float] = None, grad_norm: Optional[float] = None):
+        """One update; `max_grad_norm` > 0 applies accelerator.clip_grad_norm_ (utils.py:806-808) as a gradient scale
+        (`grad_norm`: the norm when the caller has already computed it)."""
         self.step_count += 1
         scale = 1.0
         if max_grad_norm is not None and max_grad_norm > 0:
-            n = self.grad_norm()
+            n = self.grad_norm() if grad_norm is None else grad_norm
             scale = min(1.0, max_grad_norm / (n + 1e-6))
         for p in self.params:
             if p.grad is None:
@@ -548,6 +550,160 @@ def allreduce_gradients(params, group=None, bucket_bytes: int = 512 << 20):
         if size >= bucket_bytes:
             flush()
     flush()
+
+
+class ConstantLR:
+    """`torch.optim.lr_scheduler.ConstantLR(optimizer)` as launch_training_task builds it (utils.py:756) — with torch's DEFAULTS, i.e.
+    the learning rate is lr / 3 for the first 5 optimiser steps and lr from the sixth on (factor 1/3, total_iters 5).  The same
+    chained arithmetic as torch (`lr * factor`, later `lr * (1 / factor)`), so the floats agree."""
+
+    def __init__(self, optimizer: "AdamW", factor: float = 1.0 / 3, total_iters: int = 5):
+        self.optimizer, self.factor, self.total_iters, self.last_epoch = optimizer, factor, total_iters, 0
+        optimizer.lr = optimizer.lr * factor
+
+    def step(self):
+        self.last_epoch += 1
+        if self.last_epoch == self.total_iters:
+            self.optimizer.lr = self.optimizer.lr * (1.0 / self.factor)
+
+
+class ModelLogger:
+    """utils.py:592-650: counts optimiser steps, writes `step-<N>.safetensors` every `save_steps` (and once more at the end if the last
+    step was not a multiple), or `epoch-<k>.safetensors` when save_steps is None.  Checkpoint keys: the trainable parameters under
+    their names in the training module, `pipe.controlnet.<name>` (the scripts pass --remove_prefix_in_ckpt "pipe.dit.", which leaves
+    them as they are; `load_controlnet_weights` strips `pipe.controlnet.`, GF:176-178).  Written by rank 0 only."""
+
+    def __init__(self, output_path, remove_prefix_in_ckpt=None, log=None, log_every=10):
+        self.output_path, self.remove_prefix_in_ckpt, self.num_steps = output_path, remove_prefix_in_ckpt, 0
+        self.log, self.log_every = log, log_every
+
+    def on_step_end(self, pipe, loss, learning_rate, grad_norm=None, save_steps=None):
+        self.num_steps += 1
+        if self.log is not None and self.num_steps % self.log_every == 0:            # wandb.log every 10 steps (utils.py:604-615)
+            rec = {"training_loss": float(loss), "learning_rate": learning_rate}
+            if grad_norm is not None:
+                rec["gradient_norm"] = grad_norm
+            self.log(rec, self.num_steps)
+        if save_steps is not None and self.num_steps % save_steps == 0:
+            self.save_model(pipe, f"step-{self.num_steps}.safetensors")
+
+    def on_epoch_end(self, pipe, epoch_id):
+        self.save_model(pipe, f"epoch-{epoch_id}.safetensors")
+
+    def on_training_end(self, pipe, save_steps=None):
+        if save_steps is not None and self.num_steps % save_steps != 0:
+            self.save_model(pipe, f"step-{self.num_steps}.safetensors")
+
+    def save_model(self, pipe, file_name):
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.barrier()
+            if dist.get_rank() != 0:
+                return None
+        from safetensors.torch import save_file
+        sd = {"pipe.controlnet." + k: v.detach().cpu().contiguous() for k, v in pipe.controlnet.named_parameters() if v.requires_grad}
+        if self.remove_prefix_in_ckpt is not None:
+            sd = {(k[len(self.remove_prefix_in_ckpt):] if k.startswith(self.remove_prefix_in_ckpt) else k): v for k, v in sd.items()}
+        os.makedirs(self.output_path, exist_ok=True)
+        path = os.path.join(self.output_path, file_name)
+        save_file(sd, path)
+        return path
+
+
+def data_is_correct_shape_and_type(data, control_signal_type, num_frames) -> bool:
+    """utils.py:653-679: every frame a PIL image of 832 x 480, the control video [num_frames, 480, 832, 3]."""
+    from PIL import Image
+    if control_signal_type not in ("canny_edge", "direct_force_and_goal_force_and_mass"):
+        raise NotImplementedError(control_signal_type)
+    ok = all(isinstance(f, Image.Image) and f.size == (832, 480) for f in data["video"])
+    return ok and tuple(data["control_video"].shape) == (num_frames, 480, 832, 3)
+
+
+def should_skip_batch(local_condition_is_met: bool, device="cpu") -> bool:
+    """utils.py:682-698 — the ONE collective of the reference's own code: any rank with a bad batch makes every rank skip it."""
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return bool(local_condition_is_met)
+    t = torch.tensor(1.0 if local_condition_is_met else 0.0, device=device if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t) > 0
+
+
+def safe_collate(batch):
+    """utils.py:700-715: drop the samples that failed to load; the first of what is left (batch size 1), None if nothing is."""
+    batch = [b for b in batch if b is not None]
+    return batch[0] if batch else None
+
+
+def launch_training_task(dataset, model, learning_rate: float = 1e-5, weight_decay: float = 1e-2, num_workers: int = 8,
+                         save_steps: Optional[int] = None, num_epochs: int = 1, gradient_accumulation_steps: int = 1,
+                         find_unused_parameters: bool = False, args=None, forward=None, shuffle: bool = True, log=None, now=None):
+    """`launch_training_task` (utils.py:734-826) on the HIP training step: AdamW over the trainable (ControlNet) parameters,
+    `ConstantLR` (lr / 3 for the first five steps), a shuffled DataLoader with `safe_collate`, the bad-batch consensus, gradient
+    clipping at `args.max_grad_norm` (> -1), `ModelLogger` checkpoints, and the resume rule — a `--controlnet_checkpoint
+    .../step-<N>.safetensors` moves the output directory next to it, fast-forwards the LR schedule N steps and continues the step
+    count at N + 1 (sic, utils.py:781-785).  Data parallel: one process per GPU under torch.distributed (RCCL); gradients are
+    averaged by `allreduce_gradients` where the reference uses Accelerate's DDP.
+    `model`: the pipeline, or an object with `.pipe` (+ optional extra_inputs / max_timestep_boundary / min_timestep_boundary, as
+    WanTrainingModule carries them, train.py:70-74).  `forward(pipe, data) -> loss` replaces the default
+    `training_loss(pipe, **forward_preprocess(pipe, data))` (tests pin the random draws through it); `shuffle`, `log(record, step)`
+    (where the reference calls wandb.log) and `now` (the run directory's time stamp) are the other seams.  Returns the ModelLogger."""
+    import datetime
+    if args is not None:
+        learning_rate, weight_decay, num_workers = args.learning_rate, args.weight_decay, args.dataset_num_workers
+        save_steps, num_epochs = args.save_steps, args.num_epochs
+        gradient_accumulation_steps = args.gradient_accumulation_steps
+    if gradient_accumulation_steps != 1:
+        raise NotImplementedError("gradient_accumulation_steps > 1 (every script of the reference trains with 1)")
+    pipe = getattr(model, "pipe", model)
+    extra = tuple(getattr(model, "extra_inputs", None) or ("input_image",))
+    tmax, tmin = getattr(model, "max_timestep_boundary", 1.0), getattr(model, "min_timestep_boundary", 0.0)
+    if forward is None:
+        def forward(pipe_, data):
+            return training_loss(pipe_, **forward_preprocess(pipe_, data, extra_inputs=extra), max_timestep_boundary=tmax,
+                                 min_timestep_boundary=tmin)
+    params = [p_ for p_ in pipe.controlnet.parameters() if p_.requires_grad]
+    optimizer = AdamW(params, lr=learning_rate, weight_decay=weight_decay)
+    scheduler = ConstantLR(optimizer)
+    print("Dataset size: ", len(dataset))
+    dataloader = torch.utils.data.DataLoader(dataset, shuffle=shuffle, collate_fn=safe_collate, num_workers=num_workers)
+    ckpt = getattr(args, "controlnet_checkpoint", None)
+    output_path = getattr(args, "output_path", "./models")
+    if ckpt is None:
+        stamp = (now or datetime.datetime.now()).strftime("%Y-%m-%d_%H-%M-%S")                 # utils.py:18-26, 768-771
+        output_path = os.path.join(output_path, stamp)
+    else:
+        output_path = os.path.dirname(ckpt)                                                    # utils.py:773-775
+    logger = ModelLogger(output_path, remove_prefix_in_ckpt=getattr(args, "remove_prefix_in_ckpt", None), log=log)
+    if ckpt is not None:
+        step_num_initial = int(ckpt.split("/")[-1].split("step-")[1].split(".")[0])
+        for _ in range(step_num_initial):
+            scheduler.step()
+        logger.num_steps = step_num_initial + 1
+    max_grad_norm = getattr(args, "max_grad_norm", -1)
+    import torch.distributed as dist
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    for epoch_id in range(num_epochs):
+        for data in dataloader:
+            bad = data is None or not data_is_correct_shape_and_type(data, args.control_signal_type, args.num_frames)
+            if should_skip_batch(bad, pipe.device):
+                print("--> A bad batch was detected across GPUs. Skipping. <--")
+                continue
+            optimizer.zero_grad()
+            loss = forward(pipe, data)
+            loss.backward()
+            allreduce_gradients(params)
+            grad_norm = optimizer.grad_norm() if max_grad_norm > -1 else None                   # clip_grad_norm_ returns the norm BEFORE clipping
+            optimizer.step(max_grad_norm=max_grad_norm if max_grad_norm > -1 else None, grad_norm=grad_norm)
+            logger.on_step_end(pipe, loss.detach(), optimizer.lr, grad_norm=grad_norm, save_steps=save_steps)
+            # Accelerate's prepared scheduler advances the wrapped one `num_processes` times per training step (accelerate/scheduler.py,
+            # AcceleratedScheduler.step without split_batches): on the reference's 4-process runs the lr / 3 phase lasts 2 steps, not 5
+            for _ in range(world):
+                scheduler.step()
+        if save_steps is None:
+            logger.on_epoch_end(pipe, epoch_id)
+    logger.on_training_end(pipe, save_steps)
+    return logger
 
 
 def controlnet_state_dict(controlnet: nn.Module) -> dict:

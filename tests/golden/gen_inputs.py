@@ -293,3 +293,41 @@ def training_clip(seed=161, frames=9, height=64, width=96):
     rng = np.random.default_rng(seed)
     base = np.kron(rng.random((height // 8 + 4, width // 8 + 4, 3)), np.ones((8, 8, 1)))
     return [Image.fromarray((base[8:8 + height, 2 * i:2 * i + width] * 255).astype(np.uint8)) for i in range(frames)]
+
+
+# g17: the training loop.  launch_training_task refuses anything but 832x480 frames (utils.py:653-679), so the items are full-size, 5 frames
+TRAIN_LOOP = dict(num_frames=5, learning_rate=1e-3, weight_decay=1e-2, save_steps=3, num_epochs=2, max_grad_norm=1.0,
+                  max_timestep_boundary=0.358, min_timestep_boundary=0.0, remove_prefix_in_ckpt="pipe.dit.",
+                  control_signal_type="direct_force_and_goal_force_and_mass")
+
+
+def training_items(n=4, frames=5, height=480, width=832, seed=171):
+    """n training items as the datasets hand them over (DS:1488-1539): {"video": list of PIL frames, "prompt", "control_video"
+    [F,H,W,3] in [0,1] bf16, "file_id"}: drifting smooth random fields and two moving gaussian blobs."""
+    import numpy as np
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    yy, xx = torch.meshgrid(torch.arange(float(height)), torch.arange(float(width)), indexing="ij")
+    items = []
+    for k in range(n):
+        base = np.kron(rng.random((height // 16 + 4, width // 16 + 4, 3)), np.ones((16, 16, 1)))
+        video = [Image.fromarray((base[16:16 + height, 4 * i:4 * i + width] * 255).astype(np.uint8)) for i in range(frames)]
+        cx, cy = 100.0 + 150 * k, 120.0 + 60 * k
+        ctrl = []
+        for f in range(frames):
+            a = torch.exp(-((xx - cx - 12 * f) ** 2 + (yy - cy) ** 2) / (2 * 20.0 ** 2))
+            b = torch.exp(-((xx - 600) ** 2 + (yy - 300 + 8 * f) ** 2) / (2 * 12.0 ** 2))
+            ctrl.append(torch.stack([a, b, 0.5 * b], dim=-1))
+        items.append({"video": video, "prompt": PIPELINE_PROMPTS[k % 2], "control_video": torch.stack(ctrl).clamp(0, 1).to(torch.bfloat16),
+                      "file_id": f"item{k}"})
+    return items
+
+
+def train_loop_draws(step, latent_shape=(1, 16, 2, 60, 104), lo=0, hi=358):
+    """The random draws of training step `step` as g17 pinned them: the generator made the reference's forward start from
+    torch.manual_seed(1000 + step), after which NoiseInitializer draws the noise (fp32, CPU; GF:757-760) and training_loss the
+    timestep id (GF:183)."""
+    torch.manual_seed(1000 + step)
+    noise = torch.randn(latent_shape, dtype=torch.float32)
+    tid = int(torch.randint(lo, hi, (1,)))
+    return noise, tid
