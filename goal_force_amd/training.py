@@ -690,7 +690,8 @@ def launch_training_task(dataset, model, learning_rate: float = 1e-5, weight_dec
                 print("--> A bad batch was detected across GPUs. Skipping. <--")
                 continue
             optimizer.zero_grad()
-            loss = forward(pipe, data)
+            with torch.enable_grad():            # whatever the caller's global grad mode is (inference code switches it off process-wide)
+                loss = forward(pipe, data)
             loss.backward()
             allreduce_gradients(params)
             grad_norm = optimizer.grad_norm() if max_grad_norm > -1 else None                   # clip_grad_norm_ returns the norm BEFORE clipping

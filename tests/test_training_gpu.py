@@ -457,3 +457,125 @@ def test_derived_weight_caches_follow_optimizer_steps():
                 p_.mul_(0.5)
     enable_fp8(fresh)                                      # fresh copies cast from the updated masters
     assert torch.equal(b8, validate(fresh)) and not torch.equal(a8, b8)
+
+
+def test_training_loop_vs_the_reference_launch_training_task(tmp_path):
+    """`training.launch_training_task` against g17 = the reference's OWN `launch_training_task` (utils.py:734-826: Accelerate,
+    torch AdamW, ConstantLR, clip_grad_norm_, ModelLogger) around its own `WanTrainingModule.forward`, run on CPU on the same tiny
+    pipeline, the same four 832x480x5-frame items in the recorded order, the same per-step random draws (gen_inputs.train_loop_draws):
+      * bookkeeping bit for bit: learning rate of every step (lr / 3 for five steps, then lr), checkpoint names (step-3, step-6 and
+        the final step-8), checkpoint keys, the bf16-rounded timestep of every step;
+      * per-step loss and pre-clip gradient norm: no further from the reference's fp32 run than its bf16 run is (x 2, small floor);
+      * the parameter change of the final checkpoint (sampled entries of every tensor): the same bar."""
+    import argparse
+    import datetime
+    import os
+    import numpy as np
+    import gen_inputs as gi
+    from conftest import GOLDEN
+    from safetensors.torch import load_file
+    from goal_force_amd import training as tr
+    from goal_force_amd.vae import WanVideoVAE
+    g = np.load(os.path.join(GOLDEN, "g17_training_loop.npz"))
+    cfg = gi.TRAIN_LOOP
+    items = gi.training_items()
+    assert gi.same_checksum(gi.checksum([torch.from_numpy(np.stack([np.array(f) for f in it["video"]])).float() for it in items]
+                                        + [it["control_video"] for it in items]), g["ck_items"])
+    dit, cn = _tiny_train_models()
+    pipe = _tiny_train_pipe(dit, cn)
+    g6 = np.load(os.path.join(GOLDEN, "g6_vae.npz"))
+    vae = WanVideoVAE()
+    vae.load_state_dict({"model." + k: t for k, t in gi.vae_decoder_sd(list(g6["names"]), g6["shapes"], seed=61).items()}, strict=True)
+    pipe.vae = vae.to(BF).cuda()
+    pipe._after_models_attached()
+    for p_ in pipe.vae.parameters():
+        p_.requires_grad_(False)
+    inp = gi.tiny_inputs()
+
+    class Prompter:
+        def encode_prompt(self, prompt, positive=True, device="cuda"):
+            return (inp["ctx_posi"] if prompt == gi.PIPELINE_PROMPTS[0] else inp["ctx_nega"]).to(device)
+    pipe.prompter = Prompter()
+    order = [int(v) for v in g["order_bf16"]]
+    assert order == [int(v) for v in g["order_f32"]] and sorted(order[:4]) == sorted(order[4:]) == [0, 1, 2, 3]
+
+    class Replay(torch.utils.data.Dataset):              # the recorded shuffle of the reference's DataLoader, epoch after epoch
+        calls = 0
+
+        def __len__(self):
+            return len(items)
+
+        def __getitem__(self, i):
+            it = items[order[Replay.calls]]
+            Replay.calls += 1
+            return dict(it)
+    rec = {"loss": [], "timestep": []}
+
+    def forward(pipe_, data):
+        k = len(rec["loss"])
+        noise, tid = gi.train_loop_draws(k, hi=int(cfg["max_timestep_boundary"] * 1000))
+        inputs = tr.forward_preprocess(pipe_, data)
+        assert tuple(inputs["noise"].shape) == tuple(noise.shape)
+        inputs["noise"] = noise.to(BF).cuda()             # generate_noise: fp32 draws rounded to the pipeline's dtype (UTIL:117-122)
+        rec["timestep"].append(float(pipe_.scheduler.timesteps[tid].to(BF).float()))
+        with torch.enable_grad():
+            loss = tr.training_loss(pipe_, **inputs, timestep_id=tid)
+        rec["loss"].append(float(loss.detach()))
+        return loss
+    logged = []
+    args = argparse.Namespace(learning_rate=cfg["learning_rate"], weight_decay=cfg["weight_decay"], dataset_num_workers=0, save_steps=cfg["save_steps"],
+                              num_epochs=cfg["num_epochs"], gradient_accumulation_steps=1, find_unused_parameters=False, controlnet_checkpoint=None,
+                              output_path=str(tmp_path), remove_prefix_in_ckpt=cfg["remove_prefix_in_ckpt"], control_signal_type=cfg["control_signal_type"],
+                              num_frames=cfg["num_frames"], max_grad_norm=cfg["max_grad_norm"])
+    lrs, norms = [], []
+    real_end = tr.ModelLogger.on_step_end
+
+    def spy_end(self, pipe_, loss, learning_rate, grad_norm=None, save_steps=None):
+        lrs.append(learning_rate)
+        norms.append(grad_norm)
+        return real_end(self, pipe_, loss, learning_rate, grad_norm=grad_norm, save_steps=save_steps)
+    tr.ModelLogger.on_step_end = spy_end
+    try:
+        logger = tr.launch_training_task(Replay(), pipe, args=args, forward=forward, shuffle=False, log=lambda r, s_: logged.append((s_, r)),
+                                         now=datetime.datetime(2026, 1, 2, 3, 4, 5))
+    finally:
+        tr.ModelLogger.on_step_end = real_end
+    run_dir = os.path.join(str(tmp_path), "2026-01-02_03-04-05")
+    files = sorted(os.listdir(run_dir), key=lambda f: int(f.split("-")[1].split(".")[0]))
+    assert files == [str(f) for f in g["files"]] == ["step-3.safetensors", "step-6.safetensors", "step-8.safetensors"] and logger.num_steps == 8
+    assert lrs == [float(v) for v in g["lr_bf16"]], (lrs, g["lr_bf16"])                      # lr / 3 x 5, then lr: the same floats
+    assert rec["timestep"] == [float(v) for v in g["timestep_bf16"]]
+    lf, lb = g["loss_f32"], g["loss_bf16"]
+    for k in range(8):
+        assert abs(rec["loss"][k] - lf[k]) <= 2 * abs(lb[k] - lf[k]) + 2e-2 * abs(lf[k]), (k, rec["loss"][k], lf[k], lb[k])
+        nf, nb = g["grad_norm_f32"][k], g["grad_norm_bf16"][k]
+        assert abs(norms[k] - nf) <= 2 * abs(nb - nf) + 5e-2 * nf, (k, norms[k], nf, nb)
+    sd = load_file(os.path.join(run_dir, files[-1]))
+    names = [str(n) for n in g["ckpt_keys"]]
+    assert sorted(sd) == names and all(v.dtype == BF for v in sd.values())
+    csd0 = gi.controlnet_sd(gi.TINY, gi.TINY_CONTROLNET_LAYERS, seed=42)
+    got, s32, s16 = [], [], []
+    for i, n in enumerate(names):
+        d = (sd[n].double() - csd0[n[len("pipe.controlnet."):]].to(BF).double()).flatten()
+        got.append(d[gi.grad_sample_index(d.numel(), seed=4000 + i, k=2048)])
+        s32.append(torch.from_numpy(g["delta_sample_f32"][i]))
+        s16.append(torch.from_numpy(g["delta_sample_bf16"][i]))
+    got, s32, s16 = torch.cat(got), torch.cat(s32), torch.cat(s16)
+    e, e_ref = float((got - s32).norm() / s32.norm()), float((s16 - s32).norm() / s32.norm())
+    print(f"g17: parameter change after 8 steps vs the reference's fp32 run: {e:.3e} (the reference's bf16 run: {e_ref:.3e}); "
+          f"losses {[round(v, 4) for v in rec['loss']]}")
+    assert e <= 1.5 * e_ref + 2e-2, f"parameter change: {e:.3e} vs fp32 (reference bf16 {e_ref:.3e})"
+    assert float(got.abs().max()) > 0 and logged == [], "8 steps: the every-10-steps log never fires"
+    # resume rule (utils.py:773-785): output next to the checkpoint, LR schedule fast-forwarded, step count continues at N + 1 (sic)
+    Replay.calls = 0
+    rec["loss"].clear()
+    rec["timestep"].clear()
+    lrs.clear()
+    args.controlnet_checkpoint, args.num_epochs, args.save_steps = os.path.join(run_dir, "step-6.safetensors"), 1, 100
+    tr.ModelLogger.on_step_end = spy_end
+    try:
+        logger2 = tr.launch_training_task(Replay(), pipe, args=args, forward=forward, shuffle=False)
+    finally:
+        tr.ModelLogger.on_step_end = real_end
+    assert logger2.output_path == run_dir and logger2.num_steps == 6 + 1 + 4 and lrs == [cfg["learning_rate"] * (1.0 / 3) * 3.0] * 4
+    assert os.path.exists(os.path.join(run_dir, "step-11.safetensors"))
