@@ -18,11 +18,22 @@ def gaussian_blob(x, y, radius, height, width):
 
 
 def control_video(force, angle, x_pos, y_pos, tforce, tangle, tx, ty, masses, coords, num_frames=81, height=480,
-                  width=832, min_force=30.0, max_force=400.0, min_mass=1.0, max_mass=4.0):
-    """DS:775-889 with all mask-out probabilities 0 (inference).  Returns bf16 [F,H,W,3]."""
+                  width=832, min_force=30.0, max_force=400.0, min_mass=1.0, max_mass=4.0, p_mask_out_direct_force=0.0,
+                  p_mask_out_indirect_force=0.0, p_mask_out_masses=0.0):
+    """DS:775-889.  With the mask-out probabilities at 0 (inference) nothing random happens; with the training script's values the
+    two np.random.uniform draws of DS:796-801 and DS:852 decide which channels survive (pinned by g15's masked rows).  Returns bf16 [F,H,W,3]."""
     sig = torch.zeros((num_frames, 3, height, width))
-    mask_direct = force == -1
-    mask_indirect = (not mask_direct) and tforce == -1
+    if force == -1:
+        mask_direct, mask_indirect = True, False
+    elif tforce == -1:
+        mask_direct, mask_indirect = False, True
+    else:
+        mask_direct = mask_indirect = False
+        u = np.random.uniform(low=0.0, high=1.0)                 # drawn whatever the probabilities are (DS:796)
+        if u < p_mask_out_direct_force:
+            mask_direct = True
+        elif p_mask_out_direct_force <= u <= p_mask_out_direct_force + p_mask_out_indirect_force:
+            mask_indirect = True
 
     def moving(ch, xp, yp, f, ang):
         x0, y0 = xp * width, (1 - yp) * height
@@ -44,6 +55,8 @@ def control_video(force, angle, x_pos, y_pos, tforce, tangle, tx, ty, masses, co
         t = (m - min_mass) / (max_mass - min_mass)
         return gaussian_blob(x, y, (1 - t) * 5 + t * 40, height, width)[None]
 
+    if np.random.uniform(low=0.0, high=1.0) < p_mask_out_masses:         # drawn whatever the probability is (DS:852)
+        return sig.to(torch.bfloat16)                            # masses masked out: no blobs in channel 2 and NO clamp (DS:853, 887)
     if masses["projectile"] > -1:
         sig[..., 2] += mass(coords["projectile"][0], height - coords["projectile"][1], masses["projectile"])
     if masses["target"] > -1:

@@ -174,3 +174,43 @@ def test_hip_plants_and_dominos_datasets_read_their_csv_rows(tmp_path):
     raw = gi.to_u16(e["control_video"].cpu())
     dd = np.abs(raw[::8, ::8, ::8, :].astype(np.int32) - g7["down_12"].astype(np.int32))
     assert dd.max() <= 1 and e["prompt"] == "The domino falls."
+
+
+def _row13():
+    g7 = np.load(os.path.join(GOLDEN, "g7_force_maps.npz"))
+    return dict(zip(META, g7["meta"][13]))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_training_time_channel_masking_follows_the_reference_draws(seed):
+    """DS:785-802, 851-853 with the masking probabilities on (0.25 / 0.25 / 0.5): which of the three channels survive is decided by
+    np.random draws — g15 ran the reference's class under np.random.seed(seed); the oracle (sha256) and the product's plan (the same
+    channels alive, the clamp only when the masses are drawn) consume the same draws in the same order."""
+    from goal_force_amd.force_map import plan_control_video
+    g, r = _g15(), _row13()
+    masses = {"projectile": r["pmass"], "target": r["tmass"], "distractors": []}
+    coords = {"projectile": [int(r["pcx"]), int(r["pcy"])], "target": [int(r["tcx"]), int(r["tcy"])], "distractors": []}
+    np.random.seed(seed)
+    cv = fo.control_video(r["force"], r["angle"], r["x_pos"], r["y_pos"], r["tforce"], r["tangle"], r["tx"], r["ty"], masses, coords, num_frames=9,
+                          p_mask_out_direct_force=0.25, p_mask_out_indirect_force=0.25, p_mask_out_masses=0.5)
+    assert hashlib.sha256(gi.to_u16(cv).tobytes()).digest() == bytes(g[f"masked_sha256_{seed}"])
+    np.random.seed(seed)
+    plan = plan_control_video(r["force"], r["angle"], r["x_pos"], r["y_pos"], r["tforce"], r["tangle"], r["tx"], r["ty"], 9, 480, 832, masses, coords,
+                              30.0, 400.0, 30.0, 400.0, 1.0, 4.0, 0.25, 0.25, 0.5)
+    alive = [int(c in plan.channels) for c in range(3)]
+    assert alive == (g["masked_chan_sums"][seed] > 0).astype(int).tolist() and plan.clamp01 == bool(alive[2])
+
+
+@pytest.mark.gpu
+def test_hip_masked_control_videos_vs_reference_golden():
+    from goal_force_amd.force_map import plan_control_video, render_control_video
+    g, r = _g15(), _row13()
+    masses = {"projectile": r["pmass"], "target": r["tmass"], "distractors": []}
+    coords = {"projectile": [int(r["pcx"]), int(r["pcy"])], "target": [int(r["tcx"]), int(r["tcy"])], "distractors": []}
+    for seed in range(8):
+        np.random.seed(seed)
+        plan = plan_control_video(r["force"], r["angle"], r["x_pos"], r["y_pos"], r["tforce"], r["tangle"], r["tx"], r["ty"], 9, 480, 832, masses,
+                                  coords, 30.0, 400.0, 30.0, 400.0, 1.0, 4.0, 0.25, 0.25, 0.5)
+        raw = gi.to_u16(render_control_video(plan).cpu())
+        d = np.abs(raw[::4, ::8, ::8, :].astype(np.int32) - g[f"masked_down_{seed}"].astype(np.int32))
+        assert d.max() <= 1 and (d > 0).mean() < 2e-3, (seed, int(d.max()))

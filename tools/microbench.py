@@ -40,6 +40,9 @@ def main():
     ap.add_argument("--s", type=int, default=S)
     ap.add_argument("--zeros", action="store_true", help="attn: all-zero q/k/v as well (same instruction stream, no data toggling: "
                     "how much of the time is the clock the chip grants an MFMA stream on REAL data)")
+    ap.add_argument("--ramp", type=float, default=0.0, help="attn: also time an ADVERSARIAL input for the lazy-rescale softmax — every query's logits "
+                    "rise linearly along the key index by this many log2 units per 64-key tile (> 6 forces a rescale of O in every tile; "
+                    "no trained attention looks like this: the whole mass sits on the last keys) — and check it against fp64 on sampled rows")
     ap.add_argument("--ab", action="store_true", help="gemm: interleaved A/B of GF_GEMM_KERNEL=a4 (4 waves, shipped) and ph (8 waves)")
     ap.add_argument("--only", choices=["dd", "ffn1", "ffn2"], default=None, help="gemm: ONE block shape with the epilogue the block runs it "
                     "with (dd: bias; ffn1: GELU; ffn2: gate*+resid), bf16 — or e4m3 with --fp8: the target of the per-shape PMC passes "
@@ -75,6 +78,29 @@ def main():
                       f"{fl / min(ours) / 1e9:.1f} TFLOP/s best;  rel-L2 between the two outputs {err:.2e}")
             except Exception as e:      # noqa: BLE001 — a yardstick that cannot run is reported, not fatal
                 print(f"   yardstick F.scaled_dot_product_attention failed: {type(e).__name__}: {str(e)[:200]}")
+        if a.ramp > 0:
+            import math
+            hd = D // H
+            tiles = (skv + 63) // 64
+            top = a.ramp * tiles * math.log(2.0) * math.sqrt(hd)            # q.k of the LAST key so that the logit rises `ramp` log2 units per tile
+            amp = math.sqrt(top)
+            u = torch.ones((hd,), device="cuda") / math.sqrt(hd)
+            qr = (amp * u).repeat(H)[None, :].expand(s, D).contiguous().to(BF)
+            kr = ((torch.arange(skv, device="cuda", dtype=torch.float32) / skv)[:, None] * (amp * u).repeat(H)[None, :]).to(BF)
+            vr = torch.randn((skv, D), device="cuda").to(BF)
+            rounds = {"random": [], "ramp": []}
+            for _ in range(3):
+                rounds["random"].append(timeit(lambda: ops.flash_attn(q, k, v, H, out=o), a.iters)[0])
+                rounds["ramp"].append(timeit(lambda: ops.flash_attn(qr, kr, vr, H, out=o), a.iters)[0])
+            got = ops.flash_attn(qr, kr, vr, H)
+            rows = torch.tensor([0, 1, s // 2, s - 1], device="cuda")
+            h0 = 3
+            sc = (qr[rows, h0 * hd:(h0 + 1) * hd].double() @ kr[:, h0 * hd:(h0 + 1) * hd].double().T) / math.sqrt(hd)
+            ref = torch.softmax(sc, dim=-1) @ vr[:, h0 * hd:(h0 + 1) * hd].double()
+            err = float((got[rows, h0 * hd:(h0 + 1) * hd].double() - ref).norm() / ref.norm())
+            print(f"   adversarial ramp (+{a.ramp:g} log2 units per 64-key tile, every tile rescales): medians "
+                  f"{', '.join(f'{t:.3f}' for t in rounds['ramp'])} ms against random {', '.join(f'{t:.3f}' for t in rounds['random'])} ms "
+                  f"(interleaved) -> x {min(rounds['ramp']) / min(rounds['random']):.3f};  rel-L2 vs fp64 on sampled rows {err:.2e}")
         if a.ab:       # interleaved rounds of kernel 3 (16x16x32 MFMA) and kernel 2 (32x32x16) in this process
             rounds = {"3": [], "2": []}
             for _ in range(3):
