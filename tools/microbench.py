@@ -98,7 +98,7 @@ def main():
             sc = (qr[rows, h0 * hd:(h0 + 1) * hd].double() @ kr[:, h0 * hd:(h0 + 1) * hd].double().T) / math.sqrt(hd)
             ref = torch.softmax(sc, dim=-1) @ vr[:, h0 * hd:(h0 + 1) * hd].double()
             err = float((got[rows, h0 * hd:(h0 + 1) * hd].double() - ref).norm() / ref.norm())
-            print(f"   adversarial ramp (+{a.ramp:g} log2 units per 64-key tile, every tile rescales): medians "
+            print(f"   ramp (+{a.ramp:g} log2 units per 64-key tile: {'every tile rescales' if a.ramp > 6 else 'below the rescale threshold of 6'}): medians "
                   f"{', '.join(f'{t:.3f}' for t in rounds['ramp'])} ms against random {', '.join(f'{t:.3f}' for t in rounds['random'])} ms "
                   f"(interleaved) -> x {min(rounds['ramp']) / min(rounds['random']):.3f};  rel-L2 vs fp64 on sampled rows {err:.2e}")
         if a.ab:       # interleaved rounds of kernel 3 (16x16x32 MFMA) and kernel 2 (32x32x16) in this process
