@@ -707,6 +707,83 @@ def launch_training_task(dataset, model, learning_rate: float = 1e-5, weight_dec
     return logger
 
 
+def wan_parser():
+    """`wan_parser` (utils.py:854-900): the training script's command line, argument for argument and default for default (pinned
+    against the reference's own parser object by tests/golden/g18).  Arguments of branches Goal Force never trains (LoRA, strided
+    ControlNet, gradient-checkpoint offload, wandb) are accepted so that the reference's shell scripts run unchanged;
+    scripts/train.py refuses the ones that would change what is computed."""
+    import argparse
+    ap = argparse.ArgumentParser(description="Simple example of a training script.")
+    ap.add_argument("--dataset_base_path", type=str, nargs="+", default="", required=True, help="Base path(s) of the dataset.")
+    ap.add_argument("--dataset_metadata_path", type=str, nargs="+", default=None, help="Path(s) to the metadata file of the dataset.")
+    ap.add_argument("--controlnet_checkpoint", type=str, default=None, help="Path to the ckpt file of the previously trained controlnet.")
+    ap.add_argument("--control_signal_type", type=str, default=None, help="Type of control signal.")
+    ap.add_argument("--controlnet_num_layers", type=int, default=0, help="Number of DiT layers for the ControlNet")
+    ap.add_argument("--controlnet_stride", type=int, default=None)
+    ap.add_argument("--apply_strided_controlnet", action="store_true")
+    ap.add_argument("--offline_load", action="store_true", help="Whether to load models from offline local model files.")
+    ap.add_argument("--max_pixels", type=int, default=1280 * 720)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--num_frames", type=int, default=81)
+    ap.add_argument("--data_file_keys", type=str, default="image,video")
+    ap.add_argument("--dataset_repeat", type=int, default=1)
+    ap.add_argument("--model_paths", type=str, default=None, help="Paths to load models. In JSON format.")
+    ap.add_argument("--model_id_with_origin_paths", type=str, default=None)
+    ap.add_argument("--learning_rate", type=float, default=1e-4)
+    ap.add_argument("--num_epochs", type=int, default=1)
+    ap.add_argument("--output_path", type=str, default="./models")
+    ap.add_argument("--remove_prefix_in_ckpt", type=str, default="pipe.dit.")
+    ap.add_argument("--trainable_models", type=str, default=None)
+    ap.add_argument("--lora_base_model", type=str, default=None)
+    ap.add_argument("--lora_target_modules", type=str, default="q,k,v,o,ffn.0,ffn.2")
+    ap.add_argument("--lora_rank", type=int, default=32)
+    ap.add_argument("--lora_checkpoint", type=str, default=None)
+    ap.add_argument("--extra_inputs", default=None, help="Additional model inputs, comma-separated.")
+    ap.add_argument("--use_gradient_checkpointing_offload", default=False, action="store_true")
+    ap.add_argument("--gradient_accumulation_steps", type=int, default=1)
+    ap.add_argument("--max_timestep_boundary", type=float, default=1.0)
+    ap.add_argument("--min_timestep_boundary", type=float, default=0.0)
+    ap.add_argument("--find_unused_parameters", default=False, action="store_true")
+    ap.add_argument("--save_steps", type=int, default=None)
+    ap.add_argument("--dataset_num_workers", type=int, default=0)
+    ap.add_argument("--weight_decay", type=float, default=0.01)
+    ap.add_argument("--wandb_logging", default=False, action="store_true")
+    ap.add_argument("--wandb_project", type=str, default="diffsynth-training")
+    ap.add_argument("--wandb_run_name", type=str, default=None)
+    ap.add_argument("--max_grad_norm", type=float, default=-1)
+    ap.add_argument("--p_mask_out_direct_force", type=float, default=0.0)
+    ap.add_argument("--p_mask_out_indirect_force", type=float, default=0.0)
+    ap.add_argument("--p_mask_out_masses", type=float, default=0.0)
+    return ap
+
+
+def get_dataset(args, device="cuda", video_loader=None):
+    """`get_dataset` (scripts/train/train.py:126-197): `canny_edge` -> the Canny set on its own video operator; 
+    `direct_force_and_goal_force_and_mass` -> ConcatDataset([balls, dominos, plants]) in TRAINING mode, base / metadata paths in that
+    order, the three masking probabilities on the first two."""
+    from .canny import ControlSignalDataset_CannyEdge
+    from .force_map import ControlSignalDataset_Balls, ControlSignalDataset_Dominos, ControlSignalDataset_Plants
+    if args.control_signal_type == "canny_edge":
+        return ControlSignalDataset_CannyEdge(
+            base_path=args.dataset_base_path[0], metadata_path=args.dataset_metadata_path[0], repeat=args.dataset_repeat,
+            data_file_keys=args.data_file_keys.split(","), device=device,
+            main_data_operator=ControlSignalDataset_CannyEdge.default_video_operator(
+                base_path=args.dataset_base_path[0], max_pixels=args.max_pixels, height=args.height, width=args.width,
+                height_division_factor=16, width_division_factor=16, num_frames=args.num_frames, time_division_factor=4,
+                time_division_remainder=1))
+    if args.control_signal_type != "direct_force_and_goal_force_and_mass":
+        raise NotImplementedError(args.control_signal_type)
+    common = dict(repeat=args.dataset_repeat, data_file_keys=args.data_file_keys.split(","), is_validation_dataset=False,
+                  num_frames=args.num_frames, height=args.height, width=args.width, device=device, video_loader=video_loader)
+    masks = dict(p_mask_out_masses=args.p_mask_out_masses, p_mask_out_direct_force=args.p_mask_out_direct_force,
+                 p_mask_out_indirect_force=args.p_mask_out_indirect_force)
+    balls = ControlSignalDataset_Balls(base_path=args.dataset_base_path[0], metadata_path=args.dataset_metadata_path[0], **common, **masks)
+    dominos = ControlSignalDataset_Dominos(base_path=args.dataset_base_path[1], metadata_path=args.dataset_metadata_path[1], **common, **masks)
+    plants = ControlSignalDataset_Plants(base_path=args.dataset_base_path[2], metadata_path=args.dataset_metadata_path[2], **common)
+    return torch.utils.data.ConcatDataset([balls, dominos, plants])
+
+
 def controlnet_state_dict(controlnet: nn.Module) -> dict:
     """Checkpoint layout of the reference's ModelLogger (remove_prefix 'pipe.controlnet.' on load, GF:176-178)."""
     return {"pipe.controlnet." + k: v.detach().cpu() for k, v in controlnet.state_dict().items()}

@@ -331,3 +331,42 @@ def train_loop_draws(step, latent_shape=(1, 16, 2, 60, 104), lo=0, hi=358):
     noise = torch.randn(latent_shape, dtype=torch.float32)
     tid = int(torch.randint(lo, hi, (1,)))
     return noise, tid
+
+
+def write_training_tree(root):
+    """g18: a synthetic training-data tree as scripts/train/*.sh lay it out — three folders of clips with their CSV listings.  The clips
+    are EMPTY files named *.mp4 (load_metadata only checks that they exist); one CSV row per set names a clip that is missing."""
+    import os
+    hdr = ("video,projectile_force_angle,projectile_force_magnitude,projectile_coordx,projectile_coordy,projectile_mass,"
+           "target_indirect_force_angle,target_indirect_force_magnitude,target_coordx,target_coordy,target_mass,width,height,caption\n")
+    sets = {"balls": [("b0.mp4", 10, 120.0, 100, 200, 1.5, 30, 80.5, 400, 210, 2.0), ("b1.mp4", 200, 390.5, 300, 100, 3.5, -1, -1, 500, 90, -1),
+                      ("b2.mp4", 45, 33.25, 50, 60, 1.0, 350, 260.0, 70, 80, 4.0), ("b_missing.mp4", 1, 9999.0, 1, 1, 9.0, 1, 9999.0, 1, 1, 9.0)],
+            "dominos": [("d0.mp4", 0, 55.0, 10, 20, 2.0, 0, 66.0, 30, 40, 2.5), ("d1.mp4", 90, 75.0, 11, 21, 2.25, 180, 44.0, 31, 41, 3.0),
+                        ("d_missing.mp4", 1, 1.0, 1, 1, 0.5, 1, 1.0, 1, 1, 0.5)]}
+    for name, rows in sets.items():
+        os.makedirs(os.path.join(root, name), exist_ok=True)
+        with open(os.path.join(root, name + ".csv"), "w") as f:
+            f.write(hdr)
+            for r in rows:
+                f.write(f'{r[0]},{r[1]},{r[2]},{r[3]},{r[4]},{r[5]},{r[6]},{r[7]},{r[8]},{r[9]},{r[10]},832,480,"a caption"\n')
+                if "missing" not in r[0]:
+                    open(os.path.join(root, name, r[0]), "w").close()
+    os.makedirs(os.path.join(root, "plants"), exist_ok=True)
+    with open(os.path.join(root, "plants.csv"), "w") as f:
+        f.write("video,force,angle,coordx,coordy,width,height,caption\n")
+        for r in (("fern0.mp4", 12.5, 30, 100, 100), ("carnation1.mp4", 48.0, 200, 400, 240), ("p_missing.mp4", 999.0, 1, 1, 1)):
+            f.write(f'{r[0]},{r[1]},{r[2]},{r[3]},{r[4]},832,480,"a plant"\n')
+            if "missing" not in r[0]:
+                open(os.path.join(root, "plants", r[0]), "w").close()
+
+
+def training_cli(root):
+    """g18: the command line of scripts/train/train_goal_force.sh on the tree of write_training_tree(root)."""
+    import os
+    j = lambda *a: os.path.join(root, *a)
+    return ["--dataset_base_path", j("balls"), j("dominos"), j("plants"), "--dataset_metadata_path", j("balls.csv"), j("dominos.csv"), j("plants.csv"),
+            "--control_signal_type", "direct_force_and_goal_force_and_mass", "--controlnet_num_layers", "10", "--height", "480", "--width", "832",
+            "--num_frames", "81", "--dataset_repeat", "1", "--learning_rate", "1e-5", "--num_epochs", "2", "--save_steps", "500",
+            "--remove_prefix_in_ckpt", "pipe.dit.", "--trainable_models", "controlnet", "--output_path", j("out"), "--extra_inputs", "input_image",
+            "--max_timestep_boundary", "0.358", "--min_timestep_boundary", "0", "--max_grad_norm", "1", "--p_mask_out_masses", "0.5",
+            "--p_mask_out_direct_force", "0.5", "--p_mask_out_indirect_force", "0.5", "--wandb_logging"]

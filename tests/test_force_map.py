@@ -122,8 +122,6 @@ def test_plants_plan_is_one_unclamped_direct_force_blob():
     assert np.allclose(ce[0, 0], [x * w, (1 - y) * h]) and np.allclose(ce[0, -1, 0], x * w + disp * np.cos(np.deg2rad(a)), atol=1e-3)
     with pytest.raises(GoalForceError):
         ds.plan(-1, a, x, y, nf, h, w)
-    with pytest.raises(NotImplementedError):
-        ControlSignalDataset_Plants(is_validation_dataset=False)
 
 
 @pytest.mark.gpu
@@ -214,3 +212,45 @@ def test_hip_masked_control_videos_vs_reference_golden():
         raw = gi.to_u16(render_control_video(plan).cpu())
         d = np.abs(raw[::4, ::8, ::8, :].astype(np.int32) - g[f"masked_down_{seed}"].astype(np.int32))
         assert d.max() <= 1 and (d > 0).mean() < 2e-3, (seed, int(d.max()))
+
+
+@pytest.mark.gpu
+def test_hip_training_mode_items_of_the_dataset_mux(tmp_path):
+    """`training.get_dataset(args)` in training mode end to end (train.py:126-197 -> DS:1029-1080, 1488-1539, 1842-1878): every item a
+    list of num_frames PIL frames + the control video; the carnation clip goes through the random zoom-crop (DS:1773-1834) with the
+    poke point re-expressed in the crop."""
+    from goal_force_amd import training as tr
+    gi.write_training_tree(str(tmp_path))
+    rng = np.random.default_rng(3)
+    for folder, names, n in (("balls", ["b0", "b1", "b2"], 24), ("dominos", ["d0", "d1"], 30), ("plants", ["fern0", "carnation1"], 12)):
+        for nm in names:
+            os.remove(tmp_path / folder / f"{nm}.mp4")
+            np.save(tmp_path / folder / f"{nm}.npy", rng.integers(0, 255, (n, 480, 832, 3), dtype=np.uint8))
+            os.rename(tmp_path / folder / f"{nm}.npy", tmp_path / folder / f"{nm}.mp4")          # the listing names .mp4 files
+
+    def loader(path):                        # an .npy behind the listing's name (no video decoder in this image)
+        from PIL import Image
+        return [Image.fromarray(a) for a in np.load(open(path, "rb"))]
+    argv = gi.training_cli(str(tmp_path))
+    argv[argv.index("--num_frames") + 1] = "9"
+    args = tr.wan_parser().parse_args(argv)
+    ds = tr.get_dataset(args, device="cuda", video_loader=loader)
+    assert len(ds) == 7
+    np.random.seed(0)
+    items = [ds[i] for i in range(7)]
+    for it in items:
+        assert len(it["video"]) == 9 and it["video"][0].size == (832, 480) and tuple(it["control_video"].shape) == (9, 480, 832, 3)
+        assert it["control_video"].dtype == torch.bfloat16 and it["control_video"].is_cuda
+        assert tr.data_is_correct_shape_and_type(it, "direct_force_and_goal_force_and_mass", 9)
+    raw = np.load(open(tmp_path / "balls" / "b0.mp4", "rb"))
+    want = raw[::2][-9:][0].astype(int)
+    want[(want >= 1) & (want <= 63)] -= 1
+    assert np.array_equal(np.array(items[0]["video"][0]).astype(int), want), "balls: every second frame, the last 9, through the pixel round trip"
+    raw = np.load(open(tmp_path / "dominos" / "d0.mp4", "rb"))
+    want = raw[14:][0:9][8].astype(int)
+    want[(want >= 1) & (want <= 63)] -= 1
+    assert np.array_equal(np.array(items[3]["video"][8]).astype(int), want)
+    fern, carn = items[5], items[6]
+    assert fern["file_id"] == "fern0" and fern["x_pos"] == 100 / 832 and carn["file_id"] == "carnation1"
+    assert float(fern["control_video"][..., 1:].abs().max()) == 0 and float(carn["control_video"][..., 0].max()) > 0.9
+    assert 50 / 832 <= carn["x_pos"] <= 1 - 50 / 832 + 0.1 and 0 < carn["y_pos"] < 1, "the poke point stays inside the zoomed window"

@@ -382,3 +382,59 @@ def test_canny_video_operator_crops_resizes_and_counts_frames_like_the_reference
         (tmp_path / "v.mp4").write_bytes(b"")
         with pytest.raises(GoalForceError, match="imageio"):
             op("v.mp4")
+
+
+def test_training_cli_and_dataset_mux_match_the_reference_objects(tmp_path):
+    """g18 = the reference's own `wan_parser()` (utils.py:854-900) and `get_dataset(args)` (train.py:126-197) on a synthetic data tree:
+    every option of the command line with its dest / default / type / nargs / required / action, and what the three training-mode sets read
+    from their CSV listings (rows kept, force / goal-force / mass ranges, masking probabilities)."""
+    from goal_force_amd import training as tr
+    g = np.load(os.path.join(GOLDEN, "g18_training_cli.npz"))
+    rows = []
+    for a in tr.wan_parser()._actions:
+        if not a.option_strings or a.dest == "help":
+            continue
+        rows.append([a.option_strings[0], a.dest, repr(a.default), getattr(a.type, "__name__", "None"), repr(a.nargs), repr(bool(a.required)),
+                     type(a).__name__])
+    assert rows == g["parser"].tolist()
+    gi.write_training_tree(str(tmp_path))
+    args = tr.wan_parser().parse_args(gi.training_cli(str(tmp_path)))
+    ds = tr.get_dataset(args, device="cpu")
+    b, d, p = ds.datasets
+    assert [type(x).__name__ for x in ds.datasets] == ["ControlSignalDataset_Balls", "ControlSignalDataset_Dominos", "ControlSignalDataset_Plants"]
+    assert [len(b), len(d), len(p), len(ds)] == g["lengths"].tolist()
+    assert [b.min_force, b.max_force, b.min_indirect_force, b.max_indirect_force, b.min_mass, b.max_mass] == g["balls_ranges"].tolist()
+    assert [d.min_force, d.max_force, d.min_indirect_force, d.max_indirect_force, d.min_mass, d.max_mass] == g["dominos_ranges"].tolist()
+    assert [p.min_force, p.max_force] == g["plants_ranges"].tolist()
+    assert [b.p_mask_out_direct_force, b.p_mask_out_indirect_force, b.p_mask_out_masses, d.p_mask_out_direct_force, d.p_mask_out_indirect_force,
+            d.p_mask_out_masses] == g["masks"].tolist()
+    assert [",".join(x.df[x.media_type].tolist()) for x in ds.datasets] == g["kept_rows"].tolist()
+    assert not b.is_validation_dataset and b.media_type == "video"
+
+
+def test_training_mode_frame_selection_video_loading_and_the_pixel_roundtrip(tmp_path):
+    """Host logic of the training-mode sets that needs no GPU: which frames of a clip are trained on (balls `[::2][-n:]` DS:985, dominos
+    `[14:][0:n]` DS:1463), the clip containers readable here, and the reference's ToTensor -> 2x-1 -> (x+1)/2 -> ToPILImage chain, which
+    is NOT the identity in fp32: the levels 1 .. 63 come back one lower (goal_force_amd/force_map.py::reference_pixel_roundtrip)."""
+    from PIL import Image
+    from goal_force_amd import force_map as fm
+    frames = list(range(200))
+    b = object.__new__(fm.ControlSignalDataset_Balls)
+    d = object.__new__(fm.ControlSignalDataset_Dominos)
+    b.num_frames = d.num_frames = 81
+    assert b.select_frames(frames) == list(range(38, 200, 2)) and d.select_frames(frames) == list(range(14, 95))
+    ramp = np.arange(256, dtype=np.uint8).reshape(16, 16, 1).repeat(3, axis=2)
+    (back,) = fm.reference_pixel_roundtrip([Image.fromarray(ramp)])
+    got = np.array(back)[..., 0].reshape(-1).astype(int)
+    want = np.arange(256)
+    want[1:64] -= 1
+    assert got.tolist() == want.tolist(), "levels 1..63 lose one level in the reference's fp32 chain, every other level survives"
+    clip = np.random.default_rng(0).integers(0, 255, (7, 8, 12, 3), dtype=np.uint8)
+    np.save(tmp_path / "c.npy", clip)
+    fr = fm.load_video_frames(str(tmp_path / "c.npy"))
+    assert len(fr) == 7 and np.array_equal(np.array(fr[3]), clip[3])
+    (tmp_path / "dir").mkdir()
+    for i in range(3):
+        Image.fromarray(clip[i]).save(tmp_path / "dir" / f"{i:02d}.png")
+    fr = fm.load_video_frames(str(tmp_path / "dir"))
+    assert len(fr) == 3 and np.array_equal(np.array(fr[2]), clip[2])
