@@ -70,6 +70,10 @@ def plan_control_video(force, angle, x_pos, y_pos, target_indirect_force, target
     disp_max, disp_min = width / 2, width / 8      # DS:804-805
 
     def moving_blob(channel, xp, yp, f, fmin, fmax, ang):
+        if fmax == fmin:
+            # the reference divides by zero here (DS:812) and renders a video of NaNs, which then trains silently: refused by name instead
+            raise GoalForceError(f"control video: the force range is empty (min = max = {fmin}): a training set needs two different force "
+                                 "magnitudes in its CSV, an inference driver sets the range itself (INF:137-146)")
         x0 = xp * width
         y0 = (1 - yp) * height
         pct = (f - fmin) / (fmax - fmin)
@@ -91,6 +95,8 @@ def plan_control_video(force, angle, x_pos, y_pos, target_indirect_force, target
     # STEP 5 (DS:846-887): static mass blobs in channel 2, then clamp everything to [0,1]
     if not (np.random.uniform(low=0.0, high=1.0) < p_mask_out_masses):
         def mass_blob(x, y, m):
+            if max_mass == min_mass:
+                raise GoalForceError(f"control video: the mass range is empty (min = max = {min_mass}); see the force range (DS:893)")
             t = (m - min_mass) / (max_mass - min_mass)
             r = (1 - t) * MIN_MASS_RADIUS + t * MAX_MASS_RADIUS
             plan.add(2, np.tile(np.array([[float(x), float(y)]]), (num_frames, 1)), r)
