@@ -692,6 +692,10 @@ def launch_training_task(dataset, model, learning_rate: float = 1e-5, weight_dec
             optimizer.zero_grad()
             with torch.enable_grad():            # whatever the caller's global grad mode is (inference code switches it off process-wide)
                 loss = forward(pipe, data)
+            if not math.isfinite(float(loss.detach())):
+                # the reference would step the optimiser on NaN gradients and write NaN checkpoints from here on; stop with the item's name
+                raise GoalForceError(f"launch_training_task: non-finite loss {float(loss.detach())} at step {logger.num_steps + 1} "
+                                     f"(item {data.get('file_id', '?')!r}): no optimiser step taken, nothing written")
             loss.backward()
             allreduce_gradients(params)
             grad_norm = optimizer.grad_norm() if max_grad_norm > -1 else None                   # clip_grad_norm_ returns the norm BEFORE clipping
