@@ -370,3 +370,15 @@ def training_cli(root):
             "--remove_prefix_in_ckpt", "pipe.dit.", "--trainable_models", "controlnet", "--output_path", j("out"), "--extra_inputs", "input_image",
             "--max_timestep_boundary", "0.358", "--min_timestep_boundary", "0", "--max_grad_norm", "1", "--p_mask_out_masses", "0.5",
             "--p_mask_out_direct_force", "0.5", "--p_mask_out_indirect_force", "0.5", "--wandb_logging"]
+
+
+def shape_check_cases():
+    """g18: items for `data_is_correct_shape_and_type` (utils.py:653-679) — name, item, num_frames."""
+    from PIL import Image
+    ok = Image.new("RGB", (832, 480))
+    small = Image.new("RGB", (416, 240))
+    cv = lambda f, h=480, w=832, c=3: torch.zeros((f, h, w, c), dtype=torch.bfloat16)
+    return [("good", {"video": [ok] * 5, "control_video": cv(5)}, 5), ("one small frame", {"video": [ok, small, ok], "control_video": cv(3)}, 3),
+            ("control too short", {"video": [ok] * 5, "control_video": cv(4)}, 5), ("control wrong size", {"video": [ok] * 5, "control_video": cv(5, 240, 416)}, 5),
+            ("frames are arrays", {"video": [torch.zeros(3, 480, 832)] * 5, "control_video": cv(5)}, 5),
+            ("more frames than the control video checks", {"video": [ok] * 9, "control_video": cv(5)}, 5)]

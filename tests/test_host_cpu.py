@@ -410,6 +410,14 @@ def test_training_cli_and_dataset_mux_match_the_reference_objects(tmp_path):
             d.p_mask_out_masses] == g["masks"].tolist()
     assert [",".join(x.df[x.media_type].tolist()) for x in ds.datasets] == g["kept_rows"].tolist()
     assert not b.is_validation_dataset and b.media_type == "video"
+    verdicts = []
+    for name, item, nf in gi.shape_check_cases():
+        try:
+            verdicts.append(str(bool(tr.data_is_correct_shape_and_type(item, "direct_force_and_goal_force_and_mass", nf))))
+        except Exception as e:      # noqa: BLE001
+            verdicts.append(type(e).__name__)
+    assert verdicts == g["shape_check_verdicts"].tolist(), list(zip([c[0] for c in gi.shape_check_cases()], verdicts, g["shape_check_verdicts"]))
+    assert [repr(tr.safe_collate(x)) for x in ([None, None], [None, 7, 8], [3], [])] == g["safe_collate"].tolist()
 
 
 def test_training_mode_frame_selection_video_loading_and_the_pixel_roundtrip(tmp_path):
