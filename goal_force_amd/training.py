@@ -666,7 +666,16 @@ def launch_training_task(dataset, model, learning_rate: float = 1e-5, weight_dec
     optimizer = AdamW(params, lr=learning_rate, weight_decay=weight_decay)
     scheduler = ConstantLR(optimizer)
     print("Dataset size: ", len(dataset))
-    dataloader = torch.utils.data.DataLoader(dataset, shuffle=shuffle, collate_fn=safe_collate, num_workers=num_workers)
+    import torch.distributed as dist
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    sampler = None
+    if world > 1:
+        # what accelerator.prepare(dataloader) does to the reference's loader: every process draws its share of ONE shuffled order per
+        # epoch; the shares are padded to equal length, so every rank runs the same number of steps (the bad-batch consensus and the
+        # gradient all-reduce are collectives: unequal step counts would hang)
+        sampler = torch.utils.data.distributed.DistributedSampler(dataset, num_replicas=world, rank=dist.get_rank(), shuffle=shuffle, drop_last=False)
+    dataloader = torch.utils.data.DataLoader(dataset, shuffle=shuffle if sampler is None else False, sampler=sampler, collate_fn=safe_collate,
+                                             num_workers=num_workers)
     ckpt = getattr(args, "controlnet_checkpoint", None)
     output_path = getattr(args, "output_path", "./models")
     if ckpt is None:
@@ -681,9 +690,9 @@ def launch_training_task(dataset, model, learning_rate: float = 1e-5, weight_dec
             scheduler.step()
         logger.num_steps = step_num_initial + 1
     max_grad_norm = getattr(args, "max_grad_norm", -1)
-    import torch.distributed as dist
-    world = dist.get_world_size() if dist.is_initialized() else 1
     for epoch_id in range(num_epochs):
+        if sampler is not None:
+            sampler.set_epoch(epoch_id)
         for data in dataloader:
             bad = data is None or not data_is_correct_shape_and_type(data, args.control_signal_type, args.num_frames)
             if should_skip_batch(bad, pipe.device):

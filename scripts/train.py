@@ -85,9 +85,7 @@ def main(argv=None):
     if world > 1 and "OMP_NUM_THREADS" not in os.environ:
         torch.set_num_threads(max(1, min(16, (os.cpu_count() or 8) // world)))
     device = torch.device("cuda", local)
-    dataset = tr.get_dataset(args, device=device)
-    if world > 1:                                                          # Accelerate shards the prepared DataLoader over the processes
-        dataset = torch.utils.data.Subset(dataset, list(range(rank, len(dataset), world)))
+    dataset = tr.get_dataset(args, device=device)                          # (launch_training_task shards it over the ranks, as accelerator.prepare does)
     model = WanTrainingModule(args, device)
     log = (lambda rec, step: print(f"[step {step}] " + ", ".join(f"{k} {v:.6g}" for k, v in rec.items()), flush=True)) if rank == 0 else None
     tr.launch_training_task(dataset, model, args=args, log=log)

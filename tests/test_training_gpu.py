@@ -579,3 +579,78 @@ def test_training_loop_vs_the_reference_launch_training_task(tmp_path):
         tr.ModelLogger.on_step_end = real_end
     assert logger2.output_path == run_dir and logger2.num_steps == 6 + 1 + 4 and lrs == [cfg["learning_rate"] * (1.0 / 3) * 3.0] * 4
     assert os.path.exists(os.path.join(run_dir, "step-11.safetensors"))
+
+
+def _loop_worker(rank, world, port, out):
+    """Two ranks (gloo rendezvous, both on cuda:0 — the box has one GPU) through launch_training_task with a toy trainable module."""
+    import argparse
+    import os
+    import types
+    import torch.distributed as dist
+    from PIL import Image
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from goal_force_amd import training as tr
+        torch.manual_seed(5)
+        cn = torch.nn.Module()
+        cn.w = torch.nn.Parameter(torch.randn(64, 32).to(BF).cuda())
+        cn.b = torch.nn.Parameter(torch.zeros(32).to(BF).cuda())
+        pipe = types.SimpleNamespace(controlnet=cn, device=torch.device("cuda", 0))
+        frame = Image.new("RGB", (832, 480))
+        good = lambda k: {"video": [frame] * 5, "control_video": torch.zeros((5, 480, 832, 3), dtype=BF), "file_id": f"item{k}", "k": float(k + 1)}
+
+        class DS(torch.utils.data.Dataset):          # 5 items: DistributedSampler pads to 3 per rank; item 3 is a clip that failed to load
+            def __len__(self):
+                return 5
+
+            def __getitem__(self, i):
+                return None if i == 3 else good(i)
+        seen = []
+
+        def forward(pipe_, data):
+            seen.append(data["file_id"])
+            x = torch.full((64,), data["k"], device="cuda")
+            return ((x @ pipe_.controlnet.w.float()) + pipe_.controlnet.b.float()).pow(2).mean() * 1e-3
+        lrs = []
+        real_end = tr.ModelLogger.on_step_end
+
+        def spy_end(self, pipe_, loss, learning_rate, grad_norm=None, save_steps=None):
+            lrs.append(learning_rate)
+            return real_end(self, pipe_, loss, learning_rate, grad_norm=grad_norm, save_steps=save_steps)
+        tr.ModelLogger.on_step_end = spy_end
+        args = argparse.Namespace(learning_rate=3e-3, weight_decay=1e-2, dataset_num_workers=0, save_steps=2, num_epochs=2, gradient_accumulation_steps=1,
+                                  find_unused_parameters=False, controlnet_checkpoint=None, output_path=os.path.join(out, "run"), remove_prefix_in_ckpt=None,
+                                  control_signal_type="direct_force_and_goal_force_and_mass", num_frames=5, max_grad_norm=1.0)
+        import datetime
+        logger = tr.launch_training_task(DS(), pipe, args=args, forward=forward, now=datetime.datetime(2026, 1, 1))
+        torch.save({"w": cn.w.detach().cpu(), "b": cn.b.detach().cpu(), "seen": seen, "lrs": lrs, "steps": logger.num_steps,
+                    "files": sorted(os.listdir(logger.output_path)) if os.path.isdir(logger.output_path) else []}, os.path.join(out, f"loop{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_training_loop_on_two_ranks_shards_the_data_averages_gradients_and_skips_bad_batches_together(tmp_path):
+    """launch_training_task under torch.distributed (what the reference gets from accelerator.prepare + DDP): each rank draws its share of
+    one shuffled order (padded to equal length), gradients are averaged, so both ranks hold the same parameters after every step; a clip
+    that failed to load on ONE rank makes BOTH skip that step (the all-reduce consensus of utils.py:682-698); the LR schedule advances
+    world-size steps per training step (Accelerate's prepared scheduler); rank 0 alone writes the checkpoints."""
+    import os
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_loop_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = (torch.load(os.path.join(tmp_path, f"loop{r}.pt")) for r in (0, 1))
+    assert torch.equal(a["w"], b["w"]) and torch.equal(a["b"], b["b"]), "the ranks trained the same parameters"
+    assert a["steps"] == b["steps"] and len(a["seen"]) == len(b["seen"]) == a["steps"]
+    # 5 items padded to 6 = 3 per rank and epoch; the rank that draws the failed clip drags its partner's step along: 2 epochs x 3 - skipped
+    # (DistributedSampler, seed 0: epoch 0 draws [4, 1, 2] / [0, 3, 4], epoch 1 [0, 2, 1] / [4, 3, 0]: the second iteration of each epoch is skipped)
+    assert a["steps"] == 4 and a["seen"] == ["item4", "item2", "item0", "item1"] and b["seen"] == ["item0", "item4", "item4", "item0"], (a["seen"], b["seen"])
+    assert "item3" not in a["seen"] + b["seen"]
+    lr, third = 3e-3, 3e-3 * (1.0 / 3)
+    want = [third, third] + [third * 3.0] * (a["steps"] - 2)         # ConstantLR's 5 iterations are used up after ceil(5 / 2) = 3 training steps
+    assert a["lrs"][:2] == want[:2] and a["lrs"][3:] == want[3:] and a["lrs"][2] == third, a["lrs"]
+    assert a["files"] == b["files"] == ["step-2.safetensors", "step-4.safetensors"]
