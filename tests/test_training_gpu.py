@@ -624,6 +624,7 @@ def _loop_worker(rank, world, port, out):
                                   control_signal_type="direct_force_and_goal_force_and_mass", num_frames=5, max_grad_norm=1.0)
         import datetime
         logger = tr.launch_training_task(DS(), pipe, args=args, forward=forward, now=datetime.datetime(2026, 1, 1))
+        dist.barrier()               # rank 0 may still be writing the last checkpoint when rank 1 comes back
         torch.save({"w": cn.w.detach().cpu(), "b": cn.b.detach().cpu(), "seen": seen, "lrs": lrs, "steps": logger.num_steps,
                     "files": sorted(os.listdir(logger.output_path)) if os.path.isdir(logger.output_path) else []}, os.path.join(out, f"loop{rank}.pt"))
     finally:
