@@ -71,7 +71,20 @@ class WanVideoPipeline:
         text encoder, the Wan VAE; `tokenizer_config.path` is handed to the prompter (GF:584-586); ControlNet blocks
         are initialised as copies of DiT blocks 0..N-1 of the matching expert, controlnet2 is a copy made before any
         ControlNet weights are loaded (GF:559-568).  The reference's call INF:81-106 runs as written.
-        `redirect_common_files` only renames download sources in the reference (GF:498-510): nothing to do for local paths."""
+        `redirect_common_files` (GF:498-510): a config given as (model_id, origin_file_pattern) whose pattern is one of the files
+        every Wan model shares — the umT5 encoder, the VAE, the CLIP encoder — is looked up under the repository the reference
+        redirects it to (`Wan-AI/Wan2.1-T2V-1.3B`, resp. `Wan-AI/Wan2.1-I2V-14B-480P`), which is where its download step puts them:
+        the training script names them under `Wan-AI/Wan2.2-I2V-A14B` (scripts/train/train_goal_force.sh) and relies on this."""
+        if redirect_common_files:
+            redirect = {"models_t5_umt5-xxl-enc-bf16.pth": "Wan-AI/Wan2.1-T2V-1.3B", "Wan2.1_VAE.pth": "Wan-AI/Wan2.1-T2V-1.3B",
+                        "models_clip_open-clip-xlm-roberta-large-vit-huge-14.pth": "Wan-AI/Wan2.1-I2V-14B-480P"}
+            for mc in model_configs:
+                if mc.origin_file_pattern is None or mc.model_id is None:
+                    continue
+                if isinstance(mc.origin_file_pattern, str) and mc.origin_file_pattern in redirect and mc.model_id != redirect[mc.origin_file_pattern]:
+                    print(f"To avoid repeatedly downloading model files, ({mc.model_id}, {mc.origin_file_pattern}) is redirected to "
+                          f"({redirect[mc.origin_file_pattern]}, {mc.origin_file_pattern}). You can use `redirect_common_files=False` to disable file redirection.")
+                    mc.model_id = redirect[mc.origin_file_pattern]
         if apply_strided_controlnet:
             raise NotImplementedError("strided ControlNet is not part of the Goal-Force sampling path")
         if audio_processor_config is not None:

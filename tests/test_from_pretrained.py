@@ -114,6 +114,16 @@ def test_from_pretrained_model_id_resolution_and_refusals(tmp_path):
                      local_model_path=str(tmp_path / "models"))
     pipe = WanVideoPipeline.from_pretrained(device="cpu", model_configs=[mc])
     assert pipe.dit is not None and pipe.dit2 is None and len(mc.path) == 3
+    # redirect_common_files (GF:498-510): the encoder / VAE named under another Wan repository are looked up where the reference's download puts them
+    _write_checkpoints(tmp_path / "models" / "Wan-AI" / "Wan2.1-T2V-1.3B")
+    cfgs = [ModelConfig(model_id="Wan-AI/Wan2.2-I2V-A14B", origin_file_pattern="Wan2.1_VAE.pth", local_model_path=str(tmp_path / "models")),
+            ModelConfig(model_id="Wan-AI/Wan2.2-I2V-A14B", origin_file_pattern="models_t5_umt5-xxl-enc-bf16.pth", local_model_path=str(tmp_path / "models"))]
+    pipe = WanVideoPipeline.from_pretrained(device="cpu", model_configs=cfgs)
+    assert pipe.vae is not None and pipe.text_encoder is not None and cfgs[0].model_id == "Wan-AI/Wan2.1-T2V-1.3B"
+    assert cfgs[0].path == str(tmp_path / "models" / "Wan-AI" / "Wan2.1-T2V-1.3B" / "Wan2.1_VAE.pth")
+    with pytest.raises(GoalForceError, match="no network"):       # ... and with the redirection off the file is not where the config says
+        WanVideoPipeline.from_pretrained(device="cpu", redirect_common_files=False, model_configs=[
+            ModelConfig(model_id="Wan-AI/Wan2.2-I2V-A14B", origin_file_pattern="Wan2.1_VAE.pth", local_model_path=str(tmp_path / "models"))])
     with pytest.raises(GoalForceError, match="no network"):
         WanVideoPipeline.from_pretrained(device="cpu", model_configs=[ModelConfig(model_id="Wan-AI/absent",
                                                                                    origin_file_pattern="*.pth",
