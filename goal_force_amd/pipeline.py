@@ -64,7 +64,7 @@ class WanVideoPipeline:
     # ------------------------------------------------------------------ construction
     @staticmethod
     def from_pretrained(torch_dtype=torch.bfloat16, device="cuda", model_configs=(),
-                        tokenizer_config=None, audio_processor_config=None, redirect_common_files=True, use_usp=False,
+                        tokenizer_config="default", audio_processor_config=None, redirect_common_files=True, use_usp=False,
                         controlnet=False, controlnet_num_layers=0, controlnet_stride=None, apply_strided_controlnet=False):
         """GF:483-595 for local files (no network): every ModelConfig is loaded and recognised by its keys
         (checkpoints.load_model) — Wan DiT experts in the order given (high-noise first, then low-noise: GF:529-533), the umT5
@@ -113,6 +113,15 @@ class WanVideoPipeline:
                 raise GoalForceError("controlnet=True needs a DiT expert among model_configs (its blocks seed the ControlNet)")
             pipe.init_controlnets()
         pipe._after_models_attached()
+        if isinstance(tokenizer_config, str) and tokenizer_config == "default":
+            # the reference's default argument (GF:486): the umT5 tokenizer of Wan2.1-T2V-1.3B under ./models — what the training script
+            # relies on (train.py:52-55 passes no tokenizer_config).  The reference would download it when absent; here an absent folder
+            # leaves the prompter without a tokenizer, and the first prompt that needs one says so.
+            tokenizer_config = ModelConfig(model_id="Wan-AI/Wan2.1-T2V-1.3B", origin_file_pattern="google/*")
+            try:
+                tokenizer_config.download_if_necessary(use_usp=use_usp)
+            except GoalForceError:
+                tokenizer_config = None
         if tokenizer_config is not None:
             tokenizer_config.download_if_necessary(use_usp=use_usp)
             pipe.prompter.fetch_tokenizer(tokenizer_config.path)                     # GF:586

@@ -121,6 +121,14 @@ def test_from_pretrained_model_id_resolution_and_refusals(tmp_path):
     pipe = WanVideoPipeline.from_pretrained(device="cpu", model_configs=cfgs)
     assert pipe.vae is not None and pipe.text_encoder is not None and cfgs[0].model_id == "Wan-AI/Wan2.1-T2V-1.3B"
     assert cfgs[0].path == str(tmp_path / "models" / "Wan-AI" / "Wan2.1-T2V-1.3B" / "Wan2.1_VAE.pth")
+    # the DEFAULT tokenizer_config (GF:486: Wan2.1-T2V-1.3B, "google/*" under ./models) — what train.py:52-55 relies on
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        pipe = WanVideoPipeline.from_pretrained(device="cpu", model_configs=[ModelConfig(path=str(tmp_path / "models" / "Wan-AI" / "Wan2.1-T2V-1.3B" / "Wan2.1_VAE.pth"))])
+        assert pipe.prompter.tokenizer is not None and int(pipe.prompter.tokenize("the red ball")[1].sum()) == 3
+    finally:
+        os.chdir(cwd)
     with pytest.raises(GoalForceError, match="no network"):       # ... and with the redirection off the file is not where the config says
         WanVideoPipeline.from_pretrained(device="cpu", redirect_common_files=False, model_configs=[
             ModelConfig(model_id="Wan-AI/Wan2.2-I2V-A14B", origin_file_pattern="Wan2.1_VAE.pth", local_model_path=str(tmp_path / "models"))])
