@@ -28,9 +28,13 @@ from .model_fn import ContextCache, model_fn_wan_video
 from .scheduler import FlowMatchScheduler
 
 
-class WanVideoPipeline:
+class WanVideoPipeline(torch.nn.Module):
+    """`WanVideoPipeline(BasePipeline)` (GF:120-737 on UTIL:13-157).  Like the reference's it IS a torch.nn.Module whose children are
+    the models (`named_children`, `parameters`, `to`, `freeze_except` work as there: the training module wraps it, utils.py:428-447)."""
+
     def __init__(self, device="cuda", torch_dtype=torch.bfloat16, tokenizer_path=None, controlnet=False,
                  controlnet_num_layers=0, controlnet_stride=None):
+        super().__init__()
         if torch_dtype != torch.bfloat16:
             raise GoalForceError("the HIP kernels compute in bf16 storage / fp32 accumulate only")
         self.device, self.torch_dtype = device, torch_dtype
@@ -176,6 +180,44 @@ class WanVideoPipeline:
     def load_models_to_device(self, model_names=()):
         return None  # no offload state machine on 288 GB parts
 
+    def enable_cpu_offload(self):
+        """UTIL:125-127 (deprecated there in favour of enable_vram_management): accepted, nothing is offloaded."""
+        self.vram_management_enabled = True
+
+    def get_vram(self):
+        """UTIL:130-131 — total memory of the pipeline's device in GiB."""
+        return torch.cuda.mem_get_info(self.device)[1] / (1024 ** 3)
+
+    def to(self, *args, **kwargs):
+        """UTIL:33-40 — the pipeline's own `device` / `torch_dtype` follow, then every child module is moved."""
+        device, dtype, _, _ = torch._C._nn._parse_to(*args, **kwargs)
+        if dtype is not None and dtype != torch.bfloat16:
+            raise GoalForceError("the HIP kernels compute in bf16 storage / fp32 accumulate only")
+        if device is not None:
+            self.device = device
+        super().to(*args, **kwargs)
+        return self
+
+    def freeze_except(self, model_names):
+        """UTIL:134-141 — what `switch_pipe_to_training_mode` calls with --trainable_models (utils.py:563)."""
+        for name, model in self.named_children():
+            if name in model_names:
+                model.train()
+                model.requires_grad_(True)
+            else:
+                model.eval()
+                model.requires_grad_(False)
+
+    def blend_with_mask(self, base, addition, mask):
+        """UTIL:144-145."""
+        return base * (1 - mask) + addition * mask
+
+    def step(self, scheduler, latents, progress_id, noise_pred, input_latents=None, inpaint_mask=None, **kwargs):
+        """UTIL:148-154 (the inpainting branch needs scheduler.return_to_timestep, which Goal Force never reaches)."""
+        if inpaint_mask is not None:
+            raise NotImplementedError("inpaint_mask: a pipeline branch Goal Force never takes")
+        return scheduler.step(noise_pred, scheduler.timesteps[progress_id], latents)
+
     # ------------------------------------------------------------------ host helpers (UTIL)
     def check_resize_height_width(self, height, width, num_frames=None):
         """UTIL:41-57 (round up to the division factors)."""
@@ -204,10 +246,22 @@ class WanVideoPipeline:
         v = vae_output.mean(dim=0).permute(1, 2, 3, 0)
         return ((v - min_value) * (255 / (max_value - min_value))).clip(0, 255).to(torch.uint8)
 
-    def vae_output_to_video(self, vae_output, min_value=-1, max_value=1):
+    def vae_output_to_video(self, vae_output, pattern="B C T H W", min_value=-1, max_value=1):
         """UTIL:85-91 — list of PIL frames."""
         from PIL import Image
+        if pattern != "B C T H W":
+            raise NotImplementedError(f"vae_output_to_video(pattern={pattern!r}): the pipeline only produces 'B C T H W'")
         return [Image.fromarray(f.numpy()) for f in self.frames_uint8(vae_output, min_value, max_value).cpu()]
+
+    def vae_output_to_image(self, vae_output, pattern="B C H W", min_value=-1, max_value=1):
+        """UTIL:76-83 — one PIL image from [B,C,H,W] (mean over B), the scale / clip / truncating cast in the tensor's own dtype."""
+        from PIL import Image
+        if pattern == "B C H W":
+            vae_output = vae_output.mean(dim=0).permute(1, 2, 0)
+        elif pattern != "H W C":
+            raise NotImplementedError(f"vae_output_to_image(pattern={pattern!r})")
+        img = ((vae_output - min_value) * (255 / (max_value - min_value))).clip(0, 255)
+        return Image.fromarray(img.to(device="cpu", dtype=torch.uint8).numpy())
 
     # ------------------------------------------------------------------ the hot loop
     @torch.no_grad()
@@ -368,15 +422,19 @@ class WanVideoPipeline:
         return video if output_type == "pt" else self.vae_output_to_video(video)
 
     # ---------------------------------------------------------------- pre-loop units that use the VAE encoder
-    def preprocess_image(self, image, min_value=-1, max_value=1):
-        """UTIL:60-66 — PIL -> bf16 [1,3,H,W] in [-1,1] (arithmetic in bf16 like the reference)."""
-        t = torch.Tensor(np.array(image, dtype=np.float32)).to(dtype=self.torch_dtype, device=self.device)
+    def preprocess_image(self, image, torch_dtype=None, device=None, pattern="B C H W", min_value=-1, max_value=1):
+        """UTIL:60-66 — PIL -> [1,3,H,W] in [-1,1], the arithmetic in the target dtype (bf16) like the reference."""
+        if pattern != "B C H W":
+            raise NotImplementedError(f"preprocess_image(pattern={pattern!r}): only the default layout is used on this path")
+        t = torch.Tensor(np.array(image, dtype=np.float32)).to(dtype=torch_dtype or self.torch_dtype, device=device or self.device)
         t = t * ((max_value - min_value) / 255) + min_value
         return t.permute(2, 0, 1).unsqueeze(0)
 
-    def preprocess_video(self, video, min_value=-1, max_value=1):
-        """UTIL:69-73 — list of PIL frames -> bf16 [1,3,T,H,W] in [-1,1] (each frame through preprocess_image, stacked along T)."""
-        return torch.stack([self.preprocess_image(f, min_value, max_value) for f in video], dim=2)
+    def preprocess_video(self, video, torch_dtype=None, device=None, pattern="B C T H W", min_value=-1, max_value=1):
+        """UTIL:69-73 — list of PIL frames -> [1,3,T,H,W] in [-1,1] (each frame through preprocess_image, stacked along T)."""
+        if pattern != "B C T H W":
+            raise NotImplementedError(f"preprocess_video(pattern={pattern!r})")
+        return torch.stack([self.preprocess_image(f, torch_dtype, device, min_value=min_value, max_value=max_value) for f in video], dim=2)
 
     def embed_input_video(self, input_video, tiled, tile_size, tile_stride):
         """WanVideoUnit_InputVideoEmbedder (GF:767-789), the `input_video is not None` branch up to its VAE encode: the latents of

@@ -61,11 +61,7 @@ class WanTrainingModule:
             tokenizer_config=ModelConfig(model_id="Wan-AI/Wan2.1-T2V-1.3B", origin_file_pattern="google/*",
                                          path=f"{MODELS}/Wan2.1-T2V-1.3B/google/umt5-xxl"))               # train.py:43-55
         self.pipe.scheduler.set_timesteps(1000, training=True)                                             # utils.py:560
-        for name in ("dit", "dit2", "vae", "text_encoder", "controlnet", "controlnet2"):                   # freeze_except(["controlnet"]), utils.py:563
-            m = getattr(self.pipe, name, None)
-            if m is not None:
-                for p in m.parameters():
-                    p.requires_grad_(name == "controlnet")
+        self.pipe.freeze_except([] if args.trainable_models is None else args.trainable_models.split(","))   # utils.py:563
         if args.controlnet_checkpoint is not None:                                                         # utils.py:586-590
             self.pipe.load_controlnet_weights(self.pipe.controlnet, args.controlnet_checkpoint, torch_dtype=torch.bfloat16)
             print(f"ControlNet checkpoint loaded: {args.controlnet_checkpoint}, total {len(self.pipe.controlnet.state_dict())} keys")

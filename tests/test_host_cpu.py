@@ -446,3 +446,45 @@ def test_training_mode_frame_selection_video_loading_and_the_pixel_roundtrip(tmp
         Image.fromarray(clip[i]).save(tmp_path / "dir" / f"{i:02d}.png")
     fr = fm.load_video_frames(str(tmp_path / "dir"))
     assert len(fr) == 3 and np.array_equal(np.array(fr[2]), clip[2])
+
+
+def test_pipeline_is_a_module_with_the_base_pipeline_helpers():
+    """BasePipeline's API shell (UTIL:13-157; SURVEY §2 #5 "keep signatures"): the pipeline is a torch.nn.Module whose children are the
+    models — `named_children`, `freeze_except` (what `--trainable_models controlnet` calls, utils.py:563), `to`, `step`,
+    `blend_with_mask`, `vae_output_to_image`, and the reference's positional order of `preprocess_image` / `vae_output_to_video`."""
+    import inspect
+    from goal_force_amd._lib import GoalForceError
+    from goal_force_amd.controlnet import ControlNet
+    from goal_force_amd.dit import WanModel
+    from goal_force_amd.pipeline import WanVideoPipeline
+    cfg = gi.TINY
+    dit = WanModel(has_image_input=False, require_clip_embedding=False, **cfg)
+    cn = ControlNet(1, dim=cfg["dim"], num_heads=cfg["num_heads"], ffn_dim=cfg["ffn_dim"])
+    pipe = WanVideoPipeline.from_modules(dit, None, cn, None, device="cpu")
+    assert isinstance(pipe, torch.nn.Module) and [n for n, _ in pipe.named_children()] == ["dit", "controlnet"]
+    pipe.freeze_except(["controlnet"])
+    assert all(p.requires_grad for p in cn.parameters()) and not any(p.requires_grad for p in dit.parameters())
+    assert cn.training and not dit.training and sum(p.numel() for p in pipe.parameters() if p.requires_grad) == sum(p.numel() for p in cn.parameters())
+    pipe.freeze_except([])
+    assert not any(p.requires_grad for p in pipe.parameters())
+    assert pipe.to("cpu") is pipe and pipe.device == torch.device("cpu")
+    with pytest.raises(GoalForceError):
+        pipe.to(torch.float16)
+    pipe.dit2 = None
+    assert pipe.dit2 is None and pipe.dit is dit
+    a, b, m = torch.full((2, 2), 2.0), torch.full((2, 2), 6.0), torch.tensor([[0.0, 1.0], [0.5, 0.25]])
+    assert torch.equal(pipe.blend_with_mask(a, b, m), a * (1 - m) + b * m)
+    pipe.scheduler.set_timesteps(4, shift=5.0)
+    lat, pred = torch.randn(1, 16, 1, 2, 2).to(BF), torch.randn(1, 16, 1, 2, 2).to(BF)
+    assert torch.equal(pipe.step(pipe.scheduler, lat, 2, pred), pipe.scheduler.step(pred, pipe.scheduler.timesteps[2], lat))
+    x = (torch.rand(1, 3, 5, 7) * 2.4 - 1.2).to(BF)
+    img = pipe.vae_output_to_image(x)
+    want = ((x.mean(dim=0).permute(1, 2, 0) + 1) * (255 / 2)).clip(0, 255).to(torch.uint8).numpy()      # UTIL:80-82 in the tensor's dtype
+    assert img.size == (7, 5) and np.array_equal(np.array(img), want)
+    for name, order in (("preprocess_image", ["image", "torch_dtype", "device", "pattern", "min_value", "max_value"]),
+                        ("preprocess_video", ["video", "torch_dtype", "device", "pattern", "min_value", "max_value"]),
+                        ("vae_output_to_video", ["vae_output", "pattern", "min_value", "max_value"]),
+                        ("vae_output_to_image", ["vae_output", "pattern", "min_value", "max_value"]),
+                        ("generate_noise", ["shape", "seed", "rand_device", "rand_torch_dtype", "device", "torch_dtype"]),
+                        ("step", ["scheduler", "latents", "progress_id", "noise_pred", "input_latents", "inpaint_mask", "kwargs"])):
+        assert list(inspect.signature(getattr(pipe, name)).parameters) == order, name
