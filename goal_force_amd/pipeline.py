@@ -213,10 +213,12 @@ class WanVideoPipeline(torch.nn.Module):
         return base * (1 - mask) + addition * mask
 
     def step(self, scheduler, latents, progress_id, noise_pred, input_latents=None, inpaint_mask=None, **kwargs):
-        """UTIL:148-154 (the inpainting branch needs scheduler.return_to_timestep, which Goal Force never reaches)."""
+        """UTIL:148-154."""
+        timestep = scheduler.timesteps[progress_id]
         if inpaint_mask is not None:
-            raise NotImplementedError("inpaint_mask: a pipeline branch Goal Force never takes")
-        return scheduler.step(noise_pred, scheduler.timesteps[progress_id], latents)
+            noise_pred_expected = scheduler.return_to_timestep(timestep, latents, input_latents)
+            noise_pred = self.blend_with_mask(noise_pred_expected, noise_pred, inpaint_mask)
+        return scheduler.step(noise_pred, timestep, latents)
 
     # ------------------------------------------------------------------ host helpers (UTIL)
     def check_resize_height_width(self, height, width, num_frames=None):

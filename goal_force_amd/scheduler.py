@@ -84,7 +84,16 @@ class FlowMatchScheduler:
         return sample + model_output * (sigma_next - sigma)      # host tensors (tests, fp32 bookkeeping)
 
     def return_to_timestep(self, timestep, sample, sample_stablized):
-        raise NotImplementedError("return_to_timestep (FM:85-91) is not on the Goal-Force path")
+        """FM:85-91 — the model output that would take `sample` to `sample_stablized` from `timestep`: (sample - stabilised) / sigma."""
+        sigma = self.sigmas[self._index(timestep)]
+        return (sample - sample_stablized) / sigma
+
+    def calculate_shift(self, image_seq_len, base_seq_len: int = 256, max_seq_len: int = 8192, base_shift: float = 0.5,
+                        max_shift: float = 0.9):
+        """FM:114-125 — the linear sequence-length -> shift map of the `exponential_shift` mode (a mode Goal Force never switches on)."""
+        m = (max_shift - base_shift) / (max_seq_len - base_seq_len)
+        b = base_shift - m * base_seq_len
+        return image_seq_len * m + b
 
     # ------------------------------------------------------------------ training (GF:180-193)
     def add_noise(self, original_samples, noise, timestep):

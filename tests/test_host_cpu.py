@@ -167,6 +167,18 @@ def test_attention_backward_workspace_size_is_host_arithmetic():
         assert n == want and n % 256 == 0, (q, kv, h, n, want)
 
 
+def test_scheduler_remaining_methods_match_the_reference():
+    """FlowMatchScheduler.return_to_timestep (FM:85-91) and calculate_shift (FM:114-125) against the reference's own (g1)."""
+    from goal_force_amd.scheduler import FlowMatchScheduler
+    g = np.load(os.path.join(GOLDEN, "g1_scheduler.npz"))
+    sch = FlowMatchScheduler(shift=5, sigma_min=0.0, extra_one_step=True)
+    sch.set_timesteps(50, denoising_strength=1.0, shift=5.0)
+    sample, stab = torch.from_numpy(g["sample"]), torch.from_numpy(g["stabilised"])
+    for i in (0, 10, 49):
+        assert torch.equal(sch.return_to_timestep(sch.timesteps[i], sample, stab), torch.from_numpy(g[f"return_f32_{i}"]))
+    assert [sch.calculate_shift(n) for n in (256, 1560, 8192, 32760)] == g["calculate_shift"].tolist()
+
+
 def test_training_keep_level_is_validated():
     import goal_force_amd.training as tr
     from goal_force_amd._lib import GoalForceError
