@@ -45,6 +45,16 @@ class RopeTable:
         self.cos = fc.real.to(torch.float32).contiguous().to(device)
         self.sin = fc.imag.to(torch.float32).contiguous().to(device)
         self.tokens = fc.shape[0]
+        self._scaled = {}
+
+    def scaled(self, c: float):
+        """(c cos, c sin): the rotation that also multiplies by c.  The self-attention's Q goes through it with c = softmax scale x
+        log2(e) (SelfAttention.attend), so that the attention kernel's operand Q' = bf16(c q) is produced from the fp32 rotation with
+        ONE rounding — where rounding q to bf16 first and c q again (what the kernel does to a plain q) costs the logits a second one."""
+        tabs = self.__dict__.setdefault("_scaled", {})          # (shard tables are built without __init__: sequence_parallel.shard_rope)
+        if c not in tabs:
+            tabs[c] = ((self.cos * c).contiguous(), (self.sin * c).contiguous())
+        return tabs[c]
 
     @staticmethod
     def from_grid(freqs3: Tuple[torch.Tensor, torch.Tensor, torch.Tensor], f: int, h: int, w: int, device):
@@ -54,6 +64,13 @@ class RopeTable:
             freqs3[2][:w].view(1, 1, w, -1).expand(f, h, w, -1),
         ], dim=-1).reshape(f * h * w, -1)
         return RopeTable(tab, device)
+
+
+def Q_PRESCALE(head_dim: int) -> float:
+    """c = fp32(fp32(1 / sqrt(head_dim)) x fp32(log2 e)) — bit for bit the factor the attention launcher folds into Q (gf_attention.hip:
+    `scale_log2e = scale * 1.4426950408889634f`)."""
+    import numpy as np
+    return float(np.float32(np.float32(1.0 / math.sqrt(head_dim)) * np.float32(1.4426950408889634)))
 
 
 def _as_rope(freqs, device) -> RopeTable:
@@ -232,6 +249,14 @@ class SelfAttention(nn.Module):
         keep["wide"] also the three projections ("qp", "kp" before their norm, "v")."""
         fp8 = getattr(self.q, "_gf_w8", None) is not None
         xin = (x2 if isinstance(x2, QuantizedInput) else QuantizedInput(x2)) if fp8 else x2
+        # Inference: Q leaves its RMSNorm + RoPE kernel already multiplied by c = softmax scale x log2(e) (the rotation table carries
+        # the factor: RopeTable.scaled), and the attention is called with scale = ln 2, i.e. c = 1 inside — its `Q <- bf16(Q c)` is then
+        # exact.  One rounding of the rotated q instead of two: at peaky logits (std 3) the self-attention kernel is 3.9e-3 from fp64 on
+        # a twice-rounded Q and at torch SDPA's level (1.8e-3) on this one (tools/fuzz_ops.py, profiles/r06).  The training forward
+        # keeps the plain q (its backward differentiates the unscaled graph).
+        q_cos, q_sin, attn_scale = rope.cos, rope.sin, None
+        if keep is None and ops._OPT["attn_q_prescale"]:
+            (q_cos, q_sin), attn_scale = rope.scaled(Q_PRESCALE(self.head_dim)), math.log(2.0)
         if sp is not None and keep is None:
             # head-parallel: every projection's tokens-for-heads exchange starts as soon as the projection is ready and flies under
             # the next one (same kernels on the same values as below: bit-identical, another issue order)
@@ -240,36 +265,36 @@ class SelfAttention(nn.Module):
             hk = sp.heads_start(k, self.num_heads)
             hv = sp.heads_start(linear(xin, self.v), self.num_heads)
             q = linear(xin, self.q)
-            ops.rmsnorm_rope(q, self.norm_q.weight, rope.cos, rope.sin, self.head_dim, self.norm_q.eps)
+            ops.rmsnorm_rope(q, self.norm_q.weight, q_cos, q_sin, self.head_dim, self.norm_q.eps)
             hq = sp.heads_start(q, self.num_heads)
-            return sp.attention_started(hq, hk, hv, self.num_heads, tuple(q.shape))
+            return sp.attention_started(hq, hk, hv, self.num_heads, tuple(q.shape), scale=attn_scale)
         q, k = linear(xin, self.q), linear(xin, self.k)
         if keep is not None and keep.get("wide"):      # training with room to spare: the pre-norm projections stay for the backward
             keep["qp"], keep["kp"] = q, k
             q, k = q.clone(), k.clone()
-        ops.rmsnorm_rope(q, self.norm_q.weight, rope.cos, rope.sin, self.head_dim, self.norm_q.eps)
+        ops.rmsnorm_rope(q, self.norm_q.weight, q_cos, q_sin, self.head_dim, self.norm_q.eps)
         ops.rmsnorm_rope(k, self.norm_k.weight, rope.cos, rope.sin, self.head_dim, self.norm_k.eps)
         if sp is None and keep is None and not fp8 and x2.is_cuda and self.v.weight.shape[0] >= 512 \
                 and ops.vt32_ok(x2.shape[0], self.num_heads, self.head_dim):
             # inference on one GPU: nothing but the attention reads V, so the projection writes it straight in the layout the
             # attention kernel wants (gf_linear_vt32: same bits as the plain projection + the transpose, one pass over V less)
-            return ops.flash_attn(q, k, None, self.num_heads, vt=ops.linear_vt32(x2, self.v.weight, self.v.bias))
+            return ops.flash_attn(q, k, None, self.num_heads, vt=ops.linear_vt32(x2, self.v.weight, self.v.bias), scale=attn_scale)
         if sp is None and keep is None and fp8 and xin.is_cuda and self.v.weight.shape[0] >= 512 and self.v.weight.shape[1] % 128 == 0 \
                 and ops.vt32_ok(xin.shape[0], self.num_heads, self.head_dim):
             # config 5 on one GPU: the fp8 V projection writes the attention kernel's V^T operand as well (gf_linear_vt32_fp8)
             if self.v._gf_w8_key != param_key(self.v.weight):
                 self.v._gf_w8 = ops.cast_fp8(self.v.weight.detach().contiguous())
                 self.v._gf_w8_key = param_key(self.v.weight)
-            return ops.flash_attn(q, k, None, self.num_heads, vt=ops.linear_vt32_fp8(xin.x8, xin.scale, self.v._gf_w8, self.v.bias))
+            return ops.flash_attn(q, k, None, self.num_heads, vt=ops.linear_vt32_fp8(xin.x8, xin.scale, self.v._gf_w8, self.v.bias), scale=attn_scale)
         v = linear(xin, self.v)
         if sp is not None:
-            return sp.attention(q, k, v, self.num_heads)
+            return sp.attention(q, k, v, self.num_heads, scale=attn_scale)
         if keep is not None:
             keep["attn"], keep["lse"] = ops.flash_attn_lse(q, k, v, self.num_heads)
             if keep.get("wide"):
                 keep["v"] = v
             return keep["attn"]
-        return ops.flash_attn(q, k, v, self.num_heads)
+        return ops.flash_attn(q, k, v, self.num_heads, scale=attn_scale)
 
     def forward(self, x, freqs):
         x2 = _tokens2d(x)

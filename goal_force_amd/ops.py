@@ -207,9 +207,10 @@ VT_MIN_KV = 2048   # key sequences at least this long go through the pre-transpo
 #   library side (gf_set_option): prefer_8wave, a4_stagger, a4_group_m, conv_nb, conv_gather, conv_direct, vae_rms3
 #   this module: attn_k3 (False: long key sequences on kernel 2), vt_from_gemm (False: V^T by gf_transpose_v32, not by the V projection),
 #                conv_padded (False: the VAE's 192 / 384-channel 3x3x3 convolutions on gf_conv3d_bf16 instead of the padded-layout kernel),
-#                fold_pad_keys (False: cross-attention over all 512 context keys instead of the prompt + ONE key of multiplicity, dit.py)
+#                fold_pad_keys (False: cross-attention over all 512 context keys instead of the prompt + ONE key of multiplicity, dit.py),
+#                attn_q_prescale (False: the self-attention's Q is rotated plainly and scaled inside the attention kernel — a second bf16 rounding)
 _LIB_DEFAULTS = {"prefer_8wave": 0, "a4_stagger": 2, "a4_group_m": 0, "conv_nb": 0, "conv_gather": 0, "conv_direct": 1, "vae_rms3": 1}
-_OPT = {"attn_k3": True, "vt_from_gemm": True, "conv_padded": True, "fold_pad_keys": True}
+_OPT = {"attn_k3": True, "vt_from_gemm": True, "conv_padded": True, "fold_pad_keys": True, "attn_q_prescale": True}
 
 
 def lib_option(name: str) -> int:

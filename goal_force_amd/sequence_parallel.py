@@ -116,7 +116,7 @@ class SequenceParallel:
         work = dist.all_to_all_single(recv, send, group=self.group, async_op=True)
         return work, recv, send                                # (send is kept alive until the wait)
 
-    def attention_started(self, hq, hk, hv, num_heads: int, out_shape) -> torch.Tensor:
+    def attention_started(self, hq, hk, hv, num_heads: int, out_shape, scale=None) -> torch.Tensor:
         """The attention over this rank's head group from three started exchanges (heads_start), and the heads-for-tokens exchange
         back.  The head group is computed in two halves: the first half's way back flies under the second half's attention."""
         p = self.size
@@ -132,7 +132,7 @@ class SequenceParallel:
         backs = []
         for h0, h1 in parts:
             c0, c1 = h0 * hd, h1 * hd
-            o = ops.flash_attn(q[:, c0:c1], k[:, c0:c1], v[:, c0:c1], h1 - h0)            # [S, (h1 - h0) * hd]
+            o = ops.flash_attn(q[:, c0:c1], k[:, c0:c1], v[:, c0:c1], h1 - h0, scale=scale)   # [S, (h1 - h0) * hd]
             back = torch.empty((p, sl, c1 - c0), dtype=o.dtype, device=o.device)
             backs.append((dist.all_to_all_single(back, o.reshape(p, sl, c1 - c0), group=self.group, async_op=True), back, o, c0, c1))
         out = torch.empty((sl, d), dtype=q.dtype, device=q.device)
@@ -142,14 +142,14 @@ class SequenceParallel:
             ov[:, :, c0:c1].copy_(back.transpose(0, 1))
         return out
 
-    def attention(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: int) -> torch.Tensor:
+    def attention(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: int, scale=None) -> torch.Tensor:
         """q, k, v: this rank's tokens [S/P, NH*DH] (already normed and rotated) -> attention output [S/P, NH*DH]."""
         if self.size == 1:
-            return ops.flash_attn(q, k, v, num_heads)
+            return ops.flash_attn(q, k, v, num_heads, scale=scale)
         if num_heads % self.size:
             raise GoalForceError(f"sequence parallel: {num_heads} heads do not divide by {self.size} ranks")
         hk, hv, hq = self.heads_start(k, num_heads), self.heads_start(v, num_heads), self.heads_start(q, num_heads)
-        return self.attention_started(hq, hk, hv, num_heads, tuple(q.shape))
+        return self.attention_started(hq, hk, hv, num_heads, tuple(q.shape), scale=scale)
 
     def preflight(self, device) -> int:
         """One head all-to-all at production size (S = 32760 tokens, D = 5120: [S/P, D] bf16 per rank) with a content check;

@@ -579,3 +579,55 @@ def test_layernorm_specialised_kernel_matches_the_general_one(ops, dim):
     big = torch.zeros((M, dim + 64), dtype=BF, device="cuda")           # strided output
     ops.layernorm_modulate(x, scale1p=a, shift=b, out=big[:, 32:32 + dim])
     assert torch.equal(big[:, 32:32 + dim], ops.layernorm_modulate(x, scale1p=a, shift=b)) and float(big[:, :32].abs().sum()) == 0
+
+
+def test_self_attention_q_prescale_removes_the_second_rounding_of_q(ops):
+    """The self-attention kernel (kernel 3, key lengths >= 2048) multiplies Q by c = softmax scale x log2(e) and rounds it to bf16 again:
+    on a q that was already rounded after its RoPE that is a SECOND rounding, and at peaky logits it shows (3.9e-3 from fp64 at logit
+    std 3, where torch's own bf16 attention sits at 1.8e-3).  SelfAttention.attend (inference) therefore has the RoPE kernel produce
+    Q' = bf16(c x rotated q) directly (the rotation table carries c) and calls the attention with scale = ln 2, which makes the in-kernel
+    factor exactly 1.  Checked on a module with norm_q weights x 3 at 4096 tokens against exact fp64 math on the same bf16 weights:
+    the pre-scaled path is closer to fp64 than the twice-rounded one and no worse than the reference's own bf16 chain (oracle graph on bf16
+    tensors through torch's SDPA) x 1.25; the option restores the old arithmetic; and the in-kernel factor really is exactly one."""
+    import math
+    import numpy as np
+    from goal_force_amd import dit
+    assert np.float32(np.float32(math.log(2.0)) * np.float32(1.4426950408889634)) == np.float32(1.0)
+    c = dit.Q_PRESCALE(128)
+    assert c == float(np.float32(np.float32(1 / math.sqrt(128)) * np.float32(1.4426950408889634)))
+    dim, heads, grid = 256, 2, (4, 32, 32)
+    S = grid[0] * grid[1] * grid[2]
+    g = torch.Generator().manual_seed(77)
+    sa = dit.SelfAttention(dim, heads).to(BF)
+    for n_, p_ in sa.named_parameters():
+        p_.data.copy_((torch.randn(p_.shape, generator=g) * (1.0 / math.sqrt(dim) if p_.dim() == 2 else 0.02)).to(BF))
+    sa.norm_q.weight.data.copy_((3.0 + 0.1 * torch.randn(dim, generator=g)).to(BF))          # peaky logits (std ~ 3)
+    sa.norm_k.weight.data.copy_((1.0 + 0.1 * torch.randn(dim, generator=g)).to(BF))
+    sa = sa.cuda()
+    x = torch.randn((1, S, dim), generator=g).to(BF).cuda()
+    freqs = wo.rope_freqs_3d(128, *grid).cuda()
+    rope = dit.RopeTable(freqs.cpu(), "cuda")
+    sd = {k: v.detach() for k, v in sa.state_dict().items()}
+    # exact math on the bf16 weights and inputs: everything in fp64, no intermediate rounding
+    sd64 = {k: v.double() for k, v in sd.items()}
+    x64 = x.double()
+
+    def lin(t, n):
+        return t @ sd64[n + ".weight"].T + sd64[n + ".bias"]
+
+    def norm(t, w):
+        return t * torch.rsqrt(t.pow(2).mean(-1, keepdim=True) + sa.norm_q.eps) * w
+
+    def rot(t):
+        tc = torch.view_as_complex(t.reshape(1, S, heads, -1, 2).contiguous())
+        return torch.view_as_real(tc * freqs[None, :, None, :]).flatten(2)
+    q64, k64, v64 = rot(norm(lin(x64, "q"), sd64["norm_q.weight"])), rot(norm(lin(x64, "k"), sd64["norm_k.weight"])), lin(x64, "v")
+    exact = lin(wo.attention_fp64(q64, k64, v64, heads), "o")
+    ref_bf = wo.self_attention(x, freqs, sd, "", heads, sa.norm_q.eps)                         # the reference's bf16 arithmetic (torch SDPA)
+    new = sa(x, rope)
+    with ops.options(attn_q_prescale=False):
+        old = sa(x, rope)
+    e_new, e_old, e_ref = rel_l2(new.double(), exact), rel_l2(old.double(), exact), rel_l2(ref_bf.double(), exact)
+    print(f"self-attention, logits std ~3, S={S}: pre-scaled Q {e_new:.3e}, twice-rounded Q {e_old:.3e}, reference bf16 chain {e_ref:.3e}")
+    assert not torch.equal(new, old)
+    assert e_new < e_old and e_new <= 1.25 * e_ref, (e_new, e_old, e_ref)

@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Randomised shape sweep of the C-ABI operators against plain torch references (GPU; not part of the suite: `python tools/fuzz_ops.py
+[--cases N] [--seed S] [--only gemm,attn,...]`).  The suite's parity tests use hand-picked shapes (the model's own and the edges the
+authors thought of); this draws shapes nobody picked — row counts around the tile sizes (1, 255, 256, 257, 511, 512, 513 ...), ragged key
+lengths around the 64-key tile and the 2048-key kernel switch, strided operands (q / k / v as column slices of one fused buffer), every
+GEMM epilogue, in-place residuals — and reports every case whose error exceeds the operator's bar, or whose call fails without being a
+refusal the header documents.  Exit code 1 when anything failed."""
+import argparse
+import math
+import os
+import random
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+from goal_force_amd import ops  # noqa: E402
+from goal_force_amd._lib import GoalForceError  # noqa: E402
+
+BF = torch.bfloat16
+EDGE_M = [1, 2, 7, 8, 15, 16, 17, 63, 64, 65, 127, 128, 129, 255, 256, 257, 383, 511, 512, 513, 767, 1023, 1024, 1025, 2047, 2049, 3000, 4097]
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def bf(t):
+    return t.to(BF)
+
+
+def case_gemm(rnd, g):
+    M = rnd.choice(EDGE_M + [rnd.randrange(1, 5000)])
+    N = 8 * rnd.choice([1, 2, 3, 8, 15, 16, 17, 24, 31, 32, 33, 48, 64, 96, 100, 160, 161, 640])
+    K = 64 * rnd.choice([1, 2, 3, 4, 5, 8, 9, 16, 21, 40, 80])
+    epi = rnd.choice([ops.EPI_BIAS, ops.EPI_BIAS_GELU_TANH, ops.EPI_BIAS_GATE_RESID, ops.EPI_BIAS_RESID, ops.EPI_BIAS_SILU, ops.EPI_BIAS_MUL])
+    lda_extra = rnd.choice([0, 0, 8, 64])
+    a_full = bf(torch.randn((M, K + lda_extra), generator=g, device="cuda"))
+    a = a_full[:, :K]
+    w = bf(torch.randn((N, K), generator=g, device="cuda") / math.sqrt(K))
+    bias = bf(torch.randn((N,), generator=g, device="cuda")) if rnd.random() < 0.8 else None
+    resid = bf(torch.randn((M, N), generator=g, device="cuda")) if epi in (ops.EPI_BIAS_GATE_RESID, ops.EPI_BIAS_RESID, ops.EPI_BIAS_MUL) else None
+    gate = bf(torch.randn((N,), generator=g, device="cuda")) if epi == ops.EPI_BIAS_GATE_RESID else None
+    inplace = resid is not None and epi != ops.EPI_BIAS_MUL and rnd.random() < 0.5
+    desc = f"gemm M={M} N={N} K={K} epi={epi} lda+{lda_extra} bias={bias is not None} inplace={inplace}"
+    acc = a.float() @ w.float().T
+    y = bf(acc + (bias.float() if bias is not None else 0)).float() if bias is not None else bf(acc).float()
+    if epi == ops.EPI_BIAS_GELU_TANH:
+        ref = F.gelu(y, approximate="tanh")
+    elif epi == ops.EPI_BIAS_SILU:
+        ref = F.silu(y)
+    elif epi == ops.EPI_BIAS_GATE_RESID:
+        ref = resid.float() + bf(gate.float() * y).float()
+    elif epi == ops.EPI_BIAS_RESID:
+        ref = resid.float() + y
+    elif epi == ops.EPI_BIAS_MUL:
+        ref = y * resid.float()
+    else:
+        ref = y
+    out = resid.clone() if inplace else None
+    got = ops.gemm(a, w, bias, epilogue=epi, resid=out if inplace else resid, gate=gate, out=out)
+    # bar: bf16 output rounding (2^-9 relative per element) + accumulation-order noise at K up to 5120
+    return desc, rel(got.float(), ref), 6e-3
+
+
+def case_attn(rnd, g):
+    heads = rnd.choice([1, 2, 3, 5, 8])
+    sq = rnd.choice([1, 5, 31, 32, 33, 63, 64, 65, 127, 129, 255, 300, 511, 513, 1000, rnd.randrange(1, 1500)])
+    skv = rnd.choice([1, 2, 7, 41, 63, 64, 65, 127, 128, 129, 511, 512, 513, 2047, 2048, 2049, 2111, 2112, 2113, 3000, rnd.randrange(1, 4200)])
+    fused = rnd.random() < 0.4 and sq == skv
+    D = heads * 128
+    scale_q = rnd.choice([0.3, 1.0, 1.0, 3.0])
+    if fused:
+        buf = bf(torch.randn((sq, 3 * D), generator=g, device="cuda"))
+        buf[:, :D] *= scale_q
+        q, k, v = buf[:, :D], buf[:, D:2 * D], buf[:, 2 * D:]
+    else:
+        q = bf(torch.randn((sq, D), generator=g, device="cuda") * scale_q)
+        k = bf(torch.randn((skv, D), generator=g, device="cuda"))
+        v = bf(torch.randn((skv, D), generator=g, device="cuda"))
+    mult = 1
+    if skv + 1 < 2048 and skv >= 2 and rnd.random() < 0.3:
+        mult = rnd.choice([2, 5, 472])
+    desc = f"attn sq={sq} skv={skv} heads={heads} fused={fused} qscale={scale_q} last_key_mult={mult}"
+    got = ops.flash_attn(q, k, v, heads, last_key_mult=mult)
+    kk, vv = k, v
+    if mult > 1:
+        kk = torch.cat([k, k[-1:].expand(mult - 1, -1)], 0)
+        vv = torch.cat([v, v[-1:].expand(mult - 1, -1)], 0)
+    qd = q.double().reshape(sq, heads, 128).transpose(0, 1)
+    kd = kk.double().reshape(-1, heads, 128).transpose(0, 1)
+    vd = vv.double().reshape(-1, heads, 128).transpose(0, 1)
+    ref = (torch.softmax(qd @ kd.transpose(1, 2) / math.sqrt(128), -1) @ vd).transpose(0, 1).reshape(sq, D)
+    # the yardstick for peaky rows (a few dominant keys: the bf16 rounding of P and of the output is all there is): what torch's own bf16
+    # attention — the reference's backend on this stack — makes of the same operands
+    sd = F.scaled_dot_product_attention(q.reshape(sq, heads, 128).transpose(0, 1)[None], kk.reshape(-1, heads, 128).transpose(0, 1)[None],
+                                        vv.reshape(-1, heads, 128).transpose(0, 1)[None])[0].transpose(0, 1).reshape(sq, D)
+    e_sdpa = rel(sd.float(), ref)
+    return desc + f" (torch SDPA bf16: {e_sdpa:.2e})", rel(got.float(), ref), max(5e-3, 1.25 * e_sdpa)
+
+
+def case_rows(rnd, g):
+    rows = rnd.choice(EDGE_M)
+    dim = 8 * rnd.choice([1, 2, 16, 32, 33, 96, 192, 640, 1024])
+    x = bf(torch.randn((rows, dim), generator=g, device="cuda") * rnd.choice([0.1, 1.0, 30.0]))
+    which = rnd.choice(["ln", "ln_affine_mod", "gate", "modulate", "rms"])
+    desc = f"{which} rows={rows} dim={dim}"
+    if which.startswith("ln"):
+        w = b = sc = sh = None
+        if which == "ln_affine_mod":
+            w, b = bf(torch.randn(dim, generator=g, device="cuda")), bf(torch.randn(dim, generator=g, device="cuda"))
+            sc, sh = bf(1 + 0.1 * torch.randn(dim, generator=g, device="cuda")), bf(torch.randn(dim, generator=g, device="cuda"))
+        got = ops.layernorm_modulate(x, w, b, sc, sh)
+        y = F.layer_norm(x.float(), (dim,), None if w is None else w.float(), None if b is None else b.float(), 1e-6)
+        if sc is not None:
+            y = bf(bf(y).float() * sc.float()).float() + sh.float()
+        return desc, rel(got.float(), y), 6e-3
+    if which == "gate":
+        gate, r = bf(torch.randn(dim, generator=g, device="cuda")), bf(torch.randn((rows, dim), generator=g, device="cuda"))
+        got = ops.gate_residual(x, gate, r)
+        ref = x + gate * r                      # bf16 eager order
+        return desc, float((got.float() - ref.float()).abs().max()), 0.0
+    if which == "modulate":
+        sh, sc = bf(torch.randn(dim, generator=g, device="cuda")), bf(torch.randn(dim, generator=g, device="cuda"))
+        got = ops.modulate(x, sh, sc)
+        ref = x * (1 + sc) + sh
+        return desc, float((got.float() - ref.float()).abs().max()), 0.0
+    hd = rnd.choice([d for d in (8, 16, 64, 128) if dim % d == 0])
+    w = bf(1 + 0.1 * torch.randn(dim, generator=g, device="cuda"))
+    ang = torch.rand((rows, hd // 2), generator=g, device="cuda") * 6.28
+    cos, sin = torch.cos(ang).contiguous(), torch.sin(ang).contiguous()
+    xx = x.clone()
+    ops.rmsnorm_rope(xx, w, cos, sin, head_dim=hd)
+    xn = bf(x.float() * torch.rsqrt(x.float().pow(2).mean(-1, keepdim=True) + 1e-6)) * w
+    pr = xn.double().reshape(rows, dim // hd, hd // 2, 2)
+    c, s = cos.double()[:, None, :], sin.double()[:, None, :]
+    ref = torch.stack([pr[..., 0] * c - pr[..., 1] * s, pr[..., 0] * s + pr[..., 1] * c], -1).reshape(rows, dim)
+    return desc + f" head_dim={hd}", rel(xx.float(), ref), 6e-3
+
+
+def case_cfg(rnd, g):
+    n = rnd.choice([8, 64, 1000, 16 * 21 * 60 * 104, rnd.randrange(1, 100000) * 8])
+    lat, p, q = (bf(torch.randn((n,), generator=g, device="cuda")) for _ in range(3))
+    cfg, ds = rnd.choice([1.0, 5.0, 7.5]), -rnd.random() * 0.1
+    want = lat + (q + cfg * (p - q)) * torch.tensor(ds, dtype=torch.float32) if cfg != 1.0 else lat + p * torch.tensor(ds, dtype=torch.float32)
+    got = lat.clone()
+    ops.cfg_euler_step(got, p, q if cfg != 1.0 else None, cfg, ds)
+    return f"cfg_euler n={n} cfg={cfg}", float((got.float() - want.to(BF).float()).abs().max()), 0.0
+
+
+CASES = {"gemm": case_gemm, "attn": case_attn, "rows": case_rows, "cfg": case_cfg}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=150)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    torch.set_grad_enabled(False)
+    names = [n for n in a.only.split(",") if n] or list(CASES)
+    bad = 0
+    for name in names:
+        rnd = random.Random(a.seed * 1000 + sum(map(ord, name)))
+        g = torch.Generator(device="cuda").manual_seed(a.seed)
+        worst, refused = (0.0, ""), 0
+        for i in range(a.cases):
+            try:
+                desc, err, bar = CASES[name](rnd, g)
+            except GoalForceError as e:
+                refused += 1
+                if "unsupported" not in str(e).lower() and "expected" not in str(e).lower() and "must" not in str(e).lower():
+                    print(f"  [{name}] case {i}: refused with an undocumented message: {e}")
+                continue
+            torch.cuda.synchronize()
+            if not (err <= bar) or err != err:
+                bad += 1
+                print(f"  FAIL [{name}] {desc}: err {err:.3e} > {bar:.1e}")
+            if err > worst[0]:
+                worst = (err, desc)
+        print(f"{name}: {a.cases} cases, {refused} refused, worst {worst[0]:.3e} ({worst[1]})", flush=True)
+    print("FAILED" if bad else "ok", bad)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
