@@ -151,7 +151,100 @@ def case_cfg(rnd, g):
     return f"cfg_euler n={n} cfg={cfg}", float((got.float() - want.to(BF).float()).abs().max()), 0.0
 
 
-CASES = {"gemm": case_gemm, "attn": case_attn, "rows": case_rows, "cfg": case_cfg}
+def case_attnbwd(rnd, g):
+    heads = rnd.choice([1, 2, 3])
+    sq = rnd.choice([1, 17, 63, 64, 65, 129, 300, 513, rnd.randrange(1, 900)])
+    skv = rnd.choice([1, 7, 47, 48, 49, 63, 64, 65, 95, 96, 97, 200, 513, 2049, rnd.randrange(1, 2500)])
+    D = heads * 128
+    q, k, v, do = (bf(torch.randn((n, D), generator=g, device="cuda")) for n in (sq, skv, skv, sq))
+    o, lse = ops.flash_attn_lse(q, k, v, heads)
+    dq, dk, dv = ops.flash_attn_bwd(q, k, v, o, do, lse, heads)
+    qf, kf, vf = (t.double().requires_grad_(True) for t in (q, k, v))
+    with torch.enable_grad():
+        qh, kh, vh = (t.view(-1, heads, 128).transpose(0, 1) for t in (qf, kf, vf))
+        ref = (torch.softmax(qh @ kh.transpose(1, 2) / math.sqrt(128), -1) @ vh).transpose(0, 1).reshape(sq, D)
+        ref.backward(do.double())
+    # a single key makes dq and dk exactly zero in exact math: errors are measured against the gradients' natural scale, not against ~0
+    floor = 1e-3 * float(do.double().norm())
+
+    def rel_f(a, b):
+        return float((a.double() - b).norm() / (b.norm() + floor))
+    e = max(rel_f(dq, qf.grad), rel_f(dk, kf.grad), rel_f(dv, vf.grad))
+    return f"attnbwd sq={sq} skv={skv} heads={heads}", e, 1.2e-2
+
+
+def case_fp8(rnd, g):
+    M = rnd.choice(EDGE_M)
+    N = 16 * rnd.choice([1, 2, 3, 8, 17, 40, 100, 320])
+    K = 128 * rnd.choice([1, 2, 3, 5, 8, 20, 40])
+    x = bf(torch.randn((M, K), generator=g, device="cuda") * rnd.choice([0.2, 1.0, 40.0, 900.0]))
+    w = bf(torch.randn((N, K), generator=g, device="cuda") / math.sqrt(K))
+    bias = bf(torch.randn((N,), generator=g, device="cuda")) if rnd.random() < 0.7 else None
+    x8, sc = ops.quant_fp8_rowscale(x)
+    w8 = ops.cast_fp8(w)
+    got = ops.gemm_fp8(x8, sc, w8, bias)
+    # the contract is a torch call sequence (VRAM:115-151: bf16 row max, clamp(max / 448, min 1).float(), bf16 x / (scale_a + 1e-8) -> e4m3,
+    # W -> e4m3, torch._scaled_mm): run LIVE here, as tests/test_fp8.py does
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_fp8_golden_gpu import scaled_mm_linear
+    zero = torch.zeros((N,), dtype=BF, device="cuda")
+    ref = scaled_mm_linear(x, w, bias if bias is not None else zero)[0]
+    ulp = (got.view(torch.int16).int() - ref.view(torch.int16).int()).abs()
+    return f"fp8 M={M} N={N} K={K} bias={bias is not None} (max ulp {int(ulp.max())}, >1 ulp: {float((ulp > 1).float().mean()):.1e})", \
+        rel(got.float(), ref.float()), 2e-3
+
+
+def case_batched(rnd, g):
+    B, M, N, K = rnd.choice([1, 2, 5, 16]), rnd.choice([1, 33, 64, 127, 256, 513, 1560]), 8 * rnd.choice([1, 5, 16, 48, 195]), 64 * rnd.choice([1, 2, 6, 25])
+    heads_side_by_side = rnd.random() < 0.5
+    if heads_side_by_side:                         # heads of one [M, B*K] tensor (the umT5 / VAE attention layouts)
+        a = bf(torch.randn((M, B * K), generator=g, device="cuda")).view(M, B, K).permute(1, 0, 2)
+    else:
+        a = bf(torch.randn((B, M, K), generator=g, device="cuda"))
+    w = bf(torch.randn((B, N, K), generator=g, device="cuda") / math.sqrt(K))
+    got = ops.gemm_batched(a, w)
+    ref = torch.einsum("bmk,bnk->bmn", a.float(), w.float())
+    return f"gemm_batched B={B} M={M} N={N} K={K} strided={heads_side_by_side}", rel(got.float(), ref), 6e-3
+
+
+def case_misc(rnd, g):
+    which = rnd.choice(["softmax", "transpose", "patchify"])
+    if which == "softmax":
+        R, C = rnd.choice([1, 7, 512, 1560, 3000]), rnd.choice([8, 41, 512, 1560, 1563])
+        ld = -(-C // 64) * 64
+        x = bf(torch.randn((R, C), generator=g, device="cuda") * 3)
+        sc = rnd.choice([1.0, 0.125, 0.051])
+        bias = bf(torch.randn((R, C), generator=g, device="cuda")) if rnd.random() < 0.5 else None
+        got = ops.softmax_rows(x, sc, ld, bias=bias)
+        z = bf(x.float() * sc + (bias.float() if bias is not None else 0)).float() if bias is not None else bf(x.float() * sc).float()
+        ref = torch.softmax(z, -1)
+        pad_zero = float(got[:, C:].float().abs().max()) if ld > C else 0.0
+        return f"softmax_rows R={R} C={C} scale={sc} bias={bias is not None} (pad max {pad_zero:g})", max(rel(got[:, :C].float(), ref), pad_zero), 6e-3
+    if which == "transpose":
+        B, R, C = rnd.choice([1, 3, 8]), rnd.choice([1, 63, 64, 65, 1560]), 8 * rnd.choice([1, 16, 48])
+        rp = -(-R // 64) * 64
+        x = bf(torch.randn((B, R, C), generator=g, device="cuda"))
+        got = ops.transpose_pad_batched(x, rp)
+        ref = torch.zeros((B, C, rp), dtype=BF, device="cuda")
+        ref[:, :, :R] = x.transpose(1, 2)
+        return f"transpose_pad_batched B={B} R={R} C={C}", float((got.float() - ref.float()).abs().max()), 0.0
+    c0, c1 = rnd.choice([16, 4, 20]), rnd.choice([0, 20, 16])
+    Fr, H, W = rnd.choice([1, 3, 21]), 2 * rnd.choice([1, 4, 30]), 2 * rnd.choice([1, 6, 52])
+    a = bf(torch.randn((c0, Fr, H, W), generator=g, device="cuda"))
+    b = bf(torch.randn((c1, Fr, H, W), generator=g, device="cuda")) if c1 else None
+    got = ops.patchify_im2col(a, b)
+    full = a if b is None else torch.cat([a, b], 0)
+    c = full.shape[0]
+    ref = full.view(c, Fr, H // 2, 2, W // 2, 2).permute(1, 2, 4, 0, 3, 5).reshape(Fr * (H // 2) * (W // 2), c * 4)     # Conv3d(k=(1,2,2)) column order
+    e = float((got[:, :c * 4].float() - ref.float()).abs().max()) + (float(got[:, c * 4:].float().abs().max()) if got.shape[1] > c * 4 else 0.0)
+    toks = bf(torch.randn((Fr * (H // 2) * (W // 2), 4 * 16), generator=g, device="cuda"))
+    up = ops.unpatchify(toks, 16, Fr, H // 2, W // 2)
+    ref_up = toks.view(Fr, H // 2, W // 2, 1, 2, 2, 16).permute(6, 0, 3, 1, 4, 2, 5).reshape(16, Fr, H, W)            # 'f h w (x y z c) -> c (f x) (h y) (w z)'
+    return f"patchify c={c0}+{c1} F={Fr} H={H} W={W}", e + float((up.float() - ref_up.float()).abs().max()), 0.0
+
+
+CASES = {"gemm": case_gemm, "attn": case_attn, "rows": case_rows, "cfg": case_cfg, "attnbwd": case_attnbwd, "fp8": case_fp8,
+         "batched": case_batched, "misc": case_misc}
 
 
 def main():
