@@ -2,7 +2,9 @@
 
 A functional (state-dict driven) torch-CPU restatement of the reference's Goal-Force denoising
 path.  It exists to CHECK the HIP product path; nothing under goal_force_amd/ may import it.
-Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it.
+Only tests/, __graft_entry__.smoke() and bench.py's two BASELINE legs use it: `cpu_baseline` (this graph timed on the host cores) and
+`gpu_eager_yardstick` (the same graph on bf16 device tensors through torch-ROCm's own kernels — what the reference's code path would run on
+the same GPU) — both reported beside `value`, never inside it.
 
 Pinning: every function here is checked against golden vectors generated in the build container
 by importing the reference's own modules (tests/golden/make_goldens.py -> tests/golden/*.npz;
