@@ -767,6 +767,9 @@ def main():
                        "cross_attention": "the context's padded rows (identical: the prompter zeroes past the 40-token prompt) are attended as "
                                           "ONE key with multiplicity 472 (41 keys instead of 512; ops.options(fold_pad_keys=False) attends all 512)"
                                           if ops._OPT["fold_pad_keys"] else "all 512 context keys attended",
+                       "self_attention_q": "Q' = bf16(scale log2e x rotated q) written by the RMSNorm + RoPE kernel (one rounding; the attention runs with "
+                                           "an in-kernel factor of exactly 1)" if ops._OPT["attn_q_prescale"] else
+                                           "plain q, scaled and rounded again inside the attention kernel",
                        "parallelism": "1 GPU: sequential CFG (block 0's context-independent half shared by the two branches)" if world == 1 else f"{videos} video(s) x CFG pair, RCCL all-gather of noise_pred per step"
                                       + (f"; head-parallel attention degree {args.sp} (RCCL all-to-all over xGMI)" if args.sp > 1 else ""),
                        "value_definition": "frames/s = videos * 81 / (50-step loop + tiled VAE decode + frame all-gather); 50-step loop = " + loop_how,
