@@ -631,3 +631,16 @@ def test_self_attention_q_prescale_removes_the_second_rounding_of_q(ops):
     print(f"self-attention, logits std ~3, S={S}: pre-scaled Q {e_new:.3e}, twice-rounded Q {e_old:.3e}, reference bf16 chain {e_ref:.3e}")
     assert not torch.equal(new, old)
     assert e_new < e_old and e_new <= 1.25 * e_ref, (e_new, e_old, e_ref)
+
+
+def test_random_shape_sweep_of_the_operators():
+    """tools/fuzz_ops.py on a fixed seed: 40 random cases per operator family — GEMM (every epilogue, strided A, in-place residual), both
+    attention kernels (ragged lengths around the tiles and the kernel switch, fused q/k/v buffers, last-key multiplicity), row kernels,
+    CFG / Euler, attention backward, fp8 GEMM against the live torch._scaled_mm sequence, batched GEMM, softmax / transposes / patchify —
+    against torch references (the sweep that found the second rounding of Q; 15 000 cases were run by hand, profiles/r06/README.md)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_ops.py"), "--cases", "40", "--seed", "11"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok 0"), r.stdout[-3000:] + r.stderr[-2000:]
+    assert all(f"{n}: 40 cases" in r.stdout for n in ("gemm", "attn", "rows", "cfg", "attnbwd", "fp8", "batched", "misc"))
