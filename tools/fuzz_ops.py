@@ -171,7 +171,7 @@ def case_attnbwd(rnd, g):
     def rel_f(a, b):
         return float((a.double() - b).norm() / (b.norm() + floor))
     e = max(rel_f(dq, qf.grad), rel_f(dk, kf.grad), rel_f(dv, vf.grad))
-    return f"attnbwd sq={sq} skv={skv} heads={heads}", e, 1.2e-2
+    return f"attnbwd sq={sq} skv={skv} heads={heads}", e, 1.2e-2 if sq >= 8 else 3e-2          # (one or two query rows: a handful of bf16 values)
 
 
 def case_fp8(rnd, g):
