@@ -76,6 +76,21 @@ def psnr_u8(a, b):
 
 
 PRETRAINED = None      # {"models_dir": ..., "ckpt": ...} when main() found trained weights to load (--models-dir / --model-ckpt-path)
+PEAKY = 1.0            # --peaky f: every self-attention's norm_q weight x f (logits x f: near-one-hot softmax rows, what trained attention looks like)
+
+
+def make_peaky(pipe):
+    """Random-init attention is near-uniform — the friendliest data for a flash-attention kernel and for its bf16 roundings.  Scaling the
+    self-attention's norm_q weights scales its logits: the same model with peaky softmax rows (bench.py's `data_sensitivity` times this;
+    here its PARITY is measured).  The weights live in the modules, so the oracle runs (LazySD) see the same scaled weights."""
+    if PEAKY == 1.0:
+        return
+    for m in (pipe.dit, pipe.dit2, pipe.controlnet, pipe.controlnet2):
+        if m is None:
+            continue
+        for blk in m.modules():
+            if hasattr(blk, "self_attn") and hasattr(blk.self_attn, "norm_q"):
+                blk.self_attn.norm_q.weight.data.mul_(PEAKY)
 
 
 def pretrained_paths(models_dir):
@@ -248,13 +263,14 @@ def run_forward(layers=40, cn_layers=10, grid=(21, 60, 104), fp8=True, taps=(0, 
     taps = tuple(t for t in taps if t < layers)
     t_all = time.time()
     cfg, pipe = build(layers, cn_layers, dev, need_low=False)
+    make_peaky(pipe)
     inp = inputs(pipe, grid, dev)
     tokens = grid[0] * (grid[1] // 2) * (grid[2] // 2)
     pipe.scheduler.set_timesteps(50, shift=5.0)
     ts = pipe.scheduler.timesteps[0].unsqueeze(0).to(dtype=torch.bfloat16, device=dev)          # GF:707
     rep = {"config": {"layers": layers, "controlnet_layers": cn_layers, "latent": [1, 16, *grid], "tokens": tokens,
                       "what": "one cond forward, step 0 of the 50-step shift-5 schedule", "timestep_bf16": float(ts.float()),
-                      "taps_after_dit_block": [t + 1 for t in taps], "weights": "random-init bf16 (bench.py seeds 100/300)",
+                      "taps_after_dit_block": [t + 1 for t in taps], "weights": "random-init bf16 (bench.py seeds 100/300)" + ("" if PEAKY == 1.0 else f", self-attention logits x {PEAKY:g}"),
                       "device": torch.cuda.get_device_name(0), "fp32_attention_q_chunk": q_chunk}}
     log(f"  built {layers} + {cn_layers} blocks in {time.time() - t_all:.1f} s")
     t0 = time.time()
@@ -320,10 +336,12 @@ def run(layers=40, cn_layers=10, grid=(21, 60, 104), steps=4, fp8=False, taps=(0
     dev = torch.device("cuda", torch.cuda.current_device())
     taps = tuple(t for t in taps if t < layers)
     cfg, pipe = build(layers, cn_layers, dev, need_low=steps >= 2)
+    make_peaky(pipe)
     inp = inputs(pipe, grid, dev)
     tokens = grid[0] * (grid[1] // 2) * (grid[2] // 2)
     rep = {"config": {"layers": layers, "controlnet_layers": cn_layers, "latent": [1, 16, *grid], "tokens": tokens, "steps": steps,
-                      "taps_after_dit_block": [t + 1 for t in taps], "weights": "random-init bf16 (bench.py seeds 100/200/300/400)" if PRETRAINED is None else f"TRAINED: {PRETRAINED}",
+                      "taps_after_dit_block": [t + 1 for t in taps], "weights": ("random-init bf16 (bench.py seeds 100/200/300/400)" if PRETRAINED is None else f"TRAINED: {PRETRAINED}")
+                                 + ("" if PEAKY == 1.0 else f", self-attention logits x {PEAKY:g}"),
                       "device": torch.cuda.get_device_name(0), "fp32_attention_q_chunk": q_chunk}}
 
     # ---- the product
@@ -393,11 +411,14 @@ def main():
     ap.add_argument("--q-chunk", type=int, default=2048)
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--peaky", type=float, default=1.0, help="multiply every self-attention's norm_q weight by this factor (logits x f): parity on "
+                    "peaky softmax rows, the regime trained attention lives in")
     ap.add_argument("--models-dir", default="./models/Wan-AI", help="where the reference keeps its checkpoints (INF:81-106): when both experts' "
                     "shards and Wan2.1_VAE.pth are there the run uses TRAINED weights through from_pretrained, else random-init ones")
     ap.add_argument("--model-ckpt-path", default=None, help="ControlNet checkpoint step-N.safetensors (INF:51, 108); only with trained weights")
     a = ap.parse_args()
-    global PRETRAINED
+    global PRETRAINED, PEAKY
+    PEAKY = a.peaky
     if pretrained_paths(a.models_dir) is not None:
         PRETRAINED = {"models_dir": a.models_dir, "ckpt": a.model_ckpt_path}
         print(f"fullsize_parity: TRAINED weights from {a.models_dir}" + (f" + ControlNet {a.model_ckpt_path}" if a.model_ckpt_path else
