@@ -26,6 +26,23 @@ def test_stacked_blocks_cfg_loop_within_reference_bf16_drift():
     assert ps["hip_bf16_vs_fp32"] >= ps["ref_bf16_vs_fp32"] - 1.0, ps
 
 
+def test_stacked_blocks_on_peaky_attention_within_reference_bf16_drift():
+    """The same stack with every self-attention's logits x 4 (norm_q weights scaled: near-one-hot softmax rows — the regime of trained
+    attention; random-init rows are near-uniform and flatter every bf16 rounding of P): one forward, HIP-vs-fp32 <= 1.25 x (reference
+    arithmetic vs fp32) at every tap.  The 40 + 10-block runs at x 3 / x 8 are in profiles/r06/fullsize_forward_peaky*.json."""
+    import fullsize_parity as fp
+    fp.PEAKY = 4.0
+    try:
+        rep = fp.run_forward(layers=8, cn_layers=2, grid=(9, 60, 104), fp8=False, taps=(0, 3, 7), log=lambda s: print(s, flush=True))
+    finally:
+        fp.PEAKY = 1.0
+    assert "logits x 4" in rep["config"]["weights"]
+    hip, ref = rep["hip_bf16_vs_fp32"], rep["ref_bf16_vs_fp32"]
+    for k in hip["after_block"]:
+        assert hip["after_block"][k] <= 1.25 * ref["after_block"][k], (k, hip["after_block"], ref["after_block"])
+    assert hip["noise_pred_step0_cond"] <= 1.25 * ref["noise_pred_step0_cond"], (hip, ref)
+
+
 def test_stacked_blocks_fp8_within_scaled_mm_chain_drift():
     """The same stack on the fp8_linear contract (BASELINE config 5): HIP fp8 kernels vs the oracle graph with a LIVE
     torch._scaled_mm behind every block Linear (VRAM:115-151).  The contract's own quantisation noise dominates, so the bar is
