@@ -20,7 +20,7 @@ SYMBOLS = (
     "gf_modulation", "gf_layernorm_modulate", "gf_rmsnorm_rope", "gf_gemm_bf16", "gf_flash_attn_fwd",
     "gf_patchify_im2col", "gf_unpatchify", "gf_cfg_euler_step", "gf_act", "gf_add_bf16",
     "gf_force_map",
-    "gf_vae_prep_latent", "gf_vae_im2col", "gf_vae_finish_latent", "gf_vae_rmsnorm_silu", "gf_softmax_rows", "gf_transpose_pad",
+    "gf_vae_prep_latent", "gf_vae_im2col", "gf_vae_finish_latent", "gf_vae_rmsnorm_silu", "gf_softmax_rows", "gf_rowmax_neg_bf16", "gf_transpose_pad",
     "gf_vae_tile_blend", "gf_vae_tile_finalize",
     "gf_quant_fp8_rowscale", "gf_cast_fp8", "gf_gemm_fp8", "gf_layernorm_modulate_fp8", "gf_modulate", "gf_gate_residual", "gf_rope_apply", "gf_linear_vt32_fp8",
     "gf_flash_attn_fwd_lse", "gf_flash_attn_bwd", "gf_flash_attn_bwd_workspace_bytes",
@@ -33,7 +33,7 @@ SYMBOLS = (
 # the C ABI revision these bindings were written against (csrc/gf_abi.hip: GF_ABI_VERSION).  A stale or foreign .so whose entry
 # points take differently sized buffers (gf_flash_attn_bwd's workspace grew 3x between revisions 7 and 10 under an unchanged
 # signature) is refused at load time instead of overrunning memory.
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 EPI_BIAS, EPI_BIAS_GELU_TANH, EPI_BIAS_GATE_RESID, EPI_BIAS_RESID, EPI_BIAS_SILU, EPI_BIAS_MUL = range(6)
 
@@ -99,6 +99,7 @@ def _declare(lib):
         "gf_conv3d_padded_bf16": [_vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _int, _vp, _i64, _vp],
         "gf_vae_upsample2x_padded": [_vp, _vp, _i64, _i64, _i64, _i64, _vp],
         "gf_softmax_rows": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _f32, _vp],
+        "gf_rowmax_neg_bf16": [_vp, _i64, _vp, _i64, _i64, _i64, _vp],
         "gf_transpose_pad": [_vp, _i64, _vp, _i64, _i64, _i64, _vp],
         "gf_transpose_pad_batched": [_vp, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _vp],
         "gf_gemm_bf16_batched": [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp],

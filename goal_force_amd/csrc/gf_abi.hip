@@ -5,7 +5,7 @@
 #include <cstdlib>
 #include <cstring>
 
-#define GF_ABI_VERSION 17
+#define GF_ABI_VERSION 18
 
 static thread_local char g_err[512] = "";
 

@@ -308,6 +308,21 @@ __global__ __launch_bounds__(VT) void softmax_rows_kernel(const u16* __restrict_
         orow[c] = c < nvalid ? f2bf(expf(val(c) - mx) * inv) : (u16)0;
 }
 
+// out[r * ldo] = bf16(-max_c x[r, c]) — the per-row offset of the AttentionBlock's score GEMM (gf_rowmax_neg_bf16 below).  One
+// workgroup per row; the value is exact (a maximum of bf16 numbers, negated).
+__global__ __launch_bounds__(VT) void rowmax_neg_kernel(const u16* __restrict__ x, long ldx, u16* __restrict__ out, long ldo, int ncols) {
+    __shared__ float red[VT / 64];
+    const long row = blockIdx.x;
+    const u16* xr = x + row * ldx;
+    float mx = -INFINITY;
+    for (int c = threadIdx.x; c < ncols; c += VT) mx = fmaxf(mx, bf2f(xr[c]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) out[row * ldo] = f2bf(-fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+}
+
 // dst[c, r] = src[r, c] for r < R (zero for R <= r < rpad); 32x32 tiles through LDS.
 __global__ __launch_bounds__(VT) void transpose_pad_kernel(const u16* __restrict__ src, long lds_, u16* __restrict__ dst,
                                                            int R, int C, int rpad, long bsrc, long bdst) {
@@ -536,6 +551,21 @@ extern "C" GF_API int gf_softmax_rows(const void* x, int64_t ldx, const void* bi
     hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(VT), 0, (hipStream_t)stream, (const u16*)x,
                        (long)ldx, (const u16*)bias, (long)ldb, (u16*)out, (long)ldo, (int)ncols, (int)nvalid, scale);
     GF_CHECK_LAUNCH("gf_softmax_rows");
+    return GF_OK;
+}
+
+// gf_rowmax_neg_bf16 — out[r * ldo] = -max_c x[r, c] (bf16, exact).  The VAE AttentionBlock (VAE:304-342) takes its softmax over
+// scores that went through a bf16 GEMM output: rounding the RAW scores costs 2^-9 of their magnitude, a 1 % change of a softmax weight
+// at logit 5, which F.scaled_dot_product_attention (fp32 scores) does not pay.  The softmax only needs s - (row constant): this
+// kernel writes minus the row maximum of a first, coarse score GEMM into an extra K column of the Q operand (k' carries a 1
+// there), and the second GEMM then accumulates q.k - max in fp32 and rounds a number that is SMALL exactly where the softmax weight is
+// large (goal_force_amd/vae.py::_attention).
+extern "C" GF_API int gf_rowmax_neg_bf16(const void* x, int64_t ldx, void* out, int64_t ldo, int64_t rows, int64_t ncols, void* stream) {
+    GF_CHECK_ARG(x && out && rows >= 0 && ncols > 0 && ldx >= ncols && ldo >= 1, "gf_rowmax_neg_bf16: bad arguments");
+    if (rows == 0) return GF_OK;
+    hipLaunchKernelGGL(rowmax_neg_kernel, dim3((unsigned)rows), dim3(VT), 0, (hipStream_t)stream, (const u16*)x, (long)ldx, (u16*)out,
+                       (long)ldo, (int)ncols);
+    GF_CHECK_LAUNCH("gf_rowmax_neg_bf16");
     return GF_OK;
 }
 

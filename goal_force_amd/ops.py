@@ -208,9 +208,10 @@ VT_MIN_KV = 2048   # key sequences at least this long go through the pre-transpo
 #   this module: attn_k3 (False: long key sequences on kernel 2), vt_from_gemm (False: V^T by gf_transpose_v32, not by the V projection),
 #                conv_padded (False: the VAE's 192 / 384-channel 3x3x3 convolutions on gf_conv3d_bf16 instead of the padded-layout kernel),
 #                fold_pad_keys (False: cross-attention over all 512 context keys instead of the prompt + ONE key of multiplicity, dit.py),
-#                attn_q_prescale (False: the self-attention's Q is rotated plainly and scaled inside the attention kernel — a second bf16 rounding)
+#                attn_q_prescale (False: the self-attention's Q is rotated plainly and scaled inside the attention kernel — a second bf16 rounding),
+#                vae_attn_offset (False: the VAE attention's softmax on the bf16-rounded RAW scores — one GEMM instead of two, coarser)
 _LIB_DEFAULTS = {"prefer_8wave": 0, "a4_stagger": 2, "a4_group_m": 0, "conv_nb": 0, "conv_gather": 0, "conv_direct": 1, "vae_rms3": 1}
-_OPT = {"attn_k3": True, "vt_from_gemm": True, "conv_padded": True, "fold_pad_keys": True, "attn_q_prescale": True}
+_OPT = {"attn_k3": True, "vt_from_gemm": True, "conv_padded": True, "fold_pad_keys": True, "attn_q_prescale": True, "vae_attn_offset": True}
 
 
 def lib_option(name: str) -> int:
@@ -736,6 +737,18 @@ def softmax_rows(x, scale, ldo, bias=None, nvalid=None):
                                            x.shape[1] if nvalid is None else int(nvalid), float(scale), _stream(x)),
                "gf_softmax_rows")
     return out
+
+
+def rowmax_neg(x, out_col):
+    """out_col[r] = -max_c x[r, c] (bf16, exact): x [R, C] with contiguous rows, out_col a [R] VIEW (any stride) — a column of the
+    augmented Q operand of the VAE attention's second score GEMM (gf_rowmax_neg_bf16)."""
+    _req(x, "rowmax_neg.x")
+    _req(out_col, "rowmax_neg.out_col")
+    if x.dim() != 2 or x.stride(1) != 1 or out_col.dim() != 1 or out_col.shape[0] != x.shape[0]:
+        raise GoalForceError("rowmax_neg: x [R, C] with contiguous rows, out_col [R]")
+    _lib.check(_lib.load().gf_rowmax_neg_bf16(_ptr(x), x.stride(0), _ptr(out_col), out_col.stride(0) if out_col.shape[0] > 1 else 1,
+                                              x.shape[0], x.shape[1], _stream(x)), "gf_rowmax_neg_bf16")
+    return out_col
 
 
 def transpose_pad(x, rpad):

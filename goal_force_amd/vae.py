@@ -209,6 +209,31 @@ class VideoVAE_(_ParamTree):
             self.put(name, t)
 
 
+def frame_attention(qkv, C, out):
+    """softmax(q k^T / sqrt(C)) v per frame: qkv [g, hw, 3C] bf16 (q | k | v along the last dim), out [g, hw, C] (VAE:326-333).
+
+    Scores: the reference's F.scaled_dot_product_attention (VAE:331) keeps q k^T in fp32; a GEMM with a bf16 output rounds the RAW
+    scores (2^-9 of their magnitude: 1e-2 on the block's output at logit std 3, where SDPA sits at 1.8e-3).  The softmax only needs
+    s - (row constant), so: a first, coarse GEMM -> minus its row maximum into an extra K column of Q (gf_rowmax_neg_bf16; K's extra
+    column is 1) -> the second GEMM accumulates q.k - max in fp32 and rounds a number that is small where the softmax weight is large.
+    ops.options(vae_attn_offset=False) is the one-GEMM form (tests/test_vae.py measures both against fp64)."""
+    g, hw, _ = qkv.shape
+    kp = _pad_to(hw, 64)
+    q, k, v = qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:]
+    scores = ops.gemm_batched(q, k)                                                # q k^T  [g, hw, hw]
+    if ops._OPT["vae_attn_offset"]:
+        qa = torch.zeros((g, hw, C + 64), dtype=qkv.dtype, device=qkv.device)      # [q, -rowmax, 0 ...]
+        ka = torch.zeros((g, hw, C + 64), dtype=qkv.dtype, device=qkv.device)      # [k,    1,    0 ...]
+        qa[:, :, :C].copy_(q)
+        ka[:, :, :C].copy_(k)
+        ka[:, :, C] = 1
+        ops.rowmax_neg(scores.view(g * hw, hw), qa.view(g * hw, C + 64)[:, C])
+        ops.gemm_batched(qa, ka, out=scores)                                       # q k^T - rowmax, rounded once
+    p = ops.softmax_rows(scores.view(g * hw, hw), 1.0 / math.sqrt(C), kp)          # [g hw, kp]
+    vt = ops.transpose_pad_batched(v, kp)                                          # [g, C, kp]
+    return ops.gemm_batched(p.view(g, hw, kp), vt, out=out)                        # [g, hw, C]
+
+
 class WanVideoVAE(nn.Module):
     def __init__(self, z_dim=16):
         super().__init__()
@@ -395,7 +420,6 @@ class WanVideoVAE(nn.Module):
         hw = H * W
         if hw % 8:
             raise GoalForceError("VAE attention needs h*w to be a multiple of 8")
-        kp = _pad_to(hw, 64)
         xn = ops.vae_rmsnorm_silu(x, P[name + ".norm.gamma"], silu=False)
         qkv_c, proj_c = P[name + ".to_qkv"], P[name + ".proj"]
         # the two 1x1 convolutions (to_qkv, proj + residual) for all frames of the chunk in one GEMM each; the attention itself per frame
@@ -404,12 +428,7 @@ class WanVideoVAE(nn.Module):
         # the frames' attention in groups (one launch per product and group; a group's scores stay below ~1 GB)
         gsz = max(1, min(T, (1 << 29) // (hw * hw)))
         for t0 in range(0, T, gsz):
-            qkv = qkv_all[t0:t0 + gsz]                                                     # [g, hw, 3C]
-            g = qkv.shape[0]
-            scores = ops.gemm_batched(qkv[:, :, :C], qkv[:, :, C:2 * C])                   # q k^T  [g, hw, hw]
-            p = ops.softmax_rows(scores.view(g * hw, hw), 1.0 / math.sqrt(C), kp)          # [g hw, kp]
-            vt = ops.transpose_pad_batched(qkv[:, :, 2 * C:], kp)                          # [g, C, kp]
-            ops.gemm_batched(p.view(g, hw, kp), vt, out=o_all[t0:t0 + gsz])                # [g, hw, C]
+            frame_attention(qkv_all[t0:t0 + gsz], C, o_all[t0:t0 + gsz])
         out = ops.gemm(o_all.view(T * hw, C), proj_c["w"], proj_c["b"], epilogue=ops.EPI_BIAS_RESID, resid=x.reshape(T * hw, C))
         return out.view(T, H, W, C)
 

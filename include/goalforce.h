@@ -351,6 +351,12 @@ GF_API int gf_vae_rmsnorm_silu(const void* x, const void* gamma, void* out, int6
 GF_API int gf_softmax_rows(const void* x, int64_t ldx, const void* bias, int64_t ldb, void* out, int64_t ldo,
                            int64_t rows, int64_t ncols, int64_t nvalid, float scale, void* stream);
 
+/* gf_rowmax_neg_bf16 — out[r * ldo] = bf16(-max_c x[r, c]) (exact: a maximum of bf16 values).  The per-row offset of the
+ * AttentionBlock's score GEMM (VAE:326-333): written into an extra K column of the Q operand whose counterpart in the K operand
+ * is 1, it makes the GEMM accumulate q.k - rowmax in fp32, so that the bf16 rounding of the scores is small where the softmax
+ * weight is large (F.scaled_dot_product_attention, which the reference calls, keeps its scores in fp32).  x [rows, ncols] bf16 (ldx). */
+GF_API int gf_rowmax_neg_bf16(const void* x, int64_t ldx, void* out, int64_t ldo, int64_t rows, int64_t ncols, void* stream);
+
 /* gf_transpose_pad — dst[c, r] = src[r, c], r >= R zero-filled up to rpad (V^T operand
  * of the AttentionBlock's P·V GEMM).                                                   */
 GF_API int gf_transpose_pad(const void* src, int64_t ld_src, void* dst, int64_t R, int64_t C, int64_t rpad,

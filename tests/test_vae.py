@@ -1,6 +1,7 @@
 """VAE decoder: (CPU) oracle pinned to the reference's own WanVideoVAE outputs; (GPU) HIP decode path vs the
 same goldens.  Tolerances: bf16 oracle vs reference bf16 bit-exact (same torch ops); HIP vs fp32 golden
 rel-L2 <= max(1.5e-2, 1.5x the reference-bf16's own distance from fp32) — the decoder is ~50 bf16 convs deep."""
+import math
 import os
 
 import numpy as np
@@ -489,6 +490,47 @@ def test_hip_vae_silu_is_within_one_ulp_of_exact_division(C):
     frac = float((d != 0).float().mean())
     print(f"SiLU C={C}: {int((d != 0).sum())} of {d.numel()} values differ from exact-division SiLU ({frac:.2e}), max {int(d.max())} bf16 ulp")
     assert int(d.max()) <= 1 and frac < 2e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hw,g", [(1560, 1), (392, 3), (8, 2)])
+def test_hip_rowmax_neg_is_exact(hw, g):
+    from goal_force_amd import ops
+    gen = torch.Generator(device="cuda").manual_seed(hw)
+    x = (torch.randn((g * hw, hw), generator=gen, device="cuda") * 50).to(torch.bfloat16)
+    x[0] = -7.5                                                              # an all-negative row: the maximum is not clipped at 0
+    buf = torch.full((g * hw, 448), 3.0, dtype=torch.bfloat16, device="cuda")
+    ops.rowmax_neg(x, buf[:, 384])
+    assert torch.equal(buf[:, 384], -x.float().amax(dim=1).to(torch.bfloat16))
+    assert bool((buf[:, :384] == 3).all()) and bool((buf[:, 385:] == 3).all())      # only that one column is written
+    with pytest.raises(ops.GoalForceError):
+        ops.rowmax_neg(x, buf[:-1, 384])
+
+
+@pytest.mark.gpu
+def test_hip_vae_frame_attention_keeps_sdpa_precision_at_peaky_scores():
+    """The AttentionBlock's softmax (VAE:326-333) on scores whose row offset went through the GEMM's fp32 accumulator: within 2x of
+    torch's SDPA (fp32 scores; what the reference calls) against fp64 at every logit scale, where the one-GEMM form (bf16 RAW scores,
+    ops.options(vae_attn_offset=False)) is 5-10x off at logit std >= 3.  Production tile: hw = 30*52, C = 384."""
+    import torch.nn.functional as F
+    from goal_force_amd import ops, vae
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    hw, C = 1560, 384
+    rel = lambda a, b: float((a.double() - b).norm() / b.norm())
+    for qs, bar_one_gemm in ((1.0, None), (3.0, 3.0), (8.0, 5.0)):
+        qkv = torch.randn((2, hw, 3 * C), generator=gen, device="cuda")
+        qkv[:, :, :C] *= qs
+        qkv = qkv.to(torch.bfloat16)
+        q, k, v = (qkv[:, :, i * C:(i + 1) * C].double() for i in range(3))
+        ref = torch.softmax(q @ k.transpose(1, 2) / math.sqrt(C), -1) @ v
+        sdpa = rel(F.scaled_dot_product_attention(*(qkv[:, None, :, i * C:(i + 1) * C] for i in range(3)))[:, 0], ref)
+        got = rel(vae.frame_attention(qkv, C, torch.empty((2, hw, C), dtype=torch.bfloat16, device="cuda")), ref)
+        with ops.options(vae_attn_offset=False):
+            one = rel(vae.frame_attention(qkv, C, torch.empty((2, hw, C), dtype=torch.bfloat16, device="cuda")), ref)
+        print(f"VAE attention, logit std {qs:g}: two-GEMM {got:.2e}  one-GEMM {one:.2e}  torch SDPA {sdpa:.2e}")
+        assert got < 2.0 * sdpa + 1e-3, (qs, got, sdpa)
+        if bar_one_gemm:
+            assert one > bar_one_gemm * got, (qs, one, got)                  # the switch really is the coarser form
 
 
 @pytest.mark.gpu
