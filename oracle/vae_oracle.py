@@ -6,7 +6,8 @@ reference's own WanVideoVAE with seeded random weights (tests/test_vae.py).
 
 Formulation: every causal conv keeps a 2-frame history that starts as zeros and becomes the last two frames of
 (history ++ input) after each chunk — equivalent to the reference's feat_cache/None/'Rep' bookkeeping.
-Tensors are NCTHW like the reference; dtype follows the inputs (bf16 = the reference's own arithmetic)."""
+Tensors are NCTHW like the reference; dtype AND device follow the inputs (bf16 = the reference's own arithmetic; on a GPU the same
+torch ops run on torch-ROCm's kernels: tests/fullsize_vae_parity.py uses that for the full-size decode / encode)."""
 import math
 
 import torch
@@ -97,8 +98,8 @@ def _decoder_chunk(x, sd, st, first):
 
 def decode(z, sd):
     """VideoVAE_.decode: z [1,16,T,h,w] -> [1,3,4T-3,8h,8w] (un-clamped).  sd keys without the 'model.' prefix."""
-    mean = torch.tensor(MEAN).to(z.dtype).view(1, -1, 1, 1, 1)
-    inv_std = (1.0 / torch.tensor(STD)).to(z.dtype).view(1, -1, 1, 1, 1)
+    mean = torch.tensor(MEAN).to(z).view(1, -1, 1, 1, 1)                     # .to(z): dtype and device of the input
+    inv_std = (1.0 / torch.tensor(STD)).to(z).view(1, -1, 1, 1, 1)
     z = z / inv_std + mean
     x = F.conv3d(z, sd["conv2.weight"], sd["conv2.bias"])
     st = _State()
@@ -150,8 +151,8 @@ def encode(video, sd):
         outs.append(_encoder_chunk(chunk, sd, st))
     out = torch.cat(outs, 2)
     mu, _ = F.conv3d(out, sd["conv1.weight"], sd["conv1.bias"]).chunk(2, dim=1)
-    mean = torch.tensor(MEAN).to(mu.dtype).view(1, -1, 1, 1, 1)
-    inv_std = (1.0 / torch.tensor(STD)).to(mu.dtype).view(1, -1, 1, 1, 1)
+    mean = torch.tensor(MEAN).to(mu).view(1, -1, 1, 1, 1)
+    inv_std = (1.0 / torch.tensor(STD)).to(mu).view(1, -1, 1, 1, 1)
     return (mu - mean) * inv_std
 
 
@@ -168,14 +169,14 @@ def tiled_encode(video, sd, tile_size, tile_stride, up=8):
                 continue
             tasks.append((h, h + sh, w, w + sw))
     oT = (T + 3) // 4
-    weight = torch.zeros((1, 1, oT, H // up, W // up), dtype=video.dtype)
-    values = torch.zeros((1, 16, oT, H // up, W // up), dtype=video.dtype)
+    weight = torch.zeros((1, 1, oT, H // up, W // up), dtype=video.dtype, device=video.device)
+    values = torch.zeros((1, 16, oT, H // up, W // up), dtype=video.dtype, device=video.device)
     for h, h_, w, w_ in tasks:
         tile = encode(video[:, :, :, h:h_, w:w_], sd)
         mh = _ramp(tile.shape[3], h == 0, h_ >= H, (sh - th) // up)
         mw = _ramp(tile.shape[4], w == 0, w_ >= W, (sw - tw) // up)
         mask = torch.minimum(mh[:, None].expand(-1, tile.shape[4]), mw[None, :].expand(tile.shape[3], -1))
-        mask = mask.view(1, 1, 1, *mask.shape).to(video.dtype)
+        mask = mask.view(1, 1, 1, *mask.shape).to(video)
         values[:, :, :, h // up:h // up + tile.shape[3], w // up:w // up + tile.shape[4]] += tile * mask
         weight[:, :, :, h // up:h // up + tile.shape[3], w // up:w // up + tile.shape[4]] += mask
     return values / weight
@@ -203,14 +204,14 @@ def tiled_decode(z, sd, tile_size, tile_stride, up=8):
                 continue
             tasks.append((h, h + sh, w, w + sw))
     oT = 4 * T - 3
-    weight = torch.zeros((1, 1, oT, H * up, W * up), dtype=z.dtype)
-    values = torch.zeros((1, 3, oT, H * up, W * up), dtype=z.dtype)
+    weight = torch.zeros((1, 1, oT, H * up, W * up), dtype=z.dtype, device=z.device)
+    values = torch.zeros((1, 3, oT, H * up, W * up), dtype=z.dtype, device=z.device)
     for h, h_, w, w_ in tasks:
         tile = decode(z[:, :, :, h:h_, w:w_], sd)
         mh = _ramp(tile.shape[3], h == 0, h_ >= H, (sh - th) * up)
         mw = _ramp(tile.shape[4], w == 0, w_ >= W, (sw - tw) * up)
         mask = torch.minimum(mh[:, None].expand(-1, tile.shape[4]), mw[None, :].expand(tile.shape[3], -1))
-        mask = mask.view(1, 1, 1, *mask.shape).to(z.dtype)
+        mask = mask.view(1, 1, 1, *mask.shape).to(z)
         values[:, :, :, h * up:h * up + tile.shape[3], w * up:w * up + tile.shape[4]] += tile * mask
         weight[:, :, :, h * up:h * up + tile.shape[3], w * up:w * up + tile.shape[4]] += mask
     return (values / weight).clamp_(-1, 1)
