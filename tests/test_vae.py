@@ -666,13 +666,14 @@ def test_hip_vae_production_tile_vs_reference_golden():
 
 @pytest.mark.gpu
 def test_hip_tiled_vae_decode_and_encode_all_tiles_within_reference_drift():
-    """All 9 tiles of an 832 x 480 video and the blend (GF:733; VAE:1103-1203) — 5 latent frames = 17 pixel frames here, the
+    """All 9 tiles of an 832 x 480 video and the blend (GF:733; VAE:1103-1203) — 3 latent frames = 9 pixel frames here (the
+    first-frame path and two streamed chunks; most of the test's time is torch-ROCm's fp32 convolutions being set up), the
     whole 21 / 81 in profiles/r06/fullsize_vae_parity.json — on the HIP path against the reference's arithmetic on torch-ROCm's
     kernels (oracle/vae_oracle.py on this GPU, bf16) with the same arithmetic in fp32 as the yardstick.  Bar as for the DiT at
     full size: HIP-vs-fp32 <= 1.25 x (reference bf16 vs fp32); frames: PSNR not more than 0.5 dB below the reference's."""
     import fullsize_vae_parity as fv
-    rep = fv.run(grid=(5, 60, 104), log=lambda s: print(s, flush=True))
-    assert rep["decode"]["shape"] == [1, 3, 17, 480, 832] and rep["encode"]["shape"] == [1, 16, 5, 60, 104]
+    rep = fv.run(grid=(3, 60, 104), log=lambda s: print(s, flush=True))
+    assert rep["decode"]["shape"] == [1, 3, 9, 480, 832] and rep["encode"]["shape"] == [1, 16, 3, 60, 104]
     for leg in ("decode", "encode"):
         r = rep[leg]["rel_l2"]
         assert r["hip_bf16_vs_fp32"] <= 1.25 * r["ref_bf16_vs_fp32"], (leg, r)
