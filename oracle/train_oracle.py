@@ -27,12 +27,15 @@ def training_schedule(num_steps: int = 1000, shift: float = 5.0):
 
 
 def training_loss(dit_sd, cn_sd, cfg, n_cn, input_latents, noise, context, y, control_latents, timestep_id,
-                  num_steps: int = 1000, shift: float = 5.0):
-    """GF:180-193 with the random timestep draw pinned to `timestep_id`.  Tensors carry the dtype to compute in."""
+                  num_steps: int = 1000, shift: float = 5.0, timestep_dtype=None):
+    """GF:180-193 with the random timestep draw pinned to `timestep_id`.  Tensors carry the dtype to compute in.
+    timestep_dtype: the dtype the drawn timestep is rounded to when it differs from the compute dtype — an fp32 YARDSTICK of a bf16
+    run must see the bf16-rounded timestep (and the sigma / weight it selects), or it measures a different step (GF:184)."""
     dt = input_latents.dtype
     sigmas, timesteps, weights = training_schedule(num_steps, shift)
-    timestep = timesteps[timestep_id:timestep_id + 1].to(dt)                       # GF:184 (rounded to the model dtype)
+    timestep = timesteps[timestep_id:timestep_id + 1].to(timestep_dtype or dt).to(dt)   # GF:184 (rounded to the model dtype)
     tid = int(torch.argmin((timesteps - timestep.float()).abs()))                   # FM:97, 109
+    timestep = timestep.to(input_latents.device)                                    # the inputs' device (tests/fullsize_train_parity.py runs this on the GPU)
     sigma = sigmas[tid]
     latents = (1 - sigma) * input_latents + sigma * noise                            # FM:94-100
     target = noise - input_latents                                                   # FM:103-105
