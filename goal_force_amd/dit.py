@@ -249,13 +249,16 @@ class SelfAttention(nn.Module):
         keep["wide"] also the three projections ("qp", "kp" before their norm, "v")."""
         fp8 = getattr(self.q, "_gf_w8", None) is not None
         xin = (x2 if isinstance(x2, QuantizedInput) else QuantizedInput(x2)) if fp8 else x2
-        # Inference: Q leaves its RMSNorm + RoPE kernel already multiplied by c = softmax scale x log2(e) (the rotation table carries
-        # the factor: RopeTable.scaled), and the attention is called with scale = ln 2, i.e. c = 1 inside — its `Q <- bf16(Q c)` is then
-        # exact.  One rounding of the rotated q instead of two: at peaky logits (std 3) the self-attention kernel is 3.9e-3 from fp64 on
-        # a twice-rounded Q and at torch SDPA's level (1.8e-3) on this one (tools/fuzz_ops.py, profiles/r06).  The training forward
-        # keeps the plain q (its backward differentiates the unscaled graph).
+        # Q leaves its RMSNorm + RoPE kernel already multiplied by c = softmax scale x log2(e) (the rotation table carries the factor:
+        # RopeTable.scaled), and the attention is called with scale = ln 2, i.e. c = 1 inside — its `Q <- bf16(Q c)` is then exact.
+        # One rounding of the rotated q instead of two: at peaky logits (std 3) the self-attention kernel is 3.9e-3 from fp64 on a
+        # twice-rounded Q and at torch SDPA's level (1.8e-3) on this one (tools/fuzz_ops.py, profiles/r06).  Training too (`keep`):
+        # the backward rebuilds P from q.k and the forward's log-sum-exp, and a forward that rounded Q a second time hands it an lse
+        # of OTHER scores — rows of P off by 2^-9 of the logit, dQ / dK / dV 1.7e-2 from fp64 at logit std 8 where torch's SDPA
+        # backward is at 4e-3 (tools/attnbwd_precision.py).  On the pre-scaled q forward and backward see the same scores; the
+        # backward of the norm + rotation takes the same scaled table (training.DiTBlockFn) and so returns d/d(projection).
         q_cos, q_sin, attn_scale = rope.cos, rope.sin, None
-        if keep is None and ops._OPT["attn_q_prescale"]:
+        if ops._OPT["attn_q_prescale"]:
             (q_cos, q_sin), attn_scale = rope.scaled(Q_PRESCALE(self.head_dim)), math.log(2.0)
         if sp is not None and keep is None:
             # head-parallel: every projection's tokens-for-heads exchange starts as soon as the projection is ready and flies under
@@ -290,7 +293,7 @@ class SelfAttention(nn.Module):
         if sp is not None:
             return sp.attention(q, k, v, self.num_heads, scale=attn_scale)
         if keep is not None:
-            keep["attn"], keep["lse"] = ops.flash_attn_lse(q, k, v, self.num_heads)
+            keep["attn"], keep["lse"] = ops.flash_attn_lse(q, k, v, self.num_heads, scale=attn_scale)
             if keep.get("wide"):
                 keep["v"] = v
             return keep["attn"]

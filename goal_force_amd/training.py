@@ -29,7 +29,7 @@ import torch.nn as nn
 
 from . import ops
 from ._lib import GoalForceError
-from .dit import DiTBlock, RopeTable, WanModel, _tokens2d
+from .dit import Q_PRESCALE, DiTBlock, RopeTable, WanModel, _tokens2d
 
 BF = torch.bfloat16
 
@@ -256,6 +256,7 @@ class DiTBlockFn(torch.autograd.Function):
             # the backward recomputes the block on the bf16 kernels: an fp8 forward would not be the function differentiated
             raise GoalForceError("training through an enable_fp8 block is refused: call enable_fp8(module, False) first")
         ctx.param_needs = [p.requires_grad for p in params]
+        ctx.q_prescale = bool(ops._OPT["attn_q_prescale"])       # what the forward's self-attention saw is what the backward rebuilds (dit.SelfAttention.attend)
         keep = ({"wide": True} if _wide_fits(x2) else {}) if KEEP_ATTENTION else None
         with torch.no_grad():
             out = block(x2, ctx2, t_mod, rope, keep=keep, fold_pad_keys=False)   # the backward differentiates the unfolded graph
@@ -307,9 +308,12 @@ class DiTBlockFn(torch.autograd.Function):
         else:
             qp, kp, vv = lin(h1, sa.q), lin(h1, sa.k), lin(h1, sa.v)
         qn, kn = qp.clone(), kp.clone()
-        ops.rmsnorm_rope(qn, sa.norm_q.weight, rope.cos, rope.sin, hd, sa.norm_q.eps)
+        # the self-attention's q as the forward made it: pre-scaled through its rotation table, scale = ln 2 in the kernels (one
+        # rounding of q, and the SAME scores in the forward's log-sum-exp and in the backward's P)
+        (q_cos, q_sin), sa_scale = ((rope.scaled(Q_PRESCALE(hd)), math.log(2.0)) if ctx.q_prescale else ((rope.cos, rope.sin), None))
+        ops.rmsnorm_rope(qn, sa.norm_q.weight, q_cos, q_sin, hd, sa.norm_q.eps)
         ops.rmsnorm_rope(kn, sa.norm_k.weight, rope.cos, rope.sin, hd, sa.norm_k.eps)
-        a, lse = kept if len(kept) else ops.flash_attn_lse(qn, kn, vv, heads)
+        a, lse = kept if len(kept) else ops.flash_attn_lse(qn, kn, vv, heads, scale=sa_scale)
         o = lin(a, sa.o) if (wide is None or need["modulation"]) else None            # o: x1 (unless kept) and the gate's gradient
         x1 = wide["x1"] if wide is not None else ops.add(x, ops.colsum(o, gate=mod[2]))   # x + gate_msa * o
         h2 = ops.layernorm_modulate(x1, weight=block.norm3.weight, bias=block.norm3.bias, eps=eps)
@@ -364,10 +368,10 @@ class DiTBlockFn(torch.autograd.Function):
         dgate1 = acc()
         do = ops.colsum(d_x1, b=o, gate=mod[2], acc=dgate1)
         da = lin_bwd(do, a, sa.o, "self_attn.o")
-        dqn, dkn, dvv = ops.flash_attn_bwd(qn, kn, vv, a, da, lse, heads)
+        dqn, dkn, dvv = ops.flash_attn_bwd(qn, kn, vv, a, da, lse, heads, scale=sa_scale)
         wq_acc = _zeros_f32(d, dev) if need["self_attn.norm_q.weight"] else None
         wk_acc = _zeros_f32(d, dev) if need["self_attn.norm_k.weight"] else None
-        dqp = ops.rmsnorm_rope_bwd(qp, dqn, sa.norm_q.weight, rope.cos, rope.sin, hd, sa.norm_q.eps, dw_acc=wq_acc)
+        dqp = ops.rmsnorm_rope_bwd(qp, dqn, sa.norm_q.weight, q_cos, q_sin, hd, sa.norm_q.eps, dw_acc=wq_acc)   # linear in the table: d/d(qp) of the scaled q
         dkp = ops.rmsnorm_rope_bwd(kp, dkn, sa.norm_k.weight, rope.cos, rope.sin, hd, sa.norm_k.eps, dw_acc=wk_acc)
         if wq_acc is not None:
             g["self_attn.norm_q.weight"] = ops.f32_to_bf16(wq_acc)

@@ -14,6 +14,9 @@ reference trains with gradient checkpointing too (train_goal_force.sh: --use_gra
     python tests/fullsize_train_parity.py                                     # 40 + 10 blocks, 21 latent frames (~5 GPU-minutes)
     python tests/fullsize_train_parity.py --layers 4 --cn-layers 2 --frames 5    # quick look
 
+`--peaky f`: every self-attention's norm_q weight x f (logits x f).  The report also carries the HIP step under
+ops.options(attn_q_prescale=False) — rounds 1-5's training path, whose forward rounds Q a second time.
+
 Reported: loss (hip / reference bf16 / fp32); relative L2 distance from the fp32 gradients of hip and of the reference's bf16
 arithmetic, over all ControlNet parameters together and per group (patch embedding, each block, zero-convs)."""
 import argparse
@@ -89,7 +92,7 @@ def distances(grads, ref):
     return {k: math.sqrt(num[k] / max(den[k], 1e-300)) for k in num}
 
 
-def run(layers=40, cn_layers=10, frames=21, timestep_id=500, q_chunk=2048, log=print):
+def run(layers=40, cn_layers=10, frames=21, timestep_id=500, q_chunk=2048, peaky=1.0, log=print):
     from fullsize_parity import LazySD, config_of
     from goal_force_amd import training as tr
     from goal_force_amd.dit import A14B_CONFIG
@@ -101,6 +104,11 @@ def run(layers=40, cn_layers=10, frames=21, timestep_id=500, q_chunk=2048, log=p
     for p in dit.parameters():
         p.requires_grad_(False)
     cn = build_random_controlnet(cn_layers, cfg, seed=300, device=dev)
+    if peaky != 1.0:                                                     # every self-attention's logits x peaky (what trained attention looks like)
+        for m in (dit, cn):
+            for n, p in m.named_parameters():
+                if n.endswith("self_attn.norm_q.weight"):
+                    p.data.mul_(peaky)
     pipe = WanVideoPipeline.from_modules(dit, None, cn, None, device=dev)
     pipe.scheduler.set_timesteps(1000, training=True)                    # utils.py:560
     g = torch.Generator().manual_seed(0)
@@ -108,7 +116,7 @@ def run(layers=40, cn_layers=10, frames=21, timestep_id=500, q_chunk=2048, log=p
     inp = dict(input_latents=torch.randn(shp, generator=g), noise=torch.randn(shp, generator=g), y=torch.randn((1, 20) + shp[2:], generator=g),
                control=torch.randn(shp, generator=g), context=torch.randn((1, TEXT_TOKENS, 4096), generator=g))
     inp = {k: v.to(BF).to(dev) for k, v in inp.items()}
-    rep = {"config": {"layers": layers, "controlnet_layers": cn_layers, "tokens": frames * 30 * 52, "latents": list(shp), "timestep_id": timestep_id,
+    rep = {"config": {"layers": layers, "controlnet_layers": cn_layers, "tokens": frames * 30 * 52, "latents": list(shp), "timestep_id": timestep_id, "self_attention_logits_x": peaky,
                       "trainable_params": sum(p.numel() for p in cn.parameters()), "weights": "random init (bench.py's seeds)"}}
 
     # ---- the product: training_loss + backward through the HIP kernels
@@ -127,6 +135,10 @@ def run(layers=40, cn_layers=10, frames=21, timestep_id=500, q_chunk=2048, log=p
     t_hip = time.time() - t0
     hip_grads = {n: p.grad.detach().clone() for n, p in cn.named_parameters()}
     assert all(p.grad is None for p in dit.parameters())
+    from goal_force_amd import ops
+    with ops.options(attn_q_prescale=False):                             # rounds 1-5's training path: a plain q, rounded again inside the forward kernel
+        plain_loss = hip_step()
+    plain_grads = {n: p.grad.detach().float().cpu() for n, p in cn.named_parameters()}
     for p in cn.parameters():
         p.grad = None
     log(f"hip: loss {hip_loss:.6f}, forward + backward {t_hip:.2f} s, peak {torch.cuda.max_memory_allocated() / 2 ** 30:.0f} GB")
@@ -155,16 +167,16 @@ def run(layers=40, cn_layers=10, frames=21, timestep_id=500, q_chunk=2048, log=p
     f32_grads = {k: v.cpu() for k, v in f32_grads.items()}
     hip_cpu = {k: v.float().cpu() for k, v in hip_grads.items()}
     assert sorted(hip_cpu) == sorted(f32_grads)
-    rep["loss"] = {"hip": hip_loss, "ref_bf16": ref_loss, "fp32": f32_loss}
+    rep["loss"] = {"hip": hip_loss, "hip_plain_q": plain_loss, "ref_bf16": ref_loss, "fp32": f32_loss}
     rep["grad_rel_l2"] = {"hip_bf16_vs_fp32": distances(hip_cpu, f32_grads), "ref_bf16_vs_fp32": distances(ref_grads, f32_grads),
-                          "hip_bf16_vs_ref_bf16": distances(hip_cpu, ref_grads)}
+                          "hip_bf16_vs_ref_bf16": distances(hip_cpu, ref_grads), "hip_plain_q_vs_fp32": distances(plain_grads, f32_grads)}
     rep["grad_norm"] = {"hip": math.sqrt(sum(float(v.double().pow(2).sum()) for v in hip_cpu.values())),
                         "ref_bf16": math.sqrt(sum(float(v.double().pow(2).sum()) for v in ref_grads.values())),
                         "fp32": math.sqrt(sum(float(v.double().pow(2).sum()) for v in f32_grads.values()))}
     rep["seconds_forward_backward"] = {"hip": t_hip, "reference_arithmetic_on_torch_rocm_bf16_recomputing": t_ref, "fp32_recomputing": t_f32}
     log(f"  loss {rep['loss']}")
     log(f"  gradient norm {rep['grad_norm']}")
-    for k in ("hip_bf16_vs_fp32", "ref_bf16_vs_fp32", "hip_bf16_vs_ref_bf16"):
+    for k in ("hip_bf16_vs_fp32", "ref_bf16_vs_fp32", "hip_bf16_vs_ref_bf16", "hip_plain_q_vs_fp32"):
         log(f"  {k}: " + ", ".join(f"{g} {v:.3e}" for g, v in rep["grad_rel_l2"][k].items()))
     return rep
 
@@ -176,9 +188,10 @@ if __name__ == "__main__":
     ap.add_argument("--frames", type=int, default=21, help="latent frames (21 = 81 video frames)")
     ap.add_argument("--timestep-id", type=int, default=500)
     ap.add_argument("--q-chunk", type=int, default=2048)
+    ap.add_argument("--peaky", type=float, default=1.0, help="multiply every self-attention's norm_q weight by this factor (logits x f)")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
-    rep = run(a.layers, a.cn_layers, a.frames, a.timestep_id, a.q_chunk)
+    rep = run(a.layers, a.cn_layers, a.frames, a.timestep_id, a.q_chunk, a.peaky)
     if a.out:
         os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
         with open(a.out, "w") as f:

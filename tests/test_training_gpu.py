@@ -273,6 +273,93 @@ def test_dit_block_backward_mid_size_vs_oracle():
         assert e < (8e-2 if n.endswith("attn.k.bias") else 2.5e-2), f"{n}: rel_l2={e:.3e}"
 
 
+def test_attention_backward_on_the_prescaled_q_keeps_sdpa_precision_at_peaky_logits():
+    """Forward (lse) + backward on q' = bf16(c q) with scale = ln 2 — what SelfAttention.attend / DiTBlockFn hand the kernels — against
+    fp64 autograd beside torch's bf16 SDPA under autograd, at logit std 8: dQ / dK / dV within 1.25 x SDPA's distance.  On a plain q
+    (rounds 1-5: the forward rounds Q' a second time and the backward rebuilds P from other scores than the lse's) the same kernels
+    are 3-6 x further away: the test holds that signature too, so that it cannot pass on the wrong path."""
+    import torch.nn.functional as F
+    from goal_force_amd import ops
+    from goal_force_amd.dit import Q_PRESCALE
+    S, H, c = ops.VT_MIN_KV, 4, Q_PRESCALE(HD)          # the key length from which the forward runs on kernel 3 (the one that pre-scales Q)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    q32 = torch.randn((S, H * HD), generator=g, device="cuda") * 8.0
+    k, v, do = (torch.randn((S, H * HD), generator=g, device="cuda").to(BF) for _ in range(3))
+    heads = lambda t: t.view(S, H, HD).transpose(0, 1)
+
+    def fp64(q):
+        q64, k64, v64 = (t.double().requires_grad_(True) for t in (q, k, v))
+        with torch.enable_grad():
+            p = torch.softmax(heads(q64) @ heads(k64).transpose(1, 2) / math.sqrt(HD), -1)
+            (p @ heads(v64)).transpose(0, 1).reshape(S, H * HD).backward(do.double())
+        return q64.grad, k64.grad, v64.grad
+    rel = lambda a, b: float((a.double() - b).norm() / b.norm())
+    q = q32.to(BF)
+    ref = fp64(q)
+    qb, kb, vb = (t.clone().requires_grad_(True) for t in (q, k, v))
+    with torch.enable_grad():
+        F.scaled_dot_product_attention(heads(qb)[None], heads(kb)[None], heads(vb)[None])[0].transpose(0, 1).reshape(S, H * HD).backward(do)
+    sdpa = [rel(a.grad, r) for a, r in zip((qb, kb, vb), ref)]
+    o, lse = ops.flash_attn_lse(q, k, v, H)
+    plain = [rel(a, r) for a, r in zip(ops.flash_attn_bwd(q, k, v, o, do, lse, H), ref)]
+    qp = (q32 * c).to(BF)
+    refp = fp64(qp.double() / c)
+    o, lse = ops.flash_attn_lse(qp, k, v, H, scale=math.log(2.0))
+    dqp, dk, dv = ops.flash_attn_bwd(qp, k, v, o, do, lse, H, scale=math.log(2.0))
+    pre = [rel(dqp.double() * c, refp[0]), rel(dk, refp[1]), rel(dv, refp[2])]
+    print(f"attention backward at logit std 8 (dq, dk, dv vs fp64): pre-scaled q {pre}  plain q {plain}  torch SDPA {sdpa}")
+    for a, b in zip(pre, sdpa):
+        assert a <= 1.25 * b + 2e-4, (pre, sdpa)
+    assert plain[0] > 2.5 * pre[0] and plain[2] > 2.5 * pre[2], (plain, pre)
+
+
+def test_dit_block_backward_at_peaky_self_attention_logits_with_and_without_the_prescaled_q():
+    """The block's backward (DiTBlockFn) with norm_q's weight x 8 (self-attention logits x 8) at 2048 tokens (kernel 3 in the forward)
+    against fp32 autograd of the oracle: dx and the self-attention's gradients within 1.25 x the distance of the reference's own bf16
+    arithmetic (the oracle's autograd on bf16 tensors: near-one-hot rows amplify every upstream rounding, 2-3e-2 for either path), with
+    the pre-scaled q (shipped); ops.options(attn_q_prescale=False) — rounds 1-5's training path — is further away in sum.  (Weight
+    gradients add the attention's per-token errors over all tokens, so most of the operator-level gap of the test above averages
+    out here and at production size: profiles/r06/fullsize_train_parity_peaky3.json.)"""
+    import gen_inputs as gi
+    from goal_force_amd import ops
+    from goal_force_amd.dit import DiTBlock, RopeTable, precompute_freqs_cis_3d
+    from goal_force_amd.training import block_forward
+    from oracle import wan_oracle as wo
+    cfg = gi.MID
+    sd = gi.block_sd(torch.Generator().manual_seed(21), cfg["dim"], cfg["ffn_dim"], "", BF)
+    sd["self_attn.norm_q.weight"] = (sd["self_attn.norm_q.weight"].float() * 8).to(BF)
+    x, ctx, t_mod = gi.block_inputs(cfg["dim"], 2048, 512, seed=22)
+    dout = torch.randn(x.shape, generator=torch.Generator().manual_seed(23)).to(BF)
+    sdf = {k: v.float().requires_grad_(True) for k, v in sd.items()}
+    xf = x.float().requires_grad_(True)
+    freqs = wo.rope_freqs_3d(cfg["dim"] // cfg["num_heads"], 8, 16, 16)
+    wo.dit_block(xf, ctx.float(), t_mod.float(), freqs, sdf, "", cfg["num_heads"], cfg["eps"]).backward(dout.float())
+    sdb = {k: v.clone().requires_grad_(True) for k, v in sd.items()}                     # the reference's bf16 arithmetic under autograd
+    xb = x.clone().requires_grad_(True)
+    wo.dit_block(xb, ctx, t_mod, freqs, sdb, "", cfg["num_heads"], cfg["eps"]).backward(dout)
+    blk = DiTBlock(False, cfg["dim"], cfg["num_heads"], cfg["ffn_dim"], cfg["eps"])
+    blk.load_state_dict(sd, strict=True)
+    blk = blk.to(BF).cuda()
+    rope = RopeTable.from_grid(precompute_freqs_cis_3d(cfg["dim"] // cfg["num_heads"]), 8, 16, 16, "cuda")
+    names = ["self_attn.q.weight", "self_attn.k.weight", "self_attn.v.weight", "self_attn.norm_q.weight", "self_attn.o.weight"]
+    named = dict(blk.named_parameters())
+    err = {}
+    for flag in (True, False):
+        for p_ in blk.parameters():
+            p_.grad = None
+        xc = x[0].cuda().requires_grad_(True)
+        with ops.options(attn_q_prescale=flag):
+            block_forward(blk, xc, ctx[0].cuda(), t_mod.cuda(), rope).backward(dout[0].cuda())
+        err[flag] = {"dx": rel_l2(xc.grad.float().cpu(), xf.grad[0])}
+        err[flag].update({n: rel_l2(named[n].grad.float().cpu().reshape(sdf[n].grad.shape), sdf[n].grad) for n in names})
+    ref = {"dx": rel_l2(xb.grad.float(), xf.grad)}
+    ref.update({n: rel_l2(sdb[n].grad.float(), sdf[n].grad) for n in names})
+    print(f"block backward, self-attention logits x 8, vs fp32 autograd: pre-scaled q {err[True]}  plain q {err[False]}  reference bf16 {ref}")
+    for n in ["dx"] + names:
+        assert err[True][n] <= 1.25 * ref[n], (n, err[True], ref)
+    assert sum(err[True].values()) < sum(err[False].values()), err
+
+
 def test_dit_block_backward_is_the_same_whatever_the_forward_kept(monkeypatch):
     """training.set_keep_level none / attn / wide: kept tensors are the forward's own values, so the gradients agree to rounding (the fused
     forward rounds x1 / x2b once where the un-fused recompute rounds per op), for a trainable and for a frozen block."""
