@@ -81,3 +81,45 @@ def test_oracle_training_step_bf16_matches_reference():
                                     gi.TINY_CONTROLNET_LAYERS, gi.train_inputs(), gi.TRAIN_TIMESTEP_ID, dtype=torch.bfloat16)
     assert abs(float(loss) - float(g["loss_bf16"])) < 2e-2 * float(g["loss_bf16"])
     _check(grads, g, "bf16", rtol=5e-2)       # same ops, same dtype; the oracle's LayerNorm is the fp32-autocast variant
+
+
+def test_the_production_size_tool_recomputes_the_pinned_oracle_and_changes_no_value():
+    """tests/fullsize_train_parity.py runs the oracle's blocks under torch.utils.checkpoint (and its fp32 attention in checkpointed query
+    chunks) because autograd over 50 blocks at 32760 tokens does not fit otherwise: on the tiny configuration that form gives the
+    gradients of the g9-pinned oracle — bit for bit in bf16 (SDPA either way), to summation order in fp32 (chunked attention)."""
+    import fullsize_train_parity as ft
+    cfg, n_cn = gi.TINY, gi.TINY_CONTROLNET_LAYERS
+    dsd, csd0, inp = gi.dit_sd(cfg, seed=41), gi.controlnet_sd(cfg, n_cn, seed=42), gi.train_inputs()
+    for dtype, bar in ((torch.bfloat16, 0.0), (torch.float32, 1e-5)):
+        l0, g0 = to.loss_and_grads(dsd, csd0, cfg, n_cn, inp, gi.TRAIN_TIMESTEP_ID, dtype=dtype)
+        d = {k: v.to(dtype) for k, v in dsd.items()}
+        c = {k: v.detach().to(dtype).clone().requires_grad_(True) for k, v in csd0.items()}
+        i = {k: v.to(dtype) for k, v in inp.items()}
+        with ft.recomputing(8):
+            loss = to.training_loss(d, c, cfg, n_cn, i["input_latents"], i["noise"], i["context"], i["y"], i["control"], gi.TRAIN_TIMESTEP_ID)
+            loss.backward()
+        dist = ft.distances({k: v.grad for k, v in c.items()}, g0)
+        assert abs(float(loss.detach()) - float(l0)) <= bar * abs(float(l0)) and dist["all"] <= bar, (dtype, dist)
+        assert set(dist) == {"all", "patch embedding", "zero-convs"} | {f"block {b}" for b in range(n_cn)}
+
+
+def test_an_fp32_yardstick_of_a_bf16_step_sees_the_bf16_rounded_timestep():
+    """GF:184 rounds the drawn timestep to the model dtype; the sigma and the loss weight follow the ROUNDED value (FM:97, 109).  With
+    timestep_dtype=bfloat16 an fp32 run of training_loss is the same training step as the bf16 run (close losses); without it, it
+    is a neighbouring step wherever the rounding crosses a grid point."""
+    cfg, n_cn = gi.TINY, gi.TINY_CONTROLNET_LAYERS
+    dsd, csd, inp = gi.dit_sd(cfg, seed=41), gi.controlnet_sd(cfg, n_cn, seed=42), gi.train_inputs()
+    _, ts, _ = to.training_schedule(1000, 5.0)
+    moved = [t for t in range(1000) if int(torch.argmin((ts - ts[t].to(torch.bfloat16).float()).abs())) != t]
+    assert moved, "bf16 rounding must move some timestep to a neighbouring grid point"
+    tid = moved[len(moved) // 2]
+
+    def loss(dtype, **kw):
+        d = {k: v.to(dtype) for k, v in dsd.items()}
+        c = {k: v.to(dtype) for k, v in csd.items()}
+        i = {k: v.to(dtype) for k, v in inp.items()}
+        with torch.no_grad():
+            return float(to.training_loss(d, c, cfg, n_cn, i["input_latents"], i["noise"], i["context"], i["y"], i["control"], tid, **kw))
+    lb, l32, l32r = loss(torch.bfloat16), loss(torch.float32), loss(torch.float32, timestep_dtype=torch.bfloat16)
+    assert abs(l32r - lb) < abs(l32 - lb), (lb, l32, l32r)
+    assert abs(l32r - lb) < 2e-2 * abs(lb), (lb, l32r)
