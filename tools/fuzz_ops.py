@@ -209,7 +209,26 @@ def case_batched(rnd, g):
 
 
 def case_misc(rnd, g):
-    which = rnd.choice(["softmax", "transpose", "patchify"])
+    which = rnd.choice(["softmax", "transpose", "patchify", "rowmax", "vae_attn"])
+    if which == "rowmax":
+        R, C, ld = rnd.choice([1, 7, 512, 1560]), rnd.choice([8, 41, 512, 1560, 4097]), rnd.choice([1, 3, 448])
+        x = bf(torch.randn((R, C), generator=g, device="cuda") * 40 - rnd.choice([0.0, 500.0]))
+        buf = torch.full((R, ld), 7.0, dtype=BF, device="cuda")
+        col = rnd.randrange(ld)
+        ops.rowmax_neg(x, buf[:, col])
+        want = torch.full((R, ld), 7.0, dtype=BF, device="cuda")
+        want[:, col] = (-x.float().amax(dim=1)).to(BF)
+        return f"rowmax_neg R={R} C={C} ld={ld} col={col}", float((buf.float() - want.float()).abs().max()), 0.0
+    if which == "vae_attn":                      # the VAE AttentionBlock's core (vae.frame_attention): fp64 softmax(q k^T / sqrt(C)) v
+        from goal_force_amd import vae
+        G, hw, C, qs = rnd.choice([1, 2, 5]), 8 * rnd.choice([1, 8, 49, 195]), rnd.choice([64, 384]), rnd.choice([1.0, 3.0, 8.0])
+        qkv = torch.randn((G, hw, 3 * C), generator=g, device="cuda")
+        qkv[:, :, :C] *= qs
+        qkv = bf(qkv)
+        got = vae.frame_attention(qkv, C, torch.empty((G, hw, C), dtype=BF, device="cuda"))
+        q, k, v = (qkv[:, :, i * C:(i + 1) * C].double() for i in range(3))
+        ref = torch.softmax(q @ k.transpose(1, 2) / math.sqrt(C), -1) @ v
+        return f"vae.frame_attention G={G} hw={hw} C={C} logit std {qs:g}", rel(got, ref), 6e-3
     if which == "softmax":
         R, C = rnd.choice([1, 7, 512, 1560, 3000]), rnd.choice([8, 41, 512, 1560, 1563])
         ld = -(-C // 64) * 64
