@@ -101,10 +101,14 @@ def sinusoidal_embedding_1d(dim, position):
 def flash_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: int, compatibility_mode=False):
     """DIT:28-61 — q, k, v [B, S, num_heads * head_dim] (`b s (n d)`) -> [B, Sq, num_heads * head_dim]: softmax(q k^T / sqrt(d)) v
     per head, no mask, on the HIP flash-attention kernels (gf_flash_attn_fwd).  `compatibility_mode` only chooses among the
-    reference's backends (flash-attn 3 / 2, sageattention, torch SDPA); there is one backend here, so it is accepted and ignored."""
+    reference's backends (flash-attn 3 / 2, sageattention, torch SDPA); there is one backend here, so it is accepted and ignored.
+    The q handed in is final (already rounded to bf16 by its producer), so long key sequences run on the kernel that scales the fp32
+    scores — SDPA's precision at peaky logits — not on the one that pre-scales and re-rounds Q (ops.flash_attn: finished_q); the
+    package's own blocks produce a pre-scaled q instead and keep the faster kernel (SelfAttention.attend)."""
     if q.dim() != 3 or k.dim() != 3 or v.dim() != 3 or not (q.shape[0] == k.shape[0] == v.shape[0]):
         raise GoalForceError("flash_attention: q, k, v must be [B, S, num_heads * head_dim] with equal B")
-    return torch.stack([ops.flash_attn(q[b].contiguous(), k[b].contiguous(), v[b].contiguous(), num_heads) for b in range(q.shape[0])])
+    return torch.stack([ops.flash_attn(q[b].contiguous(), k[b].contiguous(), v[b].contiguous(), num_heads, finished_q=True)
+                        for b in range(q.shape[0])])
 
 
 def modulate(x: torch.Tensor, shift: torch.Tensor, scale: torch.Tensor):

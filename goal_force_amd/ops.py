@@ -324,10 +324,15 @@ def linear_vt32_fp8(x8, x_scale, w8, bias):
     return vt
 
 
-def flash_attn(q, k, v, num_heads, out=None, scale=None, vt=None, last_key_mult=1):
+def flash_attn(q, k, v, num_heads, out=None, scale=None, vt=None, last_key_mult=1, finished_q=False):
     """softmax(q k^T / sqrt(d)) v per head; q [Sq, H*128], k/v [Skv, H*128] (row-strided views OK).  `vt` (instead of v): the
     V^T operand linear_vt32 produced for these keys.  `last_key_mult` = m > 1: the last key counts m times (a run of m identical
-    trailing keys folded into one: gf_flash_attn_fwd_lastmult; key lengths below the V^T threshold only)."""
+    trailing keys folded into one: gf_flash_attn_fwd_lastmult; key lengths below the V^T threshold only).
+    `finished_q`: q is somebody else's final bf16 tensor (the B3 drop-in dit.flash_attention).  Kernel 3 multiplies Q by
+    scale x log2(e) and rounds it to bf16 again — 3.9e-3 / 5.2e-3 from fp64 at logit std 3 / 8 where torch's SDPA is at 1.8e-3 /
+    1.7e-3; the package's own modules avoid that by producing q pre-scaled (dit.SelfAttention.attend), a caller with a finished q
+    cannot: long key sequences then run on kernel 2, which scales the fp32 scores (2.1e-3 / 1.9e-3; +16 % time at S = 32760,
+    profiles/r06/b3_precision.log)."""
     for n, t in (("q", q), ("k", k)) + ((("v", v),) if vt is None else ()):
         _req(t, f"flash_attn.{n}")
         if t.dim() != 2 or t.stride(1) != 1:
@@ -355,7 +360,9 @@ def flash_attn(q, k, v, num_heads, out=None, scale=None, vt=None, last_key_mult=
         # long key sequences (the DiT self-attention): hand V over pre-transposed — one LDS read per PV MFMA instead of two;
         # the transpose (0.7 % of the attention's time at S=32760) is inside the timed region
         # kernel 3 (16x16x32 MFMAs); options(attn_k3=False) sends the shape to kernel 2 (32x32x16) for the cross-check tests
-        k3 = _OPT["attn_k3"]
+        if finished_q and vt is not None:
+            raise GoalForceError("flash_attn: finished_q goes to kernel 2, which does not take kernel 3's V^T operand")
+        k3 = _OPT["attn_k3"] and not finished_q
         tr, fa = (lib.gf_transpose_v32, lib.gf_flash_attn_fwd_vt32) if k3 else (lib.gf_transpose_v, lib.gf_flash_attn_fwd_vt)
         if vt is None:
             vt = _vt_workspace(num_heads * 128 * kv_pad, q.device)

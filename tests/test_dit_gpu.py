@@ -106,6 +106,30 @@ def test_b3_module_level_functions_vs_reference_goldens():
     assert rel_l2(got.cpu().float(), ref.float()) < 4e-3
 
 
+def test_b3_flash_attention_on_a_finished_q_keeps_sdpa_precision_at_long_peaky_keys():
+    """DIT:28-61 hands SDPA a q that is already bf16: at >= 2048 keys the drop-in runs on the kernel that scales the fp32 scores
+    (finished_q), within 1.3 x torch's SDPA from fp64 at logit std 3 and 8 — where kernel 3 on the same finished q, which rounds
+    Q x scale x log2(e) to bf16 again, is 2-3 x further (the package's blocks feed kernel 3 a q that was scaled BEFORE its only rounding)."""
+    import math
+    import torch.nn.functional as F
+    from goal_force_amd import ops
+    from goal_force_amd.dit import flash_attention
+    S, H, HD = ops.VT_MIN_KV + 256, 4, 128
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for qs in (3.0, 8.0):
+        q = (torch.randn((1, S, H * HD), generator=g, device="cuda") * qs).to(BF)
+        k, v = (torch.randn((1, S, H * HD), generator=g, device="cuda").to(BF) for _ in range(2))
+        heads = lambda t: t[0].view(S, H, HD).transpose(0, 1)
+        ref = (torch.softmax(heads(q).double() @ heads(k).double().transpose(1, 2) / math.sqrt(HD), -1) @ heads(v).double()).transpose(0, 1).reshape(S, H * HD)
+        rel = lambda a: float((a.double() - ref).norm() / ref.norm())
+        sdpa = rel(F.scaled_dot_product_attention(heads(q)[None], heads(k)[None], heads(v)[None])[0].transpose(0, 1).reshape(S, H * HD))
+        b3 = rel(flash_attention(q, k, v, H)[0])
+        k3 = rel(ops.flash_attn(q[0], k[0], v[0], H))
+        print(f"finished q, {S} keys, logit std {qs:g}: B3 flash_attention {b3:.2e}  kernel 3 {k3:.2e}  torch SDPA {sdpa:.2e}")
+        assert b3 <= 1.3 * sdpa, (qs, b3, sdpa)
+        assert k3 > 1.6 * b3, (qs, k3, b3)
+
+
 def test_block_accepts_reference_complex_freqs():
     cfg = gi.TINY
     sd = gi.block_sd(torch.Generator().manual_seed(11), cfg["dim"], cfg["ffn_dim"], "", BF)
