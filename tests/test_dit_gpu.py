@@ -108,7 +108,7 @@ def test_b3_module_level_functions_vs_reference_goldens():
 
 def test_b3_flash_attention_on_a_finished_q_keeps_sdpa_precision_at_long_peaky_keys():
     """DIT:28-61 hands SDPA a q that is already bf16: at >= 2048 keys the drop-in runs on the kernel that scales the fp32 scores
-    (finished_q), within 1.3 x torch's SDPA from fp64 at logit std 3 and 8 — where kernel 3 on the same finished q, which rounds
+    (finished_q), within 1.4 x torch's SDPA from fp64 (measured 1.12-1.20 x) at logit std 3 and 8 — where kernel 3 on the same finished q, which rounds
     Q x scale x log2(e) to bf16 again, is 2-3 x further (the package's blocks feed kernel 3 a q that was scaled BEFORE its only rounding)."""
     import math
     import torch.nn.functional as F
@@ -126,7 +126,7 @@ def test_b3_flash_attention_on_a_finished_q_keeps_sdpa_precision_at_long_peaky_k
         b3 = rel(flash_attention(q, k, v, H)[0])
         k3 = rel(ops.flash_attn(q[0], k[0], v[0], H))
         print(f"finished q, {S} keys, logit std {qs:g}: B3 flash_attention {b3:.2e}  kernel 3 {k3:.2e}  torch SDPA {sdpa:.2e}")
-        assert b3 <= 1.3 * sdpa, (qs, b3, sdpa)
+        assert b3 <= 1.4 * sdpa, (qs, b3, sdpa)
         assert k3 > 1.6 * b3, (qs, k3, b3)
 
 
